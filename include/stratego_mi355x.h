@@ -1,0 +1,136 @@
+/*
+ * stratego_mi355x.h -- C ABI of libstratego_mi355x.so, the MI355X (gfx950) batched Stratego env.
+ *
+ * The reference (JBLanier/stratego_env) has no FFI: its seam is the Python class
+ * StrategoProceduralEnv (stratego_env/game/stratego_procedural_env.py:20-181) under
+ * StrategoMultiAgentEnv (stratego_env/stratego_multiagent_env.py:316-834).  Each entry point below
+ * names the reference interface it replaces for a batch of N independent games.  Conventions:
+ *   - plain C, no C++/torch types; every *_dev pointer is a DEVICE pointer owned by the caller
+ *     (e.g. a torch tensor's data_ptr()); the library owns only its internal state tensor;
+ *   - all device work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream)
+ *     and is asynchronous; no entry point synchronises the device except sgx_destroy;
+ *   - return 0 on success, a negative SGX_E* code on failure (sgx_last_error() has the text);
+ *     nothing throws across the ABI; invalid *actions* are not API errors: they are reported per env
+ *     in invalid_action[] with that env's state left unchanged (the reference raises ValueError,
+ *     stratego_procedural_impl.py:899-902 -- the Python facade turns the flag back into ValueError);
+ *   - a handle is bound to one device and is not thread-safe; different handles are independent.
+ *
+ * Data layouts (C order):
+ *   obs    float32 [N][R][C][67]   normalised partial observation of the env's NEXT mover, mover's
+ *                                  perspective (impl:1335-1397 + maenv:261-313,388-391,506-508)
+ *   mask   uint8   [N][R][C][K]    valid-actions mask of the next mover, K = 2(R-1)+2(C-1)+1
+ *                                  (impl:399-517; the reference dtype is int64 with values 0/1)
+ *   action int32   [N]             flat index into (R,C,K) in the MOVER's perspective (maenv:684-689)
+ *   state  int64   [N][34][R][C]   the reference's own state layout, absolute coordinates (impl:16-60)
+ */
+#ifndef STRATEGO_MI355X_H
+#define STRATEGO_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGX_ABI_VERSION 1
+#define SGX_MAX_CELLS 256        /* rows*cols <= 256 (largest reference variant: 15x15) */
+#define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
+#define SGX_STATE_LAYERS 34      /* impl:109 */
+#define SGX_OBS_LUT_STRIDE 16    /* entries per channel in the normalisation LUT */
+
+enum {
+    SGX_OK = 0,
+    SGX_EINVAL = -1,   /* bad argument / unsupported board size */
+    SGX_ENOMEM = -2,   /* device allocation failed */
+    SGX_EDEVICE = -3,  /* HIP runtime error (no device, launch failure, ...) */
+    SGX_ESTATE = -4    /* call not valid in the handle's current state (e.g. no setup table) */
+};
+
+/* Game variant = one of the reference's *_STRATEGO_CONFIG dicts (game/config.py:3-313). */
+typedef struct sgx_config {
+    int32_t rows, cols;               /* >= 3 each (penv:28-30), rows*cols <= SGX_MAX_CELLS */
+    int32_t max_turns;                /* config 'max_turns' -> StateData.MAX_TURNS (impl:247) */
+    int32_t usable_rows;              /* config 'initial_state_usable_rows' */
+    int32_t piece_counts[12];         /* config 'piece_amounts' for piece codes 1..12 (SPY..BOMB) */
+    uint8_t obstacles[SGX_MAX_CELLS]; /* config 'obstacle_locations' as a row-major rows*cols 0/1 map */
+} sgx_config;
+
+typedef struct sgx_env sgx_env; /* opaque handle */
+
+/* Buffers of one batched step.  Replaces StrategoMultiAgentEnv.step(action_dict) (maenv:659-828) +
+ * _get_current_obs (maenv:447-497) for N envs.  Nullable members may be NULL to skip that output. */
+typedef struct sgx_step_io {
+    const int32_t *actions_dev;    /* [N]   in : action of each env's current mover */
+    float *obs_dev;                /* [N,R,C,67] out (nullable) */
+    uint8_t *mask_dev;             /* [N,R,C,K]  out (nullable) */
+    float *reward_dev;             /* [N,2] out: rewards[+1], rewards[-1]; 0,0 while running (maenv:769, 777-805) */
+    uint8_t *done_dev;             /* [N]   out: dones["__all__"] */
+    int8_t *player_dev;            /* [N]   out: the next mover, +1 / -1 (after auto-reset: +1) */
+    uint8_t *invalid_action_dev;   /* [N]   out: 1 where the reference would raise; state unchanged */
+    uint8_t *ending_invalid_dev;   /* [N]   out: infos['game_result_was_invalid'] (max-turn tie, maenv:777-782) */
+    float *final_obs_dev;          /* [N,2,R,C,67] out (nullable): on terminal steps, the terminal observation of
+                                      player +1 (slot 0) and -1 (slot 1) (maenv:772-773); untouched otherwise */
+    int32_t *next_actions_dev;     /* [N] out (nullable): a uniformly random valid action for the next mover, drawn
+                                      with the handle's counter RNG keyed by (seed, global env id, game, turn);
+                                      the batched counterpart of sample_random_valid_action (maenv:830-834) */
+    int32_t auto_reset;            /* 1: an env that finishes starts its next game inside the same call
+                                      (obs/mask/player then describe the new game's first mover) */
+    int32_t reserved;
+} sgx_step_io;
+
+/* Library / geometry queries (penv:32-36: action_size, spatial_action_size). */
+int sgx_abi_version(void);
+const char *sgx_last_error(void);
+int64_t sgx_num_envs(const sgx_env *h);
+int sgx_spatial_channels(const sgx_env *h);          /* K */
+int64_t sgx_num_spatial_actions(const sgx_env *h);   /* R*C*K = Discrete(n) of maenv:362 */
+int64_t sgx_action_size_1d(const sgx_env *h);        /* R*C*(R+C)+1 (impl:252-254) */
+
+/* Host-only: fills lut[67*SGX_OBS_LUT_STRIDE] with the float32 bit-exact normalised value of every
+ * (channel, raw integer value) pair: entry [ch*16 + clamp(v + bias_ch, 0, 15)] where bias is 3 for the two
+ * recent-moves channels (raw -3..1) and 0 elsewhere.  Replaces the arithmetic of
+ * normalize_p_observation (maenv:506-508) with the constants of maenv:261-313, 388-391. */
+int sgx_build_obs_lut(const sgx_config *cfg, float *lut);
+
+/* StrategoMultiAgentEnv.__init__ (maenv:318-445) for a batch: allocates the device state of n_envs games on
+ * `device`.  Env i of this handle has global id env_id_offset + i; all random draws are keyed by
+ * (seed, global id, game number, turn), so trajectories do not depend on how the batch is sharded. */
+int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64_t seed, int64_t env_id_offset, sgx_env **out);
+int sgx_destroy(sgx_env *h);
+
+/* Upload a human-setup table (game/inits/*_human_inits.py decoded to piece codes, util.py:154-180):
+ * table_host is uint8 [n_setups][usable_rows*cols] in Gravon string order.  Replaces get_random_human_init_fn
+ * (util.py:301-319).  Without a table, sampled resets place pieces uniformly at random in the usable rows
+ * (get_random_initial_state_fn, util.py:13-53). */
+int sgx_set_setup_table(sgx_env *h, const uint8_t *table_host, int64_t n_setups);
+
+/* reset() (maenv:513-657) for the envs selected by env_select_dev (uint8 [N], NULL = all).
+ * p1_maps_dev / p2_maps_dev: int8 [N][R*C] own-side piece maps, the inputs of create_initial_state
+ * (penv:38-60 -> impl:211-249); pass NULL for both to sample setups (table or random placement).
+ * Starts game number 0 (explicit maps) or the env's next game number (sampled).  Player +1 moves first. */
+int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p1_maps_dev, const int8_t *p2_maps_dev, void *stream);
+
+/* _get_current_obs (maenv:447-497) for every env's current mover, no state change.
+ * obs_dev / mask_dev / player_dev as in sgx_step_io; each nullable. */
+int sgx_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int8_t *player_dev, void *stream);
+
+/* One batched env.step(): see sgx_step_io. */
+int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);
+
+/* sample_random_valid_action (maenv:830-834) for a batch of masks laid out as mask_dev of sgx_step_io:
+ * picks the k-th set byte, k drawn with the same counter RNG as next_actions_dev (identical results). */
+int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actions_dev, void *stream);
+
+/* INTERNAL_STATE observation component / reset(initial_state_override=...) (maenv:494-495, 551-553):
+ * convert between the library's packed int8 state and the reference's int64 [N,34,R,C] layout
+ * (absolute coordinates).  player_dev int8 [N] = current mover (nullable on export; NULL on import = +1). */
+int sgx_export_state(sgx_env *h, int64_t *state_dev, int8_t *player_dev, void *stream);
+int sgx_import_state(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, void *stream);
+
+/* Per-env bookkeeping: int32 [N][4] = {turn count, game number, game_over, current player}. */
+int sgx_get_env_info(sgx_env *h, int32_t *info_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STRATEGO_MI355X_H */

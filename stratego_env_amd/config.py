@@ -1,0 +1,104 @@
+"""Game-variant tables (reference: stratego_env/game/config.py:3-313).
+
+Each variant is a `Variant` with the same information the reference keeps in its `*_STRATEGO_CONFIG`
+dicts: board size, max_turns, obstacle cells, pieces per side by piece code, usable back rows.
+`tests/test_config.py` checks every field against `tests/golden/variants.json`, which
+`tools/oracle/gen_golden.py` dumps from the imported reference.
+"""
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .enums import GameVersions
+
+_LAKES_10 = ((4, 2), (5, 2), (4, 3), (5, 3), (4, 6), (5, 6), (4, 7), (5, 7))
+
+#                      spy scout miner sgt lt cpt maj col gen mar flag bomb   (piece codes 1..12)
+_STANDARD_PIECES = (1, 8, 5, 4, 4, 4, 3, 2, 1, 1, 1, 6)
+_BARRAGE_PIECES = (1, 2, 1, 0, 0, 0, 0, 0, 1, 1, 1, 1)
+
+NUM_PIECE_TYPES = 12
+PO_OBS_CHANNELS = 67   # reference impl:1332
+FO_OBS_CHANNELS = 79   # reference impl:1227
+NUM_STATE_LAYERS = 34  # reference impl:109
+
+
+@dataclass(frozen=True)
+class Variant:
+    name: str
+    rows: int
+    columns: int
+    max_turns: int
+    obstacle_locations: Tuple[Tuple[int, int], ...]
+    piece_counts: Tuple[int, ...]          # index t-1 holds the count of piece code t (1..12)
+    initial_state_usable_rows: int
+    human_inits: str = ''                  # name of the packed Gravon table, '' if unsupported (util.py:305-310)
+
+    @property
+    def cells(self) -> int:
+        return self.rows * self.columns
+
+    @property
+    def spatial_channels(self) -> int:
+        """K = ways to move = 2(R-1) + 2(C-1) + 1 (reference impl:257-259)."""
+        return 2 * (self.rows - 1) + 2 * (self.columns - 1) + 1
+
+    @property
+    def spatial_action_size(self) -> Tuple[int, int, int]:
+        return (self.rows, self.columns, self.spatial_channels)
+
+    @property
+    def num_spatial_actions(self) -> int:
+        return self.cells * self.spatial_channels
+
+    @property
+    def action_size(self) -> int:
+        """1-D action encoding size R*C*(R+C)+1 (reference impl:252-254)."""
+        return self.cells * (self.rows + self.columns) + 1
+
+    @property
+    def pieces_per_side(self) -> int:
+        return int(sum(self.piece_counts))
+
+    def piece_amounts(self) -> Dict[int, int]:
+        """{piece code: count}, the reference's `piece_amounts` keyed by code instead of the SP enum."""
+        return {t + 1: n for t, n in enumerate(self.piece_counts)}
+
+    def obstacle_map(self) -> np.ndarray:
+        m = np.zeros((self.rows, self.columns), dtype=np.uint8)
+        for r, c in self.obstacle_locations:
+            m[r, c] = 1
+        return m
+
+    def captured_count_highs(self) -> Tuple[int, ...]:
+        """Normalisation highs of the captured-count channels: count if > 1 else 8 (maenv:288-298)."""
+        return tuple(n if n > 1 else 8 for n in self.piece_counts)
+
+
+def _v(name, r, c, turns, obst, pieces, usable, inits=''):
+    return Variant(name, r, c, turns, tuple(obst), tuple(pieces), usable, inits)
+
+
+VARIANTS: Dict[str, Variant] = {
+    'standard': _v('standard', 10, 10, 2000, _LAKES_10, _STANDARD_PIECES, 4, 'standard'),
+    'medium_standard': _v('medium_standard', 10, 10, 800, _LAKES_10, _STANDARD_PIECES, 4, 'standard'),
+    'short_standard': _v('short_standard', 10, 10, 400, _LAKES_10, _STANDARD_PIECES, 4, 'standard'),
+    'standard2': _v('standard2', 15, 15, 2000, (), (0, 0, 0, 0, 0, 0, 0, 3, 0, 0, 1, 0), 5),
+    'barrage': _v('barrage', 10, 10, 1000, _LAKES_10, _BARRAGE_PIECES, 4, 'barrage'),
+    'short_barrage': _v('short_barrage', 10, 10, 100, _LAKES_10, _BARRAGE_PIECES, 4, 'barrage'),
+    'octa_barrage': _v('octa_barrage', 8, 8, 1000, ((4, 2), (3, 2), (4, 5), (3, 5)), _BARRAGE_PIECES, 3),
+    'medium': _v('medium', 6, 6, 200, (), (0, 0, 0, 1, 1, 1, 1, 1, 0, 0, 1, 0), 1),
+    'fives': _v('fives', 5, 5, 60, (), (0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 1, 0), 1),
+    'tiny': _v('tiny', 4, 4, 100, (), (0, 0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 0), 1),
+    'micro': _v('micro', 3, 4, 20, (), (0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 1, 0), 1),
+}
+
+
+def get_variant(version) -> Variant:
+    """Accepts a GameVersions member or its string value."""
+    if isinstance(version, GameVersions):
+        version = version.value
+    if version not in VARIANTS:
+        raise ValueError("unknown game version {!r}".format(version))
+    return VARIANTS[version]
