@@ -1,0 +1,169 @@
+"""bench.py -- env steps/sec of the batched env.step() hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): 65,536 concurrent Barrage games PER GPU, synthetic
+random-valid-action rollout with auto-reset, setups from the Gravon table, everything keyed by the counter RNG on
+(seed, global env id, game, turn).  One "step" = one batched env.step() over all of the rank's games: action in,
+move/combat/capture applied, win/draw detection, next mover's valid-actions mask (uint8 [R,C,K]) and normalised
+partial observation (float32 [R,C,67]) written to HBM, plus the next random valid action.  Inputs are resident in
+HBM when the timed region starts.  Multi-GPU: env ids are sharded contiguously across ranks, no collective on the
+data path (one barrier + one MAX all-reduce of the elapsed time for reporting) => "scaling": "weak".
+
+Prints ONE JSON line (rank 0) with `roofline` (HBM, algorithmic bytes = B_alg x games per launch / measured launch
+time via HIP events on the launch stream) and `cpu_baseline` (the CPU oracle, a port of the reference's algorithm,
+timed on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BASE_SEED = 0x5712A7E60
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def b_alg(rows, cols):
+    """Algorithmic bytes per env step (SURVEY 8d / BASELINE.md): state read + compulsory write-back + action +
+    float32 obs + uint8 mask + result record."""
+    rc = rows * cols
+    k = 2 * (rows - 1) + 2 * (cols - 1) + 1
+    return (32 * rc + 16) + (rc + 16) + 4 + 4 * 67 * rc + rc * k + 12
+
+
+def cpu_baseline(version, seed, target_seconds):
+    """Time the oracle's rollout harness (same workload rule) on the host cores; bounded to ~target_seconds."""
+    from oracle import oracle as orc   # checker / baseline only
+    from stratego_env_amd import setups as S
+    from stratego_env_amd.config import VARIANTS
+    v = VARIANTS[version]
+    table = S.load_setup_table(v.human_inits) if v.human_inits else None
+    cv = orc.make_cvariant(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts,
+                           v.initial_state_usable_rows, setups=table)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    n_probe, t_probe = 4 * cores, 128
+    total, _, _ = orc.rollout(cv, seed, 0, n_probe, t_probe, threads=cores)
+    rate = total / max(time.perf_counter() - t0, 1e-6)
+    n_steps = 512
+    n_envs = int(max(cores, min(65536, rate * target_seconds / n_steps)))
+    n_envs = (n_envs // cores) * cores or cores
+    t0 = time.perf_counter()
+    total, _, _ = orc.rollout(cv, seed, 0, n_envs, n_steps, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": total / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": "%d %s games x %d steps (envs 0..%d of the same seeded workload), OpenMP over games, %.1f s"
+                      % (n_envs, version, n_steps, n_envs - 1, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=512)
+    ap.add_argument('--warmup', type=int, default=64)
+    ap.add_argument('--envs', type=int, default=65536, help='games per GPU')
+    ap.add_argument('--version', default='barrage')
+    ap.add_argument('--unfused', action='store_true', help='sample actions with the standalone sampler kernel')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from stratego_env_amd.config import VARIANTS
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    v = VARIANTS[args.version]
+    n = args.envs
+    env = VecStrategoEnv(args.version, n, device=local_rank, seed=BASE_SEED, env_id_offset=rank * n, auto_reset=True)
+    env.reset()
+    env.sample_valid_actions()
+
+    def one_step():
+        if args.unfused:
+            env.step(env.next_actions, want_next_actions=False)
+            env.sample_valid_actions()
+        else:
+            env.rollout_step()
+
+    for _ in range(args.warmup):
+        one_step()
+    games_before = env.env_info()[:, 1].to(torch.int64).sum()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        one_step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    games = int(env.env_info()[:, 1].to(torch.int64).sum() - games_before)
+    invalid = int(env.invalid_action.sum())
+    if dist:
+        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(t[0]), float(t[1])
+        c = torch.tensor([games, invalid], dtype=torch.int64, device='cuda')
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        games, invalid = int(c[0]), int(c[1])
+    assert invalid == 0, "rollout produced invalid actions"
+
+    if rank == 0:
+        total_steps = world * n * args.steps
+        launch_s = dev_ms / 1e3 / args.steps                 # average device time per batched step (HIP events)
+        bytes_per_launch = b_alg(v.rows, v.columns) * n
+        achieved = bytes_per_launch / launch_s / 1e9
+        out = {
+            "metric": "env steps/sec", "value": total_steps / elapsed, "unit": "env steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int8 state / uint8 mask / f32 obs", "data": "synthetic",
+            "config": {"workload": "%d concurrent %s games per GPU (%dx%d), random-valid-action rollout with auto-reset, "
+                                   "%s step+sample" % (n, args.version, v.rows, v.columns,
+                                                       "separate" if args.unfused else "fused"),
+                       "games_per_gpu": n, "version": args.version, "seed": BASE_SEED,
+                       "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": args.traffic_bytes, "kernel": "step_kernel<%d,%d>" % (v.rows, v.columns),
+                         "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -98,7 +98,7 @@ int sgx_build_obs_lut(const sgx_config *cfg, float *lut);
 int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64_t seed, int64_t env_id_offset, sgx_env **out);
 int sgx_destroy(sgx_env *h);
 
-/* Upload a human-setup table (game/inits/*_human_inits.py decoded to piece codes, util.py:154-180):
+/* Upload a human-setup table (game/inits/{barrage,standard}_human_inits.py decoded to piece codes, util.py:154-180):
  * table_host is uint8 [n_setups][usable_rows*cols] in Gravon string order.  Replaces get_random_human_init_fn
  * (util.py:301-319).  Without a table, sampled resets place pieces uniformly at random in the usable rows
  * (get_random_initial_state_fn, util.py:13-53). */
@@ -111,7 +111,7 @@ int sgx_set_setup_table(sgx_env *h, const uint8_t *table_host, int64_t n_setups)
 int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p1_maps_dev, const int8_t *p2_maps_dev, void *stream);
 
 /* _get_current_obs (maenv:447-497) for every env's current mover, no state change.
- * obs_dev / mask_dev / player_dev as in sgx_step_io; each nullable. */
+ * obs_dev, mask_dev and player_dev are laid out as in sgx_step_io; each is nullable. */
 int sgx_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int8_t *player_dev, void *stream);
 
 /* One batched env.step(): see sgx_step_io. */

@@ -102,6 +102,8 @@ def lib():
         L.so_reset_env.argtypes = [C.POINTER(CVariant), C.c_uint64, C.c_uint64, C.c_uint64, P_I64]
         L.so_sample_action.restype = I64
         L.so_sample_action.argtypes = [P_U8, I64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]
+        L.so_fnv1a.restype = C.c_uint64
+        L.so_fnv1a.argtypes = [C.c_uint64, C.c_void_p, I64]
         L.so_rollout.restype = I64
         L.so_rollout.argtypes = [C.POINTER(CVariant), C.c_uint64, I64, I64, I64, C.c_int, P_U64, P_I64]
         _lib = L
@@ -374,3 +376,12 @@ def rollout(cv, seed, g0, n_envs, n_steps, threads=1):
     fin = np.zeros(n_envs, dtype=np.int64)
     total = lib().so_rollout(C.byref(cv), seed, g0, n_envs, n_steps, threads, _p(dig, P_U64), _p(fin, P_I64))
     return int(total), dig, fin
+
+
+FNV_OFFSET = 0xCBF29CE484222325
+
+
+def fnv1a(h, data: bytes):
+    """FNV-1a 64 continuation over `data` (the digest so_rollout() keeps per env)."""
+    buf = C.create_string_buffer(data, len(data))
+    return int(lib().so_fnv1a(h, C.cast(buf, C.c_void_p), len(data)))

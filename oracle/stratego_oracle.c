@@ -640,6 +640,7 @@ static uint64_t fnv1a(uint64_t h, const void *p, size_t n) {
     for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001B3ull; }
     return h;
 }
+SO_EXPORT uint64_t so_fnv1a(uint64_t h, const void *p, int64_t n) { return fnv1a(h, p, (size_t)n); }
 
 /* Play `n_steps` batched steps of envs [g0, g0+n_envs) with auto-reset, the way bench.py's GPU loop
  * does.  Per env: running FNV-1a digest over each step's (mask bytes, obs bytes, rewards, done,

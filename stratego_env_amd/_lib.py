@@ -1,0 +1,105 @@
+"""ctypes binding of libstratego_mi355x.so (declared in include/stratego_mi355x.h).
+
+There is no CPU fallback: if the HIP library is missing or fails to load, importing the env classes
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+SGX_MAX_CELLS = 256
+SGX_OBS_LUT_STRIDE = 16
+PO_OBS_CHANNELS = 67
+
+# every symbol include/stratego_mi355x.h declares
+EXPORTED_SYMBOLS = (
+    'sgx_abi_version', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
+    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
+    'sgx_observe', 'sgx_step', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_get_env_info',
+)
+
+
+class SgxConfig(C.Structure):
+    _fields_ = [('rows', C.c_int32), ('cols', C.c_int32), ('max_turns', C.c_int32), ('usable_rows', C.c_int32),
+                ('piece_counts', C.c_int32 * 12), ('obstacles', C.c_uint8 * SGX_MAX_CELLS)]
+
+
+class SgxStepIO(C.Structure):
+    _fields_ = [('actions_dev', C.c_void_p), ('obs_dev', C.c_void_p), ('mask_dev', C.c_void_p),
+                ('reward_dev', C.c_void_p), ('done_dev', C.c_void_p), ('player_dev', C.c_void_p),
+                ('invalid_action_dev', C.c_void_p), ('ending_invalid_dev', C.c_void_p), ('final_obs_dev', C.c_void_p),
+                ('next_actions_dev', C.c_void_p), ('auto_reset', C.c_int32), ('reserved', C.c_int32)]
+
+
+class SgxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SgxError("libstratego_mi355x.so is not built (%s missing). Run `python -m stratego_env_amd.build` "
+                       "or __graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64
+    L.sgx_abi_version.restype = C.c_int
+    L.sgx_abi_version.argtypes = []
+    L.sgx_last_error.restype = C.c_char_p
+    L.sgx_last_error.argtypes = []
+    L.sgx_num_envs.restype = i64
+    L.sgx_num_envs.argtypes = [vp]
+    L.sgx_spatial_channels.restype = C.c_int
+    L.sgx_spatial_channels.argtypes = [vp]
+    L.sgx_num_spatial_actions.restype = i64
+    L.sgx_num_spatial_actions.argtypes = [vp]
+    L.sgx_action_size_1d.restype = i64
+    L.sgx_action_size_1d.argtypes = [vp]
+    L.sgx_build_obs_lut.restype = C.c_int
+    L.sgx_build_obs_lut.argtypes = [C.POINTER(SgxConfig), C.POINTER(C.c_float)]
+    L.sgx_create.restype = C.c_int
+    L.sgx_create.argtypes = [C.POINTER(SgxConfig), i64, C.c_int, u64, i64, C.POINTER(vp)]
+    L.sgx_destroy.restype = C.c_int
+    L.sgx_destroy.argtypes = [vp]
+    L.sgx_set_setup_table.restype = C.c_int
+    L.sgx_set_setup_table.argtypes = [vp, vp, i64]
+    L.sgx_reset.restype = C.c_int
+    L.sgx_reset.argtypes = [vp, vp, vp, vp, vp]
+    L.sgx_observe.restype = C.c_int
+    L.sgx_observe.argtypes = [vp, vp, vp, vp, vp]
+    L.sgx_step.restype = C.c_int
+    L.sgx_step.argtypes = [vp, C.POINTER(SgxStepIO), vp]
+    L.sgx_sample_valid.restype = C.c_int
+    L.sgx_sample_valid.argtypes = [vp, vp, vp, vp]
+    L.sgx_export_state.restype = C.c_int
+    L.sgx_export_state.argtypes = [vp, vp, vp, vp]
+    L.sgx_import_state.restype = C.c_int
+    L.sgx_import_state.argtypes = [vp, vp, vp, vp]
+    L.sgx_get_env_info.restype = C.c_int
+    L.sgx_get_env_info.argtypes = [vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise SgxError("libstratego_mi355x error %d: %s" % (rc, load().sgx_last_error().decode('utf-8', 'replace')))
+
+
+def make_config(variant) -> SgxConfig:
+    """stratego_env_amd.config.Variant -> sgx_config."""
+    cfg = SgxConfig()
+    cfg.rows, cfg.cols = variant.rows, variant.columns
+    cfg.max_turns = variant.max_turns
+    cfg.usable_rows = variant.initial_state_usable_rows
+    for i, n in enumerate(variant.piece_counts):
+        cfg.piece_counts[i] = n
+    for r, c in variant.obstacle_locations:
+        cfg.obstacles[r * variant.columns + c] = 1
+    return cfg

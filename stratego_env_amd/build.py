@@ -1,0 +1,43 @@
+"""Builds libstratego_mi355x.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+The shared library lands in stratego_env_amd/_build/ (git-ignored, travels to the GPU box with the
+repo snapshot).  hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+"""
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+SRC = os.path.join(_PKG, 'csrc', 'stratego_mi355x.hip')
+INCLUDE = os.path.join(_ROOT, 'include')
+OUT_DIR = os.path.join(_PKG, '_build')
+LIB_PATH = os.path.join(OUT_DIR, 'libstratego_mi355x.so')
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    newest = max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(INCLUDE, 'stratego_mi355x.h')))
+    return os.path.getmtime(LIB_PATH) < newest
+
+
+def build(force=False, verbose=False):
+    """Compile the library if it is missing or older than its sources.  Returns the .so path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libstratego_mi355x.so")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-fvisibility=hidden',
+           '-Wno-unused-value', '-I', INCLUDE, SRC, '-o', LIB_PATH + '.tmp']
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + '.tmp', LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build(force=True, verbose=True))

@@ -1,0 +1,1001 @@
+// stratego_mi355x.hip -- HIP kernels (gfx950 / CDNA4) and C-ABI of the batched Stratego env.
+//
+// One wavefront (64 lanes) per game.  A game's state record (32 int8 boards, absolute coordinates)
+// is staged in LDS, the move is applied there, the next mover's valid-actions mask is built in LDS
+// and its 67-channel normalised observation is rendered straight into 16-byte coalesced global stores.
+// HBM-bound integer/byte work: no MFMA.  See DESIGN.md for the data layout and byte accounting.
+//
+// Reference functions reproduced (paths relative to /root/reference/stratego_env):
+//   game/stratego_procedural_impl.py  (impl)   stratego_multiagent_env.py (maenv)   game/util.py (util)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+
+#include "stratego_mi355x.h"
+
+#define SGX_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, const char *detail = "") {
+    char buf[512];
+    snprintf(buf, sizeof(buf), fmt, detail);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(SGX_EDEVICE, #expr ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Geometry and layout
+// ---------------------------------------------------------------------------------------------
+constexpr int OBS_CH = SGX_PO_OBS_CHANNELS;  // 67
+constexpr int LUT_STRIDE = SGX_OBS_LUT_STRIDE;
+constexpr int LUT_SIZE = OBS_CH * LUT_STRIDE;
+
+// internal board indices inside an env record (each board is S bytes, absolute coordinates)
+constexpr int B_PIECES = 0;   // +pi : true pieces of player index pi (0 = player +1, 1 = player -1)   impl layers 0/1
+constexpr int B_PO = 2;       // +pi : what the opponent knows of pi's pieces                           impl layers 3/4
+constexpr int B_RECENT = 4;   // +pi : two-square bookkeeping                                           impl layers 6/7
+constexpr int B_STILL = 6;    // +pi : never-moved flags                                                impl layers 32/33
+constexpr int B_CAP = 8;      // +12*pi + (type-1) : captured counts                                    impl layers 8-19 / 20-31
+constexpr int N_BOARDS = 32;
+constexpr int B_OBST = 32;    // LDS only: per-variant obstacle map (impl layer 2)
+
+// scal[env] = {turn, flags, max_turns, game_no}
+constexpr int F_OVER = 1, F_WIN_P1 = 2, F_WIN_M1 = 4, F_END_INVALID = 8, F_PLAYER_M1 = 16;
+
+enum { SP_SPY = 1, SP_SCOUT = 2, SP_MINER = 3, SP_MARSHALL = 10, SP_FLAG = 11, SP_BOMB = 12, SP_UNKNOWN = 13 };
+
+template <int R_, int C_>
+struct Geo {
+    static constexpr int R = R_, C = C_;
+    static constexpr int RC = R * C;
+    static constexpr int S = (RC + 3) & ~3;           // board stride (bytes)
+    static constexpr int REC = N_BOARDS * S;          // bytes of one env record (multiple of 128)
+    static constexpr int K = 2 * (R - 1) + 2 * (C - 1) + 1;
+    static constexpr int NA = RC * K;                 // spatial actions
+    static constexpr int NA_PAD = (NA + 15) & ~15;
+    static constexpr int MPA = R + C;
+    static constexpr int AS = RC * MPA + 1;           // 1-D action size (impl:252-254)
+    static constexpr int NOBS = RC * OBS_CH;          // floats per observation
+    static constexpr int CPL = (RC + 63) / 64;        // cells per lane
+    static constexpr int CNT_PAD = CPL * 64;
+};
+
+struct DevTables {
+    float obs_lut[LUT_SIZE];
+    uint8_t obstacles[SGX_MAX_CELLS];
+};
+
+struct KParams {
+    int8_t *boards;
+    int4 *scal;
+    const DevTables *tab;
+    const uint8_t *setups;
+    int32_t n_setups;
+    int32_t max_turns;
+    int32_t usable_rows;
+    int32_t piece_counts[12];
+    int64_t n_envs;
+    uint64_t seed;
+    int64_t env_id_offset;
+    sgx_step_io io;
+    int32_t mode;  // 0 = step, 1 = observe
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <class G>
+struct alignas(16) Lds {
+    int8_t b[N_BOARDS + 1][G::S];
+    alignas(16) uint8_t mask[G::NA_PAD];
+    alignas(16) float lut[LUT_SIZE];
+    alignas(16) uint8_t cnt[G::CNT_PAD];
+};
+
+// ---------------------------------------------------------------------------------------------
+// Counter RNG of the synthetic-rollout harness; restated in oracle/stratego_oracle.c
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t sm_fin(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__host__ __device__ inline uint64_t sgx_rng(uint64_t seed, uint64_t g, uint64_t j, uint32_t stream, uint32_t t) {
+    uint64_t h = sm_fin(seed + 0x9E3779B97F4A7C15ull * (g + 1));
+    uint64_t ctr = ((uint64_t)stream << 32) | t;
+    return sm_fin(h ^ (j * 0xD1B54A32D192ED03ull + ctr * 0x8CB92BA72F3D8DD7ull + 0x2545F4914F6CDD1Dull));
+}
+__host__ __device__ inline uint32_t rng_below(uint64_t r, uint32_t n) { return (uint32_t)(((r >> 32) * (uint64_t)n) >> 32); }
+enum { STREAM_SETUP = 0, STREAM_ACTION = 1, STREAM_SHUFFLE_P1 = 2, STREAM_SHUFFLE_P2 = 3 };
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ inline int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// XCD-aware block -> env map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+// range of envs so neighbouring envs' output lines meet in one L2.
+__device__ inline int64_t env_of_block(int64_t n_envs) {
+    const int64_t nb = gridDim.x, b = blockIdx.x;
+    const int64_t chunk = nb >> 3;  // grid is a multiple of 8
+    return (b & 7) * chunk + (b >> 3);
+}
+
+template <class G>
+__device__ inline void wave_sync() { __syncthreads(); }  // one wave per block: cheap, orders LDS phases
+
+// board holding observation channel `ch` for perspective player index qi (impl:1306-1332 + impl:645-675)
+__device__ inline int board_for_channel(int ch, int qi) {
+    if (ch < 12) return B_PIECES + qi;
+    if (ch < 25) return B_PO + qi;
+    if (ch < 38) return B_PO + (1 - qi);
+    if (ch == 38) return B_OBST;
+    if (ch == 39) return B_RECENT + qi;
+    if (ch == 40) return B_RECENT + (1 - qi);
+    if (ch < 53) return B_CAP + 12 * qi + (ch - 41);
+    if (ch < 65) return B_CAP + 12 * (1 - qi) + (ch - 53);
+    if (ch == 65) return B_STILL + qi;
+    return B_STILL + (1 - qi);
+}
+__device__ inline int lut_bias(int ch) { return (ch == 39 || ch == 40) ? 3 : 0; }
+__device__ inline int clamp15(int v) { return min(max(v, 0), 15); }
+
+// ---------------------------------------------------------------------------------------------
+// Observation render: float32 [R][C][67], perspective of player index qi  (impl:1335-1397, maenv:506-508)
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__device__ void emit_obs(const Lds<G> &L, int qi, float *__restrict__ dst, int lane) {
+    constexpr int RC = G::RC, S = G::S;
+    const int8_t *bb = &L.b[0][0];
+    if constexpr (RC % 4 == 0) {
+        // 4 cells = 268 floats = 67 float4 "quads".  Lane l renders quad l of every 4-cell group, so its four
+        // (cell offset, channel) pairs are loop-invariant; quads 64..66 are swept afterwards.
+        int baddr[4], lrow[4], lbias[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = 4 * lane + j, rc = f / OBS_CH, ch = f - rc * OBS_CH;
+            baddr[j] = board_for_channel(ch, qi) * S + (qi ? RC - 1 - rc : rc);
+            lrow[j] = ch * LUT_STRIDE;
+            lbias[j] = lut_bias(ch);
+        }
+        const int step = qi ? -4 : 4;
+        f32x4 *out = reinterpret_cast<f32x4 *>(dst) + lane;
+#pragma unroll 5
+        for (int s = 0; s < RC / 4; ++s) {
+            f32x4 o;
+            o.x = L.lut[lrow[0] + clamp15(bb[baddr[0]] + lbias[0])];
+            o.y = L.lut[lrow[1] + clamp15(bb[baddr[1]] + lbias[1])];
+            o.z = L.lut[lrow[2] + clamp15(bb[baddr[2]] + lbias[2])];
+            o.w = L.lut[lrow[3] + clamp15(bb[baddr[3]] + lbias[3])];
+            out[s * OBS_CH] = o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) baddr[j] += step;
+        }
+        for (int t = lane; t < (RC / 4) * 3; t += 64) {
+            const int s = t / 3, qd = t - 3 * s;
+            const int pcell = 4 * s + 3, cell = qi ? RC - 1 - pcell : pcell;
+            f32x4 o;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = 55 + 4 * qd + j;
+                v[j] = L.lut[ch * LUT_STRIDE + clamp15(bb[board_for_channel(ch, qi) * S + cell] + lut_bias(ch))];
+            }
+            o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
+            reinterpret_cast<f32x4 *>(dst)[s * OBS_CH + 64 + qd] = o;
+        }
+    } else {
+        // odd cell counts (5x5, 15x15): an env's observation is not 16-byte aligned; dword path
+        for (int f = lane; f < G::NOBS; f += 64) {
+            const int pcell = f / OBS_CH, ch = f - pcell * OBS_CH;
+            const int cell = qi ? RC - 1 - pcell : pcell;
+            dst[f] = L.lut[ch * LUT_STRIDE + clamp15(bb[board_for_channel(ch, qi) * S + cell] + lut_bias(ch))];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Valid-actions mask of player index qi in qi's perspective, into L.mask (bytes) and L.cnt (per
+// perspective cell).  Returns the number of valid moves (0 => the no-op byte was set).  impl:399-517
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__device__ int gen_mask(Lds<G> &L, int qi, bool game_over, int lane) {
+    constexpr int R = G::R, C = G::C, RC = G::RC, K = G::K;
+    {
+        const int4 z = make_int4(0, 0, 0, 0);
+        for (int i = lane; i < G::NA_PAD / 16; i += 64) reinterpret_cast<int4 *>(L.mask)[i] = z;
+        for (int i = lane; i < G::CNT_PAD / 4; i += 64) reinterpret_cast<int *>(L.cnt)[i] = 0;
+    }
+    wave_sync<G>();
+    int total = 0;
+    if (!game_over) {
+        const int8_t *own = L.b[B_PIECES + qi], *enemy = L.b[B_PIECES + 1 - qi], *rec = L.b[B_RECENT + qi], *obst = L.b[B_OBST];
+        const int sgn = qi ? -1 : 1;  // perspective +r is absolute -r for player -1 (impl:678-695)
+        int mine = 0;
+#pragma unroll
+        for (int cc = 0; cc < G::CPL; ++cc) {
+            const int i = lane + 64 * cc;
+            if (i < RC) {
+                const int t = own[i];
+                if (t != 0 && t != SP_FLAG && t != SP_BOMB) {
+                    const int r = i / C, c = i - r * C;
+                    const int pcell = qi ? RC - 1 - i : i;
+                    const bool pinned = rec[i] == -3;  // JUST_ARRIVED_AND_CANT_DOUBLE_BACK
+                    uint8_t *mrow = L.mask + pcell * K;
+                    int n = 0;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int dr = (d == 0 ? sgn : d == 1 ? -sgn : 0), dc = (d == 2 ? sgn : d == 3 ? -sgn : 0);
+                        const int base = (d == 0 ? 0 : d == 1 ? R - 1 : d == 2 ? 2 * (R - 1) : 2 * (R - 1) + (C - 1));
+                        const int maxk = (t == SP_SCOUT) ? (d < 2 ? R - 1 : C - 1) : 1;
+                        int er = r, ec = c;
+                        for (int k = 1; k <= maxk; ++k) {
+                            er += dr; ec += dc;
+                            if (er < 0 || er >= R || ec < 0 || ec >= C) break;
+                            const int e = er * C + ec;
+                            if (obst[e] != 0 || own[e] != 0) break;
+                            const int en = enemy[e];
+                            if (pinned && rec[e] == 1 && en == 0) continue;  // two-square veto: skip, keep walking (impl:439-445)
+                            mrow[base + k - 1] = 1;
+                            ++n;
+                            if (en != 0) break;
+                        }
+                    }
+                    L.cnt[pcell] = (uint8_t)n;
+                    mine += n;
+                }
+            }
+        }
+        // wave sum
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        total = uni(mine);
+    }
+    if (total == 0 && lane == 0) {
+        L.mask[K - 1] = 1;  // valid_moves_mask[0, 0, -1] (impl:514-515)
+        L.cnt[0] = 1;
+    }
+    wave_sync<G>();
+    return total;
+}
+
+template <class G>
+__device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) {
+    if constexpr (G::NA % 4 == 0) {
+        const int *src = reinterpret_cast<const int *>(L.mask);
+        int *d = reinterpret_cast<int *>(dst);
+        for (int i = lane; i < G::NA / 4; i += 64) d[i] = src[i];
+    } else {
+        for (int i = lane; i < G::NA; i += 64) dst[i] = L.mask[i];
+    }
+}
+
+// k-th (0-based) valid action in ascending flat index order, from L.mask / L.cnt
+template <class G>
+__device__ int kth_valid(const Lds<G> &L, int k, int lane) {
+    constexpr int K = G::K;
+    int cell = 0, before = 0, run = 0;
+    bool found = false;
+#pragma unroll
+    for (int cc = 0; cc < G::CPL; ++cc) {
+        const int c0 = L.cnt[lane + 64 * cc];
+        int incl = c0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const unsigned long long hit = __ballot(run + incl > k);
+        if (!found && hit) {
+            const int l = __ffsll((long long)hit) - 1;
+            cell = 64 * cc + l;
+            before = run + __shfl(incl - c0, l);
+            found = true;
+        }
+        run += __shfl(incl, 63);
+    }
+    cell = uni(cell);
+    int kk = uni(k - before);
+    unsigned long long bits = __ballot(lane < K && L.mask[cell * K + (lane < K ? lane : 0)] != 0);
+    for (int i = 0; i < kk; ++i) bits &= bits - 1;
+    const int ch = __ffsll((long long)bits) - 1;
+    return cell * K + ch;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fresh game into LDS boards: _create_initial_state (impl:211-249) from own-side maps (explicit, from the
+// human-setup table: util:241-275 net effect, or random back-row placement: util:13-30)
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__device__ void clear_boards(Lds<G> &L, int lane) {
+    const int4 z = make_int4(0, 0, 0, 0);
+    for (int i = lane; i < G::REC / 16; i += 64) reinterpret_cast<int4 *>(&L.b[0][0])[i] = z;
+}
+
+// place code `t` of player index pi at absolute cell
+template <class G>
+__device__ inline void place(Lds<G> &L, int pi, int cell, int t) {
+    L.b[B_PIECES + pi][cell] = (int8_t)t;
+    L.b[B_PO + pi][cell] = t ? SP_UNKNOWN : 0;
+    L.b[B_STILL + pi][cell] = t ? 1 : 0;
+}
+
+template <class G>
+__device__ void sample_boards(Lds<G> &L, const KParams &P, uint64_t g, uint64_t j, int lane) {
+    constexpr int C = G::C, RC = G::RC;
+    const int U = P.usable_rows, n = U * C;
+    clear_boards(L, lane);
+    wave_sync<G>();
+    if (P.setups) {
+        const uint32_t i1 = rng_below(sgx_rng(P.seed, g, j, STREAM_SETUP, 0), (uint32_t)P.n_setups);
+        const uint32_t i2 = rng_below(sgx_rng(P.seed, g, j, STREAM_SETUP, 1), (uint32_t)P.n_setups);
+        const uint8_t *s1 = P.setups + (int64_t)i1 * n, *s2 = P.setups + (int64_t)i2 * n;
+        for (int x = lane; x < n; x += 64) {
+            const int r = x / C, c = x - r * C;
+            place(L, 0, r * C + c, s1[(U - 1 - r) * C + c]);           // p1 own-side row r = string row U-1-r
+            place(L, 1, RC - n + x, s2[x]);                            // absolute rows R-U.. = string rows 0..
+        }
+    } else if (lane == 0) {
+        uint8_t *loc = L.cnt;  // scratch, n <= CNT_PAD
+        for (int pl = 0; pl < 2; ++pl) {
+            for (int i = 0; i < n; ++i) loc[i] = (uint8_t)i;
+            for (int i = n - 1; i > 0; --i) {
+                const uint32_t k = rng_below(sgx_rng(P.seed, g, j, pl ? STREAM_SHUFFLE_P2 : STREAM_SHUFFLE_P1, (uint32_t)i), (uint32_t)(i + 1));
+                const uint8_t t = loc[i]; loc[i] = loc[k]; loc[k] = t;
+            }
+            int at = 0;
+            for (int t = 1; t <= 12; ++t)
+                for (int q = 0; q < P.piece_counts[t - 1]; ++q) {
+                    const int own_cell = loc[at++];                        // own-side (r, c), r < U
+                    place(L, pl, pl ? RC - 1 - own_cell : own_cell, t);    // p2 map rotated 180 degrees (impl:221)
+                }
+        }
+    }
+    wave_sync<G>();
+}
+
+// python-style floor division / modulo by a positive constant
+__device__ inline int fdiv_(int a, int b) { int q = a / b; return (a % b < 0) ? q - 1 : q; }
+__device__ inline int fmod_(int a, int b) { int m = a % b; return m < 0 ? m + b : m; }
+
+// ---------------------------------------------------------------------------------------------
+// The step kernel: env.step() of N games (maenv:659-828), one wave per game
+// ---------------------------------------------------------------------------------------------
+template <int R_, int C_>
+__global__ __launch_bounds__(64) void step_kernel(const KParams P) {
+    using G = Geo<R_, C_>;
+    constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
+    __shared__ Lds<G> L;
+    const int lane = threadIdx.x;
+    const int64_t env = env_of_block(P.n_envs);
+    if (env >= P.n_envs) return;
+
+    int8_t *rec_g = P.boards + env * (int64_t)G::REC;
+    {   // ---- stage: state record, obstacle map, normalisation LUT -> LDS
+        const int4 *src = reinterpret_cast<const int4 *>(rec_g);
+        int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
+        for (int i = lane; i < G::REC / 16; i += 64) dst[i] = src[i];
+        for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
+        for (int i = lane; i < LUT_SIZE / 4; i += 64) reinterpret_cast<f32x4 *>(L.lut)[i] = reinterpret_cast<const f32x4 *>(P.tab->obs_lut)[i];
+    }
+    const int4 sc = P.scal[env];
+    int turn = uni(sc.x), flags = uni(sc.y), game_no = uni(sc.w);
+    const int max_turns = uni(sc.z);
+    wave_sync<G>();
+
+    int player = (flags & F_PLAYER_M1) ? -1 : 1;
+    bool over = (flags & F_OVER) != 0;
+    bool applied = false, invalid_action = false, noop_path = false;
+    int mover = player;
+
+    if (P.mode == 0) {
+        // ------------------------------------------------------------------------------------------
+        // decode (maenv:684-689): flat spatial index -> positions -> 1-D index -> absolute 1-D index
+        // ------------------------------------------------------------------------------------------
+        const int a = uni(P.io.actions_dev[env]);
+        int sr = 0, sc_ = 0, er = 0, ec = 0;
+        bool valid = true;
+        if (a < 0 || a >= NA) {
+            valid = false;  // np.unravel_index raises
+        } else {
+            const int cell = a / K, ch = a - cell * K;
+            sr = cell / C; sc_ = cell - sr * C;
+            if (ch < R - 1) { er = sr + ch + 1; ec = sc_; }                                   // impl:322-324
+            else if (ch < 2 * (R - 1)) { er = sr - (ch - (R - 1) + 1); ec = sc_; }
+            else if (ch < 2 * (R - 1) + (C - 1)) { er = sr; ec = sc_ + (ch - 2 * (R - 1) + 1); }
+            else { er = sr; ec = sc_ - (ch - (2 * (R - 1) + (C - 1)) + 1); }                   // also the no-op channel
+            int idx = (sr * C + sc_) * MPA + ((er != sr) ? er : R + ec);                     // impl:268-277
+            if (player == -1 && idx != AS - 1) {                                             // impl:698-720
+                const int q = fdiv_(idx, MPA), off = fmod_(idx, MPA);
+                int r0 = fdiv_(q, C), c0 = fmod_(q, C), r1, c1;
+                if (off >= R) { c1 = off - R; r1 = r0; } else { r1 = off; c1 = c0; }
+                r0 = R - 1 - r0; r1 = R - 1 - r1; c0 = C - 1 - c0; c1 = C - 1 - c1;
+                idx = (r0 * C + c0) * MPA + ((r1 != r0) ? r1 : R + c1);
+            }
+            if (idx == AS - 1) {
+                noop_path = true;                                                            // impl:809-814
+            } else {                                                                         // impl:369-383
+                const int q = fdiv_(idx, MPA), off = fmod_(idx, MPA);
+                sr = fdiv_(q, C); sc_ = fmod_(q, C);
+                if (off >= R) { ec = off - R; er = sr; } else { er = off; ec = sc_; }
+            }
+        }
+        const int pi = player == 1 ? 0 : 1;
+        int8_t *own = L.b[B_PIECES + pi], *enemy = L.b[B_PIECES + 1 - pi];
+        int8_t *own_po = L.b[B_PO + pi], *enemy_po = L.b[B_PO + 1 - pi];
+        int8_t *own_still = L.b[B_STILL + pi], *enemy_still = L.b[B_STILL + 1 - pi];
+        int8_t *recent = L.b[B_RECENT + pi];
+        const int8_t *obst = L.b[B_OBST];
+
+        if (valid && noop_path) {
+            // no-op is legal only if the mover has no move (or the game is over); finished games stay unchanged
+            if (!over) {
+                const int nmoves = gen_mask(L, pi, false, lane);
+                if (nmoves != 0) valid = false;
+                else { turn += 1; over = true; flags |= F_OVER | (player == 1 ? F_WIN_M1 : F_WIN_P1); }  // impl:916-920
+            }
+        } else if (valid) {
+            // ---- _is_move_valid_by_position (impl:723-798)
+            int s = 0, e = 0, t = 0;
+            if (over) valid = false;
+            if (valid && (sc_ < 0 || sc_ >= C || sr < 0 || sr >= R)) valid = false;
+            if (valid) { s = sr * C + sc_; if (uni(obst[s]) != 0) valid = false; }
+            if (valid && (ec < 0 || ec >= C || er < 0 || er >= R)) valid = false;
+            if (valid) { e = er * C + ec; if (uni(obst[e]) != 0) valid = false; }
+            if (valid) { t = uni(own[s]); if (t == 0 || t == SP_FLAG || t == SP_BOMB) valid = false; }
+            if (valid && uni(own[e]) != 0) valid = false;
+            if (valid && er != sr && ec != sc_) valid = false;
+            int dest = 0;
+            if (valid) {
+                dest = uni(enemy[e]);
+                if (uni(recent[s]) == -3 && uni(recent[e]) == 1 && dest == 0) valid = false;
+            }
+            if (valid) {
+                const int dist = (er != sr) ? abs(er - sr) : abs(ec - sc_);
+                if (t == SP_SCOUT) {
+                    const int stepc = (er != sr) ? ((er > sr) ? C : -C) : ((ec > sc_) ? 1 : -1);
+                    const int k = lane + 1;  // lanes 0.. check the intermediate cells
+                    bool blk = false;
+                    if (k < dist) { const int m = s + k * stepc; blk = own[m] != 0 || enemy[m] != 0 || obst[m] != 0; }
+                    if (__ballot(blk) != 0ull) valid = false;
+                } else if (dist > 1) valid = false;
+            }
+            if (valid) {
+                // ---- _get_next_state (impl:905-1028)
+                const int moved = t, moved_po = uni(own_po[s]);
+                const int old_end = uni(recent[e]), old_start = uni(recent[s]);
+                turn += 1;
+                bool wins = false, tied = false;
+                if (dest != 0) {
+                    if (moved == SP_MINER && dest == SP_BOMB) wins = true;
+                    else if (moved == SP_SPY && dest == SP_MARSHALL) wins = true;
+                    else if (dest == SP_FLAG) { wins = true; over = true; flags |= F_OVER | (player == 1 ? F_WIN_P1 : F_WIN_M1); }
+                    else if (dest != SP_BOMB) { if (moved == dest) tied = true; else if (moved > dest) wins = true; }
+                }
+                wave_sync<G>();
+                // clear the mover's recent-moves board (np.zeros_like, impl:1014)
+                for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(recent)[i] = 0;
+                wave_sync<G>();
+                if (lane == 0) {
+                    own_still[s] = 0; own_still[e] = 0; enemy_still[e] = 0;  // impl:939-941
+                    own[s] = 0; own_po[s] = 0;                               // impl:950-951
+                    if (dest == 0) {
+                        own[e] = (int8_t)moved;
+                        const int far = (abs(er - sr) > 1 || abs(ec - sc_) > 1);
+                        own_po[e] = (int8_t)(far ? SP_SCOUT : moved_po);      // impl:960-964
+                        recent[s] = 1;                                       // impl:1019-1026
+                        recent[e] = (int8_t)(old_end == 1 ? (old_start == -2 ? -3 : -2) : -1);
+                    } else {
+                        if (tied || wins) { enemy[e] = 0; enemy_po[e] = 0; }
+                        if (wins) { own[e] = (int8_t)moved; own_po[e] = (int8_t)moved; }
+                        if (!wins && !tied) enemy_po[e] = (int8_t)dest;
+                        if (!wins) L.b[B_CAP + 12 * pi + moved - 1][e] += 1;               // impl:1001-1004
+                        if (wins || tied) L.b[B_CAP + 12 * (1 - pi) + dest - 1][e] += 1;   // impl:1006-1009
+                    }
+                }
+                wave_sync<G>();
+            }
+        }
+        if (valid) { applied = true; player = -player; } else invalid_action = true;
+    }
+
+    // ---- next mover's mask; opponent-stuck and max-turn endings (impl:1031-1043)
+    int qi = player == 1 ? 0 : 1;
+    int nvalid = gen_mask(L, qi, over, lane);
+    bool ended_now = false;
+    if (applied && !noop_path) {
+        const bool was_over = over;
+        if (nvalid == 0) { over = true; flags = (flags & ~(F_WIN_P1 | F_WIN_M1)) | F_OVER | (mover == 1 ? F_WIN_P1 : F_WIN_M1); }
+        if (turn >= max_turns && !over) { over = true; flags |= F_OVER | F_END_INVALID; }
+        if (over && !was_over && nvalid != 0) nvalid = gen_mask(L, qi, true, lane);  // finished: mask shows the no-op only
+        ended_now = over;
+    } else if (applied && noop_path) {
+        ended_now = over;
+        if (nvalid != 0) nvalid = gen_mask(L, qi, true, lane);
+    }
+    flags = (flags & ~F_PLAYER_M1) | (player == -1 ? F_PLAYER_M1 : 0);
+
+    // ---- rewards / dones (maenv:699-805)
+    const bool done = over;
+    const bool end_invalid = over && (flags & F_END_INVALID);
+    float rew_p1 = 0.f, rew_m1 = 0.f;
+    if (over && !end_invalid) {
+        const int w = (flags & F_WIN_P1) ? 1 : (flags & F_WIN_M1) ? -1 : 0;
+        rew_p1 = w == 0 ? 1e-4f : (float)w;     // impl:838-840
+        rew_m1 = w == 0 ? 1e-4f : (float)-w;
+    }
+    if (P.mode == 0 && lane == 0) {
+        if (P.io.reward_dev) { P.io.reward_dev[2 * env] = rew_p1; P.io.reward_dev[2 * env + 1] = rew_m1; }
+        if (P.io.done_dev) P.io.done_dev[env] = done ? 1 : 0;
+        if (P.io.invalid_action_dev) P.io.invalid_action_dev[env] = invalid_action ? 1 : 0;
+        if (P.io.ending_invalid_dev) P.io.ending_invalid_dev[env] = end_invalid ? 1 : 0;
+    }
+
+    // ---- terminal observations of both players (maenv:772-773)
+    if (P.mode == 0 && ended_now && P.io.final_obs_dev) {
+        float *fo = P.io.final_obs_dev + env * (int64_t)(2 * G::NOBS);
+        emit_obs(L, 0, fo, lane);
+        emit_obs(L, 1, fo + G::NOBS, lane);
+    }
+
+    // ---- auto-reset: the finished env starts its next game now
+    bool wrote_reset = false;
+    if (P.mode == 0 && ended_now && P.io.auto_reset) {
+        game_no += 1;
+        sample_boards(L, P, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, lane);
+        turn = 0; flags = 0; player = 1; qi = 0; over = false;
+        nvalid = gen_mask(L, 0, false, lane);
+        wrote_reset = true;
+    }
+
+    // ---- outputs for the next mover
+    if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
+    if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
+    if (P.io.obs_dev) emit_obs(L, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
+    if (P.mode == 0 && P.io.next_actions_dev) {
+        const int total = nvalid == 0 ? 1 : nvalid;
+        const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, STREAM_ACTION, (uint32_t)turn), (uint32_t)total);
+        const int na = kth_valid(L, (int)k, lane);
+        if (lane == 0) P.io.next_actions_dev[env] = na;
+    }
+
+    // ---- write the record back
+    if (applied || wrote_reset) {
+        const int4 *src = reinterpret_cast<const int4 *>(&L.b[0][0]);
+        int4 *dst = reinterpret_cast<int4 *>(rec_g);
+        for (int i = lane; i < G::REC / 16; i += 64) dst[i] = src[i];
+        if (lane == 0) P.scal[env] = make_int4(turn, flags, max_turns, game_no);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// reset kernel: explicit own-side maps or sampled setups
+// ---------------------------------------------------------------------------------------------
+struct ResetParams {
+    KParams k;
+    const uint8_t *select;
+    const int8_t *p1_maps, *p2_maps;
+};
+
+template <int R_, int C_>
+__global__ __launch_bounds__(64) void reset_kernel(const ResetParams P) {
+    using G = Geo<R_, C_>;
+    constexpr int RC = G::RC;
+    __shared__ Lds<G> L;
+    const int lane = threadIdx.x;
+    const int64_t env = blockIdx.x;
+    if (env >= P.k.n_envs) return;
+    if (P.select && P.select[env] == 0) return;
+    int game_no;
+    if (P.p1_maps) {
+        clear_boards(L, lane);
+        wave_sync<G>();
+        const int8_t *m1 = P.p1_maps + env * (int64_t)RC, *m2 = P.p2_maps + env * (int64_t)RC;
+        for (int i = lane; i < RC; i += 64) {
+            place(L, 0, i, m1[i]);
+            place(L, 1, i, m2[RC - 1 - i]);  // p2 map rotated 180 degrees (impl:221)
+        }
+        wave_sync<G>();
+        game_no = 0;
+    } else {
+        game_no = uni(P.k.scal[env].w) + 1;
+        sample_boards(L, P.k, (uint64_t)(P.k.env_id_offset + env), (uint64_t)game_no, lane);
+    }
+    const int4 *src = reinterpret_cast<const int4 *>(&L.b[0][0]);
+    int4 *dst = reinterpret_cast<int4 *>(P.k.boards + env * (int64_t)G::REC);
+    for (int i = lane; i < G::REC / 16; i += 64) dst[i] = src[i];
+    if (lane == 0) P.k.scal[env] = make_int4(0, 0, P.k.max_turns, game_no);
+}
+
+// ---------------------------------------------------------------------------------------------
+// standalone sampler: k-th set byte of each env's mask (maenv:830-834 with the counter RNG)
+// ---------------------------------------------------------------------------------------------
+template <int R_, int C_>
+__global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8_t *__restrict__ mask, int32_t *__restrict__ actions) {
+    using G = Geo<R_, C_>;
+    constexpr int RC = G::RC, K = G::K, NA = G::NA;
+    __shared__ Lds<G> L;
+    const int lane = threadIdx.x;
+    const int64_t env = blockIdx.x;
+    if (env >= P.n_envs) return;
+    const uint8_t *m = mask + env * (int64_t)NA;
+    if constexpr (NA % 4 == 0) {
+        for (int i = lane; i < NA / 4; i += 64) reinterpret_cast<int *>(L.mask)[i] = reinterpret_cast<const int *>(m)[i];
+    } else {
+        for (int i = lane; i < NA; i += 64) L.mask[i] = m[i];
+    }
+    wave_sync<G>();
+    int mine = 0;
+#pragma unroll
+    for (int cc = 0; cc < G::CPL; ++cc) {
+        const int cell = lane + 64 * cc;
+        int n = 0;
+        if (cell < RC)
+            for (int c = 0; c < K; ++c) n += L.mask[cell * K + c] != 0;
+        L.cnt[cell] = (uint8_t)n;
+        mine += n;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    wave_sync<G>();
+    const int total = uni(mine);
+    const int4 sc = P.scal[env];
+    int na = -1;
+    if (total > 0) {
+        const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)sc.w, STREAM_ACTION, (uint32_t)sc.x), (uint32_t)total);
+        na = kth_valid(L, (int)k, lane);
+    }
+    if (lane == 0) actions[env] = na;
+}
+
+// ---------------------------------------------------------------------------------------------
+// export / import in the reference's int64 [N,34,R,C] layout (impl:16-60)
+// ---------------------------------------------------------------------------------------------
+__device__ inline int ref_layer_to_board(int l) {  // reference layer -> internal board (or -1: obstacles, -2: scalars)
+    if (l == 0 || l == 1) return B_PIECES + l;
+    if (l == 2) return -1;
+    if (l == 3 || l == 4) return B_PO + (l - 3);
+    if (l == 5) return -2;
+    if (l == 6 || l == 7) return B_RECENT + (l - 6);
+    if (l < 32) return B_CAP + (l - 8);
+    return B_STILL + (l - 32);
+}
+
+template <int R_, int C_>
+__global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t *__restrict__ player_out) {
+    using G = Geo<R_, C_>;
+    constexpr int RC = G::RC, C = G::C;
+    const int64_t env = blockIdx.x;
+    if (env >= P.n_envs) return;
+    const int8_t *rec = P.boards + env * (int64_t)G::REC;
+    const int4 sc = P.scal[env];
+    int64_t *o = out + env * (int64_t)(SGX_STATE_LAYERS * RC);
+    for (int x = threadIdx.x; x < SGX_STATE_LAYERS * RC; x += blockDim.x) {
+        const int l = x / RC, cell = x - l * RC;
+        const int b = ref_layer_to_board(l);
+        int64_t v;
+        if (b >= 0) v = rec[b * G::S + cell];
+        else if (b == -1) v = P.tab->obstacles[cell];
+        else {
+            v = 0;
+            const int w = (sc.y & F_WIN_P1) ? 1 : (sc.y & F_WIN_M1) ? -1 : 0;
+            if (cell == 0) v = sc.x;                               // TURN_COUNT  [5,0,0]
+            else if (cell == 1) v = (sc.y & F_OVER) ? 1 : 0;       // GAME_OVER   [5,0,1]
+            else if (cell == 2) v = w;                             // WINNER      [5,0,2]
+            else if (cell == C) v = sc.z;                          // MAX_TURNS   [5,1,0]
+            else if (cell == C + 1) v = (sc.y & F_END_INVALID) ? 1 : 0;  // ENDING_INVALID [5,1,1]
+        }
+        o[x] = v;
+    }
+    if (threadIdx.x == 0 && player_out) player_out[env] = (sc.y & F_PLAYER_M1) ? -1 : 1;
+}
+
+template <int R_, int C_>
+__global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in) {
+    using G = Geo<R_, C_>;
+    constexpr int RC = G::RC, C = G::C;
+    const int64_t env = blockIdx.x;
+    if (env >= P.n_envs) return;
+    int8_t *rec = P.boards + env * (int64_t)G::REC;
+    const int64_t *s = in + env * (int64_t)(SGX_STATE_LAYERS * RC);
+    for (int x = threadIdx.x; x < N_BOARDS * G::S; x += blockDim.x) {
+        const int b = x / G::S, cell = x - b * G::S;
+        int l;
+        if (b < 2) l = b; else if (b < 4) l = 3 + (b - 2); else if (b < 6) l = 6 + (b - 4); else if (b < 8) l = 32 + (b - 6); else l = 8 + (b - 8);
+        rec[x] = cell < RC ? (int8_t)s[l * RC + cell] : 0;
+    }
+    if (threadIdx.x == 0) {
+        const int64_t *d = s + 5 * RC;
+        int flags = 0;
+        if (d[1] != 0) flags |= F_OVER;
+        if (d[2] > 0) flags |= F_WIN_P1; else if (d[2] < 0) flags |= F_WIN_M1;
+        if (d[C + 1] != 0) flags |= F_END_INVALID;
+        if (player_in && player_in[env] < 0) flags |= F_PLAYER_M1;
+        const int game_no = P.scal[env].w < 0 ? 0 : P.scal[env].w;
+        P.scal[env] = make_int4((int)d[0], flags, (int)d[C], game_no);
+    }
+}
+
+__global__ void info_kernel(const int4 *__restrict__ scal, int32_t *__restrict__ out, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 s = scal[i];
+    reinterpret_cast<int4 *>(out)[i] = make_int4(s.x, s.w, (s.y & F_OVER) ? 1 : 0, (s.y & F_PLAYER_M1) ? -1 : 1);
+}
+
+__global__ void init_scal_kernel(int4 *scal, int64_t n, int max_turns) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) scal[i] = make_int4(0, 0, max_turns, -1);
+}
+
+}  // namespace
+
+// =============================================================================================
+// Host side: handle + C ABI
+// =============================================================================================
+struct sgx_env {
+    sgx_config cfg;
+    int64_t n_envs;
+    int device;
+    uint64_t seed;
+    int64_t env_id_offset;
+    int8_t *boards;
+    int4 *scal;
+    DevTables *tab;
+    uint8_t *setups;
+    int64_t n_setups;
+    int rec_bytes;
+    int K;
+};
+
+namespace {
+
+bool supported_geometry(int r, int c) {
+    return (r == 10 && c == 10) || (r == 15 && c == 15) || (r == 8 && c == 8) || (r == 6 && c == 6) || (r == 5 && c == 5) ||
+           (r == 4 && c == 4) || (r == 3 && c == 4);
+}
+
+#define DISPATCH_GEOMETRY(h, CALL)                                   \
+    do {                                                             \
+        const int r_ = (h)->cfg.rows, c_ = (h)->cfg.cols;            \
+        if (r_ == 10 && c_ == 10) { CALL(10, 10); }                  \
+        else if (r_ == 15 && c_ == 15) { CALL(15, 15); }             \
+        else if (r_ == 8 && c_ == 8) { CALL(8, 8); }                 \
+        else if (r_ == 6 && c_ == 6) { CALL(6, 6); }                 \
+        else if (r_ == 5 && c_ == 5) { CALL(5, 5); }                 \
+        else if (r_ == 4 && c_ == 4) { CALL(4, 4); }                 \
+        else if (r_ == 3 && c_ == 4) { CALL(3, 4); }                 \
+        else return fail(SGX_EINVAL, "unsupported board size%s");    \
+    } while (0)
+
+KParams make_params(const sgx_env *h) {
+    KParams p;
+    memset(&p, 0, sizeof(p));
+    p.boards = h->boards;
+    p.scal = h->scal;
+    p.tab = h->tab;
+    p.setups = h->setups;
+    p.n_setups = (int32_t)h->n_setups;
+    p.max_turns = h->cfg.max_turns;
+    p.usable_rows = h->cfg.usable_rows;
+    for (int i = 0; i < 12; ++i) p.piece_counts[i] = h->cfg.piece_counts[i];
+    p.n_envs = h->n_envs;
+    p.seed = h->seed;
+    p.env_id_offset = h->env_id_offset;
+    return p;
+}
+
+unsigned grid_for(int64_t n) { return (unsigned)((n + 7) & ~(int64_t)7); }
+
+int check_cfg(const sgx_config *cfg) {
+    if (!cfg) return fail(SGX_EINVAL, "cfg is NULL%s");
+    if (cfg->rows < 3 || cfg->cols < 3) return fail(SGX_EINVAL, "Both rows and columns have to be at least 3%s");
+    if (cfg->rows * cfg->cols > SGX_MAX_CELLS) return fail(SGX_EINVAL, "rows*cols exceeds SGX_MAX_CELLS%s");
+    if (cfg->usable_rows < 1 || cfg->usable_rows * 2 > cfg->rows) return fail(SGX_EINVAL, "usable_rows out of range%s");
+    int total = 0;
+    for (int i = 0; i < 12; ++i) {
+        if (cfg->piece_counts[i] < 0) return fail(SGX_EINVAL, "negative piece count%s");
+        total += cfg->piece_counts[i];
+    }
+    if (total > cfg->usable_rows * cfg->cols) return fail(SGX_EINVAL, "more pieces than usable cells%s");
+    return SGX_OK;
+}
+
+}  // namespace
+
+SGX_API int sgx_abi_version(void) { return SGX_ABI_VERSION; }
+SGX_API const char *sgx_last_error(void) { return g_last_error.c_str(); }
+SGX_API int64_t sgx_num_envs(const sgx_env *h) { return h ? h->n_envs : 0; }
+SGX_API int sgx_spatial_channels(const sgx_env *h) { return h ? h->K : 0; }
+SGX_API int64_t sgx_num_spatial_actions(const sgx_env *h) { return h ? (int64_t)h->cfg.rows * h->cfg.cols * h->K : 0; }
+SGX_API int64_t sgx_action_size_1d(const sgx_env *h) {
+    return h ? (int64_t)h->cfg.rows * h->cfg.cols * (h->cfg.rows + h->cfg.cols) + 1 : 0;
+}
+
+// maenv:261-313 (highs/lows), maenv:388-391 (ranges/mids), maenv:506-508 ((x - mid) / range in float32)
+SGX_API int sgx_build_obs_lut(const sgx_config *cfg, float *lut) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!lut) return fail(SGX_EINVAL, "lut is NULL%s");
+    float hi[OBS_CH], lo[OBS_CH];
+    for (int ch = 0; ch < OBS_CH; ++ch) { hi[ch] = 1.0f; lo[ch] = -1.0f; }
+    hi[39] = hi[40] = 1.0f; lo[39] = lo[40] = -3.0f;   // RecentMoves JUST_CAME_FROM .. JUST_ARRIVED_AND_CANT_DOUBLE_BACK
+    for (int ch = 41; ch < 65; ++ch) { hi[ch] = 8.0f; lo[ch] = 0.0f; }
+    for (int t = 1; t <= 12; ++t)
+        if (cfg->piece_counts[t - 1] > 1) hi[41 + t - 1] = hi[53 + t - 1] = (float)cfg->piece_counts[t - 1];
+    for (int ch = 0; ch < OBS_CH; ++ch) {
+        volatile float range = (hi[ch] - lo[ch]) / 2.0f, mid = (hi[ch] + lo[ch]) / 2.0f;
+        for (int i = 0; i < LUT_STRIDE; ++i) {
+            float raw;
+            if (ch < 38) {                       // one-hot piece channels: raw = (board value == piece type)
+                const int type = ch < 12 ? ch + 1 : ch < 25 ? ch - 11 : ch - 24;
+                raw = (i == type) ? 1.0f : 0.0f;
+            } else if (ch == 39 || ch == 40) raw = (float)(i - 3);
+            else raw = (float)i;
+            volatile float d = raw - mid;        // two IEEE float32 roundings, as numpy does
+            lut[ch * LUT_STRIDE + i] = d / range;
+        }
+    }
+    return SGX_OK;
+}
+
+SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64_t seed, int64_t env_id_offset, sgx_env **out) {
+    if (!out) return fail(SGX_EINVAL, "out is NULL%s");
+    *out = nullptr;
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!supported_geometry(cfg->rows, cfg->cols)) return fail(SGX_EINVAL, "unsupported board size (built for 10x10, 15x15, 8x8, 6x6, 5x5, 4x4, 3x4)%s");
+    if (n_envs <= 0 || n_envs > (int64_t)1 << 30) return fail(SGX_EINVAL, "n_envs out of range%s");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(SGX_EDEVICE, "no HIP device available: %s", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(SGX_EINVAL, "device index out of range%s");
+    HIP_TRY(hipSetDevice(device));
+    sgx_env *h = new sgx_env();
+    memset(h, 0, sizeof(*h));
+    h->cfg = *cfg;
+    h->n_envs = n_envs;
+    h->device = device;
+    h->seed = seed;
+    h->env_id_offset = env_id_offset;
+    const int rc_cells = cfg->rows * cfg->cols;
+    h->rec_bytes = N_BOARDS * ((rc_cells + 3) & ~3);
+    h->K = 2 * (cfg->rows - 1) + 2 * (cfg->cols - 1) + 1;
+    DevTables host_tab;
+    memset(&host_tab, 0, sizeof(host_tab));
+    sgx_build_obs_lut(cfg, host_tab.obs_lut);
+    memcpy(host_tab.obstacles, cfg->obstacles, rc_cells);
+    if (hipMalloc((void **)&h->boards, (size_t)n_envs * h->rec_bytes) != hipSuccess ||
+        hipMalloc((void **)&h->scal, (size_t)n_envs * sizeof(int4)) != hipSuccess ||
+        hipMalloc((void **)&h->tab, sizeof(DevTables)) != hipSuccess) {
+        sgx_destroy(h);
+        return fail(SGX_ENOMEM, "device allocation failed%s");
+    }
+    HIP_TRY(hipMemset(h->boards, 0, (size_t)n_envs * h->rec_bytes));
+    HIP_TRY(hipMemcpy(h->tab, &host_tab, sizeof(DevTables), hipMemcpyHostToDevice));
+    init_scal_kernel<<<(unsigned)((n_envs + 255) / 256), 256>>>(h->scal, n_envs, cfg->max_turns);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    *out = h;
+    return SGX_OK;
+}
+
+SGX_API int sgx_destroy(sgx_env *h) {
+    if (!h) return SGX_OK;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    if (h->boards) hipFree(h->boards);
+    if (h->scal) hipFree(h->scal);
+    if (h->tab) hipFree(h->tab);
+    if (h->setups) hipFree(h->setups);
+    delete h;
+    return SGX_OK;
+}
+
+SGX_API int sgx_set_setup_table(sgx_env *h, const uint8_t *table_host, int64_t n_setups) {
+    if (!h || !table_host || n_setups <= 0 || n_setups > 0x7fffffff) return fail(SGX_EINVAL, "bad setup table%s");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t bytes = (size_t)n_setups * h->cfg.usable_rows * h->cfg.cols;
+    for (size_t i = 0; i < bytes; ++i)
+        if (table_host[i] > 12) return fail(SGX_EINVAL, "setup table holds a piece code > 12%s");
+    if (h->setups) { HIP_TRY(hipFree(h->setups)); h->setups = nullptr; }
+    HIP_TRY(hipMalloc((void **)&h->setups, bytes));
+    HIP_TRY(hipMemcpy(h->setups, table_host, bytes, hipMemcpyHostToDevice));
+    h->n_setups = n_setups;
+    return SGX_OK;
+}
+
+SGX_API int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p1_maps_dev, const int8_t *p2_maps_dev, void *stream) {
+    if (!h) return fail(SGX_EINVAL, "handle is NULL%s");
+    if ((p1_maps_dev == nullptr) != (p2_maps_dev == nullptr)) return fail(SGX_EINVAL, "pass both piece maps or neither%s");
+    HIP_TRY(hipSetDevice(h->device));
+    ResetParams rp;
+    rp.k = make_params(h);
+    rp.select = env_select_dev;
+    rp.p1_maps = p1_maps_dev;
+    rp.p2_maps = p2_maps_dev;
+#define CALL_RESET(R, C) reset_kernel<R, C><<<(unsigned)h->n_envs, 64, 0, (hipStream_t)stream>>>(rp)
+    DISPATCH_GEOMETRY(h, CALL_RESET);
+#undef CALL_RESET
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}
+
+static int launch_step(sgx_env *h, const KParams &p, void *stream) {
+#define CALL_STEP(R, C) step_kernel<R, C><<<grid_for(h->n_envs), 64, 0, (hipStream_t)stream>>>(p)
+    DISPATCH_GEOMETRY(h, CALL_STEP);
+#undef CALL_STEP
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}
+
+SGX_API int sgx_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int8_t *player_dev, void *stream) {
+    if (!h) return fail(SGX_EINVAL, "handle is NULL%s");
+    HIP_TRY(hipSetDevice(h->device));
+    KParams p = make_params(h);
+    p.mode = 1;
+    p.io.obs_dev = obs_dev;
+    p.io.mask_dev = mask_dev;
+    p.io.player_dev = player_dev;
+    return launch_step(h, p, stream);
+}
+
+SGX_API int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream) {
+    if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
+    if (!io->actions_dev) return fail(SGX_EINVAL, "actions_dev is NULL%s");
+    HIP_TRY(hipSetDevice(h->device));
+    KParams p = make_params(h);
+    p.mode = 0;
+    p.io = *io;
+    return launch_step(h, p, stream);
+}
+
+SGX_API int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actions_dev, void *stream) {
+    if (!h || !mask_dev || !actions_dev) return fail(SGX_EINVAL, "NULL argument%s");
+    HIP_TRY(hipSetDevice(h->device));
+    KParams p = make_params(h);
+#define CALL_SAMPLE(R, C) sample_kernel<R, C><<<(unsigned)h->n_envs, 64, 0, (hipStream_t)stream>>>(p, mask_dev, actions_dev)
+    DISPATCH_GEOMETRY(h, CALL_SAMPLE);
+#undef CALL_SAMPLE
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}
+
+SGX_API int sgx_export_state(sgx_env *h, int64_t *state_dev, int8_t *player_dev, void *stream) {
+    if (!h || !state_dev) return fail(SGX_EINVAL, "NULL argument%s");
+    HIP_TRY(hipSetDevice(h->device));
+    KParams p = make_params(h);
+#define CALL_EXPORT(R, C) export_kernel<R, C><<<(unsigned)h->n_envs, 256, 0, (hipStream_t)stream>>>(p, state_dev, player_dev)
+    DISPATCH_GEOMETRY(h, CALL_EXPORT);
+#undef CALL_EXPORT
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}
+
+SGX_API int sgx_import_state(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, void *stream) {
+    if (!h || !state_dev) return fail(SGX_EINVAL, "NULL argument%s");
+    HIP_TRY(hipSetDevice(h->device));
+    KParams p = make_params(h);
+#define CALL_IMPORT(R, C) import_kernel<R, C><<<(unsigned)h->n_envs, 256, 0, (hipStream_t)stream>>>(p, state_dev, player_dev)
+    DISPATCH_GEOMETRY(h, CALL_IMPORT);
+#undef CALL_IMPORT
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}
+
+SGX_API int sgx_get_env_info(sgx_env *h, int32_t *info_dev, void *stream) {
+    if (!h || !info_dev) return fail(SGX_EINVAL, "NULL argument%s");
+    HIP_TRY(hipSetDevice(h->device));
+    info_kernel<<<(unsigned)((h->n_envs + 255) / 256), 256, 0, (hipStream_t)stream>>>(h->scal, info_dev, h->n_envs);
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}

@@ -1,0 +1,166 @@
+"""VecStrategoEnv: N concurrent games on one MI355X, torch tensors in / out.
+
+The batched counterpart of StrategoMultiAgentEnv (reference stratego_multiagent_env.py:316-834): every
+call goes through the C ABI in include/stratego_mi355x.h to the HIP kernels; PyTorch only owns the device
+buffers and the stream.  Outputs are written in place into preallocated tensors:
+
+    obs      float32 [N, R, C, 67]   normalised partial observation of each env's next mover
+    mask     uint8   [N, R, C, K]    valid-actions mask of the next mover (flat index = action)
+    reward   float32 [N, 2]          rewards of player +1 / -1 (non-zero only when done)
+    done     uint8   [N]
+    player   int8    [N]             next mover (+1 / -1)
+    invalid_action uint8 [N]         the reference would have raised ValueError; env unchanged
+    ending_invalid uint8 [N]         game ended by max_turns ('game_result_was_invalid')
+
+There is no CPU fallback: construction fails if the HIP library is missing or no GPU is visible.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import PO_OBS_CHANNELS, NUM_STATE_LAYERS, get_variant
+from .setups import load_setup_table
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class VecStrategoEnv:
+    def __init__(self, version='barrage', num_envs=1, device=0, seed=0, env_id_offset=0, human_inits=None,
+                 auto_reset=False, final_obs=False):
+        """human_inits: None = use the Gravon table when the variant has one (util.py:301-319), False = uniformly
+        random back-row placement (util.py:33-53), True = require the table."""
+        if not torch.cuda.is_available():
+            raise _lib.SgxError("VecStrategoEnv needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
+        self._L = _lib.load()
+        self.variant = get_variant(version)
+        v = self.variant
+        self.num_envs = int(num_envs)
+        self.device = torch.device('cuda', device if isinstance(device, int) else torch.device(device).index or 0)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.env_id_offset = int(env_id_offset)
+        self.auto_reset = bool(auto_reset)
+        self.R, self.Cc, self.K = v.rows, v.columns, v.spatial_channels
+        self._cfg = _lib.make_config(v)
+        h = C.c_void_p()
+        _lib.check(self._L.sgx_create(C.byref(self._cfg), self.num_envs, self.device.index, self.seed,
+                                      self.env_id_offset, C.byref(h)))
+        self._h = h
+        if human_inits is None:
+            human_inits = bool(v.human_inits)
+        if human_inits:
+            if not v.human_inits:
+                raise ValueError("Human inits not supported with {} game version".format(v.name))  # util.py:310
+            table = np.ascontiguousarray(load_setup_table(v.human_inits))
+            _lib.check(self._L.sgx_set_setup_table(self._h, table.ctypes.data_as(C.c_void_p), table.shape[0]))
+        self.human_inits = bool(human_inits)
+        N, R, Cc, K, dev = self.num_envs, self.R, self.Cc, self.K, self.device
+        self.obs = torch.empty((N, R, Cc, PO_OBS_CHANNELS), dtype=torch.float32, device=dev)
+        self.mask = torch.empty((N, R, Cc, K), dtype=torch.uint8, device=dev)
+        self.reward = torch.zeros((N, 2), dtype=torch.float32, device=dev)
+        self.done = torch.zeros((N,), dtype=torch.uint8, device=dev)
+        self.player = torch.ones((N,), dtype=torch.int8, device=dev)
+        self.invalid_action = torch.zeros((N,), dtype=torch.uint8, device=dev)
+        self.ending_invalid = torch.zeros((N,), dtype=torch.uint8, device=dev)
+        self.final_obs = torch.zeros((N, 2, R, Cc, PO_OBS_CHANNELS), dtype=torch.float32, device=dev) if final_obs else None
+        self.next_actions = torch.zeros((N,), dtype=torch.int32, device=dev)
+        self._io = _lib.SgxStepIO()
+
+    # ---- lifecycle -----------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.sgx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- API -----------------------------------------------------------------------------------------
+    def reset(self, p1_maps=None, p2_maps=None, env_select=None):
+        """Start new games (all envs, or those with env_select[i] != 0) and return (obs, mask, player).
+
+        p1_maps / p2_maps: int8 [N, R, C] own-side piece maps (create_initial_state inputs, penv:38-60);
+        omit both to sample setups on the device."""
+        sel = None
+        if env_select is not None:
+            sel = env_select.to(device=self.device, dtype=torch.uint8).contiguous()
+        m1 = m2 = None
+        if p1_maps is not None:
+            m1 = torch.as_tensor(p1_maps).to(device=self.device, dtype=torch.int8).contiguous().reshape(self.num_envs, -1)
+            m2 = torch.as_tensor(p2_maps).to(device=self.device, dtype=torch.int8).contiguous().reshape(self.num_envs, -1)
+            assert m1.shape[1] == self.R * self.Cc and m2.shape == m1.shape
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_reset(self._h, _ptr(sel), _ptr(m1), _ptr(m2), self._stream()))
+        return self.observe()
+
+    def observe(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_observe(self._h, _ptr(self.obs), _ptr(self.mask), _ptr(self.player), self._stream()))
+        return self.obs, self.mask, self.player
+
+    def step(self, actions, want_next_actions=False, emit_obs=True, emit_mask=True):
+        """One env.step() for every env.  actions: int32 [N] flat (R,C,K) indices in each mover's perspective."""
+        a = actions
+        if a.dtype != torch.int32 or a.device != self.device or not a.is_contiguous():
+            a = a.to(device=self.device, dtype=torch.int32).contiguous()
+        io = self._io
+        io.actions_dev = a.data_ptr()
+        io.obs_dev = self.obs.data_ptr() if emit_obs else None
+        io.mask_dev = self.mask.data_ptr() if emit_mask else None
+        io.reward_dev = self.reward.data_ptr()
+        io.done_dev = self.done.data_ptr()
+        io.player_dev = self.player.data_ptr()
+        io.invalid_action_dev = self.invalid_action.data_ptr()
+        io.ending_invalid_dev = self.ending_invalid.data_ptr()
+        io.final_obs_dev = self.final_obs.data_ptr() if self.final_obs is not None else None
+        io.next_actions_dev = self.next_actions.data_ptr() if want_next_actions else None
+        io.auto_reset = 1 if self.auto_reset else 0
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_step(self._h, C.byref(io), self._stream()))
+        return self.obs, self.mask, self.reward, self.done, self.player
+
+    def rollout_step(self):
+        """Random-valid-action rollout step: plays `next_actions` (drawn by the previous call) and draws the next."""
+        return self.step(self.next_actions, want_next_actions=True)
+
+    def sample_valid_actions(self, mask=None, out=None):
+        """Uniformly random valid action per env from `mask` (default: the current one) -- maenv:830-834."""
+        mask = self.mask if mask is None else mask
+        out = self.next_actions if out is None else out
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_sample_valid(self._h, _ptr(mask), _ptr(out), self._stream()))
+        return out
+
+    def export_state(self):
+        """(state int64 [N,34,R,C] in the reference layout, player int8 [N])."""
+        st = torch.empty((self.num_envs, NUM_STATE_LAYERS, self.R, self.Cc), dtype=torch.int64, device=self.device)
+        pl = torch.empty((self.num_envs,), dtype=torch.int8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_export_state(self._h, _ptr(st), _ptr(pl), self._stream()))
+        return st, pl
+
+    def import_state(self, state, player=None):
+        st = torch.as_tensor(state).to(device=self.device, dtype=torch.int64).contiguous()
+        assert tuple(st.shape) == (self.num_envs, NUM_STATE_LAYERS, self.R, self.Cc)
+        pl = None
+        if player is not None:
+            pl = torch.as_tensor(player).to(device=self.device, dtype=torch.int8).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_import_state(self._h, _ptr(st), _ptr(pl), self._stream()))
+        return self.observe()
+
+    def env_info(self):
+        """int32 [N,4]: turn count, game number, game_over, current player."""
+        out = torch.empty((self.num_envs, 4), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_get_env_info(self._h, _ptr(out), self._stream()))
+        return out

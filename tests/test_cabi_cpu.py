@@ -1,0 +1,102 @@
+"""C-ABI library checks that need no GPU: it builds, loads, exports every declared symbol, its host-only
+normalisation LUT is bit-exact against the reference dump, and it fails loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from stratego_env_amd import _lib
+from stratego_env_amd import build as hip_build
+from stratego_env_amd.config import VARIANTS
+from tests.helpers import load_variants_json
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    hip_build.build()
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, 'include', 'stratego_mi355x.h')).read()
+    declared = sorted(set(re.findall(r'\b(sgx_[a-z0-9_]+)\s*\(', hdr)))
+    assert declared == sorted(_lib.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.sgx_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    # sgx_config: 4 + 12 int32 + 256 bytes; sgx_step_io: 10 pointers + 2 int32
+    assert C.sizeof(_lib.SgxConfig) == 16 * 4 + 256
+    assert C.sizeof(_lib.SgxStepIO) == 10 * 8 + 8
+
+
+def test_obs_lut_bit_exact_vs_reference_constants(lib):
+    """LUT[ch][v] must equal (float32(v) - mid) / range computed the way numpy does (maenv:388-391, 506-508)."""
+    ref = load_variants_json()['variants']
+    for name, v in VARIANTS.items():
+        cfg = _lib.make_config(v)
+        lut = np.zeros(67 * 16, dtype=np.float32)
+        assert lib.sgx_build_obs_lut(C.byref(cfg), lut.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        lut = lut.reshape(67, 16)
+        mids = np.asarray(ref[name]['p_obs_mids'], dtype=np.float32)
+        ranges = np.asarray(ref[name]['p_obs_ranges'], dtype=np.float32)
+        for ch in range(67):
+            for i in range(16):
+                if ch < 38:
+                    t = ch + 1 if ch < 12 else (ch - 11 if ch < 25 else ch - 24)
+                    raw = np.float32(1.0 if i == t else 0.0)
+                elif ch in (39, 40):
+                    raw = np.float32(i - 3)
+                else:
+                    raw = np.float32(i)
+                want = (raw - mids[ch]) / ranges[ch]
+                assert want.dtype == np.float32
+                assert lut[ch, i].tobytes() == np.float32(want).tobytes(), (name, ch, i)
+    # the bit patterns SURVEY A.6 lists
+    cfg = _lib.make_config(VARIANTS['standard'])
+    lut = np.zeros(67 * 16, dtype=np.float32)
+    lib.sgx_build_obs_lut(C.byref(cfg), lut.ctypes.data_as(C.POINTER(C.c_float)))
+    lut = lut.reshape(67, 16)
+    assert lut[41 + 2, 1].view(np.uint32) == 0xbf19999a      # miner (hi 5), count 1 -> -0.6
+    assert lut[41 + 6, 1].view(np.uint32) == 0xbeaaaaab      # major (hi 3), count 1 -> -0.33333334
+    assert lut[41 + 11, 1].view(np.uint32) == 0xbf2aaaab     # bomb (hi 6), count 1 -> -0.6666667
+    assert lut[41 + 0, 1].view(np.uint32) == 0xbf400000      # spy (hi 8), count 1 -> -0.75
+
+
+def test_bad_config_rejected(lib):
+    cfg = _lib.make_config(VARIANTS['barrage'])
+    cfg.rows = 2
+    lut = (C.c_float * (67 * 16))()
+    assert lib.sgx_build_obs_lut(C.byref(cfg), lut) == -1
+    assert b'at least 3' in lib.sgx_last_error()
+
+
+def test_create_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = _lib.make_config(VARIANTS['barrage'])
+    h = C.c_void_p()
+    rc = lib.sgx_create(C.byref(cfg), 16, 0, 1, 0, C.byref(h))
+    assert rc != 0 and not h.value
+    assert lib.sgx_last_error()
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    with pytest.raises(_lib.SgxError):
+        VecStrategoEnv('barrage', 4)
+
+
+def test_product_package_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under stratego_env_amd/ may reference it."""
+    pkg = os.path.join(ROOT, 'stratego_env_amd')
+    for dp, dn, fn in os.walk(pkg):
+        for f in fn:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
+                assert 'stratego_oracle' not in src or f == 'stratego_mi355x.hip', f

@@ -1,0 +1,233 @@
+"""GPU parity: the HIP path (through the C ABI) vs the CPU oracle, bit-exact.  Run with -m gpu on an MI355X."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from stratego_env_amd import setups as S
+from stratego_env_amd.config import VARIANTS
+from tests.helpers import digest_obs, load_games, oracle_cvariant, oracle_env
+
+pytestmark = pytest.mark.gpu
+
+MASK, POBS = 'valid_actions_mask', 'partial_observation'
+
+
+def _table(name):
+    v = VARIANTS[name]
+    return S.load_setup_table(v.human_inits) if v.human_inits else None
+
+
+def _oracle_batch(name, seed, g0, n):
+    cv = oracle_cvariant(name, setups=_table(name))
+    envs = []
+    for e in range(n):
+        oe = oracle_env(name)
+        oe.reset(initial_state_override=orc.reset_state(cv, seed, g0 + e, 0))
+        oe.game_no = 0
+        envs.append(oe)
+    return cv, envs
+
+
+@pytest.mark.parametrize('name,n_envs,n_steps,garbage', [
+    ('barrage', 48, 700, 0.0), ('barrage', 32, 300, 0.15), ('standard', 16, 500, 0.05), ('octa_barrage', 32, 300, 0.1),
+    ('medium', 32, 300, 0.1), ('fives', 32, 200, 0.1), ('tiny', 64, 200, 0.1), ('micro', 64, 120, 0.1),
+    ('short_barrage', 32, 250, 0.1), ('standard2', 4, 150, 0.05),
+])
+def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage):
+    """Random-valid-action rollouts with auto-reset (+ injected garbage actions): every output of every step."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    v = VARIANTS[name]
+    seed, g0 = 0xABCDEF12345 + len(name), 1000
+    env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True, final_obs=True)
+    cv, oenvs = _oracle_batch(name, seed, g0, n_envs)
+    NA = v.num_spatial_actions
+    rs = np.random.RandomState(7)
+    obs, mask, player = env.reset()
+    obs_h, mask_h, player_h = obs.cpu().numpy(), mask.cpu().numpy(), player.cpu().numpy()
+    cur = []
+    for e, oe in enumerate(oenvs):
+        o = oe._obs(1)
+        assert np.array_equal(o[MASK], mask_h[e]) and o[POBS].tobytes() == obs_h[e].tobytes(), (name, 'reset', e)
+        assert player_h[e] == 1
+        cur.append(o)
+    st, pl = env.export_state()
+    assert np.array_equal(st.cpu().numpy(), np.stack([oe.state for oe in oenvs]))
+    sampled = env.sample_valid_actions().cpu().numpy()
+    games_done = 0
+    for t in range(n_steps):
+        acts = np.zeros(n_envs, dtype=np.int32)
+        for e, oe in enumerate(oenvs):
+            a = orc.sample_action(cur[e][MASK].astype(np.uint8), seed, g0 + e, oe.game_no, int(oe.state[5, 0, 0]))
+            assert sampled[e] == a, (name, t, e, 'sampler')
+            if garbage and rs.rand() < garbage:
+                a = int(rs.choice([rs.randint(NA), rs.randint(v.cells) * v.spatial_channels + v.spatial_channels - 1,
+                                   -1, NA, NA + 3, (v.cells - 1) * v.spatial_channels + rs.randint(v.spatial_channels)]))
+            acts[e] = a
+        env.step(torch.from_numpy(acts), want_next_actions=True)
+        obs_h, mask_h = env.obs.cpu().numpy(), env.mask.cpu().numpy()
+        rew_h, done_h, player_h = env.reward.cpu().numpy(), env.done.cpu().numpy(), env.player.cpu().numpy()
+        inv_h, einv_h, fin_h = env.invalid_action.cpu().numpy(), env.ending_invalid.cpu().numpy(), env.final_obs.cpu().numpy()
+        sampled = env.next_actions.cpu().numpy()
+        for e, oe in enumerate(oenvs):
+            try:
+                o, rew, done, info = oe.step({oe.player: int(acts[e])})
+            except ValueError:
+                assert inv_h[e] == 1, (name, t, e, acts[e], 'oracle raised, GPU accepted')
+                assert not done_h[e]
+                assert np.array_equal(cur[e][MASK], mask_h[e]) and cur[e][POBS].tobytes() == obs_h[e].tobytes()
+                assert player_h[e] == oe.player
+                continue
+            assert inv_h[e] == 0, (name, t, e, acts[e], 'GPU flagged a move the oracle accepts')
+            assert bool(done_h[e]) == done['__all__'], (name, t, e)
+            if done['__all__']:
+                games_done += 1
+                assert (rew_h[e, 0], rew_h[e, 1]) == (rew[1], rew[-1]), (name, t, e, rew_h[e], rew)
+                assert bool(einv_h[e]) == info[1]['game_result_was_invalid']
+                for slot, p in ((0, 1), (1, -1)):
+                    assert o[p][POBS].tobytes() == fin_h[e, slot].tobytes(), (name, t, e, 'final obs', p)
+                    assert int(o[p][MASK].sum()) == 1 and o[p][MASK][0, 0, -1] == 1
+                oe.game_no += 1
+                o = oe.reset(initial_state_override=orc.reset_state(cv, seed, g0 + e, oe.game_no))
+            else:
+                assert rew_h[e, 0] == 0 and rew_h[e, 1] == 0 and einv_h[e] == 0
+            p = oe.player
+            assert player_h[e] == p, (name, t, e)
+            assert np.array_equal(o[p][MASK], mask_h[e]), (name, t, e, 'mask')
+            assert o[p][POBS].tobytes() == obs_h[e].tobytes(), (name, t, e, 'obs')
+            cur[e] = o[p]
+        if t % 50 == 49:
+            st, pl = env.export_state()
+            assert np.array_equal(st.cpu().numpy(), np.stack([oe.state for oe in oenvs])), (name, t, 'state export')
+            assert np.array_equal(pl.cpu().numpy(), np.asarray([oe.player for oe in oenvs], dtype=np.int8))
+    assert games_done > 0 or name in ('standard', 'standard2')
+    env.close()
+
+
+@pytest.mark.parametrize('name,limit', [('barrage', 96), ('standard', 12), ('octa_barrage', 48), ('medium', 64),
+                                        ('fives', 64), ('tiny', 128), ('micro', 128), ('short_barrage', 32)])
+def test_replay_reference_golden_games(name, limit):
+    """Golden games recorded from the REFERENCE (tests/golden, tools/oracle/gen_golden.py): the GPU must reproduce
+    every per-step digest, reward, done flag, error flag and the final internal state."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    g = load_games(name)
+    off = g['offsets']
+    n = min(len(off) - 1, limit)
+    env = VecStrategoEnv(name, n, seed=1, auto_reset=False, final_obs=True, human_inits=False)
+    obs, mask, player = env.reset(torch.from_numpy(g['p1_maps'][:n]), torch.from_numpy(g['p2_maps'][:n]))
+    obs_h, mask_h = obs.cpu().numpy(), mask.cpu().numpy()
+    for e in range(n):
+        assert digest_obs({1: {MASK: mask_h[e], POBS: obs_h[e]}}) == int(g['init_digests'][e])
+    lens = off[1:n + 1] - off[:n]
+    final_states = {}
+    for t in range(int(lens.max())):
+        acts = np.zeros(n, dtype=np.int32)
+        live = [e for e in range(n) if t < lens[e]]
+        for e in live:
+            acts[e] = g['actions'][off[e] + t]
+        # finished envs keep receiving an out-of-range action: flagged invalid, state untouched
+        for e in range(n):
+            if t >= lens[e]:
+                acts[e] = -1
+        env.step(torch.from_numpy(acts))
+        obs_h, mask_h = env.obs.cpu().numpy(), env.mask.cpu().numpy()
+        rew_h, done_h, player_h = env.reward.cpu().numpy(), env.done.cpu().numpy(), env.player.cpu().numpy()
+        inv_h, fin_h = env.invalid_action.cpu().numpy(), env.final_obs.cpu().numpy()
+        for e in live:
+            k = off[e] + t
+            assert bool(inv_h[e]) == bool(g['errors'][k]), (name, e, t, 'error flag')
+            if g['errors'][k]:
+                continue
+            assert bool(done_h[e]) == bool(g['dones'][k]) and player_h[e] == g['players'][k], (name, e, t)
+            if done_h[e]:
+                noop = np.zeros_like(mask_h[e]); noop[0, 0, -1] = 1
+                d = digest_obs({1: {MASK: noop, POBS: fin_h[e, 0]}, -1: {MASK: noop, POBS: fin_h[e, 1]}})
+                assert np.array_equal(mask_h[e], noop)
+                assert tuple(rew_h[e]) == tuple(g['rewards'][k])
+            else:
+                d = digest_obs({int(player_h[e]): {MASK: mask_h[e], POBS: obs_h[e]}})
+            assert d == int(g['digests'][k]), (name, e, t, 'digest')
+    st, pl = env.export_state()
+    st = st.cpu().numpy()
+    for e in range(n):
+        assert np.array_equal(st[e], g['final_states'][e].astype(np.int64)), (name, e, 'final state')
+    env.close()
+
+
+def test_import_export_roundtrip_and_observe():
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    name = 'barrage'
+    g = load_games(name)
+    n = 32
+    states = g['final_states'][:n].astype(np.int64)
+    env = VecStrategoEnv(name, n, seed=3)
+    players = np.where(np.arange(n) % 2 == 0, 1, -1).astype(np.int8)
+    obs, mask, pl = env.import_state(torch.from_numpy(states), torch.from_numpy(players))
+    st, pl2 = env.export_state()
+    assert np.array_equal(st.cpu().numpy(), states) and np.array_equal(pl2.cpu().numpy(), players)
+    oe = oracle_env(name)
+    obs_h, mask_h = obs.cpu().numpy(), mask.cpu().numpy()
+    for e in range(n):
+        oe.reset(initial_state_override=states[e], first_player_override=int(players[e]))
+        o = oe._obs(int(players[e]))
+        assert np.array_equal(o[MASK], mask_h[e]) and o[POBS].tobytes() == obs_h[e].tobytes()
+    env.close()
+
+
+def test_sharding_independence():
+    """Env with global id g behaves the same whether it lives in a batch starting at 0 or at g (per-rank offsets)."""
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    seed = 99
+    a = VecStrategoEnv('barrage', 96, seed=seed, env_id_offset=0, auto_reset=True)
+    b = VecStrategoEnv('barrage', 32, seed=seed, env_id_offset=64, auto_reset=True)
+    a.reset(); b.reset()
+    a.sample_valid_actions(); b.sample_valid_actions()
+    for t in range(200):
+        a.rollout_step(); b.rollout_step()
+    assert np.array_equal(a.obs[64:].cpu().numpy(), b.obs.cpu().numpy())
+    assert np.array_equal(a.mask[64:].cpu().numpy(), b.mask.cpu().numpy())
+    sa, pa = a.export_state(); sb, pb = b.export_state()
+    assert np.array_equal(sa[64:].cpu().numpy(), sb.cpu().numpy())
+    assert np.array_equal(a.env_info()[64:].cpu().numpy(), b.env_info().cpu().numpy())
+    a.close(); b.close()
+
+
+def test_full_size_rollout_properties_and_oracle_digests():
+    """BASELINE config 2 size (65,536 Barrage games): size-independent properties on every env and the oracle's
+    rolling digest on 256 sampled envs."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    N, T, seed = 65536, 48, 0x5712A7E60
+    env = VecStrategoEnv('barrage', N, seed=seed, auto_reset=True)
+    env.reset()
+    env.sample_valid_actions()
+    n_chk = 32
+    ids = np.linspace(0, N - 1, n_chk).astype(np.int64)
+    idx = torch.from_numpy(ids).to(env.device)
+    digs = [orc.FNV_OFFSET] * n_chk
+    fin = np.zeros(n_chk, dtype=np.int64)
+    for t in range(T):
+        env.rollout_step()
+        m = env.mask.view(N, -1)
+        assert int((m.sum(dim=1) == 0).sum()) == 0                       # always at least one action (no-op if stuck)
+        assert int((m > 1).sum()) == 0
+        o = env.obs.view(N, 100, 67)
+        assert bool(torch.isfinite(o).all()) and float(o.abs().max()) <= 1.0
+        assert bool((o[:, :, 0:12].sum(dim=2) <= 1).all())                # own-piece channels are one-hot
+        assert int(env.invalid_action.sum()) == 0
+        mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
+        rw, dn, pl = env.reward[idx].cpu().numpy(), env.done[idx].cpu().numpy(), env.player[idx].cpu().numpy()
+        ei = env.ending_invalid[idx].cpu().numpy()
+        for i in range(n_chk):
+            # same byte stream as so_rollout(): mask, obs, reward +1, reward -1, {done, player, ending_invalid, error}
+            tail = np.asarray([dn[i], pl[i], ei[i], 0], dtype=np.int32)
+            digs[i] = orc.fnv1a(digs[i], mk[i].tobytes() + ob[i].tobytes() + rw[i].tobytes() + tail.tobytes())
+            fin[i] += int(dn[i])
+    cv = oracle_cvariant('barrage', setups=S.load_setup_table('barrage'))
+    for i in range(n_chk):
+        total, d, f = orc.rollout(cv, seed, int(ids[i]), 1, T, threads=1)
+        assert int(d[0]) == digs[i], ('env', int(ids[i]))
+        assert int(f[0]) == fin[i]
+    env.close()
