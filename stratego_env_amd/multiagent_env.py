@@ -1,0 +1,233 @@
+"""StrategoMultiAgentEnv: the reference's 2-agent dict API (stratego_multiagent_env.py:316-834) on the HIP path.
+
+Drop-in for examples/basic_game_loop.py: same constructor config keys, `reset()` / `step(action_dict)` return
+the same dict structures with the same keys (ObservationComponents string values, players +1 / -1,
+"__all__"), the same dtypes (mask int64 (R,C,K), partial observation float32 (R,C,67)), the same error
+behaviour (ValueError on an invalid action, AssertionError when the wrong player acts) and the same use of
+numpy's / Python's global RNGs at reset, so `np.random.seed(s); random.seed(s)` reproduces the reference's
+setups.  Every game-logic operation runs in the HIP kernels through a VecStrategoEnv of one game.
+
+Not built here (out of the hot-path scope): vs_human GUI, vs_bot sockets, HDF5 curriculum starts,
+the 'original' 32/33-layer channel mode.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from .config import PO_OBS_CHANNELS, NUM_STATE_LAYERS, get_variant
+from .enums import GameVersions, ObservationComponents, ObservationModes
+from .setups import load_setup_table, sample_initial_maps_like_reference
+from .spaces import Box, Dict, Discrete
+from .vec_env import VecStrategoEnv
+
+DEFAULT_CONFIG = {   # maenv:47-69
+    'version': GameVersions.STANDARD,
+    'repeat_games_from_other_side': False,
+    'random_player_assignment': False,
+    'observation_mode': ObservationModes.BOTH_OBSERVATIONS,
+    'observation_includes_internal_state': False,
+    'vs_bot': False,
+    'bot_player_num': 1,
+    'fixed_bot_player_num': True,
+    'bot_relative_path': 'basic_python.py',
+    'vs_human': False,
+    'human_player_num': -1,
+    'human_web_gui_port': 7000,
+    'human_inits': False,
+    'penalize_ties': False,
+    'curriculum_start_states_path': None,
+    'obs_channel_mode': 'extended',
+    'same_start_pos_everytime': False,
+}
+
+_MASK = ObservationComponents.VALID_ACTIONS_MASK.value
+_POBS = ObservationComponents.PARTIAL_OBSERVATION.value
+_ISTATE = ObservationComponents.INTERNAL_STATE.value
+
+# layer pairs swapped by the perspective flip (impl:645-675)
+_SWAP = [(0, 1), (3, 4), (6, 7), (32, 33)] + [(8 + k, 20 + k) for k in range(12)]
+
+
+def state_from_player_perspective(state, player):
+    """impl:645-675 on a host copy of the int64 [34,R,C] state (used for INTERNAL_STATE and side-swapped replays)."""
+    if player == 1:
+        return state
+    out = state.copy()
+    for a, b in _SWAP:
+        out[a] = state[b, ::-1, ::-1]
+        out[b] = state[a, ::-1, ::-1]
+    out[2] = state[2, ::-1, ::-1]
+    return out
+
+
+class StrategoMultiAgentEnv:
+
+    def __init__(self, env_config=None, device=0):
+        cfg = copy.deepcopy(DEFAULT_CONFIG)
+        cfg.update(env_config if env_config else {})
+        self.variant = get_variant(cfg['version'])
+        v = self.variant
+        for key in ('vs_human', 'vs_bot', 'curriculum_start_states_path'):
+            if cfg[key]:
+                raise NotImplementedError("%s is outside the MI355X hot-path build (SURVEY.md section 8)" % key)
+        if cfg['obs_channel_mode'] != 'extended':
+            raise NotImplementedError("only obs_channel_mode='extended' is built")
+        mode = cfg['observation_mode']
+        if isinstance(mode, str):
+            mode = ObservationModes(mode)
+        if mode != ObservationModes.PARTIALLY_OBSERVABLE:
+            raise NotImplementedError("observation_mode=%s: only PARTIALLY_OBSERVABLE is built so far "
+                                      "(fully-observable channels are the next row of SURVEY.md 8f)" % mode)
+        self.observation_mode = mode
+        self.penalize_ties = cfg['penalize_ties']
+        self.random_player_assignment = cfg['random_player_assignment']
+        self.repeat_games_from_other_side = cfg['repeat_games_from_other_side']
+        assert not (self.random_player_assignment and self.repeat_games_from_other_side)   # maenv:358
+        self.observation_includes_internal_state = cfg['observation_includes_internal_state']
+        self.human_inits = bool(cfg['human_inits'])
+        if self.human_inits and not v.human_inits:
+            raise ValueError("Human inits not supported with {} game version".format(v.name))   # util.py:310
+        self._table = load_setup_table(v.human_inits) if self.human_inits else None
+
+        self._vec = VecStrategoEnv(v.name, 1, device=device, seed=0, human_inits=False, auto_reset=False, final_obs=True)
+        self.rows, self.columns = v.rows, v.columns
+        self.spatial_action_size = v.spatial_action_size
+        self.action_size = v.action_size
+
+        self._fixed_maps = None
+        if cfg['same_start_pos_everytime']:                       # maenv:352-354
+            self._fixed_maps = self._random_initial_maps()
+
+        self.episodes_completed = 0
+        self.last_initial_state = None
+        self.action_space = Discrete(int(np.prod(self.spatial_action_size)))          # maenv:362
+        spaces = {_MASK: Box(np.float32(0), np.float32(1), self.spatial_action_size),
+                  _POBS: Box(np.float32(-1.0), np.float32(1.0), (v.rows, v.columns, PO_OBS_CHANNELS))}
+        if self.observation_includes_internal_state:
+            spaces[_ISTATE] = Box(np.float32(-np.inf), np.float32(np.inf), (NUM_STATE_LAYERS, v.rows, v.columns))
+        self.observation_space = Dict(spaces)
+        self.player = 1
+        self.player_map = lambda p: p
+        self.reverse_player_map = lambda p: p
+
+    # ---- setup sampling with the reference's RNG consumption -------------------------------------------
+    def _random_initial_maps(self):
+        v = self.variant
+        if self._fixed_maps is not None:
+            return self._fixed_maps
+        return sample_initial_maps_like_reference(v, self._table)
+
+    # ---- state access -------------------------------------------------------------------------------------
+    @property
+    def state(self):
+        """int64 [34,R,C] in the reference layout, absolute coordinates (a host copy)."""
+        st, _ = self._vec.export_state()
+        return st[0].cpu().numpy()
+
+    def _obs_dict(self, obs_t, mask_t, player):
+        d = {_MASK: mask_t.cpu().numpy().astype(np.int64), _POBS: obs_t.cpu().numpy().copy()}
+        if self.observation_includes_internal_state:
+            d[_ISTATE] = state_from_player_perspective(self.state, player)             # maenv:494-495
+        return d
+
+    # ---- reference API ----------------------------------------------------------------------------------------
+    def reset(self, first_player_override=None, initial_state_override=None):
+        v = self.variant
+        if self.repeat_games_from_other_side and self.episodes_completed % 2 == 1:      # maenv:530-534
+            initial_state = state_from_player_perspective(self.last_initial_state, -1)
+            self._vec.import_state(initial_state[None], np.asarray([-1], dtype=np.int8))
+            self.player = -1
+        else:
+            if self.random_player_assignment:                                          # maenv:537-543
+                if np.random.random() < 0.5:
+                    self.player_map = lambda p: p
+                    self.reverse_player_map = lambda p: p
+                else:
+                    self.player_map = lambda p: -p if p != "__all__" else p
+                    self.reverse_player_map = lambda p: -p if p != "__all__" else p
+            m1, m2 = self._random_initial_maps()                                       # maenv:545
+            self._vec.reset(np.asarray(m1, dtype=np.int8)[None], np.asarray(m2, dtype=np.int8)[None])
+            self.player = 1
+            initial_state = self.state
+        self.last_initial_state = initial_state
+        if initial_state_override is not None:                                         # maenv:551-553
+            st = np.asarray(initial_state_override, dtype=np.int64)
+            if st.shape != (NUM_STATE_LAYERS, v.rows, v.columns):
+                raise ValueError("initial_state_override must have shape (34, rows, columns)")
+            self._vec.import_state(st[None], np.asarray([self.player], dtype=np.int8))
+        if first_player_override is not None:                                          # maenv:555-558
+            if not (first_player_override == 1 or first_player_override == -1):
+                raise ValueError("first_player_override must either be 1 or -1 if it is not set to None.")
+            self.player = int(first_player_override)
+            self._vec.import_state(self.state[None], np.asarray([self.player], dtype=np.int8))
+        self.episodes_completed += 1
+        obs_t, mask_t, _ = self._vec.observe()
+        obs = {self.player: self._obs_dict(obs_t[0], mask_t[0], self.player)}
+        if self.random_player_assignment:                                              # maenv:654-655
+            obs = {self.player_map(k): val for k, val in obs.items()}
+        return obs
+
+    def step(self, action_dict, is_spatial_index=True):
+        if self.random_player_assignment:                                              # maenv:674-675
+            action_dict = {self.reverse_player_map(k): val for k, val in action_dict.items()}
+        assert self.player in action_dict                                              # maenv:678-679
+        assert self.player * -1 not in action_dict
+        if not is_spatial_index:
+            raise NotImplementedError("1-D action indices are not accepted by the batched kernels yet")
+        action = int(action_dict[self.player])
+        vec = self._vec
+        vec.step(torch.tensor([action], dtype=torch.int32))
+        flags = torch.stack([vec.invalid_action.to(torch.float32), vec.done.to(torch.float32),
+                             vec.player.to(torch.float32), vec.ending_invalid.to(torch.float32)]).cpu().numpy()[:, 0]
+        if flags[0]:
+            raise ValueError("Couldn't get the next state because the move wasn't valid.")   # impl:902
+        self.player = int(flags[2])
+        if not flags[1]:                                                                # maenv:767-770
+            dones = {self.player: False, "__all__": False}
+            obs = {self.player: self._obs_dict(vec.obs[0], vec.mask[0], self.player)}
+            rewards = {self.player: 0}
+            infos = {}
+        else:                                                                           # maenv:772-805
+            dones = {1: True, -1: True, "__all__": True}
+            obs = {1: self._obs_dict(vec.final_obs[0, 0], vec.mask[0], 1),
+                   -1: self._obs_dict(vec.final_obs[0, 1], vec.mask[0], -1)}
+            infos = {1: {}, -1: {}}
+            rew = vec.reward[0].cpu().numpy()
+            if flags[3]:
+                rewards = {1: 0, -1: 0}
+                for p in (1, -1):
+                    infos[p]['game_result_was_invalid'] = True
+                    infos[p]['game_result'] = 'tied'
+            else:
+                r1, r2 = np.float32(rew[0]), np.float32(rew[1])
+                for p in (1, -1):
+                    infos[p]['game_result_was_invalid'] = False
+                if r1 == 1:
+                    infos[1]['game_result'], infos[-1]['game_result'] = 'won', 'lost'
+                elif r1 == -1:
+                    infos[1]['game_result'], infos[-1]['game_result'] = 'lost', 'won'
+                else:
+                    infos[1]['game_result'], infos[-1]['game_result'] = 'tied', 'tied'
+                rewards = {1: r1, -1: r2}
+            if self.penalize_ties and infos[1]['game_result'] == 'tied':               # maenv:803-805
+                rewards = {1: -0.5, -1: -0.5}
+        if self.random_player_assignment:                                              # maenv:819-823
+            obs = {self.player_map(k): val for k, val in obs.items()}
+            rewards = {self.player_map(k): val for k, val in rewards.items()}
+            dones = {self.player_map(k): val for k, val in dones.items()}
+            infos = {self.player_map(k): val for k, val in infos.items()}
+        return obs, rewards, dones, infos
+
+    @staticmethod
+    def sample_random_valid_action(valid_actions_mask):                                # maenv:830-834
+        flat = np.reshape(valid_actions_mask, -1)
+        p = flat / np.sum(valid_actions_mask)
+        return np.random.choice(range(len(flat)), p=p)
+
+    def close(self):
+        self._vec.close()
+
+
+def make_stratego_env(env_config):                                                     # maenv:837-838
+    return StrategoMultiAgentEnv(env_config)

@@ -1,0 +1,36 @@
+"""Host-side logic of the drop-in facade that needs no GPU: reset-time RNG consumption vs the reference."""
+import json
+import os
+import random
+
+import numpy as np
+
+from stratego_env_amd import setups as S
+from stratego_env_amd.config import VARIANTS
+from tests.helpers import GOLDEN
+
+
+def test_reset_rng_consumption_matches_reference():
+    """np.random.seed(s); random.seed(s) must give the reference's setups and player relabelling (maenv:537-545)."""
+    cases = json.load(open(os.path.join(GOLDEN, 'facade_reset.json')))
+    for case in cases:
+        v = VARIANTS[case['version']]
+        table = S.load_setup_table(v.human_inits) if case['human_inits'] else None
+        np.random.seed(case['seed'])
+        random.seed(case['seed'])
+        for g in case['games']:
+            swap = not (np.random.random() < 0.5)          # maenv:538
+            m1, m2 = S.sample_initial_maps_like_reference(v, table)
+            assert (-1 if swap else 1) == g['first_key'], case
+            assert m1.tolist() == g['p1_map'] and m2.tolist() == g['p2_map'], (case['version'], case['seed'])
+
+
+def test_perspective_flip_matches_oracle():
+    from oracle import oracle as orc
+    from stratego_env_amd.multiagent_env import state_from_player_perspective
+    from tests.helpers import load_games
+    g = load_games('barrage')
+    ru = orc.OracleRules(10, 10)
+    for st in g['final_states'][:16].astype(np.int64):
+        assert np.array_equal(state_from_player_perspective(st, -1), ru.get_state_from_player_perspective(st, -1))
+        assert state_from_player_perspective(st, 1) is st
