@@ -40,6 +40,13 @@ int fail(int code, const char *fmt, const char *detail = "") {
 constexpr int OBS_CH = SGX_PO_OBS_CHANNELS;  // 67
 constexpr int LUT_STRIDE = SGX_OBS_LUT_STRIDE;
 constexpr int LUT_SIZE = OBS_CH * LUT_STRIDE;
+// Device placement of the LUT rows.  A wave renders 64 consecutive float4 "quads", so the lanes of one LDS
+// access hold channels 4q+j (mod 67): rows are placed so that bank(row(ch)) = (ch/4 + 17*(ch%4)) mod 32, which
+// makes the 32 lanes of an access group hit 32 different banks (a dense ch*16 layout put them all on 2 banks:
+// 78 % of LDS cycles were conflicts, profiles/r01_v1_*).
+constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 17 * LUT_ROW_PITCH /* 561, = 17 mod 32 */, LUT_DWORDS = 4 * LUT_BLK;  // 2244, a multiple of 4
+constexpr int WPB = 4;  // waves (= games) per workgroup; they share the LUT
+__host__ __device__ constexpr int lut_row(int ch) { return (ch & 3) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH; }
 
 // internal board indices inside an env record (each board is S bytes, absolute coordinates)
 constexpr int B_PIECES = 0;   // +pi : true pieces of player index pi (0 = player +1, 1 = player -1)   impl layers 0/1
@@ -72,7 +79,7 @@ struct Geo {
 };
 
 struct DevTables {
-    float obs_lut[LUT_SIZE];
+    float obs_lut[LUT_DWORDS];  // rows at lut_row(ch)
     uint8_t obstacles[SGX_MAX_CELLS];
 };
 
@@ -94,11 +101,11 @@ struct KParams {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// per-wave LDS: one game
 template <class G>
 struct alignas(16) Lds {
     int8_t b[N_BOARDS + 1][G::S];
-    alignas(16) uint8_t mask[G::NA_PAD];
-    alignas(16) float lut[LUT_SIZE];
+    alignas(16) uint8_t mask_region[G::NA_PAD + 16];  // mask lives at +mask_off so that LDS and global are co-aligned mod 16
     alignas(16) uint8_t cnt[G::CNT_PAD];
 };
 
@@ -126,14 +133,21 @@ __device__ inline int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // XCD-aware block -> env map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
 // range of envs so neighbouring envs' output lines meet in one L2.
-__device__ inline int64_t env_of_block(int64_t n_envs) {
+__device__ inline int64_t group_of_block() {
     const int64_t nb = gridDim.x, b = blockIdx.x;
     const int64_t chunk = nb >> 3;  // grid is a multiple of 8
     return (b & 7) * chunk + (b >> 3);
 }
 
+// Orders the LDS phases of ONE wave (each wave owns its game's LDS region; waves of a workgroup never exchange
+// data after the LUT is staged).  DS operations of a wave execute in issue order, so only the compiler has to be
+// kept from moving LDS accesses across the phase boundary.
 template <class G>
-__device__ inline void wave_sync() { __syncthreads(); }  // one wave per block: cheap, orders LDS phases
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // board holding observation channel `ch` for perspective player index qi (impl:1306-1332 + impl:645-675)
 __device__ inline int board_for_channel(int ch, int qi) {
@@ -155,7 +169,7 @@ __device__ inline int clamp15(int v) { return min(max(v, 0), 15); }
 // Observation render: float32 [R][C][67], perspective of player index qi  (impl:1335-1397, maenv:506-508)
 // ---------------------------------------------------------------------------------------------
 template <class G>
-__device__ void emit_obs(const Lds<G> &L, int qi, float *__restrict__ dst, int lane) {
+__device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__restrict__ dst, int lane) {
     constexpr int RC = G::RC, S = G::S;
     const int8_t *bb = &L.b[0][0];
     if constexpr (RC % 4 == 0) {
@@ -166,7 +180,7 @@ __device__ void emit_obs(const Lds<G> &L, int qi, float *__restrict__ dst, int l
         for (int j = 0; j < 4; ++j) {
             const int f = 4 * lane + j, rc = f / OBS_CH, ch = f - rc * OBS_CH;
             baddr[j] = board_for_channel(ch, qi) * S + (qi ? RC - 1 - rc : rc);
-            lrow[j] = ch * LUT_STRIDE;
+            lrow[j] = lut_row(ch);
             lbias[j] = lut_bias(ch);
         }
         const int step = qi ? -4 : 4;
@@ -174,10 +188,10 @@ __device__ void emit_obs(const Lds<G> &L, int qi, float *__restrict__ dst, int l
 #pragma unroll 5
         for (int s = 0; s < RC / 4; ++s) {
             f32x4 o;
-            o.x = L.lut[lrow[0] + clamp15(bb[baddr[0]] + lbias[0])];
-            o.y = L.lut[lrow[1] + clamp15(bb[baddr[1]] + lbias[1])];
-            o.z = L.lut[lrow[2] + clamp15(bb[baddr[2]] + lbias[2])];
-            o.w = L.lut[lrow[3] + clamp15(bb[baddr[3]] + lbias[3])];
+            o.x = lut[lrow[0] + clamp15(bb[baddr[0]] + lbias[0])];
+            o.y = lut[lrow[1] + clamp15(bb[baddr[1]] + lbias[1])];
+            o.z = lut[lrow[2] + clamp15(bb[baddr[2]] + lbias[2])];
+            o.w = lut[lrow[3] + clamp15(bb[baddr[3]] + lbias[3])];
             out[s * OBS_CH] = o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) baddr[j] += step;
@@ -190,7 +204,7 @@ __device__ void emit_obs(const Lds<G> &L, int qi, float *__restrict__ dst, int l
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ch = 55 + 4 * qd + j;
-                v[j] = L.lut[ch * LUT_STRIDE + clamp15(bb[board_for_channel(ch, qi) * S + cell] + lut_bias(ch))];
+                v[j] = lut[lut_row(ch) + clamp15(bb[board_for_channel(ch, qi) * S + cell] + lut_bias(ch))];
             }
             o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
             reinterpret_cast<f32x4 *>(dst)[s * OBS_CH + 64 + qd] = o;
@@ -200,7 +214,7 @@ __device__ void emit_obs(const Lds<G> &L, int qi, float *__restrict__ dst, int l
         for (int f = lane; f < G::NOBS; f += 64) {
             const int pcell = f / OBS_CH, ch = f - pcell * OBS_CH;
             const int cell = qi ? RC - 1 - pcell : pcell;
-            dst[f] = L.lut[ch * LUT_STRIDE + clamp15(bb[board_for_channel(ch, qi) * S + cell] + lut_bias(ch))];
+            dst[f] = lut[lut_row(ch) + clamp15(bb[board_for_channel(ch, qi) * S + cell] + lut_bias(ch))];
         }
     }
 }
@@ -210,11 +224,12 @@ __device__ void emit_obs(const Lds<G> &L, int qi, float *__restrict__ dst, int l
 // perspective cell).  Returns the number of valid moves (0 => the no-op byte was set).  impl:399-517
 // ---------------------------------------------------------------------------------------------
 template <class G>
-__device__ int gen_mask(Lds<G> &L, int qi, bool game_over, int lane) {
+__device__ int gen_mask(Lds<G> &L, int mask_off, int qi, bool game_over, int lane) {
+    uint8_t *mask = L.mask_region + mask_off;
     constexpr int R = G::R, C = G::C, RC = G::RC, K = G::K;
     {
         const int4 z = make_int4(0, 0, 0, 0);
-        for (int i = lane; i < G::NA_PAD / 16; i += 64) reinterpret_cast<int4 *>(L.mask)[i] = z;
+        for (int i = lane; i < (G::NA_PAD + 16) / 16; i += 64) reinterpret_cast<int4 *>(L.mask_region)[i] = z;
         for (int i = lane; i < G::CNT_PAD / 4; i += 64) reinterpret_cast<int *>(L.cnt)[i] = 0;
     }
     wave_sync<G>();
@@ -232,7 +247,7 @@ __device__ int gen_mask(Lds<G> &L, int qi, bool game_over, int lane) {
                     const int r = i / C, c = i - r * C;
                     const int pcell = qi ? RC - 1 - i : i;
                     const bool pinned = rec[i] == -3;  // JUST_ARRIVED_AND_CANT_DOUBLE_BACK
-                    uint8_t *mrow = L.mask + pcell * K;
+                    uint8_t *mrow = mask + pcell * K;
                     int n = 0;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
@@ -263,27 +278,44 @@ __device__ int gen_mask(Lds<G> &L, int qi, bool game_over, int lane) {
         total = uni(mine);
     }
     if (total == 0 && lane == 0) {
-        L.mask[K - 1] = 1;  // valid_moves_mask[0, 0, -1] (impl:514-515)
+        mask[K - 1] = 1;  // valid_moves_mask[0, 0, -1] (impl:514-515)
         L.cnt[0] = 1;
     }
     wave_sync<G>();
     return total;
 }
 
+// LDS mask -> global.  An env's mask starts at env*NA bytes: 4-byte but not 16-byte aligned (3700 = 4 mod 16), so
+// the LDS copy sits at the same offset mod 16 (L.mask_off) and whole 16-byte chunks move with one store per lane;
+// the partial first / last chunks go out as dwords.
 template <class G>
-__device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) {
+__device__ void emit_mask(const Lds<G> &L, int mask_off, uint8_t *__restrict__ dst, int lane) {
     if constexpr (G::NA % 4 == 0) {
-        const int *src = reinterpret_cast<const int *>(L.mask);
-        int *d = reinterpret_cast<int *>(dst);
-        for (int i = lane; i < G::NA / 4; i += 64) d[i] = src[i];
+        const int A = mask_off;                         // == (uintptr_t)dst & 15
+        const int nchunks = (A + G::NA + 15) >> 4;
+        const int4 *src = reinterpret_cast<const int4 *>(L.mask_region);
+        uint8_t *gbase = dst - A;                       // 16-byte aligned
+        for (int c = lane; c < nchunks; c += 64) {
+            const int lo = 16 * c, hi = lo + 16;
+            if (lo >= A && hi <= A + G::NA) {
+                reinterpret_cast<int4 *>(gbase)[c] = src[c];
+            } else {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int o = lo + 4 * w;
+                    if (o >= A && o < A + G::NA) *reinterpret_cast<int *>(gbase + o) = *reinterpret_cast<const int *>(L.mask_region + o);
+                }
+            }
+        }
     } else {
-        for (int i = lane; i < G::NA; i += 64) dst[i] = L.mask[i];
+        for (int i = lane; i < G::NA; i += 64) dst[i] = L.mask_region[mask_off + i];
     }
 }
 
 // k-th (0-based) valid action in ascending flat index order, from L.mask / L.cnt
 template <class G>
-__device__ int kth_valid(const Lds<G> &L, int k, int lane) {
+__device__ int kth_valid(const Lds<G> &L, int mask_off, int k, int lane) {
+    const uint8_t *mask = L.mask_region + mask_off;
     constexpr int K = G::K;
     int cell = 0, before = 0, run = 0;
     bool found = false;
@@ -307,7 +339,7 @@ __device__ int kth_valid(const Lds<G> &L, int k, int lane) {
     }
     cell = uni(cell);
     int kk = uni(k - before);
-    unsigned long long bits = __ballot(lane < K && L.mask[cell * K + (lane < K ? lane : 0)] != 0);
+    unsigned long long bits = __ballot(lane < K && mask[cell * K + (lane < K ? lane : 0)] != 0);
     for (int i = 0; i < kk; ++i) bits &= bits - 1;
     const int ch = __ffsll((long long)bits) - 1;
     return cell * K + ch;
@@ -373,22 +405,30 @@ __device__ inline int fmod_(int a, int b) { int m = a % b; return m < 0 ? m + b 
 // The step kernel: env.step() of N games (maenv:659-828), one wave per game
 // ---------------------------------------------------------------------------------------------
 template <int R_, int C_>
-__global__ __launch_bounds__(64) void step_kernel(const KParams P) {
+__global__ __launch_bounds__(64 * WPB) void step_kernel(const KParams P) {
     using G = Geo<R_, C_>;
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
-    __shared__ Lds<G> L;
-    const int lane = threadIdx.x;
-    const int64_t env = env_of_block(P.n_envs);
+    __shared__ Lds<G> LW[WPB];
+    __shared__ alignas(16) float lut_s[LUT_DWORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t env = group_of_block() * WPB + wave;
+
+    // ---- the workgroup's shared normalisation LUT (L2-resident source)
+    for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB)
+        reinterpret_cast<f32x4 *>(lut_s)[i] = reinterpret_cast<const f32x4 *>(P.tab->obs_lut)[i];
+    __syncthreads();   // the only workgroup-wide barrier; from here on every wave works on its own game
     if (env >= P.n_envs) return;
+    Lds<G> &L = LW[wave];
 
     int8_t *rec_g = P.boards + env * (int64_t)G::REC;
-    {   // ---- stage: state record, obstacle map, normalisation LUT -> LDS
+    {   // ---- stage: state record and obstacle map -> this wave's LDS
         const int4 *src = reinterpret_cast<const int4 *>(rec_g);
         int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
         for (int i = lane; i < G::REC / 16; i += 64) dst[i] = src[i];
         for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
-        for (int i = lane; i < LUT_SIZE / 4; i += 64) reinterpret_cast<f32x4 *>(L.lut)[i] = reinterpret_cast<const f32x4 *>(P.tab->obs_lut)[i];
     }
+    const float *lut = lut_s;
+    const int mask_off = (NA % 4 == 0) ? (int)((env * (int64_t)NA) & 15) : 0;
     const int4 sc = P.scal[env];
     int turn = uni(sc.x), flags = uni(sc.y), game_no = uni(sc.w);
     const int max_turns = uni(sc.z);
@@ -398,6 +438,7 @@ __global__ __launch_bounds__(64) void step_kernel(const KParams P) {
     bool over = (flags & F_OVER) != 0;
     bool applied = false, invalid_action = false, noop_path = false;
     int mover = player;
+    int dirty_s = -1, dirty_e = -1, dirty_cap_a = -1, dirty_cap_b = -1;   // cells / boards touched by the move
 
     if (P.mode == 0) {
         // ------------------------------------------------------------------------------------------
@@ -441,7 +482,7 @@ __global__ __launch_bounds__(64) void step_kernel(const KParams P) {
         if (valid && noop_path) {
             // no-op is legal only if the mover has no move (or the game is over); finished games stay unchanged
             if (!over) {
-                const int nmoves = gen_mask(L, pi, false, lane);
+                const int nmoves = gen_mask(L, mask_off, pi, false, lane);
                 if (nmoves != 0) valid = false;
                 else { turn += 1; over = true; flags |= F_OVER | (player == 1 ? F_WIN_M1 : F_WIN_P1); }  // impl:916-920
             }
@@ -504,6 +545,11 @@ __global__ __launch_bounds__(64) void step_kernel(const KParams P) {
                         if (wins || tied) L.b[B_CAP + 12 * (1 - pi) + dest - 1][e] += 1;   // impl:1006-1009
                     }
                 }
+                dirty_s = s; dirty_e = e;
+                if (dest != 0) {
+                    if (!wins) dirty_cap_a = B_CAP + 12 * pi + moved - 1;
+                    if (wins || tied) dirty_cap_b = B_CAP + 12 * (1 - pi) + dest - 1;
+                }
                 wave_sync<G>();
             }
         }
@@ -512,17 +558,17 @@ __global__ __launch_bounds__(64) void step_kernel(const KParams P) {
 
     // ---- next mover's mask; opponent-stuck and max-turn endings (impl:1031-1043)
     int qi = player == 1 ? 0 : 1;
-    int nvalid = gen_mask(L, qi, over, lane);
+    int nvalid = gen_mask(L, mask_off, qi, over, lane);
     bool ended_now = false;
     if (applied && !noop_path) {
         const bool was_over = over;
         if (nvalid == 0) { over = true; flags = (flags & ~(F_WIN_P1 | F_WIN_M1)) | F_OVER | (mover == 1 ? F_WIN_P1 : F_WIN_M1); }
         if (turn >= max_turns && !over) { over = true; flags |= F_OVER | F_END_INVALID; }
-        if (over && !was_over && nvalid != 0) nvalid = gen_mask(L, qi, true, lane);  // finished: mask shows the no-op only
+        if (over && !was_over && nvalid != 0) nvalid = gen_mask(L, mask_off, qi, true, lane);  // finished: mask shows the no-op only
         ended_now = over;
     } else if (applied && noop_path) {
         ended_now = over;
-        if (nvalid != 0) nvalid = gen_mask(L, qi, true, lane);
+        if (nvalid != 0) nvalid = gen_mask(L, mask_off, qi, true, lane);
     }
     flags = (flags & ~F_PLAYER_M1) | (player == -1 ? F_PLAYER_M1 : 0);
 
@@ -545,8 +591,8 @@ __global__ __launch_bounds__(64) void step_kernel(const KParams P) {
     // ---- terminal observations of both players (maenv:772-773)
     if (P.mode == 0 && ended_now && P.io.final_obs_dev) {
         float *fo = P.io.final_obs_dev + env * (int64_t)(2 * G::NOBS);
-        emit_obs(L, 0, fo, lane);
-        emit_obs(L, 1, fo + G::NOBS, lane);
+        emit_obs(L, lut, 0, fo, lane);
+        emit_obs(L, lut, 1, fo + G::NOBS, lane);
     }
 
     // ---- auto-reset: the finished env starts its next game now
@@ -555,28 +601,50 @@ __global__ __launch_bounds__(64) void step_kernel(const KParams P) {
         game_no += 1;
         sample_boards(L, P, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, lane);
         turn = 0; flags = 0; player = 1; qi = 0; over = false;
-        nvalid = gen_mask(L, 0, false, lane);
+        nvalid = gen_mask(L, mask_off, 0, false, lane);
         wrote_reset = true;
     }
 
     // ---- outputs for the next mover
     if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
-    if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
-    if (P.io.obs_dev) emit_obs(L, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
+    if (P.io.mask_dev) emit_mask(L, mask_off, P.io.mask_dev + env * (int64_t)NA, lane);
+    if (P.io.obs_dev) emit_obs(L, lut, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
     if (P.mode == 0 && P.io.next_actions_dev) {
         const int total = nvalid == 0 ? 1 : nvalid;
         const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, STREAM_ACTION, (uint32_t)turn), (uint32_t)total);
-        const int na = kth_valid(L, (int)k, lane);
+        const int na = kth_valid(L, mask_off, (int)k, lane);
         if (lane == 0) P.io.next_actions_dev[env] = na;
     }
 
-    // ---- write the record back
-    if (applied || wrote_reset) {
+    // ---- write back what changed: the whole record after a reset, otherwise the <= 11 touched bytes and the
+    //      mover's rebuilt recent-moves board (SURVEY 8d "compulsory write-back")
+    if (wrote_reset) {
         const int4 *src = reinterpret_cast<const int4 *>(&L.b[0][0]);
         int4 *dst = reinterpret_cast<int4 *>(rec_g);
         for (int i = lane; i < G::REC / 16; i += 64) dst[i] = src[i];
-        if (lane == 0) P.scal[env] = make_int4(turn, flags, max_turns, game_no);
+    } else if (applied && dirty_s >= 0) {
+        const int pi = mover == 1 ? 0 : 1;
+        int board = -1, cell = dirty_e;
+        switch (lane) {
+            case 0: board = B_PIECES + pi; cell = dirty_s; break;
+            case 1: board = B_PIECES + pi; break;
+            case 2: board = B_PIECES + 1 - pi; break;
+            case 3: board = B_PO + pi; cell = dirty_s; break;
+            case 4: board = B_PO + pi; break;
+            case 5: board = B_PO + 1 - pi; break;
+            case 6: board = B_STILL + pi; cell = dirty_s; break;
+            case 7: board = B_STILL + pi; break;
+            case 8: board = B_STILL + 1 - pi; break;
+            case 9: board = dirty_cap_a; break;
+            case 10: board = dirty_cap_b; break;
+            default: break;
+        }
+        if (board >= 0) rec_g[board * S + cell] = L.b[board][cell];
+        const int *rsrc = reinterpret_cast<const int *>(L.b[B_RECENT + pi]);
+        int *rdst = reinterpret_cast<int *>(rec_g + (B_RECENT + pi) * S);
+        for (int i = lane; i < S / 4; i += 64) rdst[i] = rsrc[i];
     }
+    if ((applied || wrote_reset) && lane == 0) P.scal[env] = make_int4(turn, flags, max_turns, game_no);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -631,9 +699,9 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
     if (env >= P.n_envs) return;
     const uint8_t *m = mask + env * (int64_t)NA;
     if constexpr (NA % 4 == 0) {
-        for (int i = lane; i < NA / 4; i += 64) reinterpret_cast<int *>(L.mask)[i] = reinterpret_cast<const int *>(m)[i];
+        for (int i = lane; i < NA / 4; i += 64) reinterpret_cast<int *>(L.mask_region)[i] = reinterpret_cast<const int *>(m)[i];
     } else {
-        for (int i = lane; i < NA; i += 64) L.mask[i] = m[i];
+        for (int i = lane; i < NA; i += 64) L.mask_region[i] = m[i];
     }
     wave_sync<G>();
     int mine = 0;
@@ -642,7 +710,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
         const int cell = lane + 64 * cc;
         int n = 0;
         if (cell < RC)
-            for (int c = 0; c < K; ++c) n += L.mask[cell * K + c] != 0;
+            for (int c = 0; c < K; ++c) n += L.mask_region[cell * K + c] != 0;
         L.cnt[cell] = (uint8_t)n;
         mine += n;
     }
@@ -654,7 +722,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
     int na = -1;
     if (total > 0) {
         const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)sc.w, STREAM_ACTION, (uint32_t)sc.x), (uint32_t)total);
-        na = kth_valid(L, (int)k, lane);
+        na = kth_valid(L, 0, (int)k, lane);
     }
     if (lane == 0) actions[env] = na;
 }
@@ -872,7 +940,12 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     h->K = 2 * (cfg->rows - 1) + 2 * (cfg->cols - 1) + 1;
     DevTables host_tab;
     memset(&host_tab, 0, sizeof(host_tab));
-    sgx_build_obs_lut(cfg, host_tab.obs_lut);
+    {   // ABI LUT [67][16] -> device placement (rows at lut_row(ch), see LUT_ROW_PITCH)
+        float dense[LUT_SIZE];
+        sgx_build_obs_lut(cfg, dense);
+        for (int ch = 0; ch < OBS_CH; ++ch)
+            for (int i = 0; i < LUT_STRIDE; ++i) host_tab.obs_lut[lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
+    }
     memcpy(host_tab.obstacles, cfg->obstacles, rc_cells);
     if (hipMalloc((void **)&h->boards, (size_t)n_envs * h->rec_bytes) != hipSuccess ||
         hipMalloc((void **)&h->scal, (size_t)n_envs * sizeof(int4)) != hipSuccess ||
@@ -931,7 +1004,7 @@ SGX_API int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p
 }
 
 static int launch_step(sgx_env *h, const KParams &p, void *stream) {
-#define CALL_STEP(R, C) step_kernel<R, C><<<grid_for(h->n_envs), 64, 0, (hipStream_t)stream>>>(p)
+#define CALL_STEP(R, C) step_kernel<R, C><<<grid_for((h->n_envs + WPB - 1) / WPB), 64 * WPB, 0, (hipStream_t)stream>>>(p)
     DISPATCH_GEOMETRY(h, CALL_STEP);
 #undef CALL_STEP
     HIP_TRY(hipGetLastError());
