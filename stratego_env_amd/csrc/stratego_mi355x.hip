@@ -41,12 +41,18 @@ constexpr int OBS_CH = SGX_PO_OBS_CHANNELS;  // 67
 constexpr int LUT_STRIDE = SGX_OBS_LUT_STRIDE;
 constexpr int LUT_SIZE = OBS_CH * LUT_STRIDE;
 // Device placement of the LUT rows.  A wave renders 64 consecutive float4 "quads", so the lanes of one LDS
-// access hold channels 4q+j (mod 67): rows are placed so that bank(row(ch)) = (ch/4 + 17*(ch%4)) mod 32, which
-// makes the 32 lanes of an access group hit 32 different banks (a dense ch*16 layout put them all on 2 banks:
-// 78 % of LDS cycles were conflicts, profiles/r01_v1_*).
-constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 17 * LUT_ROW_PITCH /* 561, = 17 mod 32 */, LUT_DWORDS = 4 * LUT_BLK;  // 2244, a multiple of 4
-constexpr int WPB = 4;  // waves (= games) per workgroup; they share the LUT
-__host__ __device__ constexpr int lut_row(int ch) { return (ch & 3) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH; }
+// access hold channels 4q+j (mod 67).  Rows are placed so that bank(row(ch)) = (ch/4 + {0,16,1,17}[ch%4]) mod 32:
+// the 32 lanes of an access group then hit 31-32 different banks (a dense ch*16 layout put them all on 2 banks:
+// 78 % of LDS cycles were bank conflicts, profiles/r01_v1_*).  Two 16-entry rows share each 33-dword pitch.
+constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 577 /* >= 17*33, = 1 mod 32 */, LUT_DWORDS = 2 * LUT_BLK + 2;  // 1156
+#ifndef SGX_WPB
+#define SGX_WPB 8
+#endif
+#ifndef SGX_MIN_WAVES
+#define SGX_MIN_WAVES 8
+#endif
+constexpr int WPB = SGX_WPB;  // waves (= games) per workgroup; they share the LUT
+__host__ __device__ constexpr int lut_row(int ch) { return ((ch >> 1) & 1) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH + (ch & 1) * 16; }
 
 // internal board indices inside an env record (each board is S bytes, absolute coordinates)
 constexpr int B_PIECES = 0;   // +pi : true pieces of player index pi (0 = player +1, 1 = player -1)   impl layers 0/1
@@ -71,6 +77,7 @@ struct Geo {
     static constexpr int K = 2 * (R - 1) + 2 * (C - 1) + 1;
     static constexpr int NA = RC * K;                 // spatial actions
     static constexpr int NA_PAD = (NA + 15) & ~15;
+    static constexpr int MB_WORDS = (((NA + 31) / 32 + 1) + 3) & ~3;  // mask as bits in LDS (+1 slack word), multiple of 4
     static constexpr int MPA = R + C;
     static constexpr int AS = RC * MPA + 1;           // 1-D action size (impl:252-254)
     static constexpr int NOBS = RC * OBS_CH;          // floats per observation
@@ -97,7 +104,23 @@ struct KParams {
     int64_t env_id_offset;
     sgx_step_io io;
     int32_t mode;  // 0 = step, 1 = observe
+#ifdef SGX_STAMPS
+    unsigned long long *stamps;  // diagnostic build only: [N][16] s_memtime stamps per phase
+#endif
 };
+
+#ifdef SGX_STAMPS
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (lane == 0 && P.stamps) P.stamps[env * 16 + (i)] = t_;                                  \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -105,8 +128,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <class G>
 struct alignas(16) Lds {
     int8_t b[N_BOARDS + 1][G::S];
-    alignas(16) uint8_t mask_region[G::NA_PAD + 16];  // mask lives at +mask_off so that LDS and global are co-aligned mod 16
-    alignas(16) uint8_t cnt[G::CNT_PAD];
+    alignas(16) uint32_t mbits[G::MB_WORDS];           // valid-actions mask of the next mover, one BIT per action
+    alignas(16) uint8_t cnt[G::CNT_PAD];               // valid moves per perspective cell (also setup-shuffle scratch)
+    alignas(16) uint8_t occ[G::S];                     // gen_mask scratch: combined occupancy byte per cell
+    alignas(16) uint8_t plist[G::CNT_PAD];             // gen_mask scratch: compacted list of movable cells
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -220,102 +245,131 @@ __device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__res
 }
 
 // ---------------------------------------------------------------------------------------------
-// Valid-actions mask of player index qi in qi's perspective, into L.mask (bytes) and L.cnt (per
-// perspective cell).  Returns the number of valid moves (0 => the no-op byte was set).  impl:399-517
+// Valid-actions mask of player index qi in qi's perspective, as BITS in L.mbits (bit a = flat action a) with
+// per-perspective-cell counts in L.cnt.  Returns the number of valid moves (0 => the no-op bit was set).
+// impl:399-517.  Work distribution: movable pieces are compacted, then every lane walks ONE ray
+// (piece, direction); a Barrage position (<= 7 movable pieces) is a single 64-lane pass of <= 9 steps.
 // ---------------------------------------------------------------------------------------------
 template <class G>
-__device__ int gen_mask(Lds<G> &L, int mask_off, int qi, bool game_over, int lane) {
-    uint8_t *mask = L.mask_region + mask_off;
+__device__ int gen_mask(Lds<G> &L, int qi, bool game_over, int lane) {
     constexpr int R = G::R, C = G::C, RC = G::RC, K = G::K;
+    constexpr int OCC_OWN = 1, OCC_ENEMY = 2, OCC_OBST = 4, OCC_CAME_FROM = 8;
+    const int8_t *own = L.b[B_PIECES + qi], *enemy = L.b[B_PIECES + 1 - qi], *rec = L.b[B_RECENT + qi], *obst = L.b[B_OBST];
     {
         const int4 z = make_int4(0, 0, 0, 0);
-        for (int i = lane; i < (G::NA_PAD + 16) / 16; i += 64) reinterpret_cast<int4 *>(L.mask_region)[i] = z;
+        for (int i = lane; i < G::MB_WORDS / 4; i += 64) reinterpret_cast<int4 *>(L.mbits)[i] = z;
         for (int i = lane; i < G::CNT_PAD / 4; i += 64) reinterpret_cast<int *>(L.cnt)[i] = 0;
     }
-    wave_sync<G>();
     int total = 0;
     if (!game_over) {
-        const int8_t *own = L.b[B_PIECES + qi], *enemy = L.b[B_PIECES + 1 - qi], *rec = L.b[B_RECENT + qi], *obst = L.b[B_OBST];
-        const int sgn = qi ? -1 : 1;  // perspective +r is absolute -r for player -1 (impl:678-695)
-        int mine = 0;
+        // pass 1: combined occupancy byte per cell (one LDS read per ray step) + compaction of movable pieces
+        int npieces = 0;
 #pragma unroll
         for (int cc = 0; cc < G::CPL; ++cc) {
             const int i = lane + 64 * cc;
+            bool movable = false;
             if (i < RC) {
                 const int t = own[i];
-                if (t != 0 && t != SP_FLAG && t != SP_BOMB) {
-                    const int r = i / C, c = i - r * C;
-                    const int pcell = qi ? RC - 1 - i : i;
-                    const bool pinned = rec[i] == -3;  // JUST_ARRIVED_AND_CANT_DOUBLE_BACK
-                    uint8_t *mrow = mask + pcell * K;
-                    int n = 0;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const int dr = (d == 0 ? sgn : d == 1 ? -sgn : 0), dc = (d == 2 ? sgn : d == 3 ? -sgn : 0);
-                        const int base = (d == 0 ? 0 : d == 1 ? R - 1 : d == 2 ? 2 * (R - 1) : 2 * (R - 1) + (C - 1));
-                        const int maxk = (t == SP_SCOUT) ? (d < 2 ? R - 1 : C - 1) : 1;
-                        int er = r, ec = c;
-                        for (int k = 1; k <= maxk; ++k) {
-                            er += dr; ec += dc;
-                            if (er < 0 || er >= R || ec < 0 || ec >= C) break;
-                            const int e = er * C + ec;
-                            if (obst[e] != 0 || own[e] != 0) break;
-                            const int en = enemy[e];
-                            if (pinned && rec[e] == 1 && en == 0) continue;  // two-square veto: skip, keep walking (impl:439-445)
-                            mrow[base + k - 1] = 1;
+                movable = t != 0 && t != SP_FLAG && t != SP_BOMB;
+                L.occ[i] = (uint8_t)((t != 0 ? OCC_OWN : 0) | (enemy[i] != 0 ? OCC_ENEMY : 0) | (obst[i] != 0 ? OCC_OBST : 0) |
+                                     (rec[i] == 1 ? OCC_CAME_FROM : 0));
+            }
+            const unsigned long long bm = __ballot(movable);
+            if (movable) L.plist[npieces + __popcll(bm & ((1ull << lane) - 1ull))] = (uint8_t)i;
+            npieces += __popcll(bm);
+        }
+        wave_sync<G>();
+        // pass 2: one ray per lane, perspective direction order +r, -r, +c, -c (impl:427-490 / 494-495)
+        const int sgn = qi ? -1 : 1;  // perspective +r is absolute -r for player -1 (impl:678-695)
+        const int nrays = 4 * npieces;
+        int mine = 0;
+        for (int j0 = 0; j0 < nrays; j0 += 64) {
+            const int j = j0 + lane;
+            const bool act = j < nrays;
+            const int i = act ? L.plist[j >> 2] : 0, d = j & 3;
+            const int t = own[i];
+            const int r = i / C, c = i - r * C;
+            const bool pinned = rec[i] == -3;  // JUST_ARRIVED_AND_CANT_DOUBLE_BACK
+            const int pcell = qi ? RC - 1 - i : i;
+            const int avail = d == 0 ? (qi ? r : R - 1 - r) : d == 1 ? (qi ? R - 1 - r : r) : d == 2 ? (qi ? c : C - 1 - c) : (qi ? C - 1 - c : c);
+            const int delta = d == 0 ? sgn * C : d == 1 ? -sgn * C : d == 2 ? sgn : -sgn;
+            const int bit0 = pcell * K + (d == 0 ? 0 : d == 1 ? R - 1 : d == 2 ? 2 * (R - 1) : 2 * (R - 1) + (C - 1)) - 1;
+            int lim = act ? (t == SP_SCOUT ? avail : min(avail, 1)) : 0;
+            int e = i, n = 0;
+            for (int k = 1; k < (R > C ? R : C); ++k) {
+                if (!__any(k <= lim)) break;
+                if (k <= lim) {
+                    e += delta;
+                    const int v = L.occ[e];
+                    if (v & (OCC_OWN | OCC_OBST)) {
+                        lim = 0;                                                  // blocked: the ray stops
+                    } else {
+                        // two-square veto: this cell is skipped but the ray goes on (impl:439-445)
+                        if (!(pinned && (v & OCC_CAME_FROM) && !(v & OCC_ENEMY))) {
+                            const int bit = bit0 + k;
+                            atomicOr(&L.mbits[bit >> 5], 1u << (bit & 31));
                             ++n;
-                            if (en != 0) break;
                         }
+                        if (v & OCC_ENEMY) lim = 0;                               // an attacked piece ends the ray
                     }
-                    L.cnt[pcell] = (uint8_t)n;
-                    mine += n;
                 }
             }
+            n += __shfl_xor(n, 1);
+            n += __shfl_xor(n, 2);                                                // moves of the piece = its 4 rays
+            if (act && d == 0) { L.cnt[pcell] = (uint8_t)n; mine += n; }
         }
-        // wave sum
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
         total = uni(mine);
     }
     if (total == 0 && lane == 0) {
-        mask[K - 1] = 1;  // valid_moves_mask[0, 0, -1] (impl:514-515)
+        L.mbits[(K - 1) >> 5] = 1u << ((K - 1) & 31);  // valid_moves_mask[0, 0, -1] (impl:514-515); mbits was just zeroed
         L.cnt[0] = 1;
     }
     wave_sync<G>();
     return total;
 }
 
-// LDS mask -> global.  An env's mask starts at env*NA bytes: 4-byte but not 16-byte aligned (3700 = 4 mod 16), so
-// the LDS copy sits at the same offset mod 16 (L.mask_off) and whole 16-byte chunks move with one store per lane;
-// the partial first / last chunks go out as dwords.
+// 4 mask bits -> 4 mask bytes
+__device__ inline uint32_t expand4(uint32_t nib) { return (nib * 0x00204081u) & 0x01010101u; }
+// `n` (<= 32) mask bits starting at bit position p
 template <class G>
-__device__ void emit_mask(const Lds<G> &L, int mask_off, uint8_t *__restrict__ dst, int lane) {
+__device__ inline uint32_t mask_bits(const Lds<G> &L, int p, int n) {
+    const unsigned long long w = (unsigned long long)L.mbits[p >> 5] | ((unsigned long long)L.mbits[(p >> 5) + 1] << 32);
+    return (uint32_t)(w >> (p & 31)) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
+}
+
+// LDS mask bits -> global uint8 [R,C,K].  An env's mask starts at env*NA bytes: 4-byte but not 16-byte aligned
+// (3700 = 4 mod 16); lanes own 16-byte-aligned chunks of the global range, so whole chunks leave as one 16-byte
+// store per lane and only the partial first / last chunks go out as dwords.
+template <class G>
+__device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) {
     if constexpr (G::NA % 4 == 0) {
-        const int A = mask_off;                         // == (uintptr_t)dst & 15
+        const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
         const int nchunks = (A + G::NA + 15) >> 4;
-        const int4 *src = reinterpret_cast<const int4 *>(L.mask_region);
         uint8_t *gbase = dst - A;                       // 16-byte aligned
         for (int c = lane; c < nchunks; c += 64) {
-            const int lo = 16 * c, hi = lo + 16;
-            if (lo >= A && hi <= A + G::NA) {
-                reinterpret_cast<int4 *>(gbase)[c] = src[c];
+            const int lo = 16 * c - A;                  // first mask byte of this chunk
+            if (lo >= 0 && lo + 16 <= G::NA) {
+                const uint32_t b16 = mask_bits(L, lo, 16);
+                reinterpret_cast<int4 *>(gbase)[c] = make_int4((int)expand4(b16 & 15), (int)expand4((b16 >> 4) & 15),
+                                                               (int)expand4((b16 >> 8) & 15), (int)expand4(b16 >> 12));
             } else {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const int o = lo + 4 * w;
-                    if (o >= A && o < A + G::NA) *reinterpret_cast<int *>(gbase + o) = *reinterpret_cast<const int *>(L.mask_region + o);
+                    if (o >= 0 && o < G::NA) *reinterpret_cast<uint32_t *>(dst + o) = expand4(mask_bits(L, o, 4));
                 }
             }
         }
     } else {
-        for (int i = lane; i < G::NA; i += 64) dst[i] = L.mask_region[mask_off + i];
+        for (int i = lane; i < G::NA; i += 64) dst[i] = (uint8_t)((L.mbits[i >> 5] >> (i & 31)) & 1u);
     }
 }
 
-// k-th (0-based) valid action in ascending flat index order, from L.mask / L.cnt
+// k-th (0-based) valid action in ascending flat index order, from L.mbits / L.cnt
 template <class G>
-__device__ int kth_valid(const Lds<G> &L, int mask_off, int k, int lane) {
-    const uint8_t *mask = L.mask_region + mask_off;
+__device__ int kth_valid(const Lds<G> &L, int k, int lane) {
     constexpr int K = G::K;
     int cell = 0, before = 0, run = 0;
     bool found = false;
@@ -339,7 +393,8 @@ __device__ int kth_valid(const Lds<G> &L, int mask_off, int k, int lane) {
     }
     cell = uni(cell);
     int kk = uni(k - before);
-    unsigned long long bits = __ballot(lane < K && mask[cell * K + (lane < K ? lane : 0)] != 0);
+    const int p = cell * K + (lane < K ? lane : 0);
+    unsigned long long bits = __ballot(lane < K && ((L.mbits[p >> 5] >> (p & 31)) & 1u) != 0);
     for (int i = 0; i < kk; ++i) bits &= bits - 1;
     const int ch = __ffsll((long long)bits) - 1;
     return cell * K + ch;
@@ -404,8 +459,17 @@ __device__ inline int fmod_(int a, int b) { int m = a % b; return m < 0 ? m + b 
 // ---------------------------------------------------------------------------------------------
 // The step kernel: env.step() of N games (maenv:659-828), one wave per game
 // ---------------------------------------------------------------------------------------------
+// waves per SIMD this geometry can reach: LDS per workgroup = WPB game regions + the shared LUT, 160 KiB per CU
+template <class G>
+constexpr int waves_per_simd() {
+    constexpr int per_wg = WPB * (int)sizeof(Lds<G>) + LUT_DWORDS * 4;
+    constexpr int wgs = (160 * 1024) / per_wg;
+    constexpr int w = wgs * WPB / 4;
+    return w > SGX_MIN_WAVES ? SGX_MIN_WAVES : (w < 1 ? 1 : w);
+}
+
 template <int R_, int C_>
-__global__ __launch_bounds__(64 * WPB) void step_kernel(const KParams P) {
+__global__ __launch_bounds__(64 * WPB, waves_per_simd<Geo<R_, C_>>()) void step_kernel(const KParams P) {
     using G = Geo<R_, C_>;
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     __shared__ Lds<G> LW[WPB];
@@ -419,6 +483,7 @@ __global__ __launch_bounds__(64 * WPB) void step_kernel(const KParams P) {
     __syncthreads();   // the only workgroup-wide barrier; from here on every wave works on its own game
     if (env >= P.n_envs) return;
     Lds<G> &L = LW[wave];
+    STAMP(0);
 
     int8_t *rec_g = P.boards + env * (int64_t)G::REC;
     {   // ---- stage: state record and obstacle map -> this wave's LDS
@@ -428,11 +493,11 @@ __global__ __launch_bounds__(64 * WPB) void step_kernel(const KParams P) {
         for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
     }
     const float *lut = lut_s;
-    const int mask_off = (NA % 4 == 0) ? (int)((env * (int64_t)NA) & 15) : 0;
     const int4 sc = P.scal[env];
     int turn = uni(sc.x), flags = uni(sc.y), game_no = uni(sc.w);
     const int max_turns = uni(sc.z);
     wave_sync<G>();
+    STAMP(1);   // state staged
 
     int player = (flags & F_PLAYER_M1) ? -1 : 1;
     bool over = (flags & F_OVER) != 0;
@@ -482,26 +547,26 @@ __global__ __launch_bounds__(64 * WPB) void step_kernel(const KParams P) {
         if (valid && noop_path) {
             // no-op is legal only if the mover has no move (or the game is over); finished games stay unchanged
             if (!over) {
-                const int nmoves = gen_mask(L, mask_off, pi, false, lane);
+                const int nmoves = gen_mask(L, pi, false, lane);
                 if (nmoves != 0) valid = false;
                 else { turn += 1; over = true; flags |= F_OVER | (player == 1 ? F_WIN_M1 : F_WIN_P1); }  // impl:916-920
             }
         } else if (valid) {
-            // ---- _is_move_valid_by_position (impl:723-798)
-            int s = 0, e = 0, t = 0;
+            // ---- _is_move_valid_by_position (impl:723-798).  All board bytes the checks (and the move) need are read
+            //      up front from clamped cell indices, so the wave pays one LDS round trip instead of ten dependent ones.
+            const bool s_in = !(sc_ < 0 || sc_ >= C || sr < 0 || sr >= R), e_in = !(ec < 0 || ec >= C || er < 0 || er >= R);
+            const int s = s_in ? sr * C + sc_ : 0, e = e_in ? er * C + ec : 0;
+            const int v_obst_s = obst[s], v_obst_e = obst[e], v_own_s = own[s], v_own_e = own[e], v_en_e = enemy[e];
+            const int v_rec_s = recent[s], v_rec_e = recent[e], v_po_s = own_po[s];
+            const int obst_s = uni(v_obst_s), obst_e = uni(v_obst_e), t = uni(v_own_s), own_e = uni(v_own_e);
+            const int dest = uni(v_en_e), old_start = uni(v_rec_s), old_end = uni(v_rec_e), moved_po = uni(v_po_s);
             if (over) valid = false;
-            if (valid && (sc_ < 0 || sc_ >= C || sr < 0 || sr >= R)) valid = false;
-            if (valid) { s = sr * C + sc_; if (uni(obst[s]) != 0) valid = false; }
-            if (valid && (ec < 0 || ec >= C || er < 0 || er >= R)) valid = false;
-            if (valid) { e = er * C + ec; if (uni(obst[e]) != 0) valid = false; }
-            if (valid) { t = uni(own[s]); if (t == 0 || t == SP_FLAG || t == SP_BOMB) valid = false; }
-            if (valid && uni(own[e]) != 0) valid = false;
-            if (valid && er != sr && ec != sc_) valid = false;
-            int dest = 0;
-            if (valid) {
-                dest = uni(enemy[e]);
-                if (uni(recent[s]) == -3 && uni(recent[e]) == 1 && dest == 0) valid = false;
-            }
+            if (!s_in || obst_s != 0) valid = false;
+            if (!e_in || obst_e != 0) valid = false;
+            if (t == 0 || t == SP_FLAG || t == SP_BOMB) valid = false;
+            if (own_e != 0) valid = false;
+            if (er != sr && ec != sc_) valid = false;
+            if (old_start == -3 && old_end == 1 && dest == 0) valid = false;
             if (valid) {
                 const int dist = (er != sr) ? abs(er - sr) : abs(ec - sc_);
                 if (t == SP_SCOUT) {
@@ -514,8 +579,7 @@ __global__ __launch_bounds__(64 * WPB) void step_kernel(const KParams P) {
             }
             if (valid) {
                 // ---- _get_next_state (impl:905-1028)
-                const int moved = t, moved_po = uni(own_po[s]);
-                const int old_end = uni(recent[e]), old_start = uni(recent[s]);
+                const int moved = t;
                 turn += 1;
                 bool wins = false, tied = false;
                 if (dest != 0) {
@@ -556,21 +620,23 @@ __global__ __launch_bounds__(64 * WPB) void step_kernel(const KParams P) {
         if (valid) { applied = true; player = -player; } else invalid_action = true;
     }
 
+    STAMP(2);   // move applied
     // ---- next mover's mask; opponent-stuck and max-turn endings (impl:1031-1043)
     int qi = player == 1 ? 0 : 1;
-    int nvalid = gen_mask(L, mask_off, qi, over, lane);
+    int nvalid = gen_mask(L, qi, over, lane);
     bool ended_now = false;
     if (applied && !noop_path) {
         const bool was_over = over;
         if (nvalid == 0) { over = true; flags = (flags & ~(F_WIN_P1 | F_WIN_M1)) | F_OVER | (mover == 1 ? F_WIN_P1 : F_WIN_M1); }
         if (turn >= max_turns && !over) { over = true; flags |= F_OVER | F_END_INVALID; }
-        if (over && !was_over && nvalid != 0) nvalid = gen_mask(L, mask_off, qi, true, lane);  // finished: mask shows the no-op only
+        if (over && !was_over && nvalid != 0) nvalid = gen_mask(L, qi, true, lane);  // finished: mask shows the no-op only
         ended_now = over;
     } else if (applied && noop_path) {
         ended_now = over;
-        if (nvalid != 0) nvalid = gen_mask(L, mask_off, qi, true, lane);
+        if (nvalid != 0) nvalid = gen_mask(L, qi, true, lane);
     }
     flags = (flags & ~F_PLAYER_M1) | (player == -1 ? F_PLAYER_M1 : 0);
+    STAMP(3);   // mask generated
 
     // ---- rewards / dones (maenv:699-805)
     const bool done = over;
@@ -601,21 +667,25 @@ __global__ __launch_bounds__(64 * WPB) void step_kernel(const KParams P) {
         game_no += 1;
         sample_boards(L, P, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, lane);
         turn = 0; flags = 0; player = 1; qi = 0; over = false;
-        nvalid = gen_mask(L, mask_off, 0, false, lane);
+        nvalid = gen_mask(L, 0, false, lane);
         wrote_reset = true;
     }
 
+    STAMP(4);   // results / terminal handling done
     // ---- outputs for the next mover
     if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
-    if (P.io.mask_dev) emit_mask(L, mask_off, P.io.mask_dev + env * (int64_t)NA, lane);
+    if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
+    STAMP(5);   // mask stores issued
     if (P.io.obs_dev) emit_obs(L, lut, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
+    STAMP(6);   // obs stores issued
     if (P.mode == 0 && P.io.next_actions_dev) {
         const int total = nvalid == 0 ? 1 : nvalid;
         const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, STREAM_ACTION, (uint32_t)turn), (uint32_t)total);
-        const int na = kth_valid(L, mask_off, (int)k, lane);
+        const int na = kth_valid(L, (int)k, lane);
         if (lane == 0) P.io.next_actions_dev[env] = na;
     }
 
+    STAMP(7);   // next action sampled
     // ---- write back what changed: the whole record after a reset, otherwise the <= 11 touched bytes and the
     //      mover's rebuilt recent-moves board (SURVEY 8d "compulsory write-back")
     if (wrote_reset) {
@@ -645,6 +715,11 @@ __global__ __launch_bounds__(64 * WPB) void step_kernel(const KParams P) {
         for (int i = lane; i < S / 4; i += 64) rdst[i] = rsrc[i];
     }
     if ((applied || wrote_reset) && lane == 0) P.scal[env] = make_int4(turn, flags, max_turns, game_no);
+    STAMP(8);   // write-back issued
+#ifdef SGX_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(9);   // all stores acknowledged
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -698,11 +773,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
     const int64_t env = blockIdx.x;
     if (env >= P.n_envs) return;
     const uint8_t *m = mask + env * (int64_t)NA;
-    if constexpr (NA % 4 == 0) {
-        for (int i = lane; i < NA / 4; i += 64) reinterpret_cast<int *>(L.mask_region)[i] = reinterpret_cast<const int *>(m)[i];
-    } else {
-        for (int i = lane; i < NA; i += 64) L.mask_region[i] = m[i];
-    }
+    for (int i = lane; i < G::MB_WORDS; i += 64) L.mbits[i] = 0;
     wave_sync<G>();
     int mine = 0;
 #pragma unroll
@@ -710,7 +781,12 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
         const int cell = lane + 64 * cc;
         int n = 0;
         if (cell < RC)
-            for (int c = 0; c < K; ++c) n += L.mask_region[cell * K + c] != 0;
+            for (int c = 0; c < K; ++c)
+                if (m[cell * K + c] != 0) {
+                    const int bit = cell * K + c;
+                    atomicOr(&L.mbits[bit >> 5], 1u << (bit & 31));
+                    ++n;
+                }
         L.cnt[cell] = (uint8_t)n;
         mine += n;
     }
@@ -722,7 +798,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
     int na = -1;
     if (total > 0) {
         const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)sc.w, STREAM_ACTION, (uint32_t)sc.x), (uint32_t)total);
-        na = kth_valid(L, 0, (int)k, lane);
+        na = kth_valid(L, (int)k, lane);
     }
     if (lane == 0) actions[env] = na;
 }
@@ -825,6 +901,7 @@ struct sgx_env {
     int64_t n_setups;
     int rec_bytes;
     int K;
+    unsigned long long *stamps;  // SGX_STAMPS builds only
 };
 
 namespace {
@@ -861,6 +938,9 @@ KParams make_params(const sgx_env *h) {
     p.n_envs = h->n_envs;
     p.seed = h->seed;
     p.env_id_offset = h->env_id_offset;
+#ifdef SGX_STAMPS
+    p.stamps = h->stamps;
+#endif
     return p;
 }
 
@@ -955,6 +1035,10 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     }
     HIP_TRY(hipMemset(h->boards, 0, (size_t)n_envs * h->rec_bytes));
     HIP_TRY(hipMemcpy(h->tab, &host_tab, sizeof(DevTables), hipMemcpyHostToDevice));
+#ifdef SGX_STAMPS
+    HIP_TRY(hipMalloc((void **)&h->stamps, (size_t)n_envs * 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->stamps, 0, (size_t)n_envs * 16 * sizeof(unsigned long long)));
+#endif
     init_scal_kernel<<<(unsigned)((n_envs + 255) / 256), 256>>>(h->scal, n_envs, cfg->max_turns);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -970,6 +1054,7 @@ SGX_API int sgx_destroy(sgx_env *h) {
     if (h->scal) hipFree(h->scal);
     if (h->tab) hipFree(h->tab);
     if (h->setups) hipFree(h->setups);
+    if (h->stamps) hipFree(h->stamps);
     delete h;
     return SGX_OK;
 }
@@ -1072,3 +1157,8 @@ SGX_API int sgx_get_env_info(sgx_env *h, int32_t *info_dev, void *stream) {
     HIP_TRY(hipGetLastError());
     return SGX_OK;
 }
+
+#ifdef SGX_STAMPS
+// diagnostic build only (tools/phase_stamps.py): device pointer of the [N][16] stamp buffer
+SGX_API void *sgx_debug_stamps(sgx_env *h) { return h ? (void *)h->stamps : nullptr; }
+#endif
