@@ -37,6 +37,31 @@ def b_alg(rows, cols):
     return (32 * rc + 16) + (rc + 16) + 4 + 4 * 67 * rc + rc * k + 12
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU boxes show
+    256 logical CPUs but run under a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def measured_traffic(version, n_envs):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+        e = t.get(version)
+        if e and e['games_per_launch'] == n_envs:
+            return e['hbm_bytes_per_launch']
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(version, seed, target_seconds):
     """Time the oracle's rollout harness (same workload rule) on the host cores; bounded to ~target_seconds."""
     from oracle import oracle as orc   # checker / baseline only
@@ -46,7 +71,7 @@ def cpu_baseline(version, seed, target_seconds):
     table = S.load_setup_table(v.human_inits) if v.human_inits else None
     cv = orc.make_cvariant(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts,
                            v.initial_state_usable_rows, setups=table)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = usable_cores()
     t0 = time.perf_counter()
     n_probe, t_probe = 4 * cores, 128
     total, _, _ = orc.rollout(cv, seed, 0, n_probe, t_probe, threads=cores)
@@ -58,8 +83,8 @@ def cpu_baseline(version, seed, target_seconds):
     total, _, _ = orc.rollout(cv, seed, 0, n_envs, n_steps, threads=cores)
     dt = time.perf_counter() - t0
     return {"value": total / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": "%d %s games x %d steps (envs 0..%d of the same seeded workload), OpenMP over games, %.1f s"
-                      % (n_envs, version, n_steps, n_envs - 1, dt)}
+            "sample": "%d %s games x %d steps (envs 0..%d of the same seeded workload), oracle C port with OpenMP over "
+                      "games on %d threads, %.1f s" % (n_envs, version, n_steps, n_envs - 1, cores, dt)}
 
 
 def main():
@@ -73,6 +98,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
+    ap.add_argument('--wake-seconds', type=float, default=2.0,
+                    help='untimed GPU wake-up before the warmup steps (a fresh box runs its first ~second at idle clocks)')
     args = ap.parse_args()
 
     import torch
@@ -89,6 +116,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    if args.wake_seconds > 0:   # bring the GPU out of its idle power state; touches no env state
+        scratch = torch.empty(1 << 28, dtype=torch.float32, device='cuda')
+        t_wake = time.perf_counter()
+        while time.perf_counter() - t_wake < args.wake_seconds:
+            scratch.fill_(1.0)
+            torch.cuda.synchronize()
+        del scratch
 
     from stratego_env_amd.config import VARIANTS
     from stratego_env_amd.vec_env import VecStrategoEnv
@@ -152,7 +187,8 @@ def main():
                        "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": args.traffic_bytes, "kernel": "step_kernel<%d,%d>" % (v.rows, v.columns),
+                         "traffic": args.traffic_bytes if args.traffic_bytes is not None else measured_traffic(args.version, n),
+                         "kernel": "step_kernel<%d,%d>" % (v.rows, v.columns),
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
         if not args.no_cpu_baseline:

@@ -36,19 +36,11 @@ class SgxError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load the HIP library; raises if it has not been built (no fallback path exists)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise SgxError("libstratego_mi355x.so is not built (%s missing). Run `python -m stratego_env_amd.build` "
-                       "or __graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
-    vp, i64, i32, u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64
+def _bind(L):
+    vp, i64, u64 = C.c_void_p, C.c_int64, C.c_uint64
     L.sgx_abi_version.restype = C.c_int
     L.sgx_abi_version.argtypes = []
     L.sgx_last_error.restype = C.c_char_p
@@ -83,13 +75,26 @@ def load():
     L.sgx_import_state.argtypes = [vp, vp, vp, vp]
     L.sgx_get_env_info.restype = C.c_int
     L.sgx_get_env_info.argtypes = [vp, vp, vp]
-    _lib = L
     return L
 
 
-def check(rc):
+def load(path=None):
+    """Load the HIP library; raises if it has not been built (no fallback path exists).
+
+    `path` / $SGX_LIB_PATH select an alternative build of the same library (kernel experiments only)."""
+    path = path or os.environ.get('SGX_LIB_PATH', LIB_PATH)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise SgxError("libstratego_mi355x.so is not built (%s missing). Run `python -m stratego_env_amd.build` "
+                       "or __graft_entry__.build(); there is no CPU fallback." % path)
+    _libs[path] = _bind(C.CDLL(path))
+    return _libs[path]
+
+
+def check(rc, lib=None):
     if rc != 0:
-        raise SgxError("libstratego_mi355x error %d: %s" % (rc, load().sgx_last_error().decode('utf-8', 'replace')))
+        raise SgxError("libstratego_mi355x error %d: %s" % (rc, (lib or load()).sgx_last_error().decode('utf-8', 'replace')))
 
 
 def make_config(variant) -> SgxConfig:

@@ -469,7 +469,7 @@ constexpr int waves_per_simd() {
 }
 
 template <int R_, int C_>
-__global__ __launch_bounds__(64 * WPB, waves_per_simd<Geo<R_, C_>>()) void step_kernel(const KParams P) {
+__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void step_kernel(const KParams P) {
     using G = Geo<R_, C_>;
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     __shared__ Lds<G> LW[WPB];

@@ -30,12 +30,12 @@ def _ptr(t):
 
 class VecStrategoEnv:
     def __init__(self, version='barrage', num_envs=1, device=0, seed=0, env_id_offset=0, human_inits=None,
-                 auto_reset=False, final_obs=False):
+                 auto_reset=False, final_obs=False, lib_path=None):
         """human_inits: None = use the Gravon table when the variant has one (util.py:301-319), False = uniformly
         random back-row placement (util.py:33-53), True = require the table."""
         if not torch.cuda.is_available():
             raise _lib.SgxError("VecStrategoEnv needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
-        self._L = _lib.load()
+        self._L = _lib.load(lib_path)
         self.variant = get_variant(version)
         v = self.variant
         self.num_envs = int(num_envs)
