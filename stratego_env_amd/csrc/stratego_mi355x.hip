@@ -49,7 +49,7 @@ constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 577 /* >= 17*33, = 1 mod 32 */, LUT_
 #define SGX_WPB 8
 #endif
 #ifndef SGX_MIN_WAVES
-#define SGX_MIN_WAVES 8
+#define SGX_MIN_WAVES 6
 #endif
 constexpr int WPB = SGX_WPB;  // waves (= games) per workgroup; they share the LUT
 __host__ __device__ constexpr int lut_row(int ch) { return ((ch >> 1) & 1) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH + (ch & 1) * 16; }
@@ -210,7 +210,10 @@ __device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__res
         }
         const int step = qi ? -4 : 4;
         f32x4 *out = reinterpret_cast<f32x4 *>(dst) + lane;
-#pragma unroll 5
+#ifndef SGX_OBS_UNROLL
+#define SGX_OBS_UNROLL 5
+#endif
+#pragma unroll SGX_OBS_UNROLL
         for (int s = 0; s < RC / 4; ++s) {
             f32x4 o;
             o.x = lut[lrow[0] + clamp15(bb[baddr[0]] + lbias[0])];

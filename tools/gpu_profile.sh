@@ -7,6 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
+python3 -c "import torch,time; x=torch.empty(1<<28,device='cuda'); t=time.time()
+while time.time()-t<3: x.fill_(1.0); torch.cuda.synchronize()"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 64 --warmup 8 --no-cpu-baseline "$@" > $OUT/stats.log 2>&1
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" \
