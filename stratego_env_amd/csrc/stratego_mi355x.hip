@@ -57,13 +57,17 @@ __host__ __device__ constexpr int lut_row(int ch) { return ((ch >> 1) & 1) * LUT
 // internal board indices inside an env record (each board is S bytes, absolute coordinates)
 constexpr int B_PIECES = 0;   // +pi : true pieces of player index pi (0 = player +1, 1 = player -1)   impl layers 0/1
 constexpr int B_PO = 2;       // +pi : what the opponent knows of pi's pieces                           impl layers 3/4
-constexpr int B_RECENT = 4;   // +pi : two-square bookkeeping                                           impl layers 6/7
-constexpr int B_STILL = 6;    // +pi : never-moved flags                                                impl layers 32/33
-constexpr int B_CAP = 8;      // +12*pi + (type-1) : captured counts                                    impl layers 8-19 / 20-31
+constexpr int B_STILL = 4;    // +pi : never-moved flags                                                impl layers 32/33
+constexpr int B_RECENT = 6;   // +pi : two-square bookkeeping (LDS only, rebuilt from scal)             impl layers 6/7
+constexpr int B_CAP = 8;      // +12*pi + (type-1) : captured counts (LDS only, rebuilt from events)    impl layers 8-19 / 20-31
 constexpr int N_BOARDS = 32;
+constexpr int STORED_BOARDS = 6;  // boards 0..5 live in HBM; recent-moves and captured counts are stored sparsely:
+//   recent moves: at most two non-zero cells per player (impl:1013-1028)  -> two (cell, code) pairs per player in scal
+//   captured counts: one event (board - B_CAP, cell) per captured piece   -> uint16 list, <= 2 * pieces per side entries
 constexpr int B_OBST = 32;    // LDS only: per-variant obstacle map (impl layer 2)
 
-// scal[env] = {turn, flags, max_turns, game_no}
+// scal[2*env] = {turn, flags, max_turns, game_no}; scal[2*env+1] = {n_events, recent pairs of +1, recent pairs of -1, 0}
+// a recent pair is cell | (code & 0xFF) << 8, two pairs per int (low / high half); code 0 = empty
 constexpr int F_OVER = 1, F_WIN_P1 = 2, F_WIN_M1 = 4, F_END_INVALID = 8, F_PLAYER_M1 = 16;
 
 enum { SP_SPY = 1, SP_SCOUT = 2, SP_MINER = 3, SP_MARSHALL = 10, SP_FLAG = 11, SP_BOMB = 12, SP_UNKNOWN = 13 };
@@ -73,7 +77,8 @@ struct Geo {
     static constexpr int R = R_, C = C_;
     static constexpr int RC = R * C;
     static constexpr int S = (RC + 3) & ~3;           // board stride (bytes)
-    static constexpr int REC = N_BOARDS * S;          // bytes of one env record (multiple of 128)
+    static constexpr int LDS_BOARDS_BYTES = N_BOARDS * S;            // bytes of the 32 LDS boards (multiple of 128)
+    static constexpr int EV_OFF = (STORED_BOARDS * S + 15) & ~15;    // HBM record: 6 dense boards, zero padding, then events
     static constexpr int K = 2 * (R - 1) + 2 * (C - 1) + 1;
     static constexpr int NA = RC * K;                 // spatial actions
     static constexpr int NA_PAD = (NA + 15) & ~15;
@@ -99,6 +104,8 @@ struct KParams {
     int32_t max_turns;
     int32_t usable_rows;
     int32_t piece_counts[12];
+    int32_t rec_bytes;   // bytes of one env record in HBM: EV_OFF + 2 * max_events rounded up to 16
+    int32_t max_events;
     int64_t n_envs;
     uint64_t seed;
     int64_t env_id_offset;
@@ -123,6 +130,14 @@ struct KParams {
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// streaming stores of the big outputs (written once per step, read by a later kernel)
+#ifdef SGX_NT_STORES
+template <class T> __device__ inline void stream_store(T *p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> __device__ inline void stream_store(T *p, T v) { *p = v; }
+#endif
 
 // per-wave LDS: one game
 template <class G>
@@ -220,7 +235,7 @@ __device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__res
             o.y = lut[lrow[1] + clamp15(bb[baddr[1]] + lbias[1])];
             o.z = lut[lrow[2] + clamp15(bb[baddr[2]] + lbias[2])];
             o.w = lut[lrow[3] + clamp15(bb[baddr[3]] + lbias[3])];
-            out[s * OBS_CH] = o;
+            stream_store(&out[s * OBS_CH], o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) baddr[j] += step;
         }
@@ -235,7 +250,7 @@ __device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__res
                 v[j] = lut[lut_row(ch) + clamp15(bb[board_for_channel(ch, qi) * S + cell] + lut_bias(ch))];
             }
             o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-            reinterpret_cast<f32x4 *>(dst)[s * OBS_CH + 64 + qd] = o;
+            stream_store(&reinterpret_cast<f32x4 *>(dst)[s * OBS_CH + 64 + qd], o);
         }
     } else {
         // odd cell counts (5x5, 15x15): an env's observation is not 16-byte aligned; dword path
@@ -355,8 +370,8 @@ __device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) 
             const int lo = 16 * c - A;                  // first mask byte of this chunk
             if (lo >= 0 && lo + 16 <= G::NA) {
                 const uint32_t b16 = mask_bits(L, lo, 16);
-                reinterpret_cast<int4 *>(gbase)[c] = make_int4((int)expand4(b16 & 15), (int)expand4((b16 >> 4) & 15),
-                                                               (int)expand4((b16 >> 8) & 15), (int)expand4(b16 >> 12));
+                i32x4 q4 = {(int)expand4(b16 & 15), (int)expand4((b16 >> 4) & 15), (int)expand4((b16 >> 8) & 15), (int)expand4(b16 >> 12)};
+                stream_store(&reinterpret_cast<i32x4 *>(gbase)[c], q4);
             } else {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
@@ -410,7 +425,7 @@ __device__ int kth_valid(const Lds<G> &L, int k, int lane) {
 template <class G>
 __device__ void clear_boards(Lds<G> &L, int lane) {
     const int4 z = make_int4(0, 0, 0, 0);
-    for (int i = lane; i < G::REC / 16; i += 64) reinterpret_cast<int4 *>(&L.b[0][0])[i] = z;
+    for (int i = lane; i < G::LDS_BOARDS_BYTES / 16; i += 64) reinterpret_cast<int4 *>(&L.b[0][0])[i] = z;
 }
 
 // place code `t` of player index pi at absolute cell
@@ -488,17 +503,30 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
     Lds<G> &L = LW[wave];
     STAMP(0);
 
-    int8_t *rec_g = P.boards + env * (int64_t)G::REC;
-    {   // ---- stage: state record and obstacle map -> this wave's LDS
-        const int4 *src = reinterpret_cast<const int4 *>(rec_g);
-        int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
-        for (int i = lane; i < G::REC / 16; i += 64) dst[i] = src[i];
-        for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
-    }
-    const float *lut = lut_s;
-    const int4 sc = P.scal[env];
+    int8_t *rec_g = P.boards + env * (int64_t)P.rec_bytes;
+    const int4 sc = P.scal[2 * env], sc2 = P.scal[2 * env + 1];
     int turn = uni(sc.x), flags = uni(sc.y), game_no = uni(sc.w);
     const int max_turns = uni(sc.z);
+    int n_events = uni(sc2.x);
+    int rec_pairs[2] = {uni(sc2.y), uni(sc2.z)};
+    {   // ---- stage: the 6 dense boards -> LDS, the sparse ones (recent moves, captured counts) rebuilt, obstacle map
+        const int4 *src = reinterpret_cast<const int4 *>(rec_g);
+        int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
+        const int4 z = make_int4(0, 0, 0, 0);
+        for (int i = lane; i < G::LDS_BOARDS_BYTES / 16; i += 64) dst[i] = (i < G::EV_OFF / 16) ? src[i] : z;
+        for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
+        wave_sync<G>();
+        const uint16_t *ev = reinterpret_cast<const uint16_t *>(rec_g + G::EV_OFF);
+        for (int i = lane; i < n_events; i += 64) {
+            const int evt = ev[i], byte = (B_CAP + (evt >> 8)) * S + (evt & 0xFF);   // event = (board - B_CAP) << 8 | cell
+            atomicAdd(reinterpret_cast<unsigned int *>(&L.b[0][0]) + (byte >> 2), 1u << (8 * (byte & 3)));
+        }
+        if (lane < 4) {
+            const int pr = (rec_pairs[lane >> 1] >> (16 * (lane & 1))) & 0xFFFF;
+            if (pr >> 8) L.b[B_RECENT + (lane >> 1)][pr & 0xFF] = (int8_t)(pr >> 8);
+        }
+    }
+    const float *lut = lut_s;
     wave_sync<G>();
     STAMP(1);   // state staged
 
@@ -616,6 +644,10 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
                 if (dest != 0) {
                     if (!wins) dirty_cap_a = B_CAP + 12 * pi + moved - 1;
                     if (wins || tied) dirty_cap_b = B_CAP + 12 * (1 - pi) + dest - 1;
+                    rec_pairs[pi] = 0;                                                   // an attack wipes the mover's layer
+                } else {
+                    const int code = old_end == 1 ? (old_start == -2 ? -3 : -2) : -1;
+                    rec_pairs[pi] = (s | (1 << 8)) | ((e | ((code & 0xFF) << 8)) << 16);
                 }
                 wave_sync<G>();
             }
@@ -670,6 +702,7 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
         game_no += 1;
         sample_boards(L, P, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, lane);
         turn = 0; flags = 0; player = 1; qi = 0; over = false;
+        n_events = 0; rec_pairs[0] = rec_pairs[1] = 0;
         nvalid = gen_mask(L, 0, false, lane);
         wrote_reset = true;
     }
@@ -689,12 +722,12 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
     }
 
     STAMP(7);   // next action sampled
-    // ---- write back what changed: the whole record after a reset, otherwise the <= 11 touched bytes and the
-    //      mover's rebuilt recent-moves board (SURVEY 8d "compulsory write-back")
+    // ---- write back what changed: the 6 dense boards after a reset, otherwise the <= 9 touched board bytes and
+    //      <= 2 new capture events; the scalars carry the turn, flags, event count and the recent-move pairs
     if (wrote_reset) {
         const int4 *src = reinterpret_cast<const int4 *>(&L.b[0][0]);
         int4 *dst = reinterpret_cast<int4 *>(rec_g);
-        for (int i = lane; i < G::REC / 16; i += 64) dst[i] = src[i];
+        for (int i = lane; i < G::EV_OFF / 16; i += 64) dst[i] = src[i];   // LDS bytes 6S..EV_OFF are zero (fresh recent board)
     } else if (applied && dirty_s >= 0) {
         const int pi = mover == 1 ? 0 : 1;
         int board = -1, cell = dirty_e;
@@ -708,16 +741,19 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
             case 6: board = B_STILL + pi; cell = dirty_s; break;
             case 7: board = B_STILL + pi; break;
             case 8: board = B_STILL + 1 - pi; break;
-            case 9: board = dirty_cap_a; break;
-            case 10: board = dirty_cap_b; break;
             default: break;
         }
         if (board >= 0) rec_g[board * S + cell] = L.b[board][cell];
-        const int *rsrc = reinterpret_cast<const int *>(L.b[B_RECENT + pi]);
-        int *rdst = reinterpret_cast<int *>(rec_g + (B_RECENT + pi) * S);
-        for (int i = lane; i < S / 4; i += 64) rdst[i] = rsrc[i];
+        uint16_t *ev = reinterpret_cast<uint16_t *>(rec_g + G::EV_OFF);
+        const int na = dirty_cap_a >= 0 ? 1 : 0, nb = dirty_cap_b >= 0 ? 1 : 0;
+        if (lane == 9 && na && n_events < P.max_events) ev[n_events] = (uint16_t)(((dirty_cap_a - B_CAP) << 8) | dirty_e);
+        if (lane == 10 && nb && n_events + na < P.max_events) ev[n_events + na] = (uint16_t)(((dirty_cap_b - B_CAP) << 8) | dirty_e);
+        n_events = min(n_events + na + nb, P.max_events);
     }
-    if ((applied || wrote_reset) && lane == 0) P.scal[env] = make_int4(turn, flags, max_turns, game_no);
+    if ((applied || wrote_reset) && lane == 0) {
+        P.scal[2 * env] = make_int4(turn, flags, max_turns, game_no);
+        P.scal[2 * env + 1] = make_int4(n_events, rec_pairs[0], rec_pairs[1], 0);
+    }
     STAMP(8);   // write-back issued
 #ifdef SGX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -755,13 +791,16 @@ __global__ __launch_bounds__(64) void reset_kernel(const ResetParams P) {
         wave_sync<G>();
         game_no = 0;
     } else {
-        game_no = uni(P.k.scal[env].w) + 1;
+        game_no = uni(P.k.scal[2 * env].w) + 1;
         sample_boards(L, P.k, (uint64_t)(P.k.env_id_offset + env), (uint64_t)game_no, lane);
     }
     const int4 *src = reinterpret_cast<const int4 *>(&L.b[0][0]);
-    int4 *dst = reinterpret_cast<int4 *>(P.k.boards + env * (int64_t)G::REC);
-    for (int i = lane; i < G::REC / 16; i += 64) dst[i] = src[i];
-    if (lane == 0) P.k.scal[env] = make_int4(0, 0, P.k.max_turns, game_no);
+    int4 *dst = reinterpret_cast<int4 *>(P.k.boards + env * (int64_t)P.k.rec_bytes);
+    for (int i = lane; i < G::EV_OFF / 16; i += 64) dst[i] = src[i];   // dense boards (+ zero padding); no events yet
+    if (lane == 0) {
+        P.k.scal[2 * env] = make_int4(0, 0, P.k.max_turns, game_no);
+        P.k.scal[2 * env + 1] = make_int4(0, 0, 0, 0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -797,7 +836,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     wave_sync<G>();
     const int total = uni(mine);
-    const int4 sc = P.scal[env];
+    const int4 sc = P.scal[2 * env];
     int na = -1;
     if (total > 0) {
         const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)sc.w, STREAM_ACTION, (uint32_t)sc.x), (uint32_t)total);
@@ -809,33 +848,31 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
 // ---------------------------------------------------------------------------------------------
 // export / import in the reference's int64 [N,34,R,C] layout (impl:16-60)
 // ---------------------------------------------------------------------------------------------
-__device__ inline int ref_layer_to_board(int l) {  // reference layer -> internal board (or -1: obstacles, -2: scalars)
-    if (l == 0 || l == 1) return B_PIECES + l;
-    if (l == 2) return -1;
-    if (l == 3 || l == 4) return B_PO + (l - 3);
-    if (l == 5) return -2;
-    if (l == 6 || l == 7) return B_RECENT + (l - 6);
-    if (l < 32) return B_CAP + (l - 8);
-    return B_STILL + (l - 32);
+__device__ inline int ref_layer_of_board(int b) {  // internal board -> reference layer
+    if (b < 2) return b;                 // pieces      -> 0/1
+    if (b < 4) return 3 + (b - 2);       // PO pieces   -> 3/4
+    if (b < 6) return 32 + (b - 4);      // still       -> 32/33
+    if (b < 8) return 6 + (b - 6);       // recent      -> 6/7
+    return 8 + (b - 8);                  // captured    -> 8..31
 }
 
 template <int R_, int C_>
 __global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t *__restrict__ player_out) {
     using G = Geo<R_, C_>;
-    constexpr int RC = G::RC, C = G::C;
+    constexpr int RC = G::RC, C = G::C, S = G::S;
     const int64_t env = blockIdx.x;
     if (env >= P.n_envs) return;
-    const int8_t *rec = P.boards + env * (int64_t)G::REC;
-    const int4 sc = P.scal[env];
+    const int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
+    const int4 sc = P.scal[2 * env], sc2 = P.scal[2 * env + 1];
     int64_t *o = out + env * (int64_t)(SGX_STATE_LAYERS * RC);
     for (int x = threadIdx.x; x < SGX_STATE_LAYERS * RC; x += blockDim.x) {
         const int l = x / RC, cell = x - l * RC;
-        const int b = ref_layer_to_board(l);
-        int64_t v;
-        if (b >= 0) v = rec[b * G::S + cell];
-        else if (b == -1) v = P.tab->obstacles[cell];
-        else {
-            v = 0;
+        int64_t v = 0;
+        if (l == 0 || l == 1) v = rec[(B_PIECES + l) * S + cell];
+        else if (l == 2) v = P.tab->obstacles[cell];
+        else if (l == 3 || l == 4) v = rec[(B_PO + l - 3) * S + cell];
+        else if (l == 32 || l == 33) v = rec[(B_STILL + l - 32) * S + cell];
+        else if (l == 5) {
             const int w = (sc.y & F_WIN_P1) ? 1 : (sc.y & F_WIN_M1) ? -1 : 0;
             if (cell == 0) v = sc.x;                               // TURN_COUNT  [5,0,0]
             else if (cell == 1) v = (sc.y & F_OVER) ? 1 : 0;       // GAME_OVER   [5,0,1]
@@ -843,24 +880,34 @@ __global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t
             else if (cell == C) v = sc.z;                          // MAX_TURNS   [5,1,0]
             else if (cell == C + 1) v = (sc.y & F_END_INVALID) ? 1 : 0;  // ENDING_INVALID [5,1,1]
         }
-        o[x] = v;
+        o[x] = v;   // recent-moves and captured layers start at 0 and are filled below
     }
-    if (threadIdx.x == 0 && player_out) player_out[env] = (sc.y & F_PLAYER_M1) ? -1 : 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int pl = 0; pl < 2; ++pl)
+            for (int h = 0; h < 2; ++h) {
+                const int pr = ((pl ? sc2.z : sc2.y) >> (16 * h)) & 0xFFFF;
+                if (pr >> 8) o[(6 + pl) * RC + (pr & 0xFF)] = (int8_t)(pr >> 8);
+            }
+        const uint16_t *ev = reinterpret_cast<const uint16_t *>(rec + G::EV_OFF);
+        for (int i = 0; i < sc2.x; ++i) o[(8 + (ev[i] >> 8)) * RC + (ev[i] & 0xFF)] += 1;
+        if (player_out) player_out[env] = (sc.y & F_PLAYER_M1) ? -1 : 1;
+    }
 }
 
+// Reachable states only: at most two non-zero recent-move cells per player (impl:1013-1028) and at most
+// max_events captured pieces; anything beyond that cannot come from play and is dropped.
 template <int R_, int C_>
 __global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in) {
     using G = Geo<R_, C_>;
-    constexpr int RC = G::RC, C = G::C;
+    constexpr int RC = G::RC, C = G::C, S = G::S;
     const int64_t env = blockIdx.x;
     if (env >= P.n_envs) return;
-    int8_t *rec = P.boards + env * (int64_t)G::REC;
+    int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
     const int64_t *s = in + env * (int64_t)(SGX_STATE_LAYERS * RC);
-    for (int x = threadIdx.x; x < N_BOARDS * G::S; x += blockDim.x) {
-        const int b = x / G::S, cell = x - b * G::S;
-        int l;
-        if (b < 2) l = b; else if (b < 4) l = 3 + (b - 2); else if (b < 6) l = 6 + (b - 4); else if (b < 8) l = 32 + (b - 6); else l = 8 + (b - 8);
-        rec[x] = cell < RC ? (int8_t)s[l * RC + cell] : 0;
+    for (int x = threadIdx.x; x < G::EV_OFF; x += blockDim.x) {
+        const int b = x / S, cell = x - b * S;
+        rec[x] = (b < STORED_BOARDS && cell < RC) ? (int8_t)s[ref_layer_of_board(b) * RC + cell] : 0;
     }
     if (threadIdx.x == 0) {
         const int64_t *d = s + 5 * RC;
@@ -869,21 +916,35 @@ __global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, c
         if (d[2] > 0) flags |= F_WIN_P1; else if (d[2] < 0) flags |= F_WIN_M1;
         if (d[C + 1] != 0) flags |= F_END_INVALID;
         if (player_in && player_in[env] < 0) flags |= F_PLAYER_M1;
-        const int game_no = P.scal[env].w < 0 ? 0 : P.scal[env].w;
-        P.scal[env] = make_int4((int)d[0], flags, (int)d[C], game_no);
+        int pairs[2] = {0, 0};
+        for (int pl = 0; pl < 2; ++pl) {
+            int k = 0;
+            for (int cell = 0; cell < RC && k < 2; ++cell) {
+                const int code = (int)s[(6 + pl) * RC + cell];
+                if (code != 0) { pairs[pl] |= (cell | ((code & 0xFF) << 8)) << (16 * k); ++k; }
+            }
+        }
+        uint16_t *ev = reinterpret_cast<uint16_t *>(rec + G::EV_OFF);
+        int n = 0;
+        for (int b = 0; b < 24; ++b)
+            for (int cell = 0; cell < RC; ++cell)
+                for (int64_t q = s[(8 + b) * RC + cell]; q > 0 && n < P.max_events; --q) ev[n++] = (uint16_t)((b << 8) | cell);
+        const int old_game = P.scal[2 * env].w;
+        P.scal[2 * env] = make_int4((int)d[0], flags, (int)d[C], old_game < 0 ? 0 : old_game);
+        P.scal[2 * env + 1] = make_int4(n, pairs[0], pairs[1], 0);
     }
 }
 
 __global__ void info_kernel(const int4 *__restrict__ scal, int32_t *__restrict__ out, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int4 s = scal[i];
+    const int4 s = scal[2 * i];
     reinterpret_cast<int4 *>(out)[i] = make_int4(s.x, s.w, (s.y & F_OVER) ? 1 : 0, (s.y & F_PLAYER_M1) ? -1 : 1);
 }
 
 __global__ void init_scal_kernel(int4 *scal, int64_t n, int max_turns) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) scal[i] = make_int4(0, 0, max_turns, -1);
+    if (i < n) { scal[2 * i] = make_int4(0, 0, max_turns, -1); scal[2 * i + 1] = make_int4(0, 0, 0, 0); }
 }
 
 }  // namespace
@@ -903,6 +964,7 @@ struct sgx_env {
     uint8_t *setups;
     int64_t n_setups;
     int rec_bytes;
+    int max_events;
     int K;
     unsigned long long *stamps;  // SGX_STAMPS builds only
 };
@@ -938,6 +1000,8 @@ KParams make_params(const sgx_env *h) {
     p.max_turns = h->cfg.max_turns;
     p.usable_rows = h->cfg.usable_rows;
     for (int i = 0; i < 12; ++i) p.piece_counts[i] = h->cfg.piece_counts[i];
+    p.rec_bytes = h->rec_bytes;
+    p.max_events = h->max_events;
     p.n_envs = h->n_envs;
     p.seed = h->seed;
     p.env_id_offset = h->env_id_offset;
@@ -1019,7 +1083,13 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     h->seed = seed;
     h->env_id_offset = env_id_offset;
     const int rc_cells = cfg->rows * cfg->cols;
-    h->rec_bytes = N_BOARDS * ((rc_cells + 3) & ~3);
+    {
+        int pieces = 0;
+        for (int i = 0; i < 12; ++i) pieces += cfg->piece_counts[i];
+        h->max_events = 2 * pieces;                                   // every piece can be captured once
+        const int ev_off = (STORED_BOARDS * ((rc_cells + 3) & ~3) + 15) & ~15;
+        h->rec_bytes = ev_off + ((2 * h->max_events + 15) & ~15);
+    }
     h->K = 2 * (cfg->rows - 1) + 2 * (cfg->cols - 1) + 1;
     DevTables host_tab;
     memset(&host_tab, 0, sizeof(host_tab));
@@ -1031,7 +1101,7 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     }
     memcpy(host_tab.obstacles, cfg->obstacles, rc_cells);
     if (hipMalloc((void **)&h->boards, (size_t)n_envs * h->rec_bytes) != hipSuccess ||
-        hipMalloc((void **)&h->scal, (size_t)n_envs * sizeof(int4)) != hipSuccess ||
+        hipMalloc((void **)&h->scal, (size_t)n_envs * 2 * sizeof(int4)) != hipSuccess ||
         hipMalloc((void **)&h->tab, sizeof(DevTables)) != hipSuccess) {
         sgx_destroy(h);
         return fail(SGX_ENOMEM, "device allocation failed%s");
