@@ -215,13 +215,14 @@ __device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__res
     if constexpr (RC % 4 == 0) {
         // 4 cells = 268 floats = 67 float4 "quads".  Lane l renders quad l of every 4-cell group, so its four
         // (cell offset, channel) pairs are loop-invariant; quads 64..66 are swept afterwards.
-        int baddr[4], lrow[4], lbias[4];
+        // Board bytes are legal by construction (reset, move application, sanitised import), so LUT[row + bias + v]
+        // needs no clamp: one v_lshl_add per element.
+        int baddr[4], lrow[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int f = 4 * lane + j, rc = f / OBS_CH, ch = f - rc * OBS_CH;
             baddr[j] = board_for_channel(ch, qi) * S + (qi ? RC - 1 - rc : rc);
-            lrow[j] = lut_row(ch);
-            lbias[j] = lut_bias(ch);
+            lrow[j] = lut_row(ch) + lut_bias(ch);
         }
         const int step = qi ? -4 : 4;
         f32x4 *out = reinterpret_cast<f32x4 *>(dst) + lane;
@@ -231,10 +232,10 @@ __device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__res
 #pragma unroll SGX_OBS_UNROLL
         for (int s = 0; s < RC / 4; ++s) {
             f32x4 o;
-            o.x = lut[lrow[0] + clamp15(bb[baddr[0]] + lbias[0])];
-            o.y = lut[lrow[1] + clamp15(bb[baddr[1]] + lbias[1])];
-            o.z = lut[lrow[2] + clamp15(bb[baddr[2]] + lbias[2])];
-            o.w = lut[lrow[3] + clamp15(bb[baddr[3]] + lbias[3])];
+            o.x = lut[lrow[0] + bb[baddr[0]]];
+            o.y = lut[lrow[1] + bb[baddr[1]]];
+            o.z = lut[lrow[2] + bb[baddr[2]]];
+            o.w = lut[lrow[3] + bb[baddr[3]]];
             stream_store(&out[s * OBS_CH], o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) baddr[j] += step;
@@ -682,11 +683,12 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
         rew_p1 = w == 0 ? 1e-4f : (float)w;     // impl:838-840
         rew_m1 = w == 0 ? 1e-4f : (float)-w;
     }
-    if (P.mode == 0 && lane == 0) {
-        if (P.io.reward_dev) { P.io.reward_dev[2 * env] = rew_p1; P.io.reward_dev[2 * env + 1] = rew_m1; }
-        if (P.io.done_dev) P.io.done_dev[env] = done ? 1 : 0;
-        if (P.io.invalid_action_dev) P.io.invalid_action_dev[env] = invalid_action ? 1 : 0;
-        if (P.io.ending_invalid_dev) P.io.ending_invalid_dev[env] = end_invalid ? 1 : 0;
+    if (P.mode == 0) {
+        // one store instruction for the rewards (lanes 0/1) and one for the three byte flags (lanes 0..2)
+        if (lane < 2 && P.io.reward_dev) P.io.reward_dev[2 * env + lane] = lane ? rew_m1 : rew_p1;
+        uint8_t *fp = lane == 0 ? P.io.done_dev : lane == 1 ? P.io.invalid_action_dev : lane == 2 ? P.io.ending_invalid_dev : nullptr;
+        const uint8_t fv = lane == 0 ? (done ? 1 : 0) : lane == 1 ? (invalid_action ? 1 : 0) : (end_invalid ? 1 : 0);
+        if (fp) fp[env] = fv;
     }
 
     // ---- terminal observations of both players (maenv:772-773)
@@ -712,6 +714,7 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
     if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
     if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
     STAMP(5);   // mask stores issued
+    // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
     if (P.io.obs_dev) emit_obs(L, lut, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
     STAMP(6);   // obs stores issued
     if (P.mode == 0 && P.io.next_actions_dev) {
@@ -907,7 +910,13 @@ __global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, c
     const int64_t *s = in + env * (int64_t)(SGX_STATE_LAYERS * RC);
     for (int x = threadIdx.x; x < G::EV_OFF; x += blockDim.x) {
         const int b = x / S, cell = x - b * S;
-        rec[x] = (b < STORED_BOARDS && cell < RC) ? (int8_t)s[ref_layer_of_board(b) * RC + cell] : 0;
+        int v = 0;
+        if (b < STORED_BOARDS && cell < RC) {
+            const int64_t raw = s[ref_layer_of_board(b) * RC + cell];
+            const int hi = b < 2 ? SP_BOMB : b < 4 ? SP_UNKNOWN : 1;     // legal range of the layer; anything else -> 0
+            v = (raw >= 0 && raw <= hi) ? (int)raw : 0;
+        }
+        rec[x] = (int8_t)v;
     }
     if (threadIdx.x == 0) {
         const int64_t *d = s + 5 * RC;
@@ -920,7 +929,8 @@ __global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, c
         for (int pl = 0; pl < 2; ++pl) {
             int k = 0;
             for (int cell = 0; cell < RC && k < 2; ++cell) {
-                const int code = (int)s[(6 + pl) * RC + cell];
+                const int64_t raw = s[(6 + pl) * RC + cell];
+                const int code = (raw >= -3 && raw <= 1) ? (int)raw : 0;
                 if (code != 0) { pairs[pl] |= (cell | ((code & 0xFF) << 8)) << (16 * k); ++k; }
             }
         }
@@ -928,7 +938,7 @@ __global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, c
         int n = 0;
         for (int b = 0; b < 24; ++b)
             for (int cell = 0; cell < RC; ++cell)
-                for (int64_t q = s[(8 + b) * RC + cell]; q > 0 && n < P.max_events; --q) ev[n++] = (uint16_t)((b << 8) | cell);
+                for (int64_t q = min((long long)s[(8 + b) * RC + cell], 12ll); q > 0 && n < P.max_events; --q) ev[n++] = (uint16_t)((b << 8) | cell);
         const int old_game = P.scal[2 * env].w;
         P.scal[2 * env] = make_int4((int)d[0], flags, (int)d[C], old_game < 0 ? 0 : old_game);
         P.scal[2 * env + 1] = make_int4(n, pairs[0], pairs[1], 0);
