@@ -269,8 +269,22 @@ __device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__res
 // impl:399-517.  Work distribution: movable pieces are compacted, then every lane walks ONE ray
 // (piece, direction); a Barrage position (<= 7 movable pieces) is a single 64-lane pass of <= 9 steps.
 // ---------------------------------------------------------------------------------------------
+#ifndef SGX_GENMASK_INLINE
+#define SGX_GENMASK_INLINE __forceinline__
+#endif
+// finished game: only the no-op bit [0,0,K-1] (impl:414, 514-515)
 template <class G>
-__device__ int gen_mask(Lds<G> &L, int qi, bool game_over, int lane) {
+__device__ __forceinline__ void mask_noop_only(Lds<G> &L, int lane) {
+    const int4 z = make_int4(0, 0, 0, 0);
+    for (int i = lane; i < G::MB_WORDS / 4; i += 64) reinterpret_cast<int4 *>(L.mbits)[i] = z;
+    for (int i = lane; i < G::CNT_PAD / 4; i += 64) reinterpret_cast<int *>(L.cnt)[i] = 0;
+    wave_sync<G>();
+    if (lane == 0) { L.mbits[(G::K - 1) >> 5] = 1u << ((G::K - 1) & 31); L.cnt[0] = 1; }
+    wave_sync<G>();
+}
+
+template <class G>
+__device__ SGX_GENMASK_INLINE int gen_mask(Lds<G> &L, int qi, bool game_over, int lane) {
     constexpr int R = G::R, C = G::C, RC = G::RC, K = G::K;
     constexpr int OCC_OWN = 1, OCC_ENEMY = 2, OCC_OBST = 4, OCC_CAME_FROM = 8;
     const int8_t *own = L.b[B_PIECES + qi], *enemy = L.b[B_PIECES + 1 - qi], *rec = L.b[B_RECENT + qi], *obst = L.b[B_OBST];
@@ -509,12 +523,16 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
     int turn = uni(sc.x), flags = uni(sc.y), game_no = uni(sc.w);
     const int max_turns = uni(sc.z);
     int n_events = uni(sc2.x);
-    int rec_pairs[2] = {uni(sc2.y), uni(sc2.z)};
+    int rp0 = uni(sc2.y), rp1 = uni(sc2.z);   // recent-move pairs of player +1 / -1 (two named scalars: a runtime-indexed
+                                              // array would live in scratch memory)
     {   // ---- stage: the 6 dense boards -> LDS, the sparse ones (recent moves, captured counts) rebuilt, obstacle map
         const int4 *src = reinterpret_cast<const int4 *>(rec_g);
         int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
-        const int4 z = make_int4(0, 0, 0, 0);
-        for (int i = lane; i < G::LDS_BOARDS_BYTES / 16; i += 64) dst[i] = (i < G::EV_OFF / 16) ? src[i] : z;
+        for (int i = lane; i < G::LDS_BOARDS_BYTES / 16; i += 64) {
+            int4 v = make_int4(0, 0, 0, 0);
+            if (i < G::EV_OFF / 16) v = src[i];     // (a `cond ? src[i] : zero` select turns into a flat load from scratch)
+            dst[i] = v;
+        }
         for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
         wave_sync<G>();
         const uint16_t *ev = reinterpret_cast<const uint16_t *>(rec_g + G::EV_OFF);
@@ -523,7 +541,7 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
             atomicAdd(reinterpret_cast<unsigned int *>(&L.b[0][0]) + (byte >> 2), 1u << (8 * (byte & 3)));
         }
         if (lane < 4) {
-            const int pr = (rec_pairs[lane >> 1] >> (16 * (lane & 1))) & 0xFFFF;
+            const int pr = (((lane >> 1) ? rp1 : rp0) >> (16 * (lane & 1))) & 0xFFFF;
             if (pr >> 8) L.b[B_RECENT + (lane >> 1)][pr & 0xFF] = (int8_t)(pr >> 8);
         }
     }
@@ -645,10 +663,11 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
                 if (dest != 0) {
                     if (!wins) dirty_cap_a = B_CAP + 12 * pi + moved - 1;
                     if (wins || tied) dirty_cap_b = B_CAP + 12 * (1 - pi) + dest - 1;
-                    rec_pairs[pi] = 0;                                                   // an attack wipes the mover's layer
+                    if (pi) rp1 = 0; else rp0 = 0;                                       // an attack wipes the mover's layer
                 } else {
                     const int code = old_end == 1 ? (old_start == -2 ? -3 : -2) : -1;
-                    rec_pairs[pi] = (s | (1 << 8)) | ((e | ((code & 0xFF) << 8)) << 16);
+                    const int pr = (s | (1 << 8)) | ((e | ((code & 0xFF) << 8)) << 16);
+                    if (pi) rp1 = pr; else rp0 = pr;
                 }
                 wave_sync<G>();
             }
@@ -665,11 +684,11 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
         const bool was_over = over;
         if (nvalid == 0) { over = true; flags = (flags & ~(F_WIN_P1 | F_WIN_M1)) | F_OVER | (mover == 1 ? F_WIN_P1 : F_WIN_M1); }
         if (turn >= max_turns && !over) { over = true; flags |= F_OVER | F_END_INVALID; }
-        if (over && !was_over && nvalid != 0) nvalid = gen_mask(L, qi, true, lane);  // finished: mask shows the no-op only
+        if (over && !was_over && nvalid != 0) { mask_noop_only(L, lane); nvalid = 0; }  // finished: the no-op only
         ended_now = over;
     } else if (applied && noop_path) {
         ended_now = over;
-        if (nvalid != 0) nvalid = gen_mask(L, qi, true, lane);
+        if (nvalid != 0) { mask_noop_only(L, lane); nvalid = 0; }
     }
     flags = (flags & ~F_PLAYER_M1) | (player == -1 ? F_PLAYER_M1 : 0);
     STAMP(3);   // mask generated
@@ -704,7 +723,7 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
         game_no += 1;
         sample_boards(L, P, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, lane);
         turn = 0; flags = 0; player = 1; qi = 0; over = false;
-        n_events = 0; rec_pairs[0] = rec_pairs[1] = 0;
+        n_events = 0; rp0 = rp1 = 0;
         nvalid = gen_mask(L, 0, false, lane);
         wrote_reset = true;
     }
@@ -755,7 +774,7 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
     }
     if ((applied || wrote_reset) && lane == 0) {
         P.scal[2 * env] = make_int4(turn, flags, max_turns, game_no);
-        P.scal[2 * env + 1] = make_int4(n_events, rec_pairs[0], rec_pairs[1], 0);
+        P.scal[2 * env + 1] = make_int4(n_events, rp0, rp1, 0);
     }
     STAMP(8);   // write-back issued
 #ifdef SGX_STAMPS
