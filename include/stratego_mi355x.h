@@ -32,9 +32,10 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 1
+#define SGX_ABI_VERSION 2
 #define SGX_MAX_CELLS 256        /* rows*cols <= 256 (largest reference variant: 15x15) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
+#define SGX_FO_OBS_CHANNELS 79   /* impl:1227 */
 #define SGX_STATE_LAYERS 34      /* impl:109 */
 #define SGX_OBS_LUT_STRIDE 16    /* entries per channel in the normalisation LUT */
 
@@ -61,7 +62,9 @@ typedef struct sgx_env sgx_env; /* opaque handle */
  * _get_current_obs (maenv:447-497) for N envs.  Nullable members may be NULL to skip that output. */
 typedef struct sgx_step_io {
     const int32_t *actions_dev;    /* [N]   in : action of each env's current mover */
-    float *obs_dev;                /* [N,R,C,67] out (nullable) */
+    float *obs_dev;                /* [N,R,C,67] out (nullable): partial observation (ObservationModes PARTIALLY / BOTH) */
+    float *fobs_dev;               /* [N,R,C,79] out (nullable): fully-observable observation (FULLY / BOTH),
+                                      impl:1230-1303 + maenv:202-258, 499-501 */
     uint8_t *mask_dev;             /* [N,R,C,K]  out (nullable) */
     float *reward_dev;             /* [N,2] out: rewards[+1], rewards[-1]; 0,0 while running (maenv:769, 777-805) */
     uint8_t *done_dev;             /* [N]   out: dones["__all__"] */
@@ -70,6 +73,7 @@ typedef struct sgx_step_io {
     uint8_t *ending_invalid_dev;   /* [N]   out: infos['game_result_was_invalid'] (max-turn tie, maenv:777-782) */
     float *final_obs_dev;          /* [N,2,R,C,67] out (nullable): on terminal steps, the terminal observation of
                                       player +1 (slot 0) and -1 (slot 1) (maenv:772-773); untouched otherwise */
+    float *final_fobs_dev;         /* [N,2,R,C,79] out (nullable): the same for the fully-observable observation */
     int32_t *next_actions_dev;     /* [N] out (nullable): a uniformly random valid action for the next mover, drawn
                                       with the handle's counter RNG keyed by (seed, global env id, game, turn);
                                       the batched counterpart of sample_random_valid_action (maenv:830-834) */
@@ -91,6 +95,8 @@ int64_t sgx_action_size_1d(const sgx_env *h);        /* R*C*(R+C)+1 (impl:252-25
  * recent-moves channels (raw -3..1) and 0 elsewhere.  Replaces the arithmetic of
  * normalize_p_observation (maenv:506-508) with the constants of maenv:261-313, 388-391. */
 int sgx_build_obs_lut(const sgx_config *cfg, float *lut);
+/* Same for the 79 fully-observable channels: lut[79*SGX_OBS_LUT_STRIDE] (maenv:202-258, 393-396, 499-501). */
+int sgx_build_full_obs_lut(const sgx_config *cfg, float *lut);
 
 /* StrategoMultiAgentEnv.__init__ (maenv:318-445) for a batch: allocates the device state of n_envs games on
  * `device`.  Env i of this handle has global id env_id_offset + i; all random draws are keyed by
@@ -111,8 +117,8 @@ int sgx_set_setup_table(sgx_env *h, const uint8_t *table_host, int64_t n_setups)
 int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p1_maps_dev, const int8_t *p2_maps_dev, void *stream);
 
 /* _get_current_obs (maenv:447-497) for every env's current mover, no state change.
- * obs_dev, mask_dev and player_dev are laid out as in sgx_step_io; each is nullable. */
-int sgx_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int8_t *player_dev, void *stream);
+ * obs_dev, fobs_dev, mask_dev and player_dev are laid out as in sgx_step_io; each is nullable. */
+int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, int8_t *player_dev, void *stream);
 
 /* One batched env.step(): see sgx_step_io. */
 int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);

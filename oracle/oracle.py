@@ -90,6 +90,11 @@ def lib():
         L.so_normalize_obs.argtypes = [I64, I64, P_F32, P_F32, P_F32]
         L.so_env_current_obs.restype = None
         L.so_env_current_obs.argtypes = [I64, I64, P_I64, I64, P_F32, P_F32, P_U8, P_F32]
+        L.so_env_current_obs2.restype = None
+        L.so_env_current_obs2.argtypes = [I64, I64, P_I64, I64, P_F32, P_F32, P_F32, P_F32, P_U8, P_F32, P_F32]
+        L.so_env_step2.restype = None
+        L.so_env_step2.argtypes = [I64, I64, P_I64, P_I64, I64, C.c_int, P_F32, P_F32, P_F32, P_F32, P_U8, P_F32, P_F32,
+                                   C.POINTER(StepResult)]
         L.so_env_step.restype = None
         L.so_env_step.argtypes = [I64, I64, P_I64, P_I64, I64, C.c_int, P_F32, P_F32, P_U8, P_F32, C.POINTER(StepResult)]
         L.so_rng.restype = C.c_uint64
@@ -238,6 +243,14 @@ def piece_amounts_array(piece_counts):
     return a
 
 
+def f_obs_norm_constants(piece_counts):
+    mids = np.zeros(79, dtype=np.float32)
+    ranges = np.zeros(79, dtype=np.float32)
+    pa = piece_amounts_array(piece_counts)
+    lib().so_f_obs_norm_constants(_p(pa, P_I64), _p(mids, P_F32), _p(ranges, P_F32))
+    return mids, ranges
+
+
 def p_obs_norm_constants(piece_counts):
     mids = np.zeros(67, dtype=np.float32)
     ranges = np.zeros(67, dtype=np.float32)
@@ -256,8 +269,12 @@ class OracleEnv:
 
     MASK = 'valid_actions_mask'
     POBS = 'partial_observation'
+    FOBS = 'full_observation'
 
-    def __init__(self, rows, columns, max_turns, obstacle_locations, piece_counts, penalize_ties=False):
+    def __init__(self, rows, columns, max_turns, obstacle_locations, piece_counts, penalize_ties=False,
+                 observation_mode='partially_observable'):
+        assert observation_mode in ('partially_observable', 'fully_observable', 'both_observations')
+        self.mode = observation_mode
         self.rules = OracleRules(rows, columns)
         self.rows, self.columns, self.max_turns = int(rows), int(columns), int(max_turns)
         self.K = self.rules.K
@@ -267,6 +284,7 @@ class OracleEnv:
         self.piece_counts = tuple(int(x) for x in piece_counts)
         self.penalize_ties = bool(penalize_ties)
         self.mids, self.ranges = p_obs_norm_constants(self.piece_counts)
+        self.f_mids, self.f_ranges = f_obs_norm_constants(self.piece_counts)
         self.state = None
         self.player = 1
 
@@ -274,9 +292,18 @@ class OracleEnv:
         R, Cc, K = self.rows, self.columns, self.K
         mask = np.zeros((R, Cc, K), dtype=np.uint8)
         pobs = np.zeros((R, Cc, 67), dtype=np.float32)
-        lib().so_env_current_obs(R, Cc, _p(self.state, P_I64), int(player), _p(self.mids, P_F32), _p(self.ranges, P_F32),
-                                 _p(mask, P_U8), _p(pobs, P_F32))
-        return {self.MASK: mask.astype(np.int64), self.POBS: pobs}
+        fobs = np.zeros((R, Cc, 79), dtype=np.float32)
+        lib().so_env_current_obs2(R, Cc, _p(self.state, P_I64), int(player), _p(self.mids, P_F32), _p(self.ranges, P_F32),
+                                  _p(self.f_mids, P_F32), _p(self.f_ranges, P_F32), _p(mask, P_U8), _p(pobs, P_F32), _p(fobs, P_F32))
+        return self._pack(mask, pobs, fobs)
+
+    def _pack(self, mask, pobs, fobs):
+        d = {self.MASK: mask.astype(np.int64)}
+        if self.mode != 'fully_observable':
+            d[self.POBS] = pobs
+        if self.mode != 'partially_observable':
+            d[self.FOBS] = fobs
+        return d
 
     def reset(self, p1_map=None, p2_map=None, initial_state_override=None, first_player_override=None):
         if initial_state_override is not None:
@@ -292,18 +319,19 @@ class OracleEnv:
         R, Cc, K = self.rows, self.columns, self.K
         mask = np.zeros((2, R, Cc, K), dtype=np.uint8)
         pobs = np.zeros((2, R, Cc, 67), dtype=np.float32)
+        fobs = np.zeros((2, R, Cc, 79), dtype=np.float32)
         res = StepResult()
         pl = C.c_int64(self.player)
-        lib().so_env_step(R, Cc, _p(self.state, P_I64), C.byref(pl), action, int(self.penalize_ties),
-                          _p(self.mids, P_F32), _p(self.ranges, P_F32), _p(mask, P_U8), _p(pobs, P_F32), C.byref(res))
+        lib().so_env_step2(R, Cc, _p(self.state, P_I64), C.byref(pl), action, int(self.penalize_ties),
+                           _p(self.mids, P_F32), _p(self.ranges, P_F32), _p(self.f_mids, P_F32), _p(self.f_ranges, P_F32),
+                           _p(mask, P_U8), _p(pobs, P_F32), _p(fobs, P_F32), C.byref(res))
         if res.error:
             raise ValueError("Couldn't get the next state because the move wasn't valid.")
         self.player = int(pl.value)
         if not res.done:
-            obs = {self.player: {self.MASK: mask[0].astype(np.int64), self.POBS: pobs[0]}}
+            obs = {self.player: self._pack(mask[0], pobs[0], fobs[0])}
             return obs, {self.player: 0}, {self.player: False, "__all__": False}, {}
-        obs = {1: {self.MASK: mask[0].astype(np.int64), self.POBS: pobs[0]},
-               -1: {self.MASK: mask[1].astype(np.int64), self.POBS: pobs[1]}}
+        obs = {1: self._pack(mask[0], pobs[0], fobs[0]), -1: self._pack(mask[1], pobs[1], fobs[1])}
         rewards = {1: float(res.reward_p1), -1: float(res.reward_m1)}
         dones = {1: True, -1: True, "__all__": True}
         inv = bool(res.ending_invalid)

@@ -483,8 +483,15 @@ SO_EXPORT void so_normalize_obs(i64 n_cells, i64 n_layers, const float *mids, co
  * ------------------------------------------------------------------------------------------ */
 
 /* maenv:447-475 : mask (R,C,K) as uint8 (reference dtype int64, values 0/1) and normalised partial obs */
+SO_EXPORT void so_env_current_obs2(i64 R, i64 C, const i64 *state, i64 player, const float *mids, const float *ranges,
+                                   const float *f_mids, const float *f_ranges, uint8_t *mask_u8, float *p_obs, float *f_obs);
 SO_EXPORT void so_env_current_obs(i64 R, i64 C, const i64 *state, i64 player, const float *mids, const float *ranges,
                                   uint8_t *mask_u8, float *p_obs) {
+    so_env_current_obs2(R, C, state, player, mids, ranges, 0, 0, mask_u8, p_obs, 0);
+}
+/* maenv:447-497 with observation_mode BOTH / FULLY_OBSERVABLE: f_obs (R,C,79) normalised (maenv:477-492) */
+SO_EXPORT void so_env_current_obs2(i64 R, i64 C, const i64 *state, i64 player, const float *mids, const float *ranges,
+                                   const float *f_mids, const float *f_ranges, uint8_t *mask_u8, float *p_obs, float *f_obs) {
     i64 K = so_spatial_channels(R, C), n = R * C * K;
     i64 *pp = (i64 *)malloc(sizeof(i64) * NUM_STATE_LAYERS * R * C);
     so_state_from_player_perspective(R, C, state, player, pp); /* maenv:452 */
@@ -497,6 +504,10 @@ SO_EXPORT void so_env_current_obs(i64 R, i64 C, const i64 *state, i64 player, co
     if (p_obs) {
         so_po_obs_extended(R, C, pp, 1, p_obs); /* maenv:461-463 */
         so_normalize_obs(R * C, PO_OBS_LAYERS, mids, ranges, p_obs); /* maenv:471 */
+    }
+    if (f_obs) {
+        so_fo_obs_extended(R, C, pp, 1, f_obs); /* maenv:480-482 */
+        so_normalize_obs(R * C, FO_OBS_LAYERS, f_mids, f_ranges, f_obs); /* maenv:488 */
     }
     free(pp);
 }
@@ -514,8 +525,17 @@ typedef struct {
 /* maenv:659-828 ; spatial flat action of the current player; state/player updated in place on success.
  * Non-terminal: obs/mask of the next mover go to slot 0.  Terminal: slot 0 = player +1, slot 1 = player -1
  * (maenv:772-773).  mask slots are R*C*K bytes, obs slots R*C*67 floats. */
+SO_EXPORT void so_env_step2(i64 R, i64 C, i64 *state, i64 *player, i64 action, int penalize_ties, const float *mids,
+                            const float *ranges, const float *f_mids, const float *f_ranges, uint8_t *mask_out, float *obs_out,
+                            float *fobs_out, so_step_result *res);
 SO_EXPORT void so_env_step(i64 R, i64 C, i64 *state, i64 *player, i64 action, int penalize_ties, const float *mids,
                            const float *ranges, uint8_t *mask_out, float *obs_out, so_step_result *res) {
+    so_env_step2(R, C, state, player, action, penalize_ties, mids, ranges, 0, 0, mask_out, obs_out, 0, res);
+}
+/* same, also producing the fully-observable observation (slots of R*C*79 floats) when fobs_out != NULL */
+SO_EXPORT void so_env_step2(i64 R, i64 C, i64 *state, i64 *player, i64 action, int penalize_ties, const float *mids,
+                            const float *ranges, const float *f_mids, const float *f_ranges, uint8_t *mask_out, float *obs_out,
+                            float *fobs_out, so_step_result *res) {
     i64 K = so_spatial_channels(R, C), NA = R * C * K;
     memset(res, 0, sizeof(*res));
     res->next_player = (int32_t)*player;
@@ -531,12 +551,13 @@ SO_EXPORT void so_env_step(i64 R, i64 C, i64 *state, i64 *player, i64 action, in
     res->next_player = (int32_t)*player;
     float reward = so_game_ended(R, C, state, *player); /* maenv:699 */
     if (reward == 0) {                                  /* maenv:767-770 */
-        so_env_current_obs(R, C, state, *player, mids, ranges, mask_out, obs_out);
+        so_env_current_obs2(R, C, state, *player, mids, ranges, f_mids, f_ranges, mask_out, obs_out, fobs_out);
         return;
     }
     res->done = 1; /* maenv:772-805 */
-    so_env_current_obs(R, C, state, 1, mids, ranges, mask_out, obs_out);
-    so_env_current_obs(R, C, state, -1, mids, ranges, mask_out ? mask_out + NA : 0, obs_out ? obs_out + R * C * PO_OBS_LAYERS : 0);
+    so_env_current_obs2(R, C, state, 1, mids, ranges, f_mids, f_ranges, mask_out, obs_out, fobs_out);
+    so_env_current_obs2(R, C, state, -1, mids, ranges, f_mids, f_ranges, mask_out ? mask_out + NA : 0,
+                        obs_out ? obs_out + R * C * PO_OBS_LAYERS : 0, fobs_out ? fobs_out + R * C * FO_OBS_LAYERS : 0);
     int tied;
     if (so_game_result_is_invalid(R, C, state)) {
         res->ending_invalid = 1;

@@ -11,11 +11,12 @@ from .build import LIB_PATH
 SGX_MAX_CELLS = 256
 SGX_OBS_LUT_STRIDE = 16
 PO_OBS_CHANNELS = 67
+FO_OBS_CHANNELS = 79
 
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
-    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
+    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
     'sgx_observe', 'sgx_step', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_get_env_info',
 )
 
@@ -26,10 +27,11 @@ class SgxConfig(C.Structure):
 
 
 class SgxStepIO(C.Structure):
-    _fields_ = [('actions_dev', C.c_void_p), ('obs_dev', C.c_void_p), ('mask_dev', C.c_void_p),
+    _fields_ = [('actions_dev', C.c_void_p), ('obs_dev', C.c_void_p), ('fobs_dev', C.c_void_p), ('mask_dev', C.c_void_p),
                 ('reward_dev', C.c_void_p), ('done_dev', C.c_void_p), ('player_dev', C.c_void_p),
                 ('invalid_action_dev', C.c_void_p), ('ending_invalid_dev', C.c_void_p), ('final_obs_dev', C.c_void_p),
-                ('next_actions_dev', C.c_void_p), ('auto_reset', C.c_int32), ('reserved', C.c_int32)]
+                ('final_fobs_dev', C.c_void_p), ('next_actions_dev', C.c_void_p), ('auto_reset', C.c_int32),
+                ('reserved', C.c_int32)]
 
 
 class SgxError(RuntimeError):
@@ -55,6 +57,8 @@ def _bind(L):
     L.sgx_action_size_1d.argtypes = [vp]
     L.sgx_build_obs_lut.restype = C.c_int
     L.sgx_build_obs_lut.argtypes = [C.POINTER(SgxConfig), C.POINTER(C.c_float)]
+    L.sgx_build_full_obs_lut.restype = C.c_int
+    L.sgx_build_full_obs_lut.argtypes = [C.POINTER(SgxConfig), C.POINTER(C.c_float)]
     L.sgx_create.restype = C.c_int
     L.sgx_create.argtypes = [C.POINTER(SgxConfig), i64, C.c_int, u64, i64, C.POINTER(vp)]
     L.sgx_destroy.restype = C.c_int
@@ -64,7 +68,7 @@ def _bind(L):
     L.sgx_reset.restype = C.c_int
     L.sgx_reset.argtypes = [vp, vp, vp, vp, vp]
     L.sgx_observe.restype = C.c_int
-    L.sgx_observe.argtypes = [vp, vp, vp, vp, vp]
+    L.sgx_observe.argtypes = [vp, vp, vp, vp, vp, vp]
     L.sgx_step.restype = C.c_int
     L.sgx_step.argtypes = [vp, C.POINTER(SgxStepIO), vp]
     L.sgx_sample_valid.restype = C.c_int

@@ -44,7 +44,8 @@ constexpr int LUT_SIZE = OBS_CH * LUT_STRIDE;
 // access hold channels 4q+j (mod 67).  Rows are placed so that bank(row(ch)) = (ch/4 + {0,16,1,17}[ch%4]) mod 32:
 // the 32 lanes of an access group then hit 31-32 different banks (a dense ch*16 layout put them all on 2 banks:
 // 78 % of LDS cycles were bank conflicts, profiles/r01_v1_*).  Two 16-entry rows share each 33-dword pitch.
-constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 577 /* >= 17*33, = 1 mod 32 */, LUT_DWORDS = 2 * LUT_BLK + 2;  // 1156
+constexpr int FOBS_CH = SGX_FO_OBS_CHANNELS;  // 79
+constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 673 /* >= 20*33 (79 channels), = 1 mod 32 */, LUT_DWORDS = 2 * LUT_BLK + 2;  // 1348
 #ifndef SGX_WPB
 #define SGX_WPB 8
 #endif
@@ -91,7 +92,8 @@ struct Geo {
 };
 
 struct DevTables {
-    float obs_lut[LUT_DWORDS];  // rows at lut_row(ch)
+    float obs_lut[LUT_DWORDS];   // partial observation, rows at lut_row(ch)
+    float fobs_lut[LUT_DWORDS];  // fully-observable observation
     uint8_t obstacles[SGX_MAX_CELLS];
 };
 
@@ -189,46 +191,68 @@ __device__ inline void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// board holding observation channel `ch` for perspective player index qi (impl:1306-1332 + impl:645-675)
-__device__ inline int board_for_channel(int ch, int qi) {
-    if (ch < 12) return B_PIECES + qi;
-    if (ch < 25) return B_PO + qi;
-    if (ch < 38) return B_PO + (1 - qi);
-    if (ch == 38) return B_OBST;
-    if (ch == 39) return B_RECENT + qi;
-    if (ch == 40) return B_RECENT + (1 - qi);
-    if (ch < 53) return B_CAP + 12 * qi + (ch - 41);
-    if (ch < 65) return B_CAP + 12 * (1 - qi) + (ch - 53);
-    if (ch == 65) return B_STILL + qi;
-    return B_STILL + (1 - qi);
-}
-__device__ inline int lut_bias(int ch) { return (ch == 39 || ch == 40) ? 3 : 0; }
+// Observation channel specs: board holding channel `ch` for perspective player index qi, and the LUT index bias
+// (recent-moves codes are -3..1).  Partial: impl:1306-1332; full: impl:1200-1227; perspective swap impl:645-675.
+struct PartialObs {
+    static constexpr int NCH = OBS_CH;
+    __device__ static inline int board(int ch, int qi) {
+        if (ch < 12) return B_PIECES + qi;
+        if (ch < 25) return B_PO + qi;
+        if (ch < 38) return B_PO + (1 - qi);
+        if (ch == 38) return B_OBST;
+        if (ch == 39) return B_RECENT + qi;
+        if (ch == 40) return B_RECENT + (1 - qi);
+        if (ch < 53) return B_CAP + 12 * qi + (ch - 41);
+        if (ch < 65) return B_CAP + 12 * (1 - qi) + (ch - 53);
+        if (ch == 65) return B_STILL + qi;
+        return B_STILL + (1 - qi);
+    }
+    __device__ static inline int bias(int ch) { return (ch == 39 || ch == 40) ? 3 : 0; }
+};
+struct FullObs {
+    static constexpr int NCH = FOBS_CH;
+    __device__ static inline int board(int ch, int qi) {
+        if (ch < 12) return B_PIECES + qi;
+        if (ch < 24) return B_PIECES + (1 - qi);
+        if (ch < 37) return B_PO + qi;
+        if (ch < 50) return B_PO + (1 - qi);
+        if (ch == 50) return B_OBST;
+        if (ch == 51) return B_RECENT + qi;
+        if (ch == 52) return B_RECENT + (1 - qi);
+        if (ch < 65) return B_CAP + 12 * qi + (ch - 53);
+        if (ch < 77) return B_CAP + 12 * (1 - qi) + (ch - 65);
+        if (ch == 77) return B_STILL + qi;
+        return B_STILL + (1 - qi);
+    }
+    __device__ static inline int bias(int ch) { return (ch == 51 || ch == 52) ? 3 : 0; }
+};
 __device__ inline int clamp15(int v) { return min(max(v, 0), 15); }
 
 // ---------------------------------------------------------------------------------------------
-// Observation render: float32 [R][C][67], perspective of player index qi  (impl:1335-1397, maenv:506-508)
+// Observation render: float32 [R][C][NCH], perspective of player index qi
+// (partial: impl:1335-1397, full: impl:1230-1303; normalisation maenv:499-508 through the LUT)
 // ---------------------------------------------------------------------------------------------
-template <class G>
+#ifndef SGX_OBS_UNROLL
+#define SGX_OBS_UNROLL 5
+#endif
+template <class G, class Spec>
 __device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__restrict__ dst, int lane) {
-    constexpr int RC = G::RC, S = G::S;
+    constexpr int RC = G::RC, S = G::S, NCH = Spec::NCH;
     const int8_t *bb = &L.b[0][0];
     if constexpr (RC % 4 == 0) {
-        // 4 cells = 268 floats = 67 float4 "quads".  Lane l renders quad l of every 4-cell group, so its four
-        // (cell offset, channel) pairs are loop-invariant; quads 64..66 are swept afterwards.
+        // 4 cells = 4*NCH floats = NCH float4 "quads".  Lane l renders quad l of every 4-cell group, so its four
+        // (cell offset, channel) pairs are loop-invariant; quads 64..NCH-1 are swept afterwards.
         // Board bytes are legal by construction (reset, move application, sanitised import), so LUT[row + bias + v]
         // needs no clamp: one v_lshl_add per element.
         int baddr[4], lrow[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int f = 4 * lane + j, rc = f / OBS_CH, ch = f - rc * OBS_CH;
-            baddr[j] = board_for_channel(ch, qi) * S + (qi ? RC - 1 - rc : rc);
-            lrow[j] = lut_row(ch) + lut_bias(ch);
+            const int f = 4 * lane + j, rc = f / NCH, ch = f - rc * NCH;
+            baddr[j] = Spec::board(ch, qi) * S + (qi ? RC - 1 - rc : rc);
+            lrow[j] = lut_row(ch) + Spec::bias(ch);
         }
         const int step = qi ? -4 : 4;
         f32x4 *out = reinterpret_cast<f32x4 *>(dst) + lane;
-#ifndef SGX_OBS_UNROLL
-#define SGX_OBS_UNROLL 5
-#endif
 #pragma unroll SGX_OBS_UNROLL
         for (int s = 0; s < RC / 4; ++s) {
             f32x4 o;
@@ -236,29 +260,30 @@ __device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__res
             o.y = lut[lrow[1] + bb[baddr[1]]];
             o.z = lut[lrow[2] + bb[baddr[2]]];
             o.w = lut[lrow[3] + bb[baddr[3]]];
-            stream_store(&out[s * OBS_CH], o);
+            stream_store(&out[s * NCH], o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) baddr[j] += step;
         }
-        for (int t = lane; t < (RC / 4) * 3; t += 64) {
-            const int s = t / 3, qd = t - 3 * s;
-            const int pcell = 4 * s + 3, cell = qi ? RC - 1 - pcell : pcell;
+        constexpr int NT = NCH - 64;  // tail quads per group
+        for (int t = lane; t < (RC / 4) * NT; t += 64) {
+            const int s = t / NT, qd = 64 + (t - NT * s);
             f32x4 o;
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int ch = 55 + 4 * qd + j;
-                v[j] = lut[lut_row(ch) + clamp15(bb[board_for_channel(ch, qi) * S + cell] + lut_bias(ch))];
+                const int f = 4 * qd + j, rc = f / NCH, ch = f - rc * NCH;
+                const int pcell = 4 * s + rc, cell = qi ? RC - 1 - pcell : pcell;
+                v[j] = lut[lut_row(ch) + Spec::bias(ch) + bb[Spec::board(ch, qi) * S + cell]];
             }
             o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-            stream_store(&reinterpret_cast<f32x4 *>(dst)[s * OBS_CH + 64 + qd], o);
+            stream_store(&reinterpret_cast<f32x4 *>(dst)[s * NCH + qd], o);
         }
     } else {
         // odd cell counts (5x5, 15x15): an env's observation is not 16-byte aligned; dword path
-        for (int f = lane; f < G::NOBS; f += 64) {
-            const int pcell = f / OBS_CH, ch = f - pcell * OBS_CH;
+        for (int f = lane; f < RC * NCH; f += 64) {
+            const int pcell = f / NCH, ch = f - pcell * NCH;
             const int cell = qi ? RC - 1 - pcell : pcell;
-            dst[f] = lut[lut_row(ch) + clamp15(bb[board_for_channel(ch, qi) * S + cell] + lut_bias(ch))];
+            dst[f] = lut[lut_row(ch) + Spec::bias(ch) + bb[Spec::board(ch, qi) * S + cell]];
         }
     }
 }
@@ -493,26 +518,30 @@ __device__ inline int fmod_(int a, int b) { int m = a % b; return m < 0 ? m + b 
 // The step kernel: env.step() of N games (maenv:659-828), one wave per game
 // ---------------------------------------------------------------------------------------------
 // waves per SIMD this geometry can reach: LDS per workgroup = WPB game regions + the shared LUT, 160 KiB per CU
-template <class G>
+template <class G, bool FULL>
 constexpr int waves_per_simd() {
-    constexpr int per_wg = WPB * (int)sizeof(Lds<G>) + LUT_DWORDS * 4;
+    constexpr int per_wg = WPB * (int)sizeof(Lds<G>) + LUT_DWORDS * 4 * (FULL ? 2 : 1);
     constexpr int wgs = (160 * 1024) / per_wg;
     constexpr int w = wgs * WPB / 4;
     return w > SGX_MIN_WAVES ? SGX_MIN_WAVES : (w < 1 ? 1 : w);
 }
 
-template <int R_, int C_>
-__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void step_kernel(const KParams P) {
+// FULL: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492)
+template <int R_, int C_, bool FULL>
+__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) void step_kernel(const KParams P) {
     using G = Geo<R_, C_>;
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     __shared__ Lds<G> LW[WPB];
-    __shared__ alignas(16) float lut_s[LUT_DWORDS];
+    __shared__ alignas(16) float lut_s[LUT_DWORDS * (FULL ? 2 : 1)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t env = group_of_block() * WPB + wave;
 
     // ---- the workgroup's shared normalisation LUT (L2-resident source)
     for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB)
         reinterpret_cast<f32x4 *>(lut_s)[i] = reinterpret_cast<const f32x4 *>(P.tab->obs_lut)[i];
+    if constexpr (FULL)
+        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB)
+            reinterpret_cast<f32x4 *>(lut_s + LUT_DWORDS)[i] = reinterpret_cast<const f32x4 *>(P.tab->fobs_lut)[i];
     __syncthreads();   // the only workgroup-wide barrier; from here on every wave works on its own game
     if (env >= P.n_envs) return;
     Lds<G> &L = LW[wave];
@@ -713,9 +742,15 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
     // ---- terminal observations of both players (maenv:772-773)
     if (P.mode == 0 && ended_now && P.io.final_obs_dev) {
         float *fo = P.io.final_obs_dev + env * (int64_t)(2 * G::NOBS);
-        emit_obs(L, lut, 0, fo, lane);
-        emit_obs(L, lut, 1, fo + G::NOBS, lane);
+        emit_obs<G, PartialObs>(L, lut, 0, fo, lane);
+        emit_obs<G, PartialObs>(L, lut, 1, fo + G::NOBS, lane);
     }
+    if constexpr (FULL)
+        if (P.mode == 0 && ended_now && P.io.final_fobs_dev) {
+            float *fo = P.io.final_fobs_dev + env * (int64_t)(2 * RC * FOBS_CH);
+            emit_obs<G, FullObs>(L, lut + LUT_DWORDS, 0, fo, lane);
+            emit_obs<G, FullObs>(L, lut + LUT_DWORDS, 1, fo + RC * FOBS_CH, lane);
+        }
 
     // ---- auto-reset: the finished env starts its next game now
     bool wrote_reset = false;
@@ -734,7 +769,9 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>>())) void ste
     if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
     STAMP(5);   // mask stores issued
     // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
-    if (P.io.obs_dev) emit_obs(L, lut, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
+    if (P.io.obs_dev) emit_obs<G, PartialObs>(L, lut, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
+    if constexpr (FULL)
+        if (P.io.fobs_dev) emit_obs<G, FullObs>(L, lut + LUT_DWORDS, qi, P.io.fobs_dev + env * (int64_t)(RC * FOBS_CH), lane);
     STAMP(6);   // obs stores issued
     if (P.mode == 0 && P.io.next_actions_dev) {
         const int total = nvalid == 0 ? 1 : nvalid;
@@ -1067,29 +1104,47 @@ SGX_API int64_t sgx_action_size_1d(const sgx_env *h) {
     return h ? (int64_t)h->cfg.rows * h->cfg.cols * (h->cfg.rows + h->cfg.cols) + 1 : 0;
 }
 
-// maenv:261-313 (highs/lows), maenv:388-391 (ranges/mids), maenv:506-508 ((x - mid) / range in float32)
-SGX_API int sgx_build_obs_lut(const sgx_config *cfg, float *lut) {
-    if (int rc = check_cfg(cfg)) return rc;
-    if (!lut) return fail(SGX_EINVAL, "lut is NULL%s");
-    float hi[OBS_CH], lo[OBS_CH];
-    for (int ch = 0; ch < OBS_CH; ++ch) { hi[ch] = 1.0f; lo[ch] = -1.0f; }
-    hi[39] = hi[40] = 1.0f; lo[39] = lo[40] = -3.0f;   // RecentMoves JUST_CAME_FROM .. JUST_ARRIVED_AND_CANT_DOUBLE_BACK
-    for (int ch = 41; ch < 65; ++ch) { hi[ch] = 8.0f; lo[ch] = 0.0f; }
+// Normalisation LUT shared by both observation kinds: channel layout = [n_own_true][n_enemy_true][13 own PO][13 enemy PO]
+// [obstacle][2 recent][12+12 captured][2 still]; partial has no enemy-true block (impl:1306-1332 vs impl:1200-1227).
+// highs/lows maenv:202-313, ranges/mids maenv:388-396, (x - mid) / range in float32 maenv:499-508.
+static void build_lut(const sgx_config *cfg, bool full, float *lut) {
+    const int nch = full ? FOBS_CH : OBS_CH;
+    const int n_true = full ? 24 : 12, po_end = n_true + 26, obst = po_end, rec0 = po_end + 1, cap0 = po_end + 3, still0 = cap0 + 24;
+    float hi[FOBS_CH], lo[FOBS_CH];
+    for (int ch = 0; ch < nch; ++ch) { hi[ch] = 1.0f; lo[ch] = -1.0f; }
+    hi[rec0] = hi[rec0 + 1] = 1.0f; lo[rec0] = lo[rec0 + 1] = -3.0f;   // RecentMoves JUST_CAME_FROM .. JUST_ARRIVED_AND_CANT_DOUBLE_BACK
+    for (int ch = cap0; ch < still0; ++ch) { hi[ch] = 8.0f; lo[ch] = 0.0f; }
     for (int t = 1; t <= 12; ++t)
-        if (cfg->piece_counts[t - 1] > 1) hi[41 + t - 1] = hi[53 + t - 1] = (float)cfg->piece_counts[t - 1];
-    for (int ch = 0; ch < OBS_CH; ++ch) {
+        if (cfg->piece_counts[t - 1] > 1) hi[cap0 + t - 1] = hi[cap0 + 12 + t - 1] = (float)cfg->piece_counts[t - 1];
+    (void)obst;
+    for (int ch = 0; ch < nch; ++ch) {
         volatile float range = (hi[ch] - lo[ch]) / 2.0f, mid = (hi[ch] + lo[ch]) / 2.0f;
         for (int i = 0; i < LUT_STRIDE; ++i) {
             float raw;
-            if (ch < 38) {                       // one-hot piece channels: raw = (board value == piece type)
-                const int type = ch < 12 ? ch + 1 : ch < 25 ? ch - 11 : ch - 24;
+            if (ch < po_end) {                   // one-hot piece channels: raw = (board value == piece type)
+                int type;
+                if (ch < n_true) type = ch % 12 + 1;                 // true pieces: types 1..12
+                else type = (ch - n_true) % 13 + 1;                  // PO pieces: types 1..13
                 raw = (i == type) ? 1.0f : 0.0f;
-            } else if (ch == 39 || ch == 40) raw = (float)(i - 3);
+            } else if (ch == rec0 || ch == rec0 + 1) raw = (float)(i - 3);
             else raw = (float)i;
             volatile float d = raw - mid;        // two IEEE float32 roundings, as numpy does
             lut[ch * LUT_STRIDE + i] = d / range;
         }
     }
+}
+
+SGX_API int sgx_build_obs_lut(const sgx_config *cfg, float *lut) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!lut) return fail(SGX_EINVAL, "lut is NULL%s");
+    build_lut(cfg, false, lut);
+    return SGX_OK;
+}
+
+SGX_API int sgx_build_full_obs_lut(const sgx_config *cfg, float *lut) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!lut) return fail(SGX_EINVAL, "lut is NULL%s");
+    build_lut(cfg, true, lut);
     return SGX_OK;
 }
 
@@ -1123,10 +1178,13 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     DevTables host_tab;
     memset(&host_tab, 0, sizeof(host_tab));
     {   // ABI LUT [67][16] -> device placement (rows at lut_row(ch), see LUT_ROW_PITCH)
-        float dense[LUT_SIZE];
-        sgx_build_obs_lut(cfg, dense);
+        float dense[FOBS_CH * LUT_STRIDE];
+        build_lut(cfg, false, dense);
         for (int ch = 0; ch < OBS_CH; ++ch)
             for (int i = 0; i < LUT_STRIDE; ++i) host_tab.obs_lut[lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
+        build_lut(cfg, true, dense);
+        for (int ch = 0; ch < FOBS_CH; ++ch)
+            for (int i = 0; i < LUT_STRIDE; ++i) host_tab.fobs_lut[lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
     }
     memcpy(host_tab.obstacles, cfg->obstacles, rc_cells);
     if (hipMalloc((void **)&h->boards, (size_t)n_envs * h->rec_bytes) != hipSuccess ||
@@ -1191,19 +1249,27 @@ SGX_API int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p
 }
 
 static int launch_step(sgx_env *h, const KParams &p, void *stream) {
-#define CALL_STEP(R, C) step_kernel<R, C><<<grid_for((h->n_envs + WPB - 1) / WPB), 64 * WPB, 0, (hipStream_t)stream>>>(p)
-    DISPATCH_GEOMETRY(h, CALL_STEP);
+    const unsigned grid = grid_for((h->n_envs + WPB - 1) / WPB);
+    if (p.io.fobs_dev || p.io.final_fobs_dev) {
+#define CALL_STEP_FULL(R, C) step_kernel<R, C, true><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p)
+        DISPATCH_GEOMETRY(h, CALL_STEP_FULL);
+#undef CALL_STEP_FULL
+    } else {
+#define CALL_STEP(R, C) step_kernel<R, C, false><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p)
+        DISPATCH_GEOMETRY(h, CALL_STEP);
 #undef CALL_STEP
+    }
     HIP_TRY(hipGetLastError());
     return SGX_OK;
 }
 
-SGX_API int sgx_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int8_t *player_dev, void *stream) {
+SGX_API int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, int8_t *player_dev, void *stream) {
     if (!h) return fail(SGX_EINVAL, "handle is NULL%s");
     HIP_TRY(hipSetDevice(h->device));
     KParams p = make_params(h);
     p.mode = 1;
     p.io.obs_dev = obs_dev;
+    p.io.fobs_dev = fobs_dev;
     p.io.mask_dev = mask_dev;
     p.io.player_dev = player_dev;
     return launch_step(h, p, stream);

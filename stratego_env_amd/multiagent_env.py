@@ -7,6 +7,7 @@ behaviour (ValueError on an invalid action, AssertionError when the wrong player
 numpy's / Python's global RNGs at reset, so `np.random.seed(s); random.seed(s)` reproduces the reference's
 setups.  Every game-logic operation runs in the HIP kernels through a VecStrategoEnv of one game.
 
+All three observation modes are built (PARTIALLY_OBSERVABLE, FULLY_OBSERVABLE, BOTH_OBSERVATIONS = the reference default).
 Not built here (out of the hot-path scope): vs_human GUI, vs_bot sockets, HDF5 curriculum starts,
 the 'original' 32/33-layer channel mode.
 """
@@ -15,7 +16,7 @@ import copy
 import numpy as np
 import torch
 
-from .config import PO_OBS_CHANNELS, NUM_STATE_LAYERS, get_variant
+from .config import FO_OBS_CHANNELS, PO_OBS_CHANNELS, NUM_STATE_LAYERS, get_variant
 from .enums import GameVersions, ObservationComponents, ObservationModes
 from .setups import load_setup_table, sample_initial_maps_like_reference
 from .spaces import Box, Dict, Discrete
@@ -43,6 +44,7 @@ DEFAULT_CONFIG = {   # maenv:47-69
 
 _MASK = ObservationComponents.VALID_ACTIONS_MASK.value
 _POBS = ObservationComponents.PARTIAL_OBSERVATION.value
+_FOBS = ObservationComponents.FULL_OBSERVATION.value
 _ISTATE = ObservationComponents.INTERNAL_STATE.value
 
 # layer pairs swapped by the perspective flip (impl:645-675)
@@ -76,10 +78,11 @@ class StrategoMultiAgentEnv:
         mode = cfg['observation_mode']
         if isinstance(mode, str):
             mode = ObservationModes(mode)
-        if mode != ObservationModes.PARTIALLY_OBSERVABLE:
-            raise NotImplementedError("observation_mode=%s: only PARTIALLY_OBSERVABLE is built so far "
-                                      "(fully-observable channels are the next row of SURVEY.md 8f)" % mode)
+        assert mode in (ObservationModes.PARTIALLY_OBSERVABLE, ObservationModes.FULLY_OBSERVABLE,
+                        ObservationModes.BOTH_OBSERVATIONS)                                        # maenv:384-385
         self.observation_mode = mode
+        self._want_p = mode in (ObservationModes.PARTIALLY_OBSERVABLE, ObservationModes.BOTH_OBSERVATIONS)
+        self._want_f = mode in (ObservationModes.FULLY_OBSERVABLE, ObservationModes.BOTH_OBSERVATIONS)
         self.penalize_ties = cfg['penalize_ties']
         self.random_player_assignment = cfg['random_player_assignment']
         self.repeat_games_from_other_side = cfg['repeat_games_from_other_side']
@@ -90,7 +93,8 @@ class StrategoMultiAgentEnv:
             raise ValueError("Human inits not supported with {} game version".format(v.name))   # util.py:310
         self._table = load_setup_table(v.human_inits) if self.human_inits else None
 
-        self._vec = VecStrategoEnv(v.name, 1, device=device, seed=0, human_inits=False, auto_reset=False, final_obs=True)
+        self._vec = VecStrategoEnv(v.name, 1, device=device, seed=0, human_inits=False, auto_reset=False, final_obs=True,
+                                   full_obs=self._want_f)
         self.rows, self.columns = v.rows, v.columns
         self.spatial_action_size = v.spatial_action_size
         self.action_size = v.action_size
@@ -102,8 +106,11 @@ class StrategoMultiAgentEnv:
         self.episodes_completed = 0
         self.last_initial_state = None
         self.action_space = Discrete(int(np.prod(self.spatial_action_size)))          # maenv:362
-        spaces = {_MASK: Box(np.float32(0), np.float32(1), self.spatial_action_size),
-                  _POBS: Box(np.float32(-1.0), np.float32(1.0), (v.rows, v.columns, PO_OBS_CHANNELS))}
+        spaces = {_MASK: Box(np.float32(0), np.float32(1), self.spatial_action_size)}             # maenv:398-417
+        if self._want_p:
+            spaces[_POBS] = Box(np.float32(-1.0), np.float32(1.0), (v.rows, v.columns, PO_OBS_CHANNELS))
+        if self._want_f:
+            spaces[_FOBS] = Box(np.float32(-1.0), np.float32(1.0), (v.rows, v.columns, FO_OBS_CHANNELS))
         if self.observation_includes_internal_state:
             spaces[_ISTATE] = Box(np.float32(-np.inf), np.float32(np.inf), (NUM_STATE_LAYERS, v.rows, v.columns))
         self.observation_space = Dict(spaces)
@@ -125,8 +132,12 @@ class StrategoMultiAgentEnv:
         st, _ = self._vec.export_state()
         return st[0].cpu().numpy()
 
-    def _obs_dict(self, obs_t, mask_t, player):
-        d = {_MASK: mask_t.cpu().numpy().astype(np.int64), _POBS: obs_t.cpu().numpy().copy()}
+    def _obs_dict(self, obs_t, fobs_t, mask_t, player):
+        d = {_MASK: mask_t.cpu().numpy().astype(np.int64)}
+        if self._want_p:
+            d[_POBS] = obs_t.cpu().numpy().copy()
+        if self._want_f:
+            d[_FOBS] = fobs_t.cpu().numpy().copy()
         if self.observation_includes_internal_state:
             d[_ISTATE] = state_from_player_perspective(self.state, player)             # maenv:494-495
         return d
@@ -163,7 +174,8 @@ class StrategoMultiAgentEnv:
             self._vec.import_state(self.state[None], np.asarray([self.player], dtype=np.int8))
         self.episodes_completed += 1
         obs_t, mask_t, _ = self._vec.observe()
-        obs = {self.player: self._obs_dict(obs_t[0], mask_t[0], self.player)}
+        fobs_t = self._vec.fobs
+        obs = {self.player: self._obs_dict(obs_t[0], fobs_t[0] if fobs_t is not None else None, mask_t[0], self.player)}
         if self.random_player_assignment:                                              # maenv:654-655
             obs = {self.player_map(k): val for k, val in obs.items()}
         return obs
@@ -185,13 +197,14 @@ class StrategoMultiAgentEnv:
         self.player = int(flags[2])
         if not flags[1]:                                                                # maenv:767-770
             dones = {self.player: False, "__all__": False}
-            obs = {self.player: self._obs_dict(vec.obs[0], vec.mask[0], self.player)}
+            obs = {self.player: self._obs_dict(vec.obs[0], vec.fobs[0] if self._want_f else None, vec.mask[0], self.player)}
             rewards = {self.player: 0}
             infos = {}
         else:                                                                           # maenv:772-805
             dones = {1: True, -1: True, "__all__": True}
-            obs = {1: self._obs_dict(vec.final_obs[0, 0], vec.mask[0], 1),
-                   -1: self._obs_dict(vec.final_obs[0, 1], vec.mask[0], -1)}
+            ff = vec.final_fobs
+            obs = {1: self._obs_dict(vec.final_obs[0, 0], ff[0, 0] if ff is not None else None, vec.mask[0], 1),
+                   -1: self._obs_dict(vec.final_obs[0, 1], ff[0, 1] if ff is not None else None, vec.mask[0], -1)}
             infos = {1: {}, -1: {}}
             rew = vec.reward[0].cpu().numpy()
             if flags[3]:

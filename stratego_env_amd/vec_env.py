@@ -5,6 +5,7 @@ call goes through the C ABI in include/stratego_mi355x.h to the HIP kernels; PyT
 buffers and the stream.  Outputs are written in place into preallocated tensors:
 
     obs      float32 [N, R, C, 67]   normalised partial observation of each env's next mover
+    fobs     float32 [N, R, C, 79]   normalised fully-observable observation (only with full_obs=True)
     mask     uint8   [N, R, C, K]    valid-actions mask of the next mover (flat index = action)
     reward   float32 [N, 2]          rewards of player +1 / -1 (non-zero only when done)
     done     uint8   [N]
@@ -20,7 +21,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .config import PO_OBS_CHANNELS, NUM_STATE_LAYERS, get_variant
+from .config import FO_OBS_CHANNELS, PO_OBS_CHANNELS, NUM_STATE_LAYERS, get_variant
 from .setups import load_setup_table
 
 
@@ -30,7 +31,7 @@ def _ptr(t):
 
 class VecStrategoEnv:
     def __init__(self, version='barrage', num_envs=1, device=0, seed=0, env_id_offset=0, human_inits=None,
-                 auto_reset=False, final_obs=False, lib_path=None):
+                 auto_reset=False, final_obs=False, full_obs=False, lib_path=None):
         """human_inits: None = use the Gravon table when the variant has one (util.py:301-319), False = uniformly
         random back-row placement (util.py:33-53), True = require the table."""
         if not torch.cuda.is_available():
@@ -66,6 +67,10 @@ class VecStrategoEnv:
         self.invalid_action = torch.zeros((N,), dtype=torch.uint8, device=dev)
         self.ending_invalid = torch.zeros((N,), dtype=torch.uint8, device=dev)
         self.final_obs = torch.zeros((N, 2, R, Cc, PO_OBS_CHANNELS), dtype=torch.float32, device=dev) if final_obs else None
+        # fully-observable observation (ObservationModes FULLY_OBSERVABLE / BOTH_OBSERVATIONS), float32 [N,R,C,79]
+        self.fobs = torch.empty((N, R, Cc, FO_OBS_CHANNELS), dtype=torch.float32, device=dev) if full_obs else None
+        self.final_fobs = (torch.zeros((N, 2, R, Cc, FO_OBS_CHANNELS), dtype=torch.float32, device=dev)
+                           if (full_obs and final_obs) else None)
         self.next_actions = torch.zeros((N,), dtype=torch.int32, device=dev)
         self._io = _lib.SgxStepIO()
 
@@ -104,7 +109,8 @@ class VecStrategoEnv:
 
     def observe(self):
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_observe(self._h, _ptr(self.obs), _ptr(self.mask), _ptr(self.player), self._stream()))
+            _lib.check(self._L.sgx_observe(self._h, _ptr(self.obs), _ptr(self.fobs), _ptr(self.mask), _ptr(self.player),
+                                           self._stream()))
         return self.obs, self.mask, self.player
 
     def step(self, actions, want_next_actions=False, emit_obs=True, emit_mask=True):
@@ -115,6 +121,8 @@ class VecStrategoEnv:
         io = self._io
         io.actions_dev = a.data_ptr()
         io.obs_dev = self.obs.data_ptr() if emit_obs else None
+        io.fobs_dev = self.fobs.data_ptr() if (emit_obs and self.fobs is not None) else None
+        io.final_fobs_dev = self.final_fobs.data_ptr() if self.final_fobs is not None else None
         io.mask_dev = self.mask.data_ptr() if emit_mask else None
         io.reward_dev = self.reward.data_ptr()
         io.done_dev = self.done.data_ptr()

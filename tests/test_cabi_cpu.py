@@ -27,13 +27,13 @@ def test_header_symbols_all_exported(lib):
     assert declared == sorted(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.sgx_abi_version() == 1
+    assert lib.sgx_abi_version() == 2
 
 
 def test_struct_sizes_match_header():
-    # sgx_config: 4 + 12 int32 + 256 bytes; sgx_step_io: 10 pointers + 2 int32
+    # sgx_config: 4 + 12 int32 + 256 bytes; sgx_step_io: 12 pointers + 2 int32
     assert C.sizeof(_lib.SgxConfig) == 16 * 4 + 256
-    assert C.sizeof(_lib.SgxStepIO) == 10 * 8 + 8
+    assert C.sizeof(_lib.SgxStepIO) == 12 * 8 + 8
 
 
 def test_obs_lut_bit_exact_vs_reference_constants(lib):
@@ -67,6 +67,28 @@ def test_obs_lut_bit_exact_vs_reference_constants(lib):
     assert lut[41 + 6, 1].view(np.uint32) == 0xbeaaaaab      # major (hi 3), count 1 -> -0.33333334
     assert lut[41 + 11, 1].view(np.uint32) == 0xbf2aaaab     # bomb (hi 6), count 1 -> -0.6666667
     assert lut[41 + 0, 1].view(np.uint32) == 0xbf400000      # spy (hi 8), count 1 -> -0.75
+
+
+def test_full_obs_lut_bit_exact_vs_reference_constants(lib):
+    ref = load_variants_json()['variants']
+    for name, v in VARIANTS.items():
+        cfg = _lib.make_config(v)
+        lut = np.zeros(79 * 16, dtype=np.float32)
+        assert lib.sgx_build_full_obs_lut(C.byref(cfg), lut.ctypes.data_as(C.POINTER(C.c_float))) == 0
+        lut = lut.reshape(79, 16)
+        mids = np.asarray(ref[name]['f_obs_mids'], dtype=np.float32)
+        ranges = np.asarray(ref[name]['f_obs_ranges'], dtype=np.float32)
+        for ch in range(79):
+            for i in range(16):
+                if ch < 50:
+                    t = (ch % 12 + 1) if ch < 24 else ((ch - 24) % 13 + 1)
+                    raw = np.float32(1.0 if i == t else 0.0)
+                elif ch in (51, 52):
+                    raw = np.float32(i - 3)
+                else:
+                    raw = np.float32(i)
+                want = (raw - mids[ch]) / ranges[ch]
+                assert lut[ch, i].tobytes() == np.float32(want).tobytes(), (name, ch, i)
 
 
 def test_bad_config_rejected(lib):

@@ -58,6 +58,13 @@ def check_index_algebra(ref, R, C):
 def compare_obs(o_ref, o_orc, where):
     assert sorted(o_ref.keys()) == sorted(o_orc.keys()), (where, o_ref.keys(), o_orc.keys())
     for p in o_ref:
+        assert sorted(o_ref[p].keys()) == sorted(o_orc[p].keys()), (where, o_ref[p].keys(), o_orc[p].keys())
+        if 'full_observation' in o_ref[p]:
+            f_r, f_o = o_ref[p]['full_observation'], o_orc[p]['full_observation']
+            assert f_r.dtype == np.float32 and f_r.tobytes() == f_o.tobytes(), (where, 'full obs', p)
+        if 'partial_observation' not in o_ref[p]:
+            assert np.array_equal(o_ref[p]['valid_actions_mask'], o_orc[p]['valid_actions_mask'])
+            continue
         m_r, m_o = o_ref[p]['valid_actions_mask'], o_orc[p]['valid_actions_mask']
         assert m_r.dtype == np.int64 and m_r.shape == m_o.shape
         assert np.array_equal(m_r, m_o), (where, 'mask', p)
@@ -66,15 +73,16 @@ def compare_obs(o_ref, o_orc, where):
         assert p_r.tobytes() == p_o.tobytes(), (where, 'obs', p, np.argwhere(p_r != p_o)[:5])
 
 
-def play_game(ref, version_name, cfg, rng, garbage_rate, check_fns):
+def play_game(ref, version_name, cfg, rng, garbage_rate, check_fns, mode='partially_observable'):
     GV, OM = ref.enums.GameVersions, ref.enums.ObservationModes
-    env = ref.maenv.StrategoMultiAgentEnv({'version': GV(version_name), 'observation_mode': OM.PARTIALLY_OBSERVABLE,
+    env = ref.maenv.StrategoMultiAgentEnv({'version': GV(version_name), 'observation_mode': OM(mode),
                                            'human_inits': version_name in ('standard', 'barrage', 'short_barrage',
                                                                            'medium_standard', 'short_standard')})
     R, C = cfg['rows'], cfg['columns']
     counts = [cfg['piece_amounts'][ref.impl.SP(t)] for t in range(1, 13)]
-    oenv = orc.OracleEnv(R, C, cfg['max_turns'], cfg['obstacle_locations'], counts)
+    oenv = orc.OracleEnv(R, C, cfg['max_turns'], cfg['obstacle_locations'], counts, observation_mode=mode)
     assert np.array_equal(env._p_obs_mids.reshape(-1), oenv.mids) and np.array_equal(env._p_obs_ranges.reshape(-1), oenv.ranges)
+    assert np.array_equal(env._f_obs_mids.reshape(-1), oenv.f_mids) and np.array_equal(env._f_obs_ranges.reshape(-1), oenv.f_ranges)
     obs_r = env.reset()
     m1, m2 = own_side_maps_from_state(env.state)
     obs_o = oenv.reset(m1, m2)
@@ -176,7 +184,8 @@ def main():
             games = max(1, games // 3)
         total = 0
         for g in range(games):
-            total += play_game(ref, name, cfg, rng, garbage_rate=0.15, check_fns=(g == 0))
+            mode = ('partially_observable', 'both_observations', 'fully_observable')[g % 3]
+            total += play_game(ref, name, cfg, rng, garbage_rate=0.15, check_fns=(g == 0), mode=mode)
         print("%-16s %d games, %d steps: OK" % (name, games, total), flush=True)
     print("oracle == reference on all checks")
 
