@@ -98,6 +98,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
+    ap.add_argument('--placement-trials', type=int, default=6,
+                    help='candidate allocations of the output tensors tried by VecStrategoEnv.tune_placement (1 = off)')
     ap.add_argument('--wake-seconds', type=float, default=2.0,
                     help='untimed GPU wake-up before the warmup steps (a fresh box runs its first ~second at idle clocks)')
     args = ap.parse_args()
@@ -112,10 +114,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     if args.wake_seconds > 0:   # bring the GPU out of its idle power state; touches no env state
         scratch = torch.empty(1 << 28, dtype=torch.float32, device='cuda')
@@ -131,6 +134,7 @@ def main():
     n = args.envs
     env = VecStrategoEnv(args.version, n, device=local_rank, seed=BASE_SEED, env_id_offset=rank * n, auto_reset=True)
     env.reset()
+    placement_us = env.tune_placement(args.placement_trials) if args.placement_trials > 1 else None
     env.sample_valid_actions()
 
     def one_step():
@@ -179,12 +183,14 @@ def main():
             "metric": "env steps/sec", "value": total_steps / elapsed, "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int8 state / uint8 mask / f32 obs", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%d concurrent %s games per GPU (%dx%d), random-valid-action rollout with auto-reset, "
                                    "%s step+sample" % (n, args.version, v.rows, v.columns,
                                                        "separate" if args.unfused else "fused"),
                        "games_per_gpu": n, "version": args.version, "seed": BASE_SEED,
-                       "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns)},
+                       "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns),
+                       "placement_trial_us": ({k: [round(x, 1) for x in t] for k, t in placement_us.items()}
+                                              if placement_us else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": args.traffic_bytes if args.traffic_bytes is not None else measured_traffic(args.version, n),

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 
@@ -113,6 +114,7 @@ struct KParams {
     int64_t env_id_offset;
     sgx_step_io io;
     int32_t mode;  // 0 = step, 1 = observe
+    int32_t map_mode;  // experiment knob (env SGX_MAP_MODE): 0 = XCD-chunked game map, 1 = linear, 2 = XCD-chunked with interleaved sub-chunks
 #ifdef SGX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [N][16] s_memtime stamps per phase
 #endif
@@ -175,10 +177,15 @@ __device__ inline int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // XCD-aware block -> env map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
 // range of envs so neighbouring envs' output lines meet in one L2.
-__device__ inline int64_t group_of_block() {
+__device__ inline int64_t group_of_block(int map_mode) {
     const int64_t nb = gridDim.x, b = blockIdx.x;
+    if ((map_mode & 15) == 1) return b;
     const int64_t chunk = nb >> 3;  // grid is a multiple of 8
-    return (b & 7) * chunk + (b >> 3);
+    if ((map_mode & 15) == 2) {            // each XCD sweeps 64-group sub-chunks that interleave with the other XCDs' sub-chunks
+        const int64_t i = b >> 3, x = b & 7;
+        return ((i >> 6) * 8 + x) * 64 + (i & 63);
+    }
+    return (((b & 7) + (map_mode >> 4)) & 7) * chunk + (b >> 3);   // bits 4..6 of map_mode: rotate the XCD -> region assignment
 }
 
 // Orders the LDS phases of ONE wave (each wave owns its game's LDS region; waves of a workgroup never exchange
@@ -534,7 +541,7 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) vo
     __shared__ Lds<G> LW[WPB];
     __shared__ alignas(16) float lut_s[LUT_DWORDS * (FULL ? 2 : 1)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t env = group_of_block() * WPB + wave;
+    const int64_t env = group_of_block(P.map_mode) * WPB + wave;
 
     // ---- the workgroup's shared normalisation LUT (L2-resident source)
     for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB)
@@ -1071,6 +1078,7 @@ KParams make_params(const sgx_env *h) {
     p.n_envs = h->n_envs;
     p.seed = h->seed;
     p.env_id_offset = h->env_id_offset;
+    { const char *mm = getenv("SGX_MAP_MODE"); p.map_mode = mm ? atoi(mm) : 0; }
 #ifdef SGX_STAMPS
     p.stamps = h->stamps;
 #endif

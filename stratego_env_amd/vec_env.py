@@ -113,6 +113,39 @@ class VecStrategoEnv:
                                            self._stream()))
         return self.obs, self.mask, self.player
 
+    def tune_placement(self, trials=6, launches=6):
+        """Pick the fastest of `trials` candidate allocations for the big output tensors (obs, mask).
+
+        Measured on MI355X (tools/grid_probe.py): the same kernel writing the same bytes runs up to
+        ~30 % slower on some device allocations than on others (offsets inside one allocation do not matter, a plain
+        `fill_` is equally fast on all of them; it is the placement of the buffer that thousands of concurrent
+        per-game store streams land on).  Physical placement cannot be requested, so this allocates candidates, times a few
+        `sgx_observe` launches (which write obs + mask and change no state) on each, keeps the fastest and frees the rest.
+        Call after reset(); returns {'obs': [...], 'mask': [...]} per-candidate launch times in microseconds."""
+        def time_observe():
+            self.observe()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
+            for _ in range(launches):
+                self.observe()
+            e1.record(torch.cuda.current_stream(self.device))
+            e1.synchronize()
+            return e0.elapsed_time(e1) / launches * 1e3
+
+        report = {}
+        for name, dtype in (('obs', torch.float32), ('mask', torch.uint8)):   # the obs buffer matters most; then the mask
+            cur = getattr(self, name)
+            cands = [cur] + [torch.empty(tuple(cur.shape), dtype=dtype, device=self.device) for _ in range(max(0, trials - 1))]
+            times = []
+            for c in cands:
+                setattr(self, name, c)
+                times.append(time_observe())
+            setattr(self, name, cands[min(range(len(cands)), key=lambda i: times[i])])
+            del cands
+            report[name] = times
+        self.observe()
+        return report
+
     def step(self, actions, want_next_actions=False, emit_obs=True, emit_mask=True):
         """One env.step() for every env.  actions: int32 [N] flat (R,C,K) indices in each mover's perspective."""
         a = actions

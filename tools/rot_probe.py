@@ -1,0 +1,23 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from stratego_env_amd.vec_env import VecStrategoEnv
+n = 65536
+x = torch.empty(1 << 28, device='cuda'); t0 = time.time()
+while time.time() - t0 < 2.0:
+    x.fill_(1.0); torch.cuda.synchronize()
+del x
+env = VecStrategoEnv('barrage', n, seed=0x5712A7E60, auto_reset=True)
+env.reset(); env.sample_valid_actions()
+for _ in range(32): env.rollout_step()
+keep = []
+for a in range(5):
+    env.obs = torch.empty((n, 10, 10, 67), dtype=torch.float32, device='cuda'); keep.append(env.obs)
+    row = []
+    for rot in range(8):
+        os.environ['SGX_MAP_MODE'] = str(rot << 4)
+        for _ in range(4): env.rollout_step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
+        for _ in range(24): env.rollout_step()
+        e1.record(); torch.cuda.synchronize(); row.append(e0.elapsed_time(e1) / 24 * 1e3)
+    print("alloc %d %#x rot0..7: %s" % (a, env.obs.data_ptr(), " ".join("%.0f" % v for v in row)))
