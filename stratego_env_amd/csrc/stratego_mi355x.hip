@@ -151,6 +151,7 @@ struct alignas(16) Lds {
     alignas(16) uint8_t cnt[G::CNT_PAD];               // valid moves per perspective cell (also setup-shuffle scratch)
     alignas(16) uint8_t occ[G::S];                     // gen_mask scratch: combined occupancy byte per cell
     alignas(16) uint8_t plist[G::CNT_PAD];             // gen_mask scratch: compacted list of movable cells
+    int qi;                                            // SGX_COOP_EMIT: perspective (player index) of the next mover
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -533,25 +534,19 @@ constexpr int waves_per_simd() {
     return w > SGX_MIN_WAVES ? SGX_MIN_WAVES : (w < 1 ? 1 : w);
 }
 
-// FULL: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492)
+// One game's env.step() by one wave (called with the wave's private LDS region).  With SGX_COOP_EMIT the big outputs
+// (mask, observations of the next mover) are not written here: the wave publishes the perspective in L.qi and the
+// workgroup emits all its games' outputs together (coop_emit_*, below).
+#ifdef SGX_COOP_EMIT
+template <class G> constexpr bool coop_emit() { return G::RC % 4 == 0 && G::NA % 4 == 0; }
+#else
+template <class G> constexpr bool coop_emit() { return false; }
+#endif
+
 template <int R_, int C_, bool FULL>
-__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) void step_kernel(const KParams P) {
+__device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, const float *lut_s, const int64_t env, const int lane) {
     using G = Geo<R_, C_>;
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
-    __shared__ Lds<G> LW[WPB];
-    __shared__ alignas(16) float lut_s[LUT_DWORDS * (FULL ? 2 : 1)];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t env = group_of_block(P.map_mode) * WPB + wave;
-
-    // ---- the workgroup's shared normalisation LUT (L2-resident source)
-    for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB)
-        reinterpret_cast<f32x4 *>(lut_s)[i] = reinterpret_cast<const f32x4 *>(P.tab->obs_lut)[i];
-    if constexpr (FULL)
-        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB)
-            reinterpret_cast<f32x4 *>(lut_s + LUT_DWORDS)[i] = reinterpret_cast<const f32x4 *>(P.tab->fobs_lut)[i];
-    __syncthreads();   // the only workgroup-wide barrier; from here on every wave works on its own game
-    if (env >= P.n_envs) return;
-    Lds<G> &L = LW[wave];
     STAMP(0);
 
     int8_t *rec_g = P.boards + env * (int64_t)P.rec_bytes;
@@ -773,13 +768,17 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) vo
     STAMP(4);   // results / terminal handling done
     // ---- outputs for the next mover
     if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
-    if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
-    STAMP(5);   // mask stores issued
-    // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
-    if (P.io.obs_dev) emit_obs<G, PartialObs>(L, lut, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
-    if constexpr (FULL)
-        if (P.io.fobs_dev) emit_obs<G, FullObs>(L, lut + LUT_DWORDS, qi, P.io.fobs_dev + env * (int64_t)(RC * FOBS_CH), lane);
-    STAMP(6);   // obs stores issued
+    if constexpr (coop_emit<G>()) {
+        if (lane == 0) L.qi = qi;
+    } else {
+        if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
+        STAMP(5);   // mask stores issued
+        // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
+        if (P.io.obs_dev) emit_obs<G, PartialObs>(L, lut, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
+        if constexpr (FULL)
+            if (P.io.fobs_dev) emit_obs<G, FullObs>(L, lut + LUT_DWORDS, qi, P.io.fobs_dev + env * (int64_t)(RC * FOBS_CH), lane);
+        STAMP(6);   // obs stores issued
+    }
     if (P.mode == 0 && P.io.next_actions_dev) {
         const int total = nvalid == 0 ? 1 : nvalid;
         const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, STREAM_ACTION, (uint32_t)turn), (uint32_t)total);
@@ -825,6 +824,107 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) vo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(9);   // all stores acknowledged
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Workgroup-cooperative emission (SGX_COOP_EMIT): after one barrier the WPB waves write the workgroup's WPB
+// consecutive games as contiguous bursts (store-pattern probe tools/microbench/coop_pattern.hip: +7 % over
+// independent per-wave streams).  Work item = one 4-cell group (NCH quads) of one game, dealt round-robin to the
+// waves, so a lane's four (cell offset, channel) pairs stay loop-invariant exactly as in emit_obs.
+// ---------------------------------------------------------------------------------------------
+template <class G, class Spec>
+__device__ void coop_emit_obs(const Lds<G> *LW, const float *lut, float *__restrict__ base, int n_active, int wave, int lane) {
+    constexpr int RC = G::RC, S = G::S, NCH = Spec::NCH, NG = RC / 4, NT = NCH - 64;
+    int b0[4], b1[4], lrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int f = 4 * lane + j, rc = f / NCH, ch = f - rc * NCH;
+        b0[j] = Spec::board(ch, 0) * S + rc;
+        b1[j] = Spec::board(ch, 1) * S + RC - 1 - rc;
+        lrow[j] = lut_row(ch) + Spec::bias(ch);
+    }
+#pragma unroll 2
+    for (int p = wave; p < n_active * NG; p += WPB) {
+        const int k = p / NG, s = p - k * NG;
+        const int qi = uni(LW[k].qi);
+        const int8_t *bb = &LW[k].b[0][0];
+        f32x4 o;
+        o.x = lut[lrow[0] + bb[qi ? b1[0] - 4 * s : b0[0] + 4 * s]];
+        o.y = lut[lrow[1] + bb[qi ? b1[1] - 4 * s : b0[1] + 4 * s]];
+        o.z = lut[lrow[2] + bb[qi ? b1[2] - 4 * s : b0[2] + 4 * s]];
+        o.w = lut[lrow[3] + bb[qi ? b1[3] - 4 * s : b0[3] + 4 * s]];
+        stream_store(reinterpret_cast<f32x4 *>(base + (int64_t)k * RC * NCH) + s * NCH + lane, o);
+    }
+    for (int t = wave * 64 + lane; t < n_active * NG * NT; t += 64 * WPB) {
+        const int k = t / (NG * NT), r = t - k * (NG * NT), s = r / NT, qd = 64 + (r - s * NT);
+        const int qi = LW[k].qi;
+        const int8_t *bb = &LW[k].b[0][0];
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = 4 * qd + j, rc = f / NCH, ch = f - rc * NCH;
+            const int pcell = 4 * s + rc, cell = qi ? RC - 1 - pcell : pcell;
+            v[j] = lut[lut_row(ch) + Spec::bias(ch) + bb[Spec::board(ch, qi) * S + cell]];
+        }
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        stream_store(reinterpret_cast<f32x4 *>(base + (int64_t)k * RC * NCH) + s * NCH + qd, o);
+    }
+}
+
+template <class G>
+__device__ void coop_emit_mask(const Lds<G> *LW, uint8_t *__restrict__ base, int n_active, int tid) {
+    constexpr int NA = G::NA;
+    const int A = (int)(reinterpret_cast<uintptr_t>(base) & 15), total = n_active * NA;
+    uint8_t *gbase = base - A;
+    for (int c = tid; c < (A + total + 15) >> 4; c += 64 * WPB) {
+        const int lo = 16 * c - A;
+        uint32_t w4[4];
+        bool in[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int o = lo + 4 * w;
+            in[w] = o >= 0 && o < total;
+            const int oo = in[w] ? o : 0, k = oo / NA, within = oo - k * NA;   // NA % 4 == 0: a dword never straddles two games
+            w4[w] = expand4(mask_bits(LW[k], within, 4));
+        }
+        if (in[0] && in[3]) {
+            i32x4 q4 = {(int)w4[0], (int)w4[1], (int)w4[2], (int)w4[3]};
+            stream_store(&reinterpret_cast<i32x4 *>(gbase)[c], q4);
+        } else {
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (in[w]) *reinterpret_cast<uint32_t *>(gbase + 16 * c + 4 * w) = w4[w];
+        }
+    }
+}
+
+// FULL: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492)
+template <int R_, int C_, bool FULL>
+__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) void step_kernel(const KParams P) {
+    using G = Geo<R_, C_>;
+    __shared__ Lds<G> LW[WPB];
+    __shared__ alignas(16) float lut_s[LUT_DWORDS * (FULL ? 2 : 1)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t env0 = group_of_block(P.map_mode) * WPB, env = env0 + wave;
+
+    // ---- the workgroup's shared normalisation LUT (L2-resident source)
+    for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB)
+        reinterpret_cast<f32x4 *>(lut_s)[i] = reinterpret_cast<const f32x4 *>(P.tab->obs_lut)[i];
+    if constexpr (FULL)
+        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB)
+            reinterpret_cast<f32x4 *>(lut_s + LUT_DWORDS)[i] = reinterpret_cast<const f32x4 *>(P.tab->fobs_lut)[i];
+    __syncthreads();   // from here on every wave works on its own game
+    if (env < P.n_envs) env_step<R_, C_, FULL>(P, LW[wave], lut_s, env, lane);
+    if constexpr (coop_emit<G>()) {
+        __syncthreads();   // all games of the workgroup are stepped; their boards / mask bits / perspectives are in LDS
+        const int n_active = (int)min((int64_t)WPB, P.n_envs - env0);
+        if (n_active <= 0) return;
+        if (P.io.mask_dev) coop_emit_mask<G>(LW, P.io.mask_dev + env0 * (int64_t)G::NA, n_active, threadIdx.x);
+        if (P.io.obs_dev) coop_emit_obs<G, PartialObs>(LW, lut_s, P.io.obs_dev + env0 * (int64_t)G::NOBS, n_active, wave, lane);
+        if constexpr (FULL)
+            if (P.io.fobs_dev)
+                coop_emit_obs<G, FullObs>(LW, lut_s + LUT_DWORDS, P.io.fobs_dev + env0 * (int64_t)(G::RC * FOBS_CH), n_active, wave, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
