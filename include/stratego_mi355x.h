@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 2
+#define SGX_ABI_VERSION 3
 #define SGX_MAX_CELLS 256        /* rows*cols <= 256 (largest reference variant: 15x15) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
 #define SGX_FO_OBS_CHANNELS 79   /* impl:1227 */
@@ -79,8 +79,17 @@ typedef struct sgx_step_io {
                                       the batched counterpart of sample_random_valid_action (maenv:830-834) */
     int32_t auto_reset;            /* 1: an env that finishes starts its next game inside the same call
                                       (obs/mask/player then describe the new game's first mover) */
-    int32_t reserved;
+    int32_t flags;                 /* SGX_STEP_* bits, 0 for the env.step() path */
 } sgx_step_io;
+
+/* sgx_step_io.flags: the functional StrategoProceduralEnv API on caller-provided states (import -> step -> export) */
+#define SGX_STEP_ACTIONS_1D 1         /* actions_dev holds absolute-coordinate 1-D indices (impl:262-277), as
+                                         get_next_state / is_move_valid_by_1d_index take them (penv:94-99, 148-155) */
+#define SGX_STEP_ALLOW_OSCILLATION 2  /* allow_piece_oscillation=True: skip the two-square check of the MOVE (impl:771-777);
+                                         masks still apply it, as in the reference */
+#define SGX_STEP_RAW_OBS 4            /* observations un-normalised, as penv:166-173 return them */
+#define SGX_STEP_ACTIONS_POSITIONS 8   /* actions_dev is int32 [N][4] = (start_r, start_c, end_r, end_c) in absolute coordinates
+                                         (is_move_valid_by_position, penv:87-92) */
 
 /* Library / geometry queries (penv:32-36: action_size, spatial_action_size). */
 int sgx_abi_version(void);
@@ -117,8 +126,9 @@ int sgx_set_setup_table(sgx_env *h, const uint8_t *table_host, int64_t n_setups)
 int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p1_maps_dev, const int8_t *p2_maps_dev, void *stream);
 
 /* _get_current_obs (maenv:447-497) for every env's current mover, no state change.
- * obs_dev, fobs_dev, mask_dev and player_dev are laid out as in sgx_step_io; each is nullable. */
-int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, int8_t *player_dev, void *stream);
+ * obs_dev, fobs_dev, mask_dev and player_dev are laid out as in sgx_step_io; each is nullable.
+ * flags: 0 or SGX_STEP_RAW_OBS. */
+int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, int8_t *player_dev, int32_t flags, void *stream);
 
 /* One batched env.step(): see sgx_step_io. */
 int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);

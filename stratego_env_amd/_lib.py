@@ -12,6 +12,7 @@ SGX_MAX_CELLS = 256
 SGX_OBS_LUT_STRIDE = 16
 PO_OBS_CHANNELS = 67
 FO_OBS_CHANNELS = 79
+STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS = 1, 2, 4, 8
 
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (
@@ -31,7 +32,7 @@ class SgxStepIO(C.Structure):
                 ('reward_dev', C.c_void_p), ('done_dev', C.c_void_p), ('player_dev', C.c_void_p),
                 ('invalid_action_dev', C.c_void_p), ('ending_invalid_dev', C.c_void_p), ('final_obs_dev', C.c_void_p),
                 ('final_fobs_dev', C.c_void_p), ('next_actions_dev', C.c_void_p), ('auto_reset', C.c_int32),
-                ('reserved', C.c_int32)]
+                ('flags', C.c_int32)]
 
 
 class SgxError(RuntimeError):
@@ -68,7 +69,7 @@ def _bind(L):
     L.sgx_reset.restype = C.c_int
     L.sgx_reset.argtypes = [vp, vp, vp, vp, vp]
     L.sgx_observe.restype = C.c_int
-    L.sgx_observe.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.sgx_observe.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp]
     L.sgx_step.restype = C.c_int
     L.sgx_step.argtypes = [vp, C.POINTER(SgxStepIO), vp]
     L.sgx_sample_valid.restype = C.c_int

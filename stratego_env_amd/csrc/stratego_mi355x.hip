@@ -95,6 +95,8 @@ struct Geo {
 struct DevTables {
     float obs_lut[LUT_DWORDS];   // partial observation, rows at lut_row(ch)
     float fobs_lut[LUT_DWORDS];  // fully-observable observation
+    float raw_lut[LUT_DWORDS];   // SGX_STEP_RAW_OBS: un-normalised channel values (penv:166-173 return raw observations)
+    float raw_flut[LUT_DWORDS];
     uint8_t obstacles[SGX_MAX_CELLS];
 };
 
@@ -590,10 +592,23 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
         // ------------------------------------------------------------------------------------------
         // decode (maenv:684-689): flat spatial index -> positions -> 1-D index -> absolute 1-D index
         // ------------------------------------------------------------------------------------------
-        const int a = uni(P.io.actions_dev[env]);
+        const int a = (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) ? 0 : uni(P.io.actions_dev[env]);
         int sr = 0, sc_ = 0, er = 0, ec = 0;
         bool valid = true;
-        if (a < 0 || a >= NA) {
+        if (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) {
+            // is_move_valid_by_position (penv:87-92): actions_dev is int32 [N][4] = (start_r, start_c, end_r, end_c), absolute
+            const int4 q = reinterpret_cast<const int4 *>(P.io.actions_dev)[env];
+            sr = uni(q.x); sc_ = uni(q.y); er = uni(q.z); ec = uni(q.w);
+        } else if (P.io.flags & SGX_STEP_ACTIONS_1D) {
+            // functional API (penv:148-155): the action already is an absolute-coordinate 1-D index (impl:262-277)
+            if (a == AS - 1) {
+                noop_path = true;
+            } else {                                                                         // impl:369-383
+                const int q = fdiv_(a, MPA), off = fmod_(a, MPA);
+                sr = fdiv_(q, C); sc_ = fmod_(q, C);
+                if (off >= R) { ec = off - R; er = sr; } else { er = off; ec = sc_; }
+            }
+        } else if (a < 0 || a >= NA) {
             valid = false;  // np.unravel_index raises
         } else {
             const int cell = a / K, ch = a - cell * K;
@@ -647,7 +662,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
             if (t == 0 || t == SP_FLAG || t == SP_BOMB) valid = false;
             if (own_e != 0) valid = false;
             if (er != sr && ec != sc_) valid = false;
-            if (old_start == -3 && old_end == 1 && dest == 0) valid = false;
+            if (old_start == -3 && old_end == 1 && dest == 0 && !(P.io.flags & SGX_STEP_ALLOW_OSCILLATION)) valid = false;   // impl:771-777
             if (valid) {
                 const int dist = (er != sr) ? abs(er - sr) : abs(ec - sc_);
                 if (t == SP_SCOUT) {
@@ -908,11 +923,13 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) vo
     const int64_t env0 = group_of_block(P.map_mode) * WPB, env = env0 + wave;
 
     // ---- the workgroup's shared normalisation LUT (L2-resident source)
-    for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB)
-        reinterpret_cast<f32x4 *>(lut_s)[i] = reinterpret_cast<const f32x4 *>(P.tab->obs_lut)[i];
-    if constexpr (FULL)
-        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB)
-            reinterpret_cast<f32x4 *>(lut_s + LUT_DWORDS)[i] = reinterpret_cast<const f32x4 *>(P.tab->fobs_lut)[i];
+    const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
+    const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(raw ? P.tab->raw_lut : P.tab->obs_lut);
+    for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
+    if constexpr (FULL) {
+        const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(raw ? P.tab->raw_flut : P.tab->fobs_lut);
+        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s + LUT_DWORDS)[i] = fsrc[i];
+    }
     __syncthreads();   // from here on every wave works on its own game
     if (env < P.n_envs) env_step<R_, C_, FULL>(P, LW[wave], lut_s, env, lane);
     if constexpr (coop_emit<G>()) {
@@ -1215,7 +1232,7 @@ SGX_API int64_t sgx_action_size_1d(const sgx_env *h) {
 // Normalisation LUT shared by both observation kinds: channel layout = [n_own_true][n_enemy_true][13 own PO][13 enemy PO]
 // [obstacle][2 recent][12+12 captured][2 still]; partial has no enemy-true block (impl:1306-1332 vs impl:1200-1227).
 // highs/lows maenv:202-313, ranges/mids maenv:388-396, (x - mid) / range in float32 maenv:499-508.
-static void build_lut(const sgx_config *cfg, bool full, float *lut) {
+static void build_lut(const sgx_config *cfg, bool full, float *lut, bool raw_values = false) {
     const int nch = full ? FOBS_CH : OBS_CH;
     const int n_true = full ? 24 : 12, po_end = n_true + 26, obst = po_end, rec0 = po_end + 1, cap0 = po_end + 3, still0 = cap0 + 24;
     float hi[FOBS_CH], lo[FOBS_CH];
@@ -1237,7 +1254,7 @@ static void build_lut(const sgx_config *cfg, bool full, float *lut) {
             } else if (ch == rec0 || ch == rec0 + 1) raw = (float)(i - 3);
             else raw = (float)i;
             volatile float d = raw - mid;        // two IEEE float32 roundings, as numpy does
-            lut[ch * LUT_STRIDE + i] = d / range;
+            lut[ch * LUT_STRIDE + i] = raw_values ? raw : d / range;
         }
     }
 }
@@ -1293,6 +1310,12 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
         build_lut(cfg, true, dense);
         for (int ch = 0; ch < FOBS_CH; ++ch)
             for (int i = 0; i < LUT_STRIDE; ++i) host_tab.fobs_lut[lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
+        build_lut(cfg, false, dense, true);
+        for (int ch = 0; ch < OBS_CH; ++ch)
+            for (int i = 0; i < LUT_STRIDE; ++i) host_tab.raw_lut[lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
+        build_lut(cfg, true, dense, true);
+        for (int ch = 0; ch < FOBS_CH; ++ch)
+            for (int i = 0; i < LUT_STRIDE; ++i) host_tab.raw_flut[lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
     }
     memcpy(host_tab.obstacles, cfg->obstacles, rc_cells);
     if (hipMalloc((void **)&h->boards, (size_t)n_envs * h->rec_bytes) != hipSuccess ||
@@ -1371,13 +1394,14 @@ static int launch_step(sgx_env *h, const KParams &p, void *stream) {
     return SGX_OK;
 }
 
-SGX_API int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, int8_t *player_dev, void *stream) {
+SGX_API int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, int8_t *player_dev, int32_t flags, void *stream) {
     if (!h) return fail(SGX_EINVAL, "handle is NULL%s");
     HIP_TRY(hipSetDevice(h->device));
     KParams p = make_params(h);
     p.mode = 1;
     p.io.obs_dev = obs_dev;
     p.io.fobs_dev = fobs_dev;
+    p.io.flags = flags & SGX_STEP_RAW_OBS;
     p.io.mask_dev = mask_dev;
     p.io.player_dev = player_dev;
     return launch_step(h, p, stream);

@@ -1,0 +1,175 @@
+"""BatchedStrategoProceduralEnv: the reference's functional operator API (StrategoProceduralEnv,
+game/stratego_procedural_env.py:20-181) for a batch of caller-provided states.
+
+Every method is a pure function of (states int64 [N,34,R,C] in the reference layout, players [N], actions [N]) and returns
+fresh tensors, like the reference's methods do for one state.  Game logic runs in the HIP kernels: the states are imported
+into a scratch handle (`sgx_import_state`), stepped / observed there, and exported again; tree-search style callers keep
+their states on the device.  Where the reference raises ValueError for an invalid move, `get_next_state` returns a
+`valid` mask and leaves that state unchanged.
+
+Limits (documented in DESIGN.md): states must be reachable ones -- at most two non-zero recent-move cells per player and
+no more captured pieces than pieces exist; the obstacle layer must equal the variant's (it is a per-handle constant).
+"""
+import numpy as np
+import torch
+
+from . import _lib, index_algebra as ia
+from .config import NUM_STATE_LAYERS, get_variant
+from .vec_env import VecStrategoEnv
+
+# layer pairs swapped by the perspective flip (impl:645-675)
+_SWAP_A = [0, 3, 6, 32] + list(range(8, 20))
+_SWAP_B = [1, 4, 7, 33] + list(range(20, 32))
+
+
+class BatchedStrategoProceduralEnv:
+    def __init__(self, version, batch_size, device=0):
+        self.variant = get_variant(version)
+        v = self.variant
+        if v.rows < 3 or v.columns < 3:
+            raise ValueError("Both rows and columns have to be at least 3")                        # penv:28-30
+        self.rows, self.columns = v.rows, v.columns
+        self.batch_size = int(batch_size)
+        self.action_size = v.action_size                                                            # penv:34
+        self.spatial_action_size = v.spatial_action_size                                            # penv:35
+        self._vec = VecStrategoEnv(v.name, batch_size, device=device, human_inits=False, full_obs=True)
+        self.device = self._vec.device
+        sp, od = ia.gather_tables(v.rows, v.columns)
+        self._spatial_src = torch.from_numpy(np.stack(sp)).to(self.device)                          # [2, NA]
+        self._onedim_src = torch.from_numpy(np.stack(od)).to(self.device)                           # [2, AS]
+        self._obstacles = torch.from_numpy(v.obstacle_map().astype(np.int64)).to(self.device)
+
+    # ---- helpers ---------------------------------------------------------------------------------------------
+    def _players(self, players):
+        p = torch.as_tensor(players).to(device=self.device, dtype=torch.int8).reshape(self.batch_size).contiguous()
+        return p
+
+    def _load(self, states, players):
+        st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64).contiguous()
+        if tuple(st.shape) != (self.batch_size, NUM_STATE_LAYERS, self.rows, self.columns):
+            raise ValueError("states must have shape (batch, 34, rows, columns)")
+        pl = self._players(players)
+        vec = self._vec
+        with torch.cuda.device(self.device):
+            _lib.check(vec._L.sgx_import_state(vec._h, st.data_ptr(), pl.data_ptr(), vec._stream()))
+        return st, pl
+
+    def _perspective_mask_ext(self):
+        """kernels' mask (mover perspective, flat) with one zero column appended."""
+        m = self._vec.mask.view(self.batch_size, -1)
+        return torch.cat([m, torch.zeros((self.batch_size, 1), dtype=m.dtype, device=self.device)], dim=1)
+
+    # ---- state construction / transition -----------------------------------------------------------------------
+    def create_initial_state(self, player_1_initial_piece_maps, player_2_initial_piece_maps):      # penv:38-60
+        """own-side piece maps int [N,R,C] -> states (obstacle map and max_turns come from the variant)."""
+        self._vec.reset(player_1_initial_piece_maps, player_2_initial_piece_maps)
+        st, _ = self._vec.export_state()
+        return st
+
+    def get_next_state(self, states, players, action_indices, allow_piece_oscillation=False):      # penv:148-155
+        """-> (new_states, new_players int8, valid bool).  action_indices: absolute 1-D indices (impl:262-277)."""
+        st, pl = self._load(states, players)
+        flags = _lib.STEP_ACTIONS_1D | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
+        a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.batch_size)
+        self._vec.step(a, emit_obs=False, emit_mask=False, flags=flags)
+        new_states, new_players = self._vec.export_state()
+        return new_states, new_players, self._vec.invalid_action == 0
+
+    def is_move_valid_by_1d_index(self, states, players, action_indices, allow_piece_oscillation=False):   # penv:94-99
+        self._load(states, players)
+        flags = _lib.STEP_ACTIONS_1D | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
+        a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.batch_size)
+        self._vec.step(a, emit_obs=False, emit_mask=False, flags=flags)
+        return self._vec.invalid_action == 0
+
+    def is_move_valid_by_position(self, states, players, start_r, start_c, end_r, end_c, allow_piece_oscillation=False):  # penv:87-92
+        self._load(states, players)
+        pos = torch.stack([torch.as_tensor(x).to(device=self.device, dtype=torch.int32).reshape(self.batch_size)
+                           for x in (start_r, start_c, end_r, end_c)], dim=1).contiguous()
+        flags = _lib.STEP_ACTIONS_POSITIONS | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
+        self._vec.step(pos.view(-1), emit_obs=False, emit_mask=False, flags=flags)
+        return self._vec.invalid_action == 0
+
+    # ---- masks ---------------------------------------------------------------------------------------------------
+    def get_valid_moves_as_spatial_mask(self, states, players):                                     # penv:127-128
+        """uint8 [N,R,C,K] in the coordinates of the given states (no perspective flip), like impl:399-517."""
+        _, pl = self._load(states, players)
+        self._vec.observe()
+        pi = (pl < 0).to(torch.int64)
+        out = torch.gather(self._perspective_mask_ext(), 1, self._spatial_src[pi])
+        return out.view(self.batch_size, *self.spatial_action_size)
+
+    def get_valid_moves_as_1d_mask(self, states, players):                                          # penv:74-80
+        """uint8 [N, action_size] in absolute coordinates, like impl:520-642 (last element = no-op)."""
+        _, pl = self._load(states, players)
+        self._vec.observe()
+        pi = (pl < 0).to(torch.int64)
+        return torch.gather(self._perspective_mask_ext(), 1, self._onedim_src[pi])
+
+    # ---- observations (raw, as the reference's operator layer returns them; maenv normalises afterwards) -----------
+    def get_partially_observable_observation_extended_channels(self, states, players):             # penv:171-173
+        self._load(states, players)
+        self._vec.observe(raw=True)
+        return self._vec.obs.clone()
+
+    def get_fully_observable_observation_extended_channels(self, states, players):                 # penv:166-169
+        self._load(states, players)
+        self._vec.observe(raw=True)
+        return self._vec.fobs.clone()
+
+    # ---- pure tensor functions (no kernel needed) -------------------------------------------------------------------
+    def get_state_from_player_perspective(self, states, players):                                   # penv:101-103 / impl:645-675
+        st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64)
+        pl = self._players(players)
+        flipped = st.clone()
+        f = st.flip(dims=(2, 3))
+        flipped[:, _SWAP_A] = f[:, _SWAP_B]
+        flipped[:, _SWAP_B] = f[:, _SWAP_A]
+        flipped[:, 2] = f[:, 2]
+        return torch.where((pl < 0).view(-1, 1, 1, 1), flipped, st)
+
+    def get_game_ended(self, states, players):                                                      # penv:141-143 / impl:834-842
+        st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64)
+        pl = self._players(players).to(torch.float32)
+        over, winner = st[:, 5, 0, 1] != 0, st[:, 5, 0, 2].to(torch.float32)
+        val = torch.where(winner == 0, torch.full_like(winner, 1e-4), winner * pl)
+        return torch.where(over, val, torch.zeros_like(val))
+
+    def get_game_result_is_invalid(self, states):                                                   # penv:145-146 / impl:845-849
+        st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64)
+        return (st[:, 5, 0, 1] != 0) & (st[:, 5, 1, 1] != 0)
+
+    # ---- index converters (batched numpy/torch-friendly; impl:262-396, 678-720) ------------------------------------------
+    def get_action_1d_index_from_positions(self, sr, sc, er, ec):
+        return ia.action_1d_from_positions(self.rows, self.columns, sr, sc, er, ec)
+
+    def get_action_positions_from_1d_index(self, action_index):
+        idx = np.asarray(action_index, dtype=np.int64)
+        if np.any(idx == self.action_size - 1):
+            raise ValueError("Action is a no-op so it doesn't translate to an actual action")     # impl:355-367
+        return ia.positions_from_1d(self.rows, self.columns, idx)
+
+    def get_action_1d_index_from_spatial_index(self, spatial_index):
+        r, c, ch = spatial_index
+        return ia.action_1d_from_spatial(self.rows, self.columns, r, c, ch)
+
+    def get_action_spatial_index_from_positions(self, sr, sc, er, ec):
+        r, c, ch = ia.spatial_from_positions(self.rows, self.columns, sr, sc, er, ec)
+        if np.any(ch < 0):
+            raise ValueError("diagonal or null move")                                              # impl:288-306
+        return r, c, ch
+
+    def get_action_positions_from_spatial_index(self, spatial_index):
+        r, c, ch = spatial_index
+        return ia.positions_from_spatial(self.rows, self.columns, r, c, ch)
+
+    def get_action_positions_from_player_perspective(self, player, sr, sc, er, ec):
+        if player == 1:
+            return sr, sc, er, ec
+        return ia.flip_positions(self.rows, self.columns, *(np.asarray(x, dtype=np.int64) for x in (sr, sc, er, ec)))
+
+    def get_action_1d_index_from_player_perspective(self, action_index, player):
+        return ia.action_1d_from_player_perspective(self.rows, self.columns, action_index, player)
+
+    def close(self):
+        self._vec.close()

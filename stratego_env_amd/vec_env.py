@@ -107,10 +107,10 @@ class VecStrategoEnv:
             _lib.check(self._L.sgx_reset(self._h, _ptr(sel), _ptr(m1), _ptr(m2), self._stream()))
         return self.observe()
 
-    def observe(self):
+    def observe(self, raw=False):
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_observe(self._h, _ptr(self.obs), _ptr(self.fobs), _ptr(self.mask), _ptr(self.player),
-                                           self._stream()))
+                                           _lib.STEP_RAW_OBS if raw else 0, self._stream()))
         return self.obs, self.mask, self.player
 
     def tune_placement(self, trials=6, launches=6):
@@ -146,11 +146,12 @@ class VecStrategoEnv:
         self.observe()
         return report
 
-    def step(self, actions, want_next_actions=False, emit_obs=True, emit_mask=True):
+    def step(self, actions, want_next_actions=False, emit_obs=True, emit_mask=True, flags=0):
         """One env.step() for every env.  actions: int32 [N] flat (R,C,K) indices in each mover's perspective."""
         a = actions
         if a.dtype != torch.int32 or a.device != self.device or not a.is_contiguous():
             a = a.to(device=self.device, dtype=torch.int32).contiguous()
+        assert a.numel() == self.num_envs * (4 if (flags & _lib.STEP_ACTIONS_POSITIONS) else 1)
         io = self._io
         io.actions_dev = a.data_ptr()
         io.obs_dev = self.obs.data_ptr() if emit_obs else None
@@ -165,6 +166,7 @@ class VecStrategoEnv:
         io.final_obs_dev = self.final_obs.data_ptr() if self.final_obs is not None else None
         io.next_actions_dev = self.next_actions.data_ptr() if want_next_actions else None
         io.auto_reset = 1 if self.auto_reset else 0
+        io.flags = int(flags)
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_step(self._h, C.byref(io), self._stream()))
         return self.obs, self.mask, self.reward, self.done, self.player
