@@ -533,7 +533,9 @@ constexpr int waves_per_simd() {
     constexpr int per_wg = WPB * (int)sizeof(Lds<G>) + LUT_DWORDS * 4 * (FULL ? 2 : 1);
     constexpr int wgs = (160 * 1024) / per_wg;
     constexpr int w = wgs * WPB / 4;
-    return w > SGX_MIN_WAVES ? SGX_MIN_WAVES : (w < 1 ? 1 : w);
+    // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
+    constexpr int want = G::RC <= 64 ? 8 : SGX_MIN_WAVES;
+    return w > want ? want : (w < 1 ? 1 : w);
 }
 
 // One game's env.step() by one wave (called with the wave's private LDS region).  With SGX_COOP_EMIT the big outputs
