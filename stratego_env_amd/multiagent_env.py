@@ -16,6 +16,7 @@ import copy
 import numpy as np
 import torch
 
+from . import _lib, index_algebra as ia
 from .config import FO_OBS_CHANNELS, PO_OBS_CHANNELS, NUM_STATE_LAYERS, get_variant
 from .enums import GameVersions, ObservationComponents, ObservationModes
 from .setups import load_setup_table, sample_initial_maps_like_reference
@@ -180,16 +181,22 @@ class StrategoMultiAgentEnv:
             obs = {self.player_map(k): val for k, val in obs.items()}
         return obs
 
-    def step(self, action_dict, is_spatial_index=True):
+    def step(self, action_dict, check_for_human_move=True, check_for_bot_move=True, allow_piece_oscillation=False,
+             is_spatial_index=True):
         if self.random_player_assignment:                                              # maenv:674-675
             action_dict = {self.reverse_player_map(k): val for k, val in action_dict.items()}
         assert self.player in action_dict                                              # maenv:678-679
         assert self.player * -1 not in action_dict
-        if not is_spatial_index:
-            raise NotImplementedError("1-D action indices are not accepted by the batched kernels yet")
         action = int(action_dict[self.player])
         vec = self._vec
-        vec.step(torch.tensor([action], dtype=torch.int32))
+        flags = _lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0
+        if not is_spatial_index:
+            # a 1-D index in the mover's perspective (maenv:684-689): flip to absolute coordinates on the host
+            action = int(ia.action_1d_from_player_perspective(self.rows, self.columns, action, self.player))
+            if not (-2 ** 31 <= action < 2 ** 31):
+                raise ValueError("Couldn't get the next state because the move wasn't valid.")
+            flags |= _lib.STEP_ACTIONS_1D
+        vec.step(torch.tensor([action], dtype=torch.int32), flags=flags)
         flags = torch.stack([vec.invalid_action.to(torch.float32), vec.done.to(torch.float32),
                              vec.player.to(torch.float32), vec.ending_invalid.to(torch.float32)]).cpu().numpy()[:, 0]
         if flags[0]:

@@ -114,3 +114,44 @@ def test_basic_game_loop_example_runs():
         assert all(r == 0.0 for r in rew.values())
     assert 1 <= n <= 20 and set(rew.keys()) == {1, -1}
     env.close()
+
+
+def test_facade_1d_actions_and_oscillation_flag():
+    """step(..., is_spatial_index=False) takes a 1-D index in the mover's perspective (maenv:684-689);
+    allow_piece_oscillation=True lifts the two-square check of the move (impl:771-777)."""
+    from oracle import oracle as orc
+    name = 'tiny'
+    g = load_games(name)
+    env = _env(name)
+    oe = __import__('tests.helpers', fromlist=['oracle_env']).oracle_env(name)
+    ru = orc.OracleRules(4, 4)
+    off = g['offsets']
+    for gi in range(3):
+        st0 = _state_from_maps(name, g['p1_maps'][gi], g['p2_maps'][gi])
+        env.reset(initial_state_override=st0)
+        oe.reset(initial_state_override=st0)
+        for k in range(off[gi], off[gi + 1]):
+            if g['errors'][k]:
+                continue
+            a = int(g['actions'][k])
+            K = ru.K
+            idx_persp = ru.get_action_1d_index_from_spatial_index((a // K // 4, a // K % 4, a % K))   # mover's perspective
+            obs, rew, done, info = env.step({env.player: idx_persp}, is_spatial_index=False)
+            o2, r2, d2, i2 = oe.step({oe.player: a})
+            assert digest_obs(obs) == digest_obs(o2) and done == d2
+            assert np.array_equal(env.state, oe.state)
+    # two-square: 4th oscillation refused, accepted with allow_piece_oscillation=True
+    m1 = np.zeros((4, 4), dtype=np.int64); m2 = np.zeros((4, 4), dtype=np.int64)
+    m1[0, 0] = 5; m1[0, 3] = 11; m2[0, 0] = 5; m2[0, 3] = 11
+    st = ru.create_initial_state(np.zeros((4, 4), dtype=np.int64), m1, m2, 100)
+    pl = 1
+    for (s_, e_) in [((0, 0), (1, 0)), ((3, 3), (2, 3)), ((1, 0), (0, 0)), ((2, 3), (3, 3)), ((0, 0), (1, 0)), ((3, 3), (2, 3))]:
+        st, pl = ru.get_next_state(st, pl, ru.get_action_1d_index_from_positions(*s_, *e_))
+    env.reset(initial_state_override=st)
+    back = ru.get_action_spatial_index_from_positions(1, 0, 0, 0)
+    flat = (back[0] * 4 + back[1]) * ru.K + back[2]
+    with pytest.raises(ValueError):
+        env.step({1: flat})
+    obs, rew, done, info = env.step({1: flat}, allow_piece_oscillation=True)
+    assert list(obs.keys()) == [-1]
+    env.close()

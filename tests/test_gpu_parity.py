@@ -231,3 +231,52 @@ def test_full_size_rollout_properties_and_oracle_digests():
         assert int(d[0]) == digs[i], ('env', int(ids[i]))
         assert int(f[0]) == fin[i]
     env.close()
+
+
+def test_standard_full_size_properties_and_oracle_digests():
+    """BASELINE config 3 size (262,144 full-Stratego games): properties on every env + oracle digests of sampled games."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    N, T, seed = 262144, 24, 0x5712A7E60
+    env = VecStrategoEnv('standard', N, seed=seed, auto_reset=True)
+    env.reset()
+    env.sample_valid_actions()
+    n_chk = 12
+    ids = np.linspace(0, N - 1, n_chk).astype(np.int64)
+    idx = torch.from_numpy(ids).to(env.device)
+    digs = [orc.FNV_OFFSET] * n_chk
+    for t in range(T):
+        env.rollout_step()
+        m = env.mask.view(N, -1)
+        assert int((m.sum(dim=1, dtype=torch.int32) == 0).sum()) == 0
+        assert int(env.invalid_action.sum()) == 0
+        if t % 8 == 0:
+            o = env.obs.view(N, 100, 67)
+            assert bool(torch.isfinite(o).all()) and float(o.abs().max()) <= 1.0
+            assert bool((o[:, :, 0:12].sum(dim=2) <= 1).all())
+        mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
+        rw, dn, pl = env.reward[idx].cpu().numpy(), env.done[idx].cpu().numpy(), env.player[idx].cpu().numpy()
+        ei = env.ending_invalid[idx].cpu().numpy()
+        for i in range(n_chk):
+            tail = np.asarray([dn[i], pl[i], ei[i], 0], dtype=np.int32)
+            digs[i] = orc.fnv1a(digs[i], mk[i].tobytes() + ob[i].tobytes() + rw[i].tobytes() + tail.tobytes())
+    cv = oracle_cvariant('standard', setups=S.load_setup_table('standard'))
+    for i in range(n_chk):
+        total, d, f = orc.rollout(cv, seed, int(ids[i]), 1, T, threads=1)
+        assert int(d[0]) == digs[i], ('env', int(ids[i]))
+    env.close()
+
+
+def test_tune_placement_keeps_outputs():
+    """Placement trials only swap which allocation the outputs live in."""
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    env = VecStrategoEnv('barrage', 4096, seed=5, auto_reset=True)
+    env.reset()
+    obs0, mask0 = env.obs.clone(), env.mask.clone()
+    rep = env.tune_placement(trials=3, launches=2)
+    assert len(rep['obs']) == 3 and len(rep['mask']) == 3
+    assert np.array_equal(env.obs.cpu().numpy(), obs0.cpu().numpy()) and np.array_equal(env.mask.cpu().numpy(), mask0.cpu().numpy())
+    env.sample_valid_actions()
+    env.rollout_step()
+    assert int(env.invalid_action.sum()) == 0
+    env.close()
