@@ -54,6 +54,9 @@ constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 673 /* >= 20*33 (79 channels), = 1 m
 #define SGX_MIN_WAVES 6
 #endif
 constexpr int WPB = SGX_WPB;  // waves (= games) per workgroup; they share the LUT
+// per observation kind in LDS: the LUT followed by the quad table (2 perspectives x NCH quads x 4 packed entries, see emit_obs)
+constexpr int QTAB_DWORDS = 2 * OBS_CH * 4, OBS_TAB_DWORDS = LUT_DWORDS + QTAB_DWORDS;   // partial kind; the full kind follows it
+constexpr int FOBS_TAB_DWORDS = LUT_DWORDS + 2 * FOBS_CH * 4;
 __host__ __device__ constexpr int lut_row(int ch) { return ((ch >> 1) & 1) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH + (ch & 1) * 16; }
 
 // internal board indices inside an env record (each board is S bytes, absolute coordinates)
@@ -153,7 +156,6 @@ struct alignas(16) Lds {
     alignas(16) uint8_t cnt[G::CNT_PAD];               // valid moves per perspective cell (also setup-shuffle scratch)
     alignas(16) uint8_t occ[G::S];                     // gen_mask scratch: combined occupancy byte per cell
     alignas(16) uint8_t plist[G::CNT_PAD];             // gen_mask scratch: compacted list of movable cells
-    int qi;                                            // SGX_COOP_EMIT: perspective (player index) of the next mover
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -243,50 +245,52 @@ __device__ inline int clamp15(int v) { return min(max(v, 0), 15); }
 // (partial: impl:1335-1397, full: impl:1230-1303; normalisation maenv:499-508 through the LUT)
 // ---------------------------------------------------------------------------------------------
 #ifndef SGX_OBS_UNROLL
-#define SGX_OBS_UNROLL 5
+#define SGX_OBS_UNROLL 4
 #endif
+// quad table entry of (perspective qi, quad qd, element j): LDS byte offset of the source board at the first 4-cell group
+// (low 16 bits) and LUT index base (high 16 bits); built once per workgroup (build_quad_table)
 template <class G, class Spec>
-__device__ void emit_obs(const Lds<G> &L, const float *lut, int qi, float *__restrict__ dst, int lane) {
+__device__ inline void build_quad_table(uint32_t *qtab, int tid, int nthreads) {
+    constexpr int RC = G::RC, S = G::S, NCH = Spec::NCH;
+    for (int i = tid; i < 2 * NCH * 4; i += nthreads) {
+        const int qi = i / (NCH * 4), r = i - qi * (NCH * 4), f = r;            // f = 4*qd + j : float index inside a 4-cell group
+        const int rc = f / NCH, ch = f - rc * NCH;
+        const uint32_t boff = (uint32_t)(Spec::board(ch, qi) * S + (qi ? RC - 1 - rc : rc));
+        const uint32_t lrow = (uint32_t)(lut_row(ch) + Spec::bias(ch));
+        qtab[i] = boff | (lrow << 16);
+    }
+}
+
+// `tab` = this observation kind's LUT followed by its quad table.
+// The observation is written in 1 KiB chunks aligned to 1 KiB ADDRESS boundaries (whole 128-byte lines per store
+// instruction).  Chunking by 4-cell group instead (64 of a group's 67 quads per store, every store 48 bytes further off a
+// line) left two partial lines per store and ran 1.5x slower in the store-pattern probe (tools/microbench/aligned_alloc.hip:
+// 490 vs 333 us).  With address-aligned chunks a lane's quad changes every iteration, hence the quad table.
+template <class G, class Spec>
+__device__ void emit_obs(const Lds<G> &L, const float *tab, int qi, float *__restrict__ dst, int lane) {
     constexpr int RC = G::RC, S = G::S, NCH = Spec::NCH;
     const int8_t *bb = &L.b[0][0];
+    const float *lut = tab;
     if constexpr (RC % 4 == 0) {
-        // 4 cells = 4*NCH floats = NCH float4 "quads".  Lane l renders quad l of every 4-cell group, so its four
-        // (cell offset, channel) pairs are loop-invariant; quads 64..NCH-1 are swept afterwards.
-        // Board bytes are legal by construction (reset, move application, sanitised import), so LUT[row + bias + v]
-        // needs no clamp: one v_lshl_add per element.
-        int baddr[4], lrow[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = 4 * lane + j, rc = f / NCH, ch = f - rc * NCH;
-            baddr[j] = Spec::board(ch, qi) * S + (qi ? RC - 1 - rc : rc);
-            lrow[j] = lut_row(ch) + Spec::bias(ch);
-        }
-        const int step = qi ? -4 : 4;
-        f32x4 *out = reinterpret_cast<f32x4 *>(dst) + lane;
+        constexpr int NQ = (RC / 4) * NCH;                                           // quads (16 B) of one observation
+        const uint4 *qtab = reinterpret_cast<const uint4 *>(tab + LUT_DWORDS) + qi * NCH;
+        const int m0 = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 63);          // quads past a 1 KiB boundary
+        f32x4 *base = reinterpret_cast<f32x4 *>(dst);
+        const int gstep = qi ? -4 : 4;
 #pragma unroll SGX_OBS_UNROLL
-        for (int s = 0; s < RC / 4; ++s) {
+        for (int q0 = -m0; q0 < NQ; q0 += 64) {
+            const int q = q0 + lane;
+            const bool in = (unsigned)q < (unsigned)NQ;
+            const int qq = in ? q : 0, g = qq / NCH, qd = qq - g * NCH;
+            const uint4 e = qtab[qd];
+            const int g4 = g * gstep;
+            // board bytes are legal by construction (reset, move application, sanitised import): no clamp on the LUT index
             f32x4 o;
-            o.x = lut[lrow[0] + bb[baddr[0]]];
-            o.y = lut[lrow[1] + bb[baddr[1]]];
-            o.z = lut[lrow[2] + bb[baddr[2]]];
-            o.w = lut[lrow[3] + bb[baddr[3]]];
-            stream_store(&out[s * NCH], o);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) baddr[j] += step;
-        }
-        constexpr int NT = NCH - 64;  // tail quads per group
-        for (int t = lane; t < (RC / 4) * NT; t += 64) {
-            const int s = t / NT, qd = 64 + (t - NT * s);
-            f32x4 o;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int f = 4 * qd + j, rc = f / NCH, ch = f - rc * NCH;
-                const int pcell = 4 * s + rc, cell = qi ? RC - 1 - pcell : pcell;
-                v[j] = lut[lut_row(ch) + Spec::bias(ch) + bb[Spec::board(ch, qi) * S + cell]];
-            }
-            o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-            stream_store(&reinterpret_cast<f32x4 *>(dst)[s * NCH + qd], o);
+            o.x = lut[(e.x >> 16) + bb[(e.x & 0xFFFF) + g4]];
+            o.y = lut[(e.y >> 16) + bb[(e.y & 0xFFFF) + g4]];
+            o.z = lut[(e.z >> 16) + bb[(e.z & 0xFFFF) + g4]];
+            o.w = lut[(e.w >> 16) + bb[(e.w & 0xFFFF) + g4]];
+            if (in) stream_store(&base[q], o);
         }
     } else {
         // odd cell counts (5x5, 15x15): an env's observation is not 16-byte aligned; dword path
@@ -416,7 +420,10 @@ __device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) 
         const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
         const int nchunks = (A + G::NA + 15) >> 4;
         uint8_t *gbase = dst - A;                       // 16-byte aligned
-        for (int c = lane; c < nchunks; c += 64) {
+        const int shift = (int)((reinterpret_cast<uintptr_t>(gbase) >> 4) & 63);   // start the sweep on a 1 KiB boundary
+        for (int c0 = -shift; c0 < nchunks; c0 += 64) {
+            const int c = c0 + lane;
+            if (c < 0 || c >= nchunks) continue;
             const int lo = 16 * c - A;                  // first mask byte of this chunk
             if (lo >= 0 && lo + 16 <= G::NA) {
                 const uint32_t b16 = mask_bits(L, lo, 16);
@@ -530,7 +537,7 @@ __device__ inline int fmod_(int a, int b) { int m = a % b; return m < 0 ? m + b 
 // waves per SIMD this geometry can reach: LDS per workgroup = WPB game regions + the shared LUT, 160 KiB per CU
 template <class G, bool FULL>
 constexpr int waves_per_simd() {
-    constexpr int per_wg = WPB * (int)sizeof(Lds<G>) + LUT_DWORDS * 4 * (FULL ? 2 : 1);
+    constexpr int per_wg = WPB * (int)sizeof(Lds<G>) + 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0));
     constexpr int wgs = (160 * 1024) / per_wg;
     constexpr int w = wgs * WPB / 4;
     // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
@@ -538,15 +545,7 @@ constexpr int waves_per_simd() {
     return w > want ? want : (w < 1 ? 1 : w);
 }
 
-// One game's env.step() by one wave (called with the wave's private LDS region).  With SGX_COOP_EMIT the big outputs
-// (mask, observations of the next mover) are not written here: the wave publishes the perspective in L.qi and the
-// workgroup emits all its games' outputs together (coop_emit_*, below).
-#ifdef SGX_COOP_EMIT
-template <class G> constexpr bool coop_emit() { return G::RC % 4 == 0 && G::NA % 4 == 0; }
-#else
-template <class G> constexpr bool coop_emit() { return false; }
-#endif
-
+// One game's env.step() by one wave (called with the wave's private LDS region).
 template <int R_, int C_, bool FULL>
 __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, const float *lut_s, const int64_t env, const int lane) {
     using G = Geo<R_, C_>;
@@ -767,8 +766,8 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     if constexpr (FULL)
         if (P.mode == 0 && ended_now && P.io.final_fobs_dev) {
             float *fo = P.io.final_fobs_dev + env * (int64_t)(2 * RC * FOBS_CH);
-            emit_obs<G, FullObs>(L, lut + LUT_DWORDS, 0, fo, lane);
-            emit_obs<G, FullObs>(L, lut + LUT_DWORDS, 1, fo + RC * FOBS_CH, lane);
+            emit_obs<G, FullObs>(L, lut + OBS_TAB_DWORDS, 0, fo, lane);
+            emit_obs<G, FullObs>(L, lut + OBS_TAB_DWORDS, 1, fo + RC * FOBS_CH, lane);
         }
 
     // ---- auto-reset: the finished env starts its next game now
@@ -785,17 +784,13 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     STAMP(4);   // results / terminal handling done
     // ---- outputs for the next mover
     if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
-    if constexpr (coop_emit<G>()) {
-        if (lane == 0) L.qi = qi;
-    } else {
-        if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
-        STAMP(5);   // mask stores issued
-        // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
-        if (P.io.obs_dev) emit_obs<G, PartialObs>(L, lut, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
-        if constexpr (FULL)
-            if (P.io.fobs_dev) emit_obs<G, FullObs>(L, lut + LUT_DWORDS, qi, P.io.fobs_dev + env * (int64_t)(RC * FOBS_CH), lane);
-        STAMP(6);   // obs stores issued
-    }
+    if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
+    STAMP(5);   // mask stores issued
+    // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
+    if (P.io.obs_dev) emit_obs<G, PartialObs>(L, lut, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
+    if constexpr (FULL)
+        if (P.io.fobs_dev) emit_obs<G, FullObs>(L, lut + OBS_TAB_DWORDS, qi, P.io.fobs_dev + env * (int64_t)(RC * FOBS_CH), lane);
+    STAMP(6);   // obs stores issued
     if (P.mode == 0 && P.io.next_actions_dev) {
         const int total = nvalid == 0 ? 1 : nvalid;
         const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, STREAM_ACTION, (uint32_t)turn), (uint32_t)total);
@@ -843,84 +838,12 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------
-// Workgroup-cooperative emission (SGX_COOP_EMIT): after one barrier the WPB waves write the workgroup's WPB
-// consecutive games as contiguous bursts (store-pattern probe tools/microbench/coop_pattern.hip: +7 % over
-// independent per-wave streams).  Work item = one 4-cell group (NCH quads) of one game, dealt round-robin to the
-// waves, so a lane's four (cell offset, channel) pairs stay loop-invariant exactly as in emit_obs.
-// ---------------------------------------------------------------------------------------------
-template <class G, class Spec>
-__device__ void coop_emit_obs(const Lds<G> *LW, const float *lut, float *__restrict__ base, int n_active, int wave, int lane) {
-    constexpr int RC = G::RC, S = G::S, NCH = Spec::NCH, NG = RC / 4, NT = NCH - 64;
-    int b0[4], b1[4], lrow[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int f = 4 * lane + j, rc = f / NCH, ch = f - rc * NCH;
-        b0[j] = Spec::board(ch, 0) * S + rc;
-        b1[j] = Spec::board(ch, 1) * S + RC - 1 - rc;
-        lrow[j] = lut_row(ch) + Spec::bias(ch);
-    }
-#pragma unroll 2
-    for (int p = wave; p < n_active * NG; p += WPB) {
-        const int k = p / NG, s = p - k * NG;
-        const int qi = uni(LW[k].qi);
-        const int8_t *bb = &LW[k].b[0][0];
-        f32x4 o;
-        o.x = lut[lrow[0] + bb[qi ? b1[0] - 4 * s : b0[0] + 4 * s]];
-        o.y = lut[lrow[1] + bb[qi ? b1[1] - 4 * s : b0[1] + 4 * s]];
-        o.z = lut[lrow[2] + bb[qi ? b1[2] - 4 * s : b0[2] + 4 * s]];
-        o.w = lut[lrow[3] + bb[qi ? b1[3] - 4 * s : b0[3] + 4 * s]];
-        stream_store(reinterpret_cast<f32x4 *>(base + (int64_t)k * RC * NCH) + s * NCH + lane, o);
-    }
-    for (int t = wave * 64 + lane; t < n_active * NG * NT; t += 64 * WPB) {
-        const int k = t / (NG * NT), r = t - k * (NG * NT), s = r / NT, qd = 64 + (r - s * NT);
-        const int qi = LW[k].qi;
-        const int8_t *bb = &LW[k].b[0][0];
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = 4 * qd + j, rc = f / NCH, ch = f - rc * NCH;
-            const int pcell = 4 * s + rc, cell = qi ? RC - 1 - pcell : pcell;
-            v[j] = lut[lut_row(ch) + Spec::bias(ch) + bb[Spec::board(ch, qi) * S + cell]];
-        }
-        f32x4 o = {v[0], v[1], v[2], v[3]};
-        stream_store(reinterpret_cast<f32x4 *>(base + (int64_t)k * RC * NCH) + s * NCH + qd, o);
-    }
-}
-
-template <class G>
-__device__ void coop_emit_mask(const Lds<G> *LW, uint8_t *__restrict__ base, int n_active, int tid) {
-    constexpr int NA = G::NA;
-    const int A = (int)(reinterpret_cast<uintptr_t>(base) & 15), total = n_active * NA;
-    uint8_t *gbase = base - A;
-    for (int c = tid; c < (A + total + 15) >> 4; c += 64 * WPB) {
-        const int lo = 16 * c - A;
-        uint32_t w4[4];
-        bool in[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int o = lo + 4 * w;
-            in[w] = o >= 0 && o < total;
-            const int oo = in[w] ? o : 0, k = oo / NA, within = oo - k * NA;   // NA % 4 == 0: a dword never straddles two games
-            w4[w] = expand4(mask_bits(LW[k], within, 4));
-        }
-        if (in[0] && in[3]) {
-            i32x4 q4 = {(int)w4[0], (int)w4[1], (int)w4[2], (int)w4[3]};
-            stream_store(&reinterpret_cast<i32x4 *>(gbase)[c], q4);
-        } else {
-#pragma unroll
-            for (int w = 0; w < 4; ++w)
-                if (in[w]) *reinterpret_cast<uint32_t *>(gbase + 16 * c + 4 * w) = w4[w];
-        }
-    }
-}
-
 // FULL: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492)
 template <int R_, int C_, bool FULL>
 __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) void step_kernel(const KParams P) {
     using G = Geo<R_, C_>;
     __shared__ Lds<G> LW[WPB];
-    __shared__ alignas(16) float lut_s[LUT_DWORDS * (FULL ? 2 : 1)];
+    __shared__ alignas(16) float lut_s[OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t env0 = group_of_block(P.map_mode) * WPB, env = env0 + wave;
 
@@ -928,22 +851,14 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) vo
     const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
     const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(raw ? P.tab->raw_lut : P.tab->obs_lut);
     for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
+    build_quad_table<G, PartialObs>(reinterpret_cast<uint32_t *>(lut_s + LUT_DWORDS), threadIdx.x, 64 * WPB);
     if constexpr (FULL) {
         const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(raw ? P.tab->raw_flut : P.tab->fobs_lut);
-        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s + LUT_DWORDS)[i] = fsrc[i];
+        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s + OBS_TAB_DWORDS)[i] = fsrc[i];
+        build_quad_table<G, FullObs>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * WPB);
     }
     __syncthreads();   // from here on every wave works on its own game
     if (env < P.n_envs) env_step<R_, C_, FULL>(P, LW[wave], lut_s, env, lane);
-    if constexpr (coop_emit<G>()) {
-        __syncthreads();   // all games of the workgroup are stepped; their boards / mask bits / perspectives are in LDS
-        const int n_active = (int)min((int64_t)WPB, P.n_envs - env0);
-        if (n_active <= 0) return;
-        if (P.io.mask_dev) coop_emit_mask<G>(LW, P.io.mask_dev + env0 * (int64_t)G::NA, n_active, threadIdx.x);
-        if (P.io.obs_dev) coop_emit_obs<G, PartialObs>(LW, lut_s, P.io.obs_dev + env0 * (int64_t)G::NOBS, n_active, wave, lane);
-        if constexpr (FULL)
-            if (P.io.fobs_dev)
-                coop_emit_obs<G, FullObs>(LW, lut_s + LUT_DWORDS, P.io.fobs_dev + env0 * (int64_t)(G::RC * FOBS_CH), n_active, wave, lane);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
