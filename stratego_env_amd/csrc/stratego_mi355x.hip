@@ -66,12 +66,12 @@ constexpr int B_STILL = 4;    // +pi : never-moved flags                        
 constexpr int B_RECENT = 6;   // +pi : two-square bookkeeping (LDS only, rebuilt from scal)             impl layers 6/7
 constexpr int B_CAP = 8;      // +12*pi + (type-1) : captured counts (LDS only, rebuilt from events)    impl layers 8-19 / 20-31
 constexpr int N_BOARDS = 32;
-constexpr int STORED_BOARDS = 6;  // boards 0..5 live in HBM; recent-moves and captured counts are stored sparsely:
+constexpr int STORED_BOARDS = 4;  // boards 0..3 live in HBM as bytes; never-moved flags as bitmaps; the rest sparsely:
 //   recent moves: at most two non-zero cells per player (impl:1013-1028)  -> two (cell, code) pairs per player in scal
 //   captured counts: one event (board - B_CAP, cell) per captured piece   -> uint16 list, <= 2 * pieces per side entries
 constexpr int B_OBST = 32;    // LDS only: per-variant obstacle map (impl layer 2)
 
-// scal[2*env] = {turn, flags, max_turns, game_no}; scal[2*env+1] = {n_events, recent pairs of +1, recent pairs of -1, 0}
+// record scalars (32 B at SC_OFF): {turn, flags, max_turns, game_no} {n_events, recent pairs of +1, recent pairs of -1, 0}
 // a recent pair is cell | (code & 0xFF) << 8, two pairs per int (low / high half); code 0 = empty
 constexpr int F_OVER = 1, F_WIN_P1 = 2, F_WIN_M1 = 4, F_END_INVALID = 8, F_PLAYER_M1 = 16;
 
@@ -83,7 +83,15 @@ struct Geo {
     static constexpr int RC = R * C;
     static constexpr int S = (RC + 3) & ~3;           // board stride (bytes)
     static constexpr int LDS_BOARDS_BYTES = N_BOARDS * S;            // bytes of the 32 LDS boards (multiple of 128)
-    static constexpr int EV_OFF = (STORED_BOARDS * S + 15) & ~15;    // HBM record: 6 dense boards, zero padding, then events
+    // HBM record (a multiple of 128 B, so every record is read and written as whole cache lines):
+    //   [0, 4S) four dense boards (true pieces, PO pieces) | zero padding to 16 | ST_OFF: never-moved bitmaps 2 x SB |
+    //   SC_OFF: 32 B scalars | EVL_OFF: capture events uint16[max_events] | zero padding
+    //   10x10: Barrage 512 B (4 lines), Standard 640 B (5 lines)
+    static constexpr int ST_OFF = (STORED_BOARDS * S + 15) & ~15;
+    static constexpr int SB = (((RC + 7) / 8) + 15) & ~15;           // bytes of one never-moved bitmap (bit i = cell i)
+    static constexpr int SC_OFF = ST_OFF + 2 * SB, EVL_OFF = SC_OFF + 32;
+    static constexpr int EVL_MAX = RC;                               // 2 * pieces per side <= cells
+    static constexpr int TAIL_BYTES = 2 * SB + 32 + ((2 * EVL_MAX + 15) & ~15);   // LDS image of the record from ST_OFF on
     static constexpr int K = 2 * (R - 1) + 2 * (C - 1) + 1;
     static constexpr int NA = RC * K;                 // spatial actions
     static constexpr int NA_PAD = (NA + 15) & ~15;
@@ -105,14 +113,13 @@ struct DevTables {
 
 struct KParams {
     int8_t *boards;
-    int4 *scal;
     const DevTables *tab;
     const uint8_t *setups;
     int32_t n_setups;
     int32_t max_turns;
     int32_t usable_rows;
     int32_t piece_counts[12];
-    int32_t rec_bytes;   // bytes of one env record in HBM: EV_OFF + 2 * max_events rounded up to 16
+    int32_t rec_bytes;   // bytes of one env record in HBM: EVL_OFF + 2 * max_events rounded up to 128
     int32_t max_events;
     int64_t n_envs;
     uint64_t seed;
@@ -156,6 +163,7 @@ struct alignas(16) Lds {
     alignas(16) uint8_t cnt[G::CNT_PAD];               // valid moves per perspective cell (also setup-shuffle scratch)
     alignas(16) uint8_t occ[G::S];                     // gen_mask scratch: combined occupancy byte per cell
     alignas(16) uint8_t plist[G::CNT_PAD];             // gen_mask scratch: compacted list of movable cells
+    alignas(16) uint8_t tail[G::TAIL_BYTES];           // record image from ST_OFF on: bitmaps, 32 B scalars, capture-event list
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -178,6 +186,11 @@ enum { STREAM_SETUP = 0, STREAM_ACTION = 1, STREAM_SHUFFLE_P1 = 2, STREAM_SHUFFL
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
+template <class G>
+__device__ inline int4 *rec_scal(int8_t *boards, int rec_bytes, int64_t env) {
+    return reinterpret_cast<int4 *>(boards + env * (int64_t)rec_bytes + G::SC_OFF);
+}
+
 __device__ inline int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // XCD-aware block -> env map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
@@ -545,6 +558,40 @@ constexpr int waves_per_simd() {
     return w > want ? want : (w < 1 ? 1 : w);
 }
 
+// Builds the record image from ST_OFF on in L.tail (never-moved bitmaps from the LDS still boards, the two scalar int4s,
+// the event list already kept in L.tail) and writes the whole record to HBM as 16-byte stores over whole 128-byte lines.
+template <class G>
+__device__ inline void write_record(Lds<G> &L, int8_t *rec_g, int rec_bytes, int4 sc0, int4 sc1, int n_events, int lane) {
+    constexpr int S = G::S, RC = G::RC;
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int w = 0; w < G::SB / 8; ++w) {
+            const int i = lane + 64 * w;
+            const unsigned long long m = __ballot(i < RC && L.b[B_STILL + pi][i < RC ? i : 0] != 0);
+            if (lane == 0) reinterpret_cast<unsigned long long *>(L.tail + pi * G::SB)[w] = m;
+        }
+    if (lane == 0) {
+        reinterpret_cast<int4 *>(L.tail + 2 * G::SB)[0] = sc0;
+        reinterpret_cast<int4 *>(L.tail + 2 * G::SB)[1] = sc1;
+    }
+    wave_sync<G>();
+    const int4 *bsrc = reinterpret_cast<const int4 *>(&L.b[0][0]), *tsrc = reinterpret_cast<const int4 *>(L.tail);
+    int4 *dst = reinterpret_cast<int4 *>(rec_g);
+    const int n_tail_q = (2 * G::SB + 32 + 2 * n_events + 15) >> 4;            // tail int4s that carry data
+    for (int i = lane; i < rec_bytes / 16; i += 64) {
+        int4 v = make_int4(0, 0, 0, 0);
+        if (i < G::ST_OFF / 16) {
+            v = bsrc[i];
+            const int keep = STORED_BOARDS * S - 16 * i;                       // bytes of this int4 that belong to the stored boards
+            if (keep < 16) { if (keep <= 12) v.w = 0; if (keep <= 8) v.z = 0; if (keep <= 4) v.y = 0; if (keep <= 0) v.x = 0; }
+        } else if (i < G::ST_OFF / 16 + n_tail_q) {
+            v = tsrc[i - G::ST_OFF / 16];
+        }
+        dst[i] = v;
+    }
+}
+
 // One game's env.step() by one wave (called with the wave's private LDS region).
 template <int R_, int C_, bool FULL>
 __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, const float *lut_s, const int64_t env, const int lane) {
@@ -553,25 +600,37 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     STAMP(0);
 
     int8_t *rec_g = P.boards + env * (int64_t)P.rec_bytes;
-    const int4 sc = P.scal[2 * env], sc2 = P.scal[2 * env + 1];
+    const int4 *scg = rec_scal<G>(P.boards, P.rec_bytes, env);
+    const int4 sc = scg[0], sc2 = scg[1];
     int turn = uni(sc.x), flags = uni(sc.y), game_no = uni(sc.w);
     const int max_turns = uni(sc.z);
     int n_events = uni(sc2.x);
     int rp0 = uni(sc2.y), rp1 = uni(sc2.z);   // recent-move pairs of player +1 / -1 (two named scalars: a runtime-indexed
                                               // array would live in scratch memory)
-    {   // ---- stage: the 6 dense boards -> LDS, the sparse ones (recent moves, captured counts) rebuilt, obstacle map
+    {   // ---- stage: the 4 dense boards -> LDS, the other 28 rebuilt (never-moved bitmaps, recent-move pairs, capture events)
         const int4 *src = reinterpret_cast<const int4 *>(rec_g);
         int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
         for (int i = lane; i < G::LDS_BOARDS_BYTES / 16; i += 64) {
             int4 v = make_int4(0, 0, 0, 0);
-            if (i < G::EV_OFF / 16) v = src[i];     // (a `cond ? src[i] : zero` select turns into a flat load from scratch)
+            if (i < G::ST_OFF / 16) v = src[i];     // (a `cond ? src[i] : zero` select turns into a flat load from scratch)
             dst[i] = v;
         }
         for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
         wave_sync<G>();
-        const uint16_t *ev = reinterpret_cast<const uint16_t *>(rec_g + G::EV_OFF);
+        const uint32_t *stb = reinterpret_cast<const uint32_t *>(rec_g + G::ST_OFF);
+#pragma unroll
+        for (int cc = 0; cc < G::CPL; ++cc) {
+            const int i = lane + 64 * cc;
+            if (i < RC) {
+                L.b[B_STILL][i] = (int8_t)((stb[i >> 5] >> (i & 31)) & 1u);
+                L.b[B_STILL + 1][i] = (int8_t)((stb[G::SB / 4 + (i >> 5)] >> (i & 31)) & 1u);
+            }
+        }
+        const uint16_t *ev = reinterpret_cast<const uint16_t *>(rec_g + G::EVL_OFF);
+        uint16_t *evl = reinterpret_cast<uint16_t *>(L.tail + 2 * G::SB + 32);
         for (int i = lane; i < n_events; i += 64) {
             const int evt = ev[i], byte = (B_CAP + (evt >> 8)) * S + (evt & 0xFF);   // event = (board - B_CAP) << 8 | cell
+            evl[i] = (uint16_t)evt;                                                  // kept for the whole-record write-back
             atomicAdd(reinterpret_cast<unsigned int *>(&L.b[0][0]) + (byte >> 2), 1u << (8 * (byte & 3)));
         }
         if (lane < 4) {
@@ -799,37 +858,17 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     }
 
     STAMP(7);   // next action sampled
-    // ---- write back what changed: the 6 dense boards after a reset, otherwise the <= 9 touched board bytes and
-    //      <= 2 new capture events; the scalars carry the turn, flags, event count and the recent-move pairs
-    if (wrote_reset) {
-        const int4 *src = reinterpret_cast<const int4 *>(&L.b[0][0]);
-        int4 *dst = reinterpret_cast<int4 *>(rec_g);
-        for (int i = lane; i < G::EV_OFF / 16; i += 64) dst[i] = src[i];   // LDS bytes 6S..EV_OFF are zero (fresh recent board)
-    } else if (applied && dirty_s >= 0) {
-        const int pi = mover == 1 ? 0 : 1;
-        int board = -1, cell = dirty_e;
-        switch (lane) {
-            case 0: board = B_PIECES + pi; cell = dirty_s; break;
-            case 1: board = B_PIECES + pi; break;
-            case 2: board = B_PIECES + 1 - pi; break;
-            case 3: board = B_PO + pi; cell = dirty_s; break;
-            case 4: board = B_PO + pi; break;
-            case 5: board = B_PO + 1 - pi; break;
-            case 6: board = B_STILL + pi; cell = dirty_s; break;
-            case 7: board = B_STILL + pi; break;
-            case 8: board = B_STILL + 1 - pi; break;
-            default: break;
+    // ---- write the record back as whole 128-byte lines: dense boards, scalars, capture events.  (Scattered stores
+    //      of only the <= 9 touched bytes + 32 B of scalars are partial-line writes: measured 7 % slower.)
+    if (applied || wrote_reset) {
+        uint16_t *evl = reinterpret_cast<uint16_t *>(L.tail + 2 * G::SB + 32);
+        if (!wrote_reset && dirty_s >= 0) {
+            const int na = dirty_cap_a >= 0 ? 1 : 0, nb = dirty_cap_b >= 0 ? 1 : 0;
+            if (lane == 0 && na && n_events < P.max_events) evl[n_events] = (uint16_t)(((dirty_cap_a - B_CAP) << 8) | dirty_e);
+            if (lane == 1 && nb && n_events + na < P.max_events) evl[n_events + na] = (uint16_t)(((dirty_cap_b - B_CAP) << 8) | dirty_e);
+            n_events = min(n_events + na + nb, P.max_events);
         }
-        if (board >= 0) rec_g[board * S + cell] = L.b[board][cell];
-        uint16_t *ev = reinterpret_cast<uint16_t *>(rec_g + G::EV_OFF);
-        const int na = dirty_cap_a >= 0 ? 1 : 0, nb = dirty_cap_b >= 0 ? 1 : 0;
-        if (lane == 9 && na && n_events < P.max_events) ev[n_events] = (uint16_t)(((dirty_cap_a - B_CAP) << 8) | dirty_e);
-        if (lane == 10 && nb && n_events + na < P.max_events) ev[n_events + na] = (uint16_t)(((dirty_cap_b - B_CAP) << 8) | dirty_e);
-        n_events = min(n_events + na + nb, P.max_events);
-    }
-    if ((applied || wrote_reset) && lane == 0) {
-        P.scal[2 * env] = make_int4(turn, flags, max_turns, game_no);
-        P.scal[2 * env + 1] = make_int4(n_events, rp0, rp1, 0);
+        write_record(L, rec_g, P.rec_bytes, make_int4(turn, flags, max_turns, game_no), make_int4(n_events, rp0, rp1, 0), n_events, lane);
     }
     STAMP(8);   // write-back issued
 #ifdef SGX_STAMPS
@@ -891,16 +930,11 @@ __global__ __launch_bounds__(64) void reset_kernel(const ResetParams P) {
         wave_sync<G>();
         game_no = 0;
     } else {
-        game_no = uni(P.k.scal[2 * env].w) + 1;
+        game_no = uni(rec_scal<G>(P.k.boards, P.k.rec_bytes, env)[0].w) + 1;
         sample_boards(L, P.k, (uint64_t)(P.k.env_id_offset + env), (uint64_t)game_no, lane);
     }
-    const int4 *src = reinterpret_cast<const int4 *>(&L.b[0][0]);
-    int4 *dst = reinterpret_cast<int4 *>(P.k.boards + env * (int64_t)P.k.rec_bytes);
-    for (int i = lane; i < G::EV_OFF / 16; i += 64) dst[i] = src[i];   // dense boards (+ zero padding); no events yet
-    if (lane == 0) {
-        P.k.scal[2 * env] = make_int4(0, 0, P.k.max_turns, game_no);
-        P.k.scal[2 * env + 1] = make_int4(0, 0, 0, 0);
-    }
+    write_record(L, P.k.boards + env * (int64_t)P.k.rec_bytes, P.k.rec_bytes, make_int4(0, 0, P.k.max_turns, game_no),
+                 make_int4(0, 0, 0, 0), 0, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -936,7 +970,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     wave_sync<G>();
     const int total = uni(mine);
-    const int4 sc = P.scal[2 * env];
+    const int4 sc = rec_scal<G>(P.boards, P.rec_bytes, env)[0];
     int na = -1;
     if (total > 0) {
         const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)sc.w, STREAM_ACTION, (uint32_t)sc.x), (uint32_t)total);
@@ -963,7 +997,7 @@ __global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t
     const int64_t env = blockIdx.x;
     if (env >= P.n_envs) return;
     const int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
-    const int4 sc = P.scal[2 * env], sc2 = P.scal[2 * env + 1];
+    const int4 sc = rec_scal<G>(P.boards, P.rec_bytes, env)[0], sc2 = rec_scal<G>(P.boards, P.rec_bytes, env)[1];
     int64_t *o = out + env * (int64_t)(SGX_STATE_LAYERS * RC);
     for (int x = threadIdx.x; x < SGX_STATE_LAYERS * RC; x += blockDim.x) {
         const int l = x / RC, cell = x - l * RC;
@@ -971,7 +1005,8 @@ __global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t
         if (l == 0 || l == 1) v = rec[(B_PIECES + l) * S + cell];
         else if (l == 2) v = P.tab->obstacles[cell];
         else if (l == 3 || l == 4) v = rec[(B_PO + l - 3) * S + cell];
-        else if (l == 32 || l == 33) v = rec[(B_STILL + l - 32) * S + cell];
+        else if (l == 32 || l == 33)
+            v = (reinterpret_cast<const uint32_t *>(rec + G::ST_OFF)[(l - 32) * (G::SB / 4) + (cell >> 5)] >> (cell & 31)) & 1u;
         else if (l == 5) {
             const int w = (sc.y & F_WIN_P1) ? 1 : (sc.y & F_WIN_M1) ? -1 : 0;
             if (cell == 0) v = sc.x;                               // TURN_COUNT  [5,0,0]
@@ -989,7 +1024,7 @@ __global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t
                 const int pr = ((pl ? sc2.z : sc2.y) >> (16 * h)) & 0xFFFF;
                 if (pr >> 8) o[(6 + pl) * RC + (pr & 0xFF)] = (int8_t)(pr >> 8);
             }
-        const uint16_t *ev = reinterpret_cast<const uint16_t *>(rec + G::EV_OFF);
+        const uint16_t *ev = reinterpret_cast<const uint16_t *>(rec + G::EVL_OFF);
         for (int i = 0; i < sc2.x; ++i) o[(8 + (ev[i] >> 8)) * RC + (ev[i] & 0xFF)] += 1;
         if (player_out) player_out[env] = (sc.y & F_PLAYER_M1) ? -1 : 1;
     }
@@ -1005,7 +1040,8 @@ __global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, c
     if (env >= P.n_envs) return;
     int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
     const int64_t *s = in + env * (int64_t)(SGX_STATE_LAYERS * RC);
-    for (int x = threadIdx.x; x < G::EV_OFF; x += blockDim.x) {
+    for (int x = threadIdx.x; x < P.rec_bytes; x += blockDim.x) {
+        if (x >= G::ST_OFF && x < G::EVL_OFF + 2 * P.max_events) continue;   // bitmaps, scalars and events are written below
         const int b = x / S, cell = x - b * S;
         int v = 0;
         if (b < STORED_BOARDS && cell < RC) {
@@ -1014,6 +1050,16 @@ __global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, c
             v = (raw >= 0 && raw <= hi) ? (int)raw : 0;
         }
         rec[x] = (int8_t)v;
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < 2 * (G::SB / 4); w += blockDim.x) {      // never-moved bitmaps from layers 32/33
+        const int pl = w / (G::SB / 4), w0 = w - pl * (G::SB / 4);
+        uint32_t bits = 0;
+        for (int k = 0; k < 32; ++k) {
+            const int cell = 32 * w0 + k;
+            if (cell < RC && s[(32 + pl) * RC + cell] == 1) bits |= 1u << k;
+        }
+        reinterpret_cast<uint32_t *>(rec + G::ST_OFF)[w] = bits;
     }
     if (threadIdx.x == 0) {
         const int64_t *d = s + 5 * RC;
@@ -1031,27 +1077,33 @@ __global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, c
                 if (code != 0) { pairs[pl] |= (cell | ((code & 0xFF) << 8)) << (16 * k); ++k; }
             }
         }
-        uint16_t *ev = reinterpret_cast<uint16_t *>(rec + G::EV_OFF);
+        uint16_t *ev = reinterpret_cast<uint16_t *>(rec + G::EVL_OFF);
         int n = 0;
         for (int b = 0; b < 24; ++b)
             for (int cell = 0; cell < RC; ++cell)
                 for (int64_t q = min((long long)s[(8 + b) * RC + cell], 12ll); q > 0 && n < P.max_events; --q) ev[n++] = (uint16_t)((b << 8) | cell);
-        const int old_game = P.scal[2 * env].w;
-        P.scal[2 * env] = make_int4((int)d[0], flags, (int)d[C], old_game < 0 ? 0 : old_game);
-        P.scal[2 * env + 1] = make_int4(n, pairs[0], pairs[1], 0);
+        for (int i = n; i < P.max_events; ++i) ev[i] = 0;
+        int4 *scg = rec_scal<G>(P.boards, P.rec_bytes, env);
+        const int old_game = scg[0].w;
+        scg[0] = make_int4((int)d[0], flags, (int)d[C], old_game < 0 ? 0 : old_game);
+        scg[1] = make_int4(n, pairs[0], pairs[1], 0);
     }
 }
 
-__global__ void info_kernel(const int4 *__restrict__ scal, int32_t *__restrict__ out, int64_t n) {
+__global__ void info_kernel(const int8_t *__restrict__ boards, int rec_bytes, int sc_off, int32_t *__restrict__ out, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int4 s = scal[2 * i];
+    const int4 s = *reinterpret_cast<const int4 *>(boards + i * (int64_t)rec_bytes + sc_off);
     reinterpret_cast<int4 *>(out)[i] = make_int4(s.x, s.w, (s.y & F_OVER) ? 1 : 0, (s.y & F_PLAYER_M1) ? -1 : 1);
 }
 
-__global__ void init_scal_kernel(int4 *scal, int64_t n, int max_turns) {
+__global__ void init_scal_kernel(int8_t *boards, int rec_bytes, int sc_off, int64_t n, int max_turns) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) { scal[2 * i] = make_int4(0, 0, max_turns, -1); scal[2 * i + 1] = make_int4(0, 0, 0, 0); }
+    if (i < n) {
+        int4 *sc = reinterpret_cast<int4 *>(boards + i * (int64_t)rec_bytes + sc_off);
+        sc[0] = make_int4(0, 0, max_turns, -1);
+        sc[1] = make_int4(0, 0, 0, 0);
+    }
 }
 
 }  // namespace
@@ -1066,11 +1118,11 @@ struct sgx_env {
     uint64_t seed;
     int64_t env_id_offset;
     int8_t *boards;
-    int4 *scal;
     DevTables *tab;
     uint8_t *setups;
     int64_t n_setups;
     int rec_bytes;
+    int sc_off;
     int max_events;
     int K;
     unsigned long long *stamps;  // SGX_STAMPS builds only
@@ -1100,7 +1152,6 @@ KParams make_params(const sgx_env *h) {
     KParams p;
     memset(&p, 0, sizeof(p));
     p.boards = h->boards;
-    p.scal = h->scal;
     p.tab = h->tab;
     p.setups = h->setups;
     p.n_setups = (int32_t)h->n_setups;
@@ -1213,8 +1264,10 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
         int pieces = 0;
         for (int i = 0; i < 12; ++i) pieces += cfg->piece_counts[i];
         h->max_events = 2 * pieces;                                   // every piece can be captured once
-        const int ev_off = (STORED_BOARDS * ((rc_cells + 3) & ~3) + 15) & ~15;
-        h->rec_bytes = ev_off + ((2 * h->max_events + 15) & ~15);
+        const int st_off = (STORED_BOARDS * ((rc_cells + 3) & ~3) + 15) & ~15, sb = (((rc_cells + 7) / 8) + 15) & ~15;
+        const int sc_off = st_off + 2 * sb;
+        h->sc_off = sc_off;
+        h->rec_bytes = (sc_off + 32 + 2 * h->max_events + 127) & ~127;   // whole 128-byte lines per game
     }
     h->K = 2 * (cfg->rows - 1) + 2 * (cfg->cols - 1) + 1;
     DevTables host_tab;
@@ -1236,7 +1289,6 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     }
     memcpy(host_tab.obstacles, cfg->obstacles, rc_cells);
     if (hipMalloc((void **)&h->boards, (size_t)n_envs * h->rec_bytes) != hipSuccess ||
-        hipMalloc((void **)&h->scal, (size_t)n_envs * 2 * sizeof(int4)) != hipSuccess ||
         hipMalloc((void **)&h->tab, sizeof(DevTables)) != hipSuccess) {
         sgx_destroy(h);
         return fail(SGX_ENOMEM, "device allocation failed%s");
@@ -1247,7 +1299,7 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     HIP_TRY(hipMalloc((void **)&h->stamps, (size_t)n_envs * 16 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(h->stamps, 0, (size_t)n_envs * 16 * sizeof(unsigned long long)));
 #endif
-    init_scal_kernel<<<(unsigned)((n_envs + 255) / 256), 256>>>(h->scal, n_envs, cfg->max_turns);
+    init_scal_kernel<<<(unsigned)((n_envs + 255) / 256), 256>>>(h->boards, h->rec_bytes, h->sc_off, n_envs, cfg->max_turns);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     *out = h;
@@ -1259,7 +1311,6 @@ SGX_API int sgx_destroy(sgx_env *h) {
     hipSetDevice(h->device);
     hipDeviceSynchronize();
     if (h->boards) hipFree(h->boards);
-    if (h->scal) hipFree(h->scal);
     if (h->tab) hipFree(h->tab);
     if (h->setups) hipFree(h->setups);
     if (h->stamps) hipFree(h->stamps);
@@ -1370,7 +1421,7 @@ SGX_API int sgx_import_state(sgx_env *h, const int64_t *state_dev, const int8_t 
 SGX_API int sgx_get_env_info(sgx_env *h, int32_t *info_dev, void *stream) {
     if (!h || !info_dev) return fail(SGX_EINVAL, "NULL argument%s");
     HIP_TRY(hipSetDevice(h->device));
-    info_kernel<<<(unsigned)((h->n_envs + 255) / 256), 256, 0, (hipStream_t)stream>>>(h->scal, info_dev, h->n_envs);
+    info_kernel<<<(unsigned)((h->n_envs + 255) / 256), 256, 0, (hipStream_t)stream>>>(h->boards, h->rec_bytes, h->sc_off, info_dev, h->n_envs);
     HIP_TRY(hipGetLastError());
     return SGX_OK;
 }
