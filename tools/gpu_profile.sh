@@ -21,4 +21,7 @@ done
 cd $R
 python3 tools/pmc_summary.py "gpurun_out/prof_$TAG" > $OUT/summary.txt 2>&1
 cat $OUT/stats/*/*kernel_stats.csv | head -4 >> $OUT/summary.txt
+# raw traces are large (gpurun merges back at most 64 MiB): keep the summaries only
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
+du -sh $OUT | sed 's/^/# kept: /'
 cat $OUT/summary.txt | grep -v "^#"
