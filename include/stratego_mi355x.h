@@ -32,10 +32,12 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 3
+#define SGX_ABI_VERSION 4
 #define SGX_MAX_CELLS 256        /* rows*cols <= 256 (largest reference variant: 15x15) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
 #define SGX_FO_OBS_CHANNELS 79   /* impl:1227 */
+#define SGX_PO_OBS_CHANNELS_ORIGINAL 32   /* impl:1148, obs_channel_mode='original' (maenv:67, 368-375) */
+#define SGX_FO_OBS_CHANNELS_ORIGINAL 33   /* impl:1070 */
 #define SGX_STATE_LAYERS 34      /* impl:109 */
 #define SGX_OBS_LUT_STRIDE 16    /* entries per channel in the normalisation LUT */
 
@@ -90,6 +92,10 @@ typedef struct sgx_step_io {
 #define SGX_STEP_RAW_OBS 4            /* observations un-normalised, as penv:166-173 return them */
 #define SGX_STEP_ACTIONS_POSITIONS 8   /* actions_dev is int32 [N][4] = (start_r, start_c, end_r, end_c) in absolute coordinates
                                          (is_move_valid_by_position, penv:87-92) */
+/* env_config['obs_channel_mode'] == 'original' (maenv:67, 368-375, 465-467, 484-486): the deprecated value-channel
+ * observations.  obs_dev / final_obs_dev then have 32 channels (impl:1126-1197) and fobs_dev / final_fobs_dev 33
+ * (impl:1048-1123), normalised with the constants of maenv:87-199. */
+#define SGX_STEP_ORIGINAL_CHANNELS 16
 
 /* Library / geometry queries (penv:32-36: action_size, spatial_action_size). */
 int sgx_abi_version(void);
@@ -106,6 +112,9 @@ int64_t sgx_action_size_1d(const sgx_env *h);        /* R*C*(R+C)+1 (impl:252-25
 int sgx_build_obs_lut(const sgx_config *cfg, float *lut);
 /* Same for the 79 fully-observable channels: lut[79*SGX_OBS_LUT_STRIDE] (maenv:202-258, 393-396, 499-501). */
 int sgx_build_full_obs_lut(const sgx_config *cfg, float *lut);
+/* Same for obs_channel_mode='original': lut[32*SGX_OBS_LUT_STRIDE] (full == 0; maenv:146-199) or
+ * lut[33*SGX_OBS_LUT_STRIDE] (full != 0; maenv:87-143). */
+int sgx_build_original_obs_lut(const sgx_config *cfg, int32_t full, float *lut);
 
 /* StrategoMultiAgentEnv.__init__ (maenv:318-445) for a batch: allocates the device state of n_envs games on
  * `device`.  Env i of this handle has global id env_id_offset + i; all random draws are keyed by
@@ -127,7 +136,7 @@ int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p1_maps_d
 
 /* _get_current_obs (maenv:447-497) for every env's current mover, no state change.
  * obs_dev, fobs_dev, mask_dev and player_dev are laid out as in sgx_step_io; each is nullable.
- * flags: 0 or SGX_STEP_RAW_OBS. */
+ * flags: 0 or any of SGX_STEP_RAW_OBS, SGX_STEP_ORIGINAL_CHANNELS. */
 int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, int8_t *player_dev, int32_t flags, void *stream);
 
 /* One batched env.step(): see sgx_step_io. */

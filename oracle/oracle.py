@@ -80,12 +80,18 @@ def lib():
         L.so_game_result_is_invalid.argtypes = [I64, I64, P_I64]
         L.so_next_state.restype = C.c_int
         L.so_next_state.argtypes = [I64, I64, P_I64, I64, I64, C.c_int, P_I64]
-        for f in (L.so_po_obs_extended, L.so_fo_obs_extended):
+        for f in (L.so_po_obs_extended, L.so_fo_obs_extended, L.so_po_obs_original, L.so_fo_obs_original):
             f.restype = None
             f.argtypes = [I64, I64, P_I64, I64, P_F32]
-        for f in (L.so_p_obs_norm_constants, L.so_f_obs_norm_constants):
+        for f in (L.so_p_obs_norm_constants, L.so_f_obs_norm_constants, L.so_p_obs_norm_constants_original,
+                  L.so_f_obs_norm_constants_original):
             f.restype = None
             f.argtypes = [P_I64, P_F32, P_F32]
+        L.so_env_current_obs3.restype = None
+        L.so_env_current_obs3.argtypes = [I64, I64, P_I64, I64, C.c_int, P_F32, P_F32, P_F32, P_F32, P_U8, P_F32, P_F32]
+        L.so_env_step3.restype = None
+        L.so_env_step3.argtypes = [I64, I64, P_I64, P_I64, I64, C.c_int, C.c_int, P_F32, P_F32, P_F32, P_F32, P_U8, P_F32, P_F32,
+                                   C.POINTER(StepResult)]
         L.so_normalize_obs.restype = None
         L.so_normalize_obs.argtypes = [I64, I64, P_F32, P_F32, P_F32]
         L.so_env_current_obs.restype = None
@@ -236,6 +242,21 @@ class OracleRules:
         return out
 
 
+    def get_partially_observable_observation(self, state, player):
+        """Deprecated 32-layer observation (impl:1153-1197)."""
+        st = _i64(state)
+        out = np.zeros((self.rows, self.columns, 32), dtype=np.float32)
+        lib().so_po_obs_original(self.rows, self.columns, _p(st, P_I64), int(player), _p(out, P_F32))
+        return out
+
+    def get_fully_observable_observation(self, state, player):
+        """Deprecated 33-layer observation (impl:1075-1123)."""
+        st = _i64(state)
+        out = np.zeros((self.rows, self.columns, 33), dtype=np.float32)
+        lib().so_fo_obs_original(self.rows, self.columns, _p(st, P_I64), int(player), _p(out, P_F32))
+        return out
+
+
 def piece_amounts_array(piece_counts):
     """(count of code 1, ..., count of code 12) -> int64[13] indexed by piece code."""
     a = np.zeros(13, dtype=np.int64)
@@ -243,19 +264,23 @@ def piece_amounts_array(piece_counts):
     return a
 
 
-def f_obs_norm_constants(piece_counts):
-    mids = np.zeros(79, dtype=np.float32)
-    ranges = np.zeros(79, dtype=np.float32)
+def f_obs_norm_constants(piece_counts, original=False):
+    n = 33 if original else 79
+    mids = np.zeros(n, dtype=np.float32)
+    ranges = np.zeros(n, dtype=np.float32)
     pa = piece_amounts_array(piece_counts)
-    lib().so_f_obs_norm_constants(_p(pa, P_I64), _p(mids, P_F32), _p(ranges, P_F32))
+    fn = lib().so_f_obs_norm_constants_original if original else lib().so_f_obs_norm_constants
+    fn(_p(pa, P_I64), _p(mids, P_F32), _p(ranges, P_F32))
     return mids, ranges
 
 
-def p_obs_norm_constants(piece_counts):
-    mids = np.zeros(67, dtype=np.float32)
-    ranges = np.zeros(67, dtype=np.float32)
+def p_obs_norm_constants(piece_counts, original=False):
+    n = 32 if original else 67
+    mids = np.zeros(n, dtype=np.float32)
+    ranges = np.zeros(n, dtype=np.float32)
     pa = piece_amounts_array(piece_counts)
-    lib().so_p_obs_norm_constants(_p(pa, P_I64), _p(mids, P_F32), _p(ranges, P_F32))
+    fn = lib().so_p_obs_norm_constants_original if original else lib().so_p_obs_norm_constants
+    fn(_p(pa, P_I64), _p(mids, P_F32), _p(ranges, P_F32))
     return mids, ranges
 
 
@@ -272,9 +297,11 @@ class OracleEnv:
     FOBS = 'full_observation'
 
     def __init__(self, rows, columns, max_turns, obstacle_locations, piece_counts, penalize_ties=False,
-                 observation_mode='partially_observable'):
+                 observation_mode='partially_observable', obs_channel_mode='extended'):
         assert observation_mode in ('partially_observable', 'fully_observable', 'both_observations')
         self.mode = observation_mode
+        self.original = obs_channel_mode != 'extended'          # maenv:368
+        self.p_ch, self.f_ch = (32, 33) if self.original else (67, 79)
         self.rules = OracleRules(rows, columns)
         self.rows, self.columns, self.max_turns = int(rows), int(columns), int(max_turns)
         self.K = self.rules.K
@@ -283,18 +310,18 @@ class OracleEnv:
             self.obstacles[r, c] = 1
         self.piece_counts = tuple(int(x) for x in piece_counts)
         self.penalize_ties = bool(penalize_ties)
-        self.mids, self.ranges = p_obs_norm_constants(self.piece_counts)
-        self.f_mids, self.f_ranges = f_obs_norm_constants(self.piece_counts)
+        self.mids, self.ranges = p_obs_norm_constants(self.piece_counts, self.original)
+        self.f_mids, self.f_ranges = f_obs_norm_constants(self.piece_counts, self.original)
         self.state = None
         self.player = 1
 
     def _obs(self, player):
         R, Cc, K = self.rows, self.columns, self.K
         mask = np.zeros((R, Cc, K), dtype=np.uint8)
-        pobs = np.zeros((R, Cc, 67), dtype=np.float32)
-        fobs = np.zeros((R, Cc, 79), dtype=np.float32)
-        lib().so_env_current_obs2(R, Cc, _p(self.state, P_I64), int(player), _p(self.mids, P_F32), _p(self.ranges, P_F32),
-                                  _p(self.f_mids, P_F32), _p(self.f_ranges, P_F32), _p(mask, P_U8), _p(pobs, P_F32), _p(fobs, P_F32))
+        pobs = np.zeros((R, Cc, self.p_ch), dtype=np.float32)
+        fobs = np.zeros((R, Cc, self.f_ch), dtype=np.float32)
+        lib().so_env_current_obs3(R, Cc, _p(self.state, P_I64), int(player), int(self.original), _p(self.mids, P_F32),
+                                  _p(self.ranges, P_F32), _p(self.f_mids, P_F32), _p(self.f_ranges, P_F32), _p(mask, P_U8), _p(pobs, P_F32), _p(fobs, P_F32))
         return self._pack(mask, pobs, fobs)
 
     def _pack(self, mask, pobs, fobs):
@@ -318,11 +345,11 @@ class OracleEnv:
         action = int(action_dict[self.player])
         R, Cc, K = self.rows, self.columns, self.K
         mask = np.zeros((2, R, Cc, K), dtype=np.uint8)
-        pobs = np.zeros((2, R, Cc, 67), dtype=np.float32)
-        fobs = np.zeros((2, R, Cc, 79), dtype=np.float32)
+        pobs = np.zeros((2, R, Cc, self.p_ch), dtype=np.float32)
+        fobs = np.zeros((2, R, Cc, self.f_ch), dtype=np.float32)
         res = StepResult()
         pl = C.c_int64(self.player)
-        lib().so_env_step2(R, Cc, _p(self.state, P_I64), C.byref(pl), action, int(self.penalize_ties),
+        lib().so_env_step3(R, Cc, _p(self.state, P_I64), C.byref(pl), action, int(self.penalize_ties), int(self.original),
                            _p(self.mids, P_F32), _p(self.ranges, P_F32), _p(self.f_mids, P_F32), _p(self.f_ranges, P_F32),
                            _p(mask, P_U8), _p(pobs, P_F32), _p(fobs, P_F32), C.byref(res))
         if res.error:

@@ -467,6 +467,87 @@ SO_EXPORT void so_f_obs_norm_constants(const i64 *piece_amounts, float *mids, fl
     }
 }
 
+/* ---- obs_channel_mode='original' (deprecated 32/33-layer observations holding piece VALUES, not one-hots) ---- */
+#define PO_OBS_LAYERS_ORIG 32 /* impl:1148 */
+#define FO_OBS_LAYERS_ORIG 33 /* impl:1070 */
+
+/* impl:1153-1197 ; raw float32 (R,C,32) */
+SO_EXPORT void so_po_obs_original(i64 R, i64 C, const i64 *state_in, i64 player, float *obs) {
+    i64 *state = (i64 *)malloc(sizeof(i64) * NUM_STATE_LAYERS * R * C);
+    so_state_from_player_perspective(R, C, state_in, player, state);
+    for (i64 r = 0; r < R; r++)
+        for (i64 c = 0; c < C; c++) {
+            float *o = obs + (r * C + c) * PO_OBS_LAYERS_ORIG;
+            o[0] = (float)AT(state, L_P1_PIECES, r, c);
+            o[1] = (float)AT(state, L_P1_PO, r, c);
+            o[2] = (float)AT(state, L_P2_PO, r, c);
+            o[3] = (float)AT(state, L_OBSTACLES, r, c);
+            o[4] = (float)AT(state, L_P1_RECENT, r, c);
+            o[5] = (float)AT(state, L_P2_RECENT, r, c);
+            for (i64 k = 0; k < 12; k++) o[6 + k] = (float)AT(state, L_P1_CAP_START + k, r, c);
+            for (i64 k = 0; k < 12; k++) o[18 + k] = (float)AT(state, L_P2_CAP_START + k, r, c);
+            o[30] = (float)AT(state, L_P1_STILL, r, c);
+            o[31] = (float)AT(state, L_P2_STILL, r, c);
+        }
+    free(state);
+}
+
+/* impl:1075-1123 ; raw float32 (R,C,33) */
+SO_EXPORT void so_fo_obs_original(i64 R, i64 C, const i64 *state_in, i64 player, float *obs) {
+    i64 *state = (i64 *)malloc(sizeof(i64) * NUM_STATE_LAYERS * R * C);
+    so_state_from_player_perspective(R, C, state_in, player, state);
+    for (i64 r = 0; r < R; r++)
+        for (i64 c = 0; c < C; c++) {
+            float *o = obs + (r * C + c) * FO_OBS_LAYERS_ORIG;
+            o[0] = (float)AT(state, L_P1_PIECES, r, c);
+            o[1] = (float)AT(state, L_P2_PIECES, r, c);
+            o[2] = (float)AT(state, L_OBSTACLES, r, c);
+            o[3] = (float)AT(state, L_P1_RECENT, r, c);
+            o[4] = (float)AT(state, L_P2_RECENT, r, c);
+            o[5] = (float)AT(state, L_P1_PO, r, c);
+            o[6] = (float)AT(state, L_P2_PO, r, c);
+            for (i64 k = 0; k < 12; k++) o[7 + k] = (float)AT(state, L_P1_CAP_START + k, r, c);
+            for (i64 k = 0; k < 12; k++) o[19 + k] = (float)AT(state, L_P2_CAP_START + k, r, c);
+            o[31] = (float)AT(state, L_P1_STILL, r, c);
+            o[32] = (float)AT(state, L_P2_STILL, r, c);
+        }
+    free(state);
+}
+
+/* maenv:146-199 (_get_partially_observable_max_and_min_vals) + maenv:388-391 */
+SO_EXPORT void so_p_obs_norm_constants_original(const i64 *piece_amounts, float *mids, float *ranges) {
+    float hi[PO_OBS_LAYERS_ORIG], lo[PO_OBS_LAYERS_ORIG];
+    hi[0] = 12; lo[0] = 0;                   /* SP.BOMB .. SP.NOPIECE */
+    hi[1] = hi[2] = 13; lo[1] = lo[2] = 0;   /* SP.UNKNOWN .. SP.NOPIECE */
+    hi[3] = 2; lo[3] = 0;
+    hi[4] = hi[5] = (float)RM_JUST_CAME_FROM;
+    lo[4] = lo[5] = (float)RM_CANT_DOUBLE_BACK;
+    for (int i = 6; i < 32; i++) { hi[i] = 2; lo[i] = 0; }
+    for (int t = 1; t <= 12; t++)
+        if (piece_amounts[t] > 1) { hi[6 + t - 1] = (float)piece_amounts[t]; hi[18 + t - 1] = (float)piece_amounts[t]; }
+    for (int i = 0; i < PO_OBS_LAYERS_ORIG; i++) {
+        ranges[i] = (hi[i] - lo[i]) / 2.0f;
+        mids[i] = (hi[i] + lo[i]) / 2.0f;
+    }
+}
+
+/* maenv:87-143 (_get_fully_observable_max_and_min_vals) + maenv:393-396 */
+SO_EXPORT void so_f_obs_norm_constants_original(const i64 *piece_amounts, float *mids, float *ranges) {
+    float hi[FO_OBS_LAYERS_ORIG], lo[FO_OBS_LAYERS_ORIG];
+    hi[0] = hi[1] = 12; lo[0] = lo[1] = 0;
+    hi[2] = 2; lo[2] = 0;
+    hi[3] = hi[4] = (float)RM_JUST_CAME_FROM;
+    lo[3] = lo[4] = (float)RM_CANT_DOUBLE_BACK;
+    hi[5] = hi[6] = 13; lo[5] = lo[6] = 0;
+    for (int i = 7; i < 33; i++) { hi[i] = 2; lo[i] = 0; }
+    for (int t = 1; t <= 12; t++)
+        if (piece_amounts[t] > 1) { hi[7 + t - 1] = (float)piece_amounts[t]; hi[19 + t - 1] = (float)piece_amounts[t]; }
+    for (int i = 0; i < FO_OBS_LAYERS_ORIG; i++) {
+        ranges[i] = (hi[i] - lo[i]) / 2.0f;
+        mids[i] = (hi[i] + lo[i]) / 2.0f;
+    }
+}
+
 /* maenv:499-508 : (obs - mids) / ranges in float32, broadcast over cells */
 SO_EXPORT void so_normalize_obs(i64 n_cells, i64 n_layers, const float *mids, const float *ranges, float *obs) {
     for (i64 i = 0; i < n_cells; i++)
@@ -490,7 +571,14 @@ SO_EXPORT void so_env_current_obs(i64 R, i64 C, const i64 *state, i64 player, co
     so_env_current_obs2(R, C, state, player, mids, ranges, 0, 0, mask_u8, p_obs, 0);
 }
 /* maenv:447-497 with observation_mode BOTH / FULLY_OBSERVABLE: f_obs (R,C,79) normalised (maenv:477-492) */
+SO_EXPORT void so_env_current_obs3(i64 R, i64 C, const i64 *state, i64 player, int original, const float *mids, const float *ranges,
+                                   const float *f_mids, const float *f_ranges, uint8_t *mask_u8, float *p_obs, float *f_obs);
 SO_EXPORT void so_env_current_obs2(i64 R, i64 C, const i64 *state, i64 player, const float *mids, const float *ranges,
+                                   const float *f_mids, const float *f_ranges, uint8_t *mask_u8, float *p_obs, float *f_obs) {
+    so_env_current_obs3(R, C, state, player, 0, mids, ranges, f_mids, f_ranges, mask_u8, p_obs, f_obs);
+}
+/* same with obs_channel_mode selectable: original != 0 => the 32/33-layer observations (maenv:460-468, 479-486) */
+SO_EXPORT void so_env_current_obs3(i64 R, i64 C, const i64 *state, i64 player, int original, const float *mids, const float *ranges,
                                    const float *f_mids, const float *f_ranges, uint8_t *mask_u8, float *p_obs, float *f_obs) {
     i64 K = so_spatial_channels(R, C), n = R * C * K;
     i64 *pp = (i64 *)malloc(sizeof(i64) * NUM_STATE_LAYERS * R * C);
@@ -502,12 +590,14 @@ SO_EXPORT void so_env_current_obs2(i64 R, i64 C, const i64 *state, i64 player, c
         free(m);
     }
     if (p_obs) {
-        so_po_obs_extended(R, C, pp, 1, p_obs); /* maenv:461-463 */
-        so_normalize_obs(R * C, PO_OBS_LAYERS, mids, ranges, p_obs); /* maenv:471 */
+        if (original) so_po_obs_original(R, C, pp, 1, p_obs); /* maenv:465-467 */
+        else so_po_obs_extended(R, C, pp, 1, p_obs);          /* maenv:461-463 */
+        so_normalize_obs(R * C, original ? PO_OBS_LAYERS_ORIG : PO_OBS_LAYERS, mids, ranges, p_obs); /* maenv:471 */
     }
     if (f_obs) {
-        so_fo_obs_extended(R, C, pp, 1, f_obs); /* maenv:480-482 */
-        so_normalize_obs(R * C, FO_OBS_LAYERS, f_mids, f_ranges, f_obs); /* maenv:488 */
+        if (original) so_fo_obs_original(R, C, pp, 1, f_obs); /* maenv:484-486 */
+        else so_fo_obs_extended(R, C, pp, 1, f_obs);          /* maenv:480-482 */
+        so_normalize_obs(R * C, original ? FO_OBS_LAYERS_ORIG : FO_OBS_LAYERS, f_mids, f_ranges, f_obs); /* maenv:488 */
     }
     free(pp);
 }
@@ -533,7 +623,16 @@ SO_EXPORT void so_env_step(i64 R, i64 C, i64 *state, i64 *player, i64 action, in
     so_env_step2(R, C, state, player, action, penalize_ties, mids, ranges, 0, 0, mask_out, obs_out, 0, res);
 }
 /* same, also producing the fully-observable observation (slots of R*C*79 floats) when fobs_out != NULL */
+SO_EXPORT void so_env_step3(i64 R, i64 C, i64 *state, i64 *player, i64 action, int penalize_ties, int original, const float *mids,
+                            const float *ranges, const float *f_mids, const float *f_ranges, uint8_t *mask_out, float *obs_out,
+                            float *fobs_out, so_step_result *res);
 SO_EXPORT void so_env_step2(i64 R, i64 C, i64 *state, i64 *player, i64 action, int penalize_ties, const float *mids,
+                            const float *ranges, const float *f_mids, const float *f_ranges, uint8_t *mask_out, float *obs_out,
+                            float *fobs_out, so_step_result *res) {
+    so_env_step3(R, C, state, player, action, penalize_ties, 0, mids, ranges, f_mids, f_ranges, mask_out, obs_out, fobs_out, res);
+}
+/* same with obs_channel_mode selectable (original != 0: slots of R*C*32 / R*C*33 floats) */
+SO_EXPORT void so_env_step3(i64 R, i64 C, i64 *state, i64 *player, i64 action, int penalize_ties, int original, const float *mids,
                             const float *ranges, const float *f_mids, const float *f_ranges, uint8_t *mask_out, float *obs_out,
                             float *fobs_out, so_step_result *res) {
     i64 K = so_spatial_channels(R, C), NA = R * C * K;
@@ -551,13 +650,14 @@ SO_EXPORT void so_env_step2(i64 R, i64 C, i64 *state, i64 *player, i64 action, i
     res->next_player = (int32_t)*player;
     float reward = so_game_ended(R, C, state, *player); /* maenv:699 */
     if (reward == 0) {                                  /* maenv:767-770 */
-        so_env_current_obs2(R, C, state, *player, mids, ranges, f_mids, f_ranges, mask_out, obs_out, fobs_out);
+        so_env_current_obs3(R, C, state, *player, original, mids, ranges, f_mids, f_ranges, mask_out, obs_out, fobs_out);
         return;
     }
     res->done = 1; /* maenv:772-805 */
-    so_env_current_obs2(R, C, state, 1, mids, ranges, f_mids, f_ranges, mask_out, obs_out, fobs_out);
-    so_env_current_obs2(R, C, state, -1, mids, ranges, f_mids, f_ranges, mask_out ? mask_out + NA : 0,
-                        obs_out ? obs_out + R * C * PO_OBS_LAYERS : 0, fobs_out ? fobs_out + R * C * FO_OBS_LAYERS : 0);
+    so_env_current_obs3(R, C, state, 1, original, mids, ranges, f_mids, f_ranges, mask_out, obs_out, fobs_out);
+    so_env_current_obs3(R, C, state, -1, original, mids, ranges, f_mids, f_ranges, mask_out ? mask_out + NA : 0,
+                        obs_out ? obs_out + R * C * (original ? PO_OBS_LAYERS_ORIG : PO_OBS_LAYERS) : 0,
+                        fobs_out ? fobs_out + R * C * (original ? FO_OBS_LAYERS_ORIG : FO_OBS_LAYERS) : 0);
     int tied;
     if (so_game_result_is_invalid(R, C, state)) {
         res->ending_invalid = 1;

@@ -12,12 +12,15 @@ SGX_MAX_CELLS = 256
 SGX_OBS_LUT_STRIDE = 16
 PO_OBS_CHANNELS = 67
 FO_OBS_CHANNELS = 79
-STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS = 1, 2, 4, 8
+PO_OBS_CHANNELS_ORIGINAL = 32
+FO_OBS_CHANNELS_ORIGINAL = 33
+ABI_VERSION = 4
+STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, STEP_ORIGINAL_CHANNELS = 1, 2, 4, 8, 16
 
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
-    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
+    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
     'sgx_observe', 'sgx_step', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_get_env_info',
 )
 
@@ -60,6 +63,8 @@ def _bind(L):
     L.sgx_build_obs_lut.argtypes = [C.POINTER(SgxConfig), C.POINTER(C.c_float)]
     L.sgx_build_full_obs_lut.restype = C.c_int
     L.sgx_build_full_obs_lut.argtypes = [C.POINTER(SgxConfig), C.POINTER(C.c_float)]
+    L.sgx_build_original_obs_lut.restype = C.c_int
+    L.sgx_build_original_obs_lut.argtypes = [C.POINTER(SgxConfig), C.c_int32, C.POINTER(C.c_float)]
     L.sgx_create.restype = C.c_int
     L.sgx_create.argtypes = [C.POINTER(SgxConfig), i64, C.c_int, u64, i64, C.POINTER(vp)]
     L.sgx_destroy.restype = C.c_int

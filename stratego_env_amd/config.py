@@ -21,6 +21,8 @@ _BARRAGE_PIECES = (1, 2, 1, 0, 0, 0, 0, 0, 1, 1, 1, 1)
 NUM_PIECE_TYPES = 12
 PO_OBS_CHANNELS = 67   # reference impl:1332
 FO_OBS_CHANNELS = 79   # reference impl:1227
+PO_OBS_CHANNELS_ORIGINAL = 32   # reference impl:1148 (obs_channel_mode='original')
+FO_OBS_CHANNELS_ORIGINAL = 33   # reference impl:1070
 NUM_STATE_LAYERS = 34  # reference impl:109
 
 

@@ -8,6 +8,7 @@
 // Reference functions reproduced (paths relative to /root/reference/stratego_env):
 //   game/stratego_procedural_impl.py  (impl)   stratego_multiagent_env.py (maenv)   game/util.py (util)
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -104,10 +105,11 @@ struct Geo {
 };
 
 struct DevTables {
-    float obs_lut[LUT_DWORDS];   // partial observation, rows at lut_row(ch)
-    float fobs_lut[LUT_DWORDS];  // fully-observable observation
-    float raw_lut[LUT_DWORDS];   // SGX_STEP_RAW_OBS: un-normalised channel values (penv:166-173 return raw observations)
-    float raw_flut[LUT_DWORDS];
+    // observation LUTs, rows at lut_row(ch); index = 4 * original + 2 * raw + full:
+    //   original: obs_channel_mode 'original' (32/33 channels) instead of 'extended' (67/79)
+    //   raw: SGX_STEP_RAW_OBS, un-normalised channel values (penv:157-173 return raw observations)
+    //   full: the fully-observable observation instead of the partial one
+    float lut[8][LUT_DWORDS];
     uint8_t obstacles[SGX_MAX_CELLS];
 };
 
@@ -250,6 +252,47 @@ struct FullObs {
         return B_STILL + (1 - qi);
     }
     __device__ static inline int bias(int ch) { return (ch == 51 || ch == 52) ? 3 : 0; }
+};
+// obs_channel_mode='original' (maenv:368-375): channels hold piece VALUES; partial impl:1126-1148, full impl:1048-1070
+struct OrigPartialObs {
+    static constexpr int NCH = SGX_PO_OBS_CHANNELS_ORIGINAL;
+    __device__ static inline int board(int ch, int qi) {
+        if (ch == 0) return B_PIECES + qi;
+        if (ch == 1) return B_PO + qi;
+        if (ch == 2) return B_PO + (1 - qi);
+        if (ch == 3) return B_OBST;
+        if (ch == 4) return B_RECENT + qi;
+        if (ch == 5) return B_RECENT + (1 - qi);
+        if (ch < 18) return B_CAP + 12 * qi + (ch - 6);
+        if (ch < 30) return B_CAP + 12 * (1 - qi) + (ch - 18);
+        if (ch == 30) return B_STILL + qi;
+        return B_STILL + (1 - qi);
+    }
+    __device__ static inline int bias(int ch) { return (ch == 4 || ch == 5) ? 3 : 0; }
+};
+struct OrigFullObs {
+    static constexpr int NCH = SGX_FO_OBS_CHANNELS_ORIGINAL;
+    __device__ static inline int board(int ch, int qi) {
+        if (ch == 0) return B_PIECES + qi;
+        if (ch == 1) return B_PIECES + (1 - qi);
+        if (ch == 2) return B_OBST;
+        if (ch == 3) return B_RECENT + qi;
+        if (ch == 4) return B_RECENT + (1 - qi);
+        if (ch == 5) return B_PO + qi;
+        if (ch == 6) return B_PO + (1 - qi);
+        if (ch < 19) return B_CAP + 12 * qi + (ch - 7);
+        if (ch < 31) return B_CAP + 12 * (1 - qi) + (ch - 19);
+        if (ch == 31) return B_STILL + qi;
+        return B_STILL + (1 - qi);
+    }
+    __device__ static inline int bias(int ch) { return (ch == 3 || ch == 4) ? 3 : 0; }
+};
+// step-kernel observation kind: bit 0 = also render the fully-observable observation, bit 1 = 'original' channels
+template <int KIND>
+struct ObsKind {
+    static constexpr bool FULL = (KIND & 1) != 0, ORIG = (KIND & 2) != 0;
+    using P = std::conditional_t<ORIG, OrigPartialObs, PartialObs>;
+    using F = std::conditional_t<ORIG, OrigFullObs, FullObs>;
 };
 __device__ inline int clamp15(int v) { return min(max(v, 0), 15); }
 
@@ -548,8 +591,9 @@ __device__ inline int fmod_(int a, int b) { int m = a % b; return m < 0 ? m + b 
 // The step kernel: env.step() of N games (maenv:659-828), one wave per game
 // ---------------------------------------------------------------------------------------------
 // waves per SIMD this geometry can reach: LDS per workgroup = WPB game regions + the shared LUT, 160 KiB per CU
-template <class G, bool FULL>
+template <class G, int KIND>
 constexpr int waves_per_simd() {
+    constexpr bool FULL = (KIND & 1) != 0;
     constexpr int per_wg = WPB * (int)sizeof(Lds<G>) + 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0));
     constexpr int wgs = (160 * 1024) / per_wg;
     constexpr int w = wgs * WPB / 4;
@@ -593,9 +637,11 @@ __device__ inline void write_record(Lds<G> &L, int8_t *rec_g, int rec_bytes, int
 }
 
 // One game's env.step() by one wave (called with the wave's private LDS region).
-template <int R_, int C_, bool FULL>
+template <int R_, int C_, int KIND>
 __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, const float *lut_s, const int64_t env, const int lane) {
     using G = Geo<R_, C_>;
+    using PS = typename ObsKind<KIND>::P;
+    using FS = typename ObsKind<KIND>::F;
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     STAMP(0);
 
@@ -818,15 +864,15 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
 
     // ---- terminal observations of both players (maenv:772-773)
     if (P.mode == 0 && ended_now && P.io.final_obs_dev) {
-        float *fo = P.io.final_obs_dev + env * (int64_t)(2 * G::NOBS);
-        emit_obs<G, PartialObs>(L, lut, 0, fo, lane);
-        emit_obs<G, PartialObs>(L, lut, 1, fo + G::NOBS, lane);
+        float *fo = P.io.final_obs_dev + env * (int64_t)(2 * RC * PS::NCH);
+        emit_obs<G, PS>(L, lut, 0, fo, lane);
+        emit_obs<G, PS>(L, lut, 1, fo + RC * PS::NCH, lane);
     }
-    if constexpr (FULL)
+    if constexpr (ObsKind<KIND>::FULL)
         if (P.mode == 0 && ended_now && P.io.final_fobs_dev) {
-            float *fo = P.io.final_fobs_dev + env * (int64_t)(2 * RC * FOBS_CH);
-            emit_obs<G, FullObs>(L, lut + OBS_TAB_DWORDS, 0, fo, lane);
-            emit_obs<G, FullObs>(L, lut + OBS_TAB_DWORDS, 1, fo + RC * FOBS_CH, lane);
+            float *fo = P.io.final_fobs_dev + env * (int64_t)(2 * RC * FS::NCH);
+            emit_obs<G, FS>(L, lut + OBS_TAB_DWORDS, 0, fo, lane);
+            emit_obs<G, FS>(L, lut + OBS_TAB_DWORDS, 1, fo + RC * FS::NCH, lane);
         }
 
     // ---- auto-reset: the finished env starts its next game now
@@ -846,9 +892,9 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
     STAMP(5);   // mask stores issued
     // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
-    if (P.io.obs_dev) emit_obs<G, PartialObs>(L, lut, qi, P.io.obs_dev + env * (int64_t)G::NOBS, lane);
-    if constexpr (FULL)
-        if (P.io.fobs_dev) emit_obs<G, FullObs>(L, lut + OBS_TAB_DWORDS, qi, P.io.fobs_dev + env * (int64_t)(RC * FOBS_CH), lane);
+    if (P.io.obs_dev) emit_obs<G, PS>(L, lut, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH), lane);
+    if constexpr (ObsKind<KIND>::FULL)
+        if (P.io.fobs_dev) emit_obs<G, FS>(L, lut + OBS_TAB_DWORDS, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH), lane);
     STAMP(6);   // obs stores issued
     if (P.mode == 0 && P.io.next_actions_dev) {
         const int total = nvalid == 0 ? 1 : nvalid;
@@ -877,10 +923,15 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
 #endif
 }
 
-// FULL: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492)
-template <int R_, int C_, bool FULL>
-__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) void step_kernel(const KParams P) {
+// KIND bit 0: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492);
+// KIND bit 1: obs_channel_mode 'original' (32/33 value channels) instead of 'extended' (67/79 one-hot channels)
+template <int R_, int C_, int KIND>
+__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) void step_kernel(const KParams P) {
     using G = Geo<R_, C_>;
+    using PS = typename ObsKind<KIND>::P;
+    using FS = typename ObsKind<KIND>::F;
+    constexpr bool FULL = ObsKind<KIND>::FULL;
+    constexpr int ORIG4 = ObsKind<KIND>::ORIG ? 4 : 0;
     __shared__ Lds<G> LW[WPB];
     __shared__ alignas(16) float lut_s[OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -888,16 +939,16 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, FULL>())) vo
 
     // ---- the workgroup's shared normalisation LUT (L2-resident source)
     const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
-    const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(raw ? P.tab->raw_lut : P.tab->obs_lut);
+    const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[ORIG4 + (raw ? 2 : 0)]);
     for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
-    build_quad_table<G, PartialObs>(reinterpret_cast<uint32_t *>(lut_s + LUT_DWORDS), threadIdx.x, 64 * WPB);
+    build_quad_table<G, PS>(reinterpret_cast<uint32_t *>(lut_s + LUT_DWORDS), threadIdx.x, 64 * WPB);
     if constexpr (FULL) {
-        const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(raw ? P.tab->raw_flut : P.tab->fobs_lut);
+        const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[ORIG4 + (raw ? 2 : 0) + 1]);
         for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s + OBS_TAB_DWORDS)[i] = fsrc[i];
-        build_quad_table<G, FullObs>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * WPB);
+        build_quad_table<G, FS>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * WPB);
     }
     __syncthreads();   // from here on every wave works on its own game
-    if (env < P.n_envs) env_step<R_, C_, FULL>(P, LW[wave], lut_s, env, lane);
+    if (env < P.n_envs) env_step<R_, C_, KIND>(P, LW[wave], lut_s, env, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1197,29 +1248,50 @@ SGX_API int64_t sgx_action_size_1d(const sgx_env *h) {
     return h ? (int64_t)h->cfg.rows * h->cfg.cols * (h->cfg.rows + h->cfg.cols) + 1 : 0;
 }
 
-// Normalisation LUT shared by both observation kinds: channel layout = [n_own_true][n_enemy_true][13 own PO][13 enemy PO]
-// [obstacle][2 recent][12+12 captured][2 still]; partial has no enemy-true block (impl:1306-1332 vs impl:1200-1227).
-// highs/lows maenv:202-313, ranges/mids maenv:388-396, (x - mid) / range in float32 maenv:499-508.
-static void build_lut(const sgx_config *cfg, bool full, float *lut, bool raw_values = false) {
-    const int nch = full ? FOBS_CH : OBS_CH;
-    const int n_true = full ? 24 : 12, po_end = n_true + 26, obst = po_end, rec0 = po_end + 1, cap0 = po_end + 3, still0 = cap0 + 24;
+// Normalisation LUT [channels][LUT_STRIDE]: entry i of a channel's row = the float32 the reference produces for board value i
+// (recent-moves channels: value i - 3).  Extended channel layout = [n_own_true][n_enemy_true][13 own PO][13 enemy PO]
+// [obstacle][2 recent][12+12 captured][2 still]; partial has no enemy-true block (impl:1306-1332 vs impl:1200-1227);
+// highs/lows maenv:202-313.  Original layout (value channels): partial impl:1126-1148 with maenv:146-199, full impl:1048-1070
+// with maenv:87-143.  ranges/mids maenv:388-396, (x - mid) / range in float32 maenv:499-508.
+static int lut_channels(bool full, bool original) {
+    return original ? (full ? SGX_FO_OBS_CHANNELS_ORIGINAL : SGX_PO_OBS_CHANNELS_ORIGINAL) : (full ? FOBS_CH : OBS_CH);
+}
+static void build_lut(const sgx_config *cfg, bool full, float *lut, bool raw_values = false, bool original = false) {
+    const int nch = lut_channels(full, original);
+    enum { ONEHOT, VALUE, RECENT };
     float hi[FOBS_CH], lo[FOBS_CH];
-    for (int ch = 0; ch < nch; ++ch) { hi[ch] = 1.0f; lo[ch] = -1.0f; }
+    int kind[FOBS_CH], type[FOBS_CH];
+    int rec0, cap0;
+    for (int ch = 0; ch < nch; ++ch) { hi[ch] = 1.0f; lo[ch] = -1.0f; kind[ch] = VALUE; type[ch] = 0; }
+    if (!original) {
+        const int n_true = full ? 24 : 12, po_end = n_true + 26;
+        for (int ch = 0; ch < po_end; ++ch) {          // one-hot piece channels: raw = (board value == piece type)
+            kind[ch] = ONEHOT;
+            type[ch] = ch < n_true ? ch % 12 + 1       // true pieces: types 1..12
+                                   : (ch - n_true) % 13 + 1;   // PO pieces: types 1..13
+        }
+        rec0 = po_end + 1; cap0 = po_end + 3;
+        for (int ch = cap0; ch < cap0 + 24; ++ch) { hi[ch] = 8.0f; lo[ch] = 0.0f; }
+    } else {
+        for (int ch = 0; ch < nch; ++ch) { hi[ch] = 2.0f; lo[ch] = 0.0f; }   // obstacles, captured, still
+        if (full) {
+            hi[0] = hi[1] = (float)SP_BOMB; hi[5] = hi[6] = (float)SP_UNKNOWN;
+            rec0 = 3; cap0 = 7;
+        } else {
+            hi[0] = (float)SP_BOMB; hi[1] = hi[2] = (float)SP_UNKNOWN;
+            rec0 = 4; cap0 = 6;
+        }
+    }
+    kind[rec0] = kind[rec0 + 1] = RECENT;
     hi[rec0] = hi[rec0 + 1] = 1.0f; lo[rec0] = lo[rec0 + 1] = -3.0f;   // RecentMoves JUST_CAME_FROM .. JUST_ARRIVED_AND_CANT_DOUBLE_BACK
-    for (int ch = cap0; ch < still0; ++ch) { hi[ch] = 8.0f; lo[ch] = 0.0f; }
     for (int t = 1; t <= 12; ++t)
         if (cfg->piece_counts[t - 1] > 1) hi[cap0 + t - 1] = hi[cap0 + 12 + t - 1] = (float)cfg->piece_counts[t - 1];
-    (void)obst;
     for (int ch = 0; ch < nch; ++ch) {
         volatile float range = (hi[ch] - lo[ch]) / 2.0f, mid = (hi[ch] + lo[ch]) / 2.0f;
         for (int i = 0; i < LUT_STRIDE; ++i) {
             float raw;
-            if (ch < po_end) {                   // one-hot piece channels: raw = (board value == piece type)
-                int type;
-                if (ch < n_true) type = ch % 12 + 1;                 // true pieces: types 1..12
-                else type = (ch - n_true) % 13 + 1;                  // PO pieces: types 1..13
-                raw = (i == type) ? 1.0f : 0.0f;
-            } else if (ch == rec0 || ch == rec0 + 1) raw = (float)(i - 3);
+            if (kind[ch] == ONEHOT) raw = (i == type[ch]) ? 1.0f : 0.0f;
+            else if (kind[ch] == RECENT) raw = (float)(i - 3);
             else raw = (float)i;
             volatile float d = raw - mid;        // two IEEE float32 roundings, as numpy does
             lut[ch * LUT_STRIDE + i] = raw_values ? raw : d / range;
@@ -1238,6 +1310,13 @@ SGX_API int sgx_build_full_obs_lut(const sgx_config *cfg, float *lut) {
     if (int rc = check_cfg(cfg)) return rc;
     if (!lut) return fail(SGX_EINVAL, "lut is NULL%s");
     build_lut(cfg, true, lut);
+    return SGX_OK;
+}
+
+SGX_API int sgx_build_original_obs_lut(const sgx_config *cfg, int32_t full, float *lut) {
+    if (int rc = check_cfg(cfg)) return rc;
+    if (!lut) return fail(SGX_EINVAL, "lut is NULL%s");
+    build_lut(cfg, full != 0, lut, false, true);
     return SGX_OK;
 }
 
@@ -1272,20 +1351,14 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     h->K = 2 * (cfg->rows - 1) + 2 * (cfg->cols - 1) + 1;
     DevTables host_tab;
     memset(&host_tab, 0, sizeof(host_tab));
-    {   // ABI LUT [67][16] -> device placement (rows at lut_row(ch), see LUT_ROW_PITCH)
+    {   // ABI LUTs [channels][16] -> device placement (rows at lut_row(ch), see LUT_ROW_PITCH)
         float dense[FOBS_CH * LUT_STRIDE];
-        build_lut(cfg, false, dense);
-        for (int ch = 0; ch < OBS_CH; ++ch)
-            for (int i = 0; i < LUT_STRIDE; ++i) host_tab.obs_lut[lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
-        build_lut(cfg, true, dense);
-        for (int ch = 0; ch < FOBS_CH; ++ch)
-            for (int i = 0; i < LUT_STRIDE; ++i) host_tab.fobs_lut[lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
-        build_lut(cfg, false, dense, true);
-        for (int ch = 0; ch < OBS_CH; ++ch)
-            for (int i = 0; i < LUT_STRIDE; ++i) host_tab.raw_lut[lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
-        build_lut(cfg, true, dense, true);
-        for (int ch = 0; ch < FOBS_CH; ++ch)
-            for (int i = 0; i < LUT_STRIDE; ++i) host_tab.raw_flut[lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
+        for (int k = 0; k < 8; ++k) {
+            const bool original = (k & 4) != 0, raw = (k & 2) != 0, full = (k & 1) != 0;
+            build_lut(cfg, full, dense, raw, original);
+            for (int ch = 0; ch < lut_channels(full, original); ++ch)
+                for (int i = 0; i < LUT_STRIDE; ++i) host_tab.lut[k][lut_row(ch) + i] = dense[ch * LUT_STRIDE + i];
+        }
     }
     memcpy(host_tab.obstacles, cfg->obstacles, rc_cells);
     if (hipMalloc((void **)&h->boards, (size_t)n_envs * h->rec_bytes) != hipSuccess ||
@@ -1349,15 +1422,21 @@ SGX_API int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p
 
 static int launch_step(sgx_env *h, const KParams &p, void *stream) {
     const unsigned grid = grid_for((h->n_envs + WPB - 1) / WPB);
-    if (p.io.fobs_dev || p.io.final_fobs_dev) {
-#define CALL_STEP_FULL(R, C) step_kernel<R, C, true><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p)
-        DISPATCH_GEOMETRY(h, CALL_STEP_FULL);
-#undef CALL_STEP_FULL
-    } else {
-#define CALL_STEP(R, C) step_kernel<R, C, false><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p)
-        DISPATCH_GEOMETRY(h, CALL_STEP);
-#undef CALL_STEP
-    }
+    const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
+#define CALL_STEP_KIND(R, C, KIND) step_kernel<R, C, KIND><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p)
+#define CALL_STEP0(R, C) CALL_STEP_KIND(R, C, 0)
+#define CALL_STEP1(R, C) CALL_STEP_KIND(R, C, 1)
+#define CALL_STEP2(R, C) CALL_STEP_KIND(R, C, 2)
+#define CALL_STEP3(R, C) CALL_STEP_KIND(R, C, 3)
+    if (!original && !full) DISPATCH_GEOMETRY(h, CALL_STEP0);
+    else if (!original) DISPATCH_GEOMETRY(h, CALL_STEP1);
+    else if (!full) DISPATCH_GEOMETRY(h, CALL_STEP2);
+    else DISPATCH_GEOMETRY(h, CALL_STEP3);
+#undef CALL_STEP0
+#undef CALL_STEP1
+#undef CALL_STEP2
+#undef CALL_STEP3
+#undef CALL_STEP_KIND
     HIP_TRY(hipGetLastError());
     return SGX_OK;
 }
@@ -1369,7 +1448,7 @@ SGX_API int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *ma
     p.mode = 1;
     p.io.obs_dev = obs_dev;
     p.io.fobs_dev = fobs_dev;
-    p.io.flags = flags & SGX_STEP_RAW_OBS;
+    p.io.flags = flags & (SGX_STEP_RAW_OBS | SGX_STEP_ORIGINAL_CHANNELS);
     p.io.mask_dev = mask_dev;
     p.io.player_dev = player_dev;
     return launch_step(h, p, stream);

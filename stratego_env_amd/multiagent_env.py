@@ -16,7 +16,7 @@ import copy
 import numpy as np
 import torch
 
-from . import _lib, index_algebra as ia
+from . import _lib, index_algebra as ia, obs_norm
 from .config import FO_OBS_CHANNELS, PO_OBS_CHANNELS, NUM_STATE_LAYERS, get_variant
 from .enums import GameVersions, ObservationComponents, ObservationModes
 from .setups import load_setup_table, sample_initial_maps_like_reference
@@ -74,8 +74,9 @@ class StrategoMultiAgentEnv:
         for key in ('vs_human', 'vs_bot', 'curriculum_start_states_path'):
             if cfg[key]:
                 raise NotImplementedError("%s is outside the MI355X hot-path build (SURVEY.md section 8)" % key)
-        if cfg['obs_channel_mode'] != 'extended':
-            raise NotImplementedError("only obs_channel_mode='extended' is built")
+        if cfg['obs_channel_mode'] not in ('extended', 'original'):
+            raise ValueError("obs_channel_mode must be 'extended' or 'original'")
+        self._extended_channels = cfg['obs_channel_mode'] == 'extended'                           # maenv:368
         mode = cfg['observation_mode']
         if isinstance(mode, str):
             mode = ObservationModes(mode)
@@ -95,7 +96,13 @@ class StrategoMultiAgentEnv:
         self._table = load_setup_table(v.human_inits) if self.human_inits else None
 
         self._vec = VecStrategoEnv(v.name, 1, device=device, seed=0, human_inits=False, auto_reset=False, final_obs=True,
-                                   full_obs=self._want_f)
+                                   full_obs=self._want_f, obs_channel_mode=cfg['obs_channel_mode'])
+        self._p_obs_num_layers, self._f_obs_num_layers = self._vec.p_channels, self._vec.f_channels   # maenv:370-382
+        original = not self._extended_channels
+        self._p_obs_highs, self._p_obs_lows = obs_norm.obs_highs_lows(v.piece_counts, full=False, original=original)
+        self._f_obs_highs, self._f_obs_lows = obs_norm.obs_highs_lows(v.piece_counts, full=True, original=original)
+        self._p_obs_ranges, self._p_obs_mids = obs_norm.ranges_mids(self._p_obs_highs, self._p_obs_lows)   # maenv:388-391
+        self._f_obs_ranges, self._f_obs_mids = obs_norm.ranges_mids(self._f_obs_highs, self._f_obs_lows)   # maenv:393-396
         self.rows, self.columns = v.rows, v.columns
         self.spatial_action_size = v.spatial_action_size
         self.action_size = v.action_size
@@ -109,15 +116,28 @@ class StrategoMultiAgentEnv:
         self.action_space = Discrete(int(np.prod(self.spatial_action_size)))          # maenv:362
         spaces = {_MASK: Box(np.float32(0), np.float32(1), self.spatial_action_size)}             # maenv:398-417
         if self._want_p:
-            spaces[_POBS] = Box(np.float32(-1.0), np.float32(1.0), (v.rows, v.columns, PO_OBS_CHANNELS))
+            spaces[_POBS] = Box(np.float32(-1.0), np.float32(1.0), (v.rows, v.columns, self._p_obs_num_layers))
         if self._want_f:
-            spaces[_FOBS] = Box(np.float32(-1.0), np.float32(1.0), (v.rows, v.columns, FO_OBS_CHANNELS))
+            spaces[_FOBS] = Box(np.float32(-1.0), np.float32(1.0), (v.rows, v.columns, self._f_obs_num_layers))
         if self.observation_includes_internal_state:
             spaces[_ISTATE] = Box(np.float32(-np.inf), np.float32(np.inf), (NUM_STATE_LAYERS, v.rows, v.columns))
         self.observation_space = Dict(spaces)
         self.player = 1
         self.player_map = lambda p: p
         self.reverse_player_map = lambda p: p
+
+    # ---- maenv:499-511 (the kernels emit normalised observations; these are the reference's public helpers) -----
+    def normalize_f_observation(self, f_obs):
+        return (f_obs - self._f_obs_mids) / self._f_obs_ranges
+
+    def denormalize_f_observation(self, f_obs):
+        return (f_obs * self._f_obs_ranges) + self._f_obs_mids
+
+    def normalize_p_observation(self, p_obs):
+        return (p_obs - self._p_obs_mids) / self._p_obs_ranges
+
+    def denormalize_p_observation(self, p_obs):
+        return (p_obs * self._p_obs_ranges) + self._p_obs_mids
 
     # ---- setup sampling with the reference's RNG consumption -------------------------------------------
     def _random_initial_maps(self):

@@ -117,6 +117,24 @@ class BatchedStrategoProceduralEnv:
         self._vec.observe(raw=True)
         return self._vec.fobs.clone()
 
+    def _observe_original(self, states, players, full):
+        vec = self._vec
+        self._load(states, players)
+        ch = _lib.FO_OBS_CHANNELS_ORIGINAL if full else _lib.PO_OBS_CHANNELS_ORIGINAL
+        out = torch.empty((self.batch_size, self.rows, self.columns, ch), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(vec._L.sgx_observe(vec._h, None if full else out.data_ptr(), out.data_ptr() if full else None, None, None,
+                                          _lib.STEP_RAW_OBS | _lib.STEP_ORIGINAL_CHANNELS, vec._stream()))
+        return out
+
+    def get_partially_observable_observation(self, states, players):                               # penv:162-164
+        """Deprecated 32-channel observation holding piece values (impl:1153-1197), raw."""
+        return self._observe_original(states, players, full=False)
+
+    def get_fully_observable_observation(self, states, players):                                   # penv:157-160
+        """Deprecated 33-channel observation (impl:1075-1123), raw."""
+        return self._observe_original(states, players, full=True)
+
     # ---- pure tensor functions (no kernel needed) -------------------------------------------------------------------
     def get_state_from_player_perspective(self, states, players):                                   # penv:101-103 / impl:645-675
         st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64)
@@ -134,6 +152,26 @@ class BatchedStrategoProceduralEnv:
         over, winner = st[:, 5, 0, 1] != 0, st[:, 5, 0, 2].to(torch.float32)
         val = torch.where(winner == 0, torch.full_like(winner, 1e-4), winner * pl)
         return torch.where(over, val, torch.zeros_like(val))
+
+    def get_heuristic_rewards_from_move(self, states, players, action_indices, reward_matrix):     # impl:852-891
+        """reward_matrix[moved own piece type, piece type on the destination] per state; 0 for the no-op.  Like the
+        reference, the move is assumed valid (absolute 1-D indices, impl:262-277)."""
+        st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64)
+        pl = self._players(players)
+        a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int64).reshape(self.batch_size)
+        rm = torch.as_tensor(reward_matrix).to(device=self.device, dtype=torch.float32)
+        R, C = self.rows, self.columns
+        noop = a == self.action_size - 1
+        a = torch.where(noop, torch.zeros_like(a), a)
+        start, k = a // (R + C), a % (R + C)                                                        # impl:350-383
+        sr, sc = start // C, start % C
+        er = torch.where(k < R, k, sr)
+        ec = torch.where(k < R, sc, k - R)
+        n = torch.arange(self.batch_size, device=self.device)
+        own_layer = (pl < 0).to(torch.int64)                                                        # impl:172-174
+        moved = st[n, own_layer, sr, sc]
+        dest = st[n, 1 - own_layer, er, ec]
+        return torch.where(noop, torch.zeros((), dtype=torch.float32, device=self.device), rm[moved, dest])
 
     def get_game_result_is_invalid(self, states):                                                   # penv:145-146 / impl:845-849
         st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64)

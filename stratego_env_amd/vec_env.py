@@ -6,6 +6,7 @@ buffers and the stream.  Outputs are written in place into preallocated tensors:
 
     obs      float32 [N, R, C, 67]   normalised partial observation of each env's next mover
     fobs     float32 [N, R, C, 79]   normalised fully-observable observation (only with full_obs=True)
+                                     (32 / 33 channels with obs_channel_mode='original')
     mask     uint8   [N, R, C, K]    valid-actions mask of the next mover (flat index = action)
     reward   float32 [N, 2]          rewards of player +1 / -1 (non-zero only when done)
     done     uint8   [N]
@@ -21,7 +22,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .config import FO_OBS_CHANNELS, PO_OBS_CHANNELS, NUM_STATE_LAYERS, get_variant
+from .config import (FO_OBS_CHANNELS, FO_OBS_CHANNELS_ORIGINAL, PO_OBS_CHANNELS, PO_OBS_CHANNELS_ORIGINAL, NUM_STATE_LAYERS,
+                     get_variant)
 from .setups import load_setup_table
 
 
@@ -31,9 +33,17 @@ def _ptr(t):
 
 class VecStrategoEnv:
     def __init__(self, version='barrage', num_envs=1, device=0, seed=0, env_id_offset=0, human_inits=None,
-                 auto_reset=False, final_obs=False, full_obs=False, lib_path=None):
+                 auto_reset=False, final_obs=False, full_obs=False, lib_path=None, obs_channel_mode='extended'):
         """human_inits: None = use the Gravon table when the variant has one (util.py:301-319), False = uniformly
-        random back-row placement (util.py:33-53), True = require the table."""
+        random back-row placement (util.py:33-53), True = require the table.
+        obs_channel_mode: 'extended' (67 / 79 one-hot channels) or 'original' (the deprecated 32 / 33 value channels,
+        maenv:67, 368-375)."""
+        if obs_channel_mode not in ('extended', 'original'):
+            raise ValueError("obs_channel_mode must be 'extended' or 'original'")
+        self.obs_channel_mode = obs_channel_mode
+        self._mode_flags = _lib.STEP_ORIGINAL_CHANNELS if obs_channel_mode == 'original' else 0
+        self.p_channels = PO_OBS_CHANNELS_ORIGINAL if self._mode_flags else PO_OBS_CHANNELS
+        self.f_channels = FO_OBS_CHANNELS_ORIGINAL if self._mode_flags else FO_OBS_CHANNELS
         if not torch.cuda.is_available():
             raise _lib.SgxError("VecStrategoEnv needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
         self._L = _lib.load(lib_path)
@@ -59,17 +69,17 @@ class VecStrategoEnv:
             _lib.check(self._L.sgx_set_setup_table(self._h, table.ctypes.data_as(C.c_void_p), table.shape[0]))
         self.human_inits = bool(human_inits)
         N, R, Cc, K, dev = self.num_envs, self.R, self.Cc, self.K, self.device
-        self.obs = torch.empty((N, R, Cc, PO_OBS_CHANNELS), dtype=torch.float32, device=dev)
+        self.obs = torch.empty((N, R, Cc, self.p_channels), dtype=torch.float32, device=dev)
         self.mask = torch.empty((N, R, Cc, K), dtype=torch.uint8, device=dev)
         self.reward = torch.zeros((N, 2), dtype=torch.float32, device=dev)
         self.done = torch.zeros((N,), dtype=torch.uint8, device=dev)
         self.player = torch.ones((N,), dtype=torch.int8, device=dev)
         self.invalid_action = torch.zeros((N,), dtype=torch.uint8, device=dev)
         self.ending_invalid = torch.zeros((N,), dtype=torch.uint8, device=dev)
-        self.final_obs = torch.zeros((N, 2, R, Cc, PO_OBS_CHANNELS), dtype=torch.float32, device=dev) if final_obs else None
+        self.final_obs = torch.zeros((N, 2, R, Cc, self.p_channels), dtype=torch.float32, device=dev) if final_obs else None
         # fully-observable observation (ObservationModes FULLY_OBSERVABLE / BOTH_OBSERVATIONS), float32 [N,R,C,79]
-        self.fobs = torch.empty((N, R, Cc, FO_OBS_CHANNELS), dtype=torch.float32, device=dev) if full_obs else None
-        self.final_fobs = (torch.zeros((N, 2, R, Cc, FO_OBS_CHANNELS), dtype=torch.float32, device=dev)
+        self.fobs = torch.empty((N, R, Cc, self.f_channels), dtype=torch.float32, device=dev) if full_obs else None
+        self.final_fobs = (torch.zeros((N, 2, R, Cc, self.f_channels), dtype=torch.float32, device=dev)
                            if (full_obs and final_obs) else None)
         self.next_actions = torch.zeros((N,), dtype=torch.int32, device=dev)
         self._io = _lib.SgxStepIO()
@@ -110,7 +120,7 @@ class VecStrategoEnv:
     def observe(self, raw=False):
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_observe(self._h, _ptr(self.obs), _ptr(self.fobs), _ptr(self.mask), _ptr(self.player),
-                                           _lib.STEP_RAW_OBS if raw else 0, self._stream()))
+                                           (_lib.STEP_RAW_OBS if raw else 0) | self._mode_flags, self._stream()))
         return self.obs, self.mask, self.player
 
     def tune_placement(self, trials=6, launches=6):
@@ -166,7 +176,7 @@ class VecStrategoEnv:
         io.final_obs_dev = self.final_obs.data_ptr() if self.final_obs is not None else None
         io.next_actions_dev = self.next_actions.data_ptr() if want_next_actions else None
         io.auto_reset = 1 if self.auto_reset else 0
-        io.flags = int(flags)
+        io.flags = int(flags) | self._mode_flags
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_step(self._h, C.byref(io), self._stream()))
         return self.obs, self.mask, self.reward, self.done, self.player

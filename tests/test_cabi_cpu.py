@@ -27,7 +27,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == sorted(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.sgx_abi_version() == 3
+    assert lib.sgx_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_struct_sizes_match_header():
@@ -89,6 +89,44 @@ def test_full_obs_lut_bit_exact_vs_reference_constants(lib):
                     raw = np.float32(i)
                 want = (raw - mids[ch]) / ranges[ch]
                 assert lut[ch, i].tobytes() == np.float32(want).tobytes(), (name, ch, i)
+
+
+def test_original_channel_luts_bit_exact_vs_reference_constants(lib):
+    """obs_channel_mode='original': LUT[ch][v] = (float32(v) - mid) / range with the reference's constants
+    (tests/golden/orig_norm.json, recorded from maenv:87-199, 388-396)."""
+    import json
+    with open(os.path.join(ROOT, 'tests', 'golden', 'orig_norm.json')) as f:
+        ref = json.load(f)
+    for name, r in ref.items():
+        cfg = _lib.make_config(VARIANTS[name])
+        for full, nch, rec, key in ((0, 32, (4, 5), 'p_obs'), (1, 33, (3, 4), 'f_obs')):
+            lut = np.zeros(nch * 16, dtype=np.float32)
+            assert lib.sgx_build_original_obs_lut(C.byref(cfg), full, lut.ctypes.data_as(C.POINTER(C.c_float))) == 0
+            lut = lut.reshape(nch, 16)
+            mids = np.asarray(r[key + '_mids'], dtype=np.float32)
+            ranges = np.asarray(r[key + '_ranges'], dtype=np.float32)
+            for ch in range(nch):
+                for i in range(16):
+                    raw = np.float32(i - 3) if ch in rec else np.float32(i)
+                    want = (raw - mids[ch]) / ranges[ch]
+                    assert lut[ch, i].tobytes() == np.float32(want).tobytes(), (name, full, ch, i)
+
+
+def test_facade_norm_constants_match_reference():
+    """stratego_env_amd.obs_norm (the facade's _p_obs_mids / _f_obs_ranges ... attributes) vs the reference dump."""
+    import json
+    from stratego_env_amd import obs_norm
+    ext = load_variants_json()['variants']
+    with open(os.path.join(ROOT, 'tests', 'golden', 'orig_norm.json')) as f:
+        orig = json.load(f)
+    for ref, original in ((ext, False), (orig, True)):
+        for name, r in ref.items():
+            for full, key in ((False, 'p_obs'), (True, 'f_obs')):
+                hi, lo = obs_norm.obs_highs_lows(VARIANTS[name].piece_counts, full, original)
+                rg, md = obs_norm.ranges_mids(hi, lo)
+                assert rg.dtype == np.float32 and rg.shape == (1, 1, hi.shape[0])
+                assert np.array_equal(md.reshape(-1), np.asarray(r[key + '_mids'], dtype=np.float32)), (name, key)
+                assert np.array_equal(rg.reshape(-1), np.asarray(r[key + '_ranges'], dtype=np.float32)), (name, key)
 
 
 def test_bad_config_rejected(lib):

@@ -19,15 +19,20 @@ MASK, POBS, FOBS = 'valid_actions_mask', 'partial_observation', 'full_observatio
 @pytest.mark.parametrize('name,n_envs,n_steps', [('barrage', 32, 500), ('standard', 6, 300), ('tiny', 48, 150), ('micro', 48, 80),
                                                  ('fives', 32, 150), ('octa_barrage', 16, 200), ('standard2', 2, 80)])
 def test_full_obs_bit_exact_vs_oracle(name, n_envs, n_steps):
-    import torch
+    check_both_obs_vs_oracle(name, n_envs, n_steps, 'extended')
+
+
+def check_both_obs_vs_oracle(name, n_envs, n_steps, channel_mode):
     from stratego_env_amd.vec_env import VecStrategoEnv
     v = VARIANTS[name]
     seed, g0 = 0x77AA55 + len(name), 500
-    env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True, final_obs=True, full_obs=True)
+    env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True, final_obs=True, full_obs=True,
+                         obs_channel_mode=channel_mode)
     cv = oracle_cvariant(name, setups=_table(name))
     oenvs = []
     for e in range(n_envs):
-        oe = orc.OracleEnv(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts, observation_mode='both_observations')
+        oe = orc.OracleEnv(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts,
+                           observation_mode='both_observations', obs_channel_mode=channel_mode)
         oe.reset(initial_state_override=orc.reset_state(cv, seed, g0 + e, 0))
         oe.game_no = 0
         oenvs.append(oe)

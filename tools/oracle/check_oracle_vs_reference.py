@@ -73,14 +73,15 @@ def compare_obs(o_ref, o_orc, where):
         assert p_r.tobytes() == p_o.tobytes(), (where, 'obs', p, np.argwhere(p_r != p_o)[:5])
 
 
-def play_game(ref, version_name, cfg, rng, garbage_rate, check_fns, mode='partially_observable'):
+def play_game(ref, version_name, cfg, rng, garbage_rate, check_fns, mode='partially_observable', channel_mode='extended'):
     GV, OM = ref.enums.GameVersions, ref.enums.ObservationModes
     env = ref.maenv.StrategoMultiAgentEnv({'version': GV(version_name), 'observation_mode': OM(mode),
+                                           'obs_channel_mode': channel_mode,
                                            'human_inits': version_name in ('standard', 'barrage', 'short_barrage',
                                                                            'medium_standard', 'short_standard')})
     R, C = cfg['rows'], cfg['columns']
     counts = [cfg['piece_amounts'][ref.impl.SP(t)] for t in range(1, 13)]
-    oenv = orc.OracleEnv(R, C, cfg['max_turns'], cfg['obstacle_locations'], counts, observation_mode=mode)
+    oenv = orc.OracleEnv(R, C, cfg['max_turns'], cfg['obstacle_locations'], counts, observation_mode=mode, obs_channel_mode=channel_mode)
     assert np.array_equal(env._p_obs_mids.reshape(-1), oenv.mids) and np.array_equal(env._p_obs_ranges.reshape(-1), oenv.ranges)
     assert np.array_equal(env._f_obs_mids.reshape(-1), oenv.f_mids) and np.array_equal(env._f_obs_ranges.reshape(-1), oenv.f_ranges)
     obs_r = env.reset()
@@ -118,6 +119,9 @@ def play_game(ref, version_name, cfg, rng, garbage_rate, check_fns, mode='partia
                 assert np.array_equal(pe.get_state_from_player_perspective(st, pl), ru.get_state_from_player_perspective(st, pl))
                 fo_r = pe.get_fully_observable_observation_extended_channels(st, pl)
                 assert fo_r.tobytes() == ru.get_fully_observable_observation_extended_channels(st, pl).tobytes()
+                assert pe.get_fully_observable_observation(st, pl).tobytes() == ru.get_fully_observable_observation(st, pl).tobytes()
+                assert pe.get_partially_observable_observation(st, pl).tobytes() == \
+                    ru.get_partially_observable_observation(st, pl).tobytes()
                 for idx in [rng.randrange(ru.action_size) for _ in range(8)]:
                     for osc in (False, True):
                         assert bool(pe.is_move_valid_by_1d_index(st, pl, idx, allow_piece_oscillation=osc)) == \
@@ -186,7 +190,10 @@ def main():
         for g in range(games):
             mode = ('partially_observable', 'both_observations', 'fully_observable')[g % 3]
             total += play_game(ref, name, cfg, rng, garbage_rate=0.15, check_fns=(g == 0), mode=mode)
-        print("%-16s %d games, %d steps: OK" % (name, games, total), flush=True)
+        # obs_channel_mode='original' (32/33-layer observations, maenv:368-375): one game in BOTH mode
+        total += play_game(ref, name, cfg, rng, garbage_rate=0.15, check_fns=False, mode='both_observations',
+                           channel_mode='original')
+        print("%-16s %d games (+1 original-channel game), %d steps: OK" % (name, games, total), flush=True)
     print("oracle == reference on all checks")
 
 
