@@ -123,15 +123,18 @@ class VecStrategoEnv:
                                            (_lib.STEP_RAW_OBS if raw else 0) | self._mode_flags, self._stream()))
         return self.obs, self.mask, self.player
 
-    def tune_placement(self, trials=6, launches=6):
-        """Pick the fastest of `trials` candidate allocations for the big output tensors (obs, mask).
+    def tune_placement(self, trials=24, launches=6, mask_trials=None, max_memory_fraction=0.25):
+        """Pick the fastest of up to `trials` candidate allocations for the big output tensors (obs, then mask).
 
-        Measured on MI355X (tools/grid_probe.py): the same kernel writing the same bytes runs up to
-        ~30 % slower on some device allocations than on others (offsets inside one allocation do not matter, a plain
-        `fill_` is equally fast on all of them; it is the placement of the buffer that thousands of concurrent
-        per-game store streams land on).  Physical placement cannot be requested, so this allocates candidates, times a few
-        `sgx_observe` launches (which write obs + mask and change no state) on each, keeps the fastest and frees the rest.
-        Call after reset(); returns {'obs': [...], 'mask': [...]} per-candidate launch times in microseconds."""
+        Measured on MI355X (tools/tlb_probe.py): device allocations come in speed classes -- the same
+        kernel writing the same bytes takes e.g. 332 / 355 / 380 / 400 us depending on which allocation `obs` is.  The class
+        is a property of the physical backing (offsets inside an allocation are equivalent, a sequential fill is equally
+        fast everywhere, a random scatter over the buffer shows the same ranking); it cannot be requested, and on some
+        boxes the first dozen allocations are all in the slow class while later ones are fast.  So this allocates
+        candidates (all held until the end, so that each one is different memory; at most `max_memory_fraction` of the
+        free device memory), times a few `sgx_observe` launches (which write obs + mask and change no state) on each,
+        keeps the fastest and frees the rest.  Call after reset(); returns {'obs': [...], 'mask': [...]} per-candidate
+        launch times in microseconds."""
         def time_observe():
             self.observe()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -143,16 +146,22 @@ class VecStrategoEnv:
             return e0.elapsed_time(e1) / launches * 1e3
 
         report = {}
-        for name, dtype in (('obs', torch.float32), ('mask', torch.uint8)):   # the obs buffer matters most; then the mask
+        mask_trials = min(trials, 8) if mask_trials is None else mask_trials
+        for name, n in (('obs', trials), ('mask', mask_trials)):   # the obs buffer matters most; then the mask
             cur = getattr(self, name)
-            cands = [cur] + [torch.empty(tuple(cur.shape), dtype=dtype, device=self.device) for _ in range(max(0, trials - 1))]
-            times = []
-            for c in cands:
-                setattr(self, name, c)
+            free_b, _ = torch.cuda.mem_get_info(self.device)
+            size_b = cur.numel() * cur.element_size()
+            n = max(1, min(n, 1 + int(free_b * max_memory_fraction) // max(size_b, 1)))
+            cands, times = [cur], []
+            for i in range(n):
+                if i:
+                    cands.append(torch.empty(tuple(cur.shape), dtype=cur.dtype, device=self.device))
+                setattr(self, name, cands[i])
                 times.append(time_observe())
             setattr(self, name, cands[min(range(len(cands)), key=lambda i: times[i])])
             del cands
             report[name] = times
+        torch.cuda.empty_cache()     # give the rejected candidates back to the device
         self.observe()
         return report
 
