@@ -98,7 +98,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
-    ap.add_argument('--placement-trials', type=int, default=24,
+    ap.add_argument('--placement-trials', type=int, default=40,
                     help='candidate allocations of the output tensors tried by VecStrategoEnv.tune_placement (1 = off)')
     ap.add_argument('--wake-seconds', type=float, default=2.0,
                     help='untimed GPU wake-up before the warmup steps (a fresh box runs its first ~second at idle clocks)')

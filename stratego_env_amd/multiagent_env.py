@@ -23,6 +23,8 @@ from .setups import load_setup_table, sample_initial_maps_like_reference
 from .spaces import Box, Dict, Discrete
 from .vec_env import VecStrategoEnv
 
+_NP_DTYPES = {torch.uint8: np.uint8, torch.int8: np.int8, torch.int32: np.int32, torch.float32: np.float32}
+
 DEFAULT_CONFIG = {   # maenv:47-69
     'version': GameVersions.STANDARD,
     'repeat_games_from_other_side': False,
@@ -103,6 +105,7 @@ class StrategoMultiAgentEnv:
         self._f_obs_highs, self._f_obs_lows = obs_norm.obs_highs_lows(v.piece_counts, full=True, original=original)
         self._p_obs_ranges, self._p_obs_mids = obs_norm.ranges_mids(self._p_obs_highs, self._p_obs_lows)   # maenv:388-391
         self._f_obs_ranges, self._f_obs_mids = obs_norm.ranges_mids(self._f_obs_highs, self._f_obs_lows)   # maenv:393-396
+        self._build_host_mirror()
         self.rows, self.columns = v.rows, v.columns
         self.spatial_action_size = v.spatial_action_size
         self.action_size = v.action_size
@@ -153,12 +156,42 @@ class StrategoMultiAgentEnv:
         st, _ = self._vec.export_state()
         return st[0].cpu().numpy()
 
-    def _obs_dict(self, obs_t, fobs_t, mask_t, player):
-        d = {_MASK: mask_t.cpu().numpy().astype(np.int64)}
+    def _build_host_mirror(self):
+        """Single-game latency: all per-step outputs of the one-env batch live in ONE device slab with a pinned host
+        mirror, so a step is one 4-byte upload, one kernel launch, one download and one synchronisation.  Order: the
+        small flags, rewards, mask, observations, then the terminal observations (fetched on terminal steps only)."""
+        vec = self._vec
+        names = ['invalid_action', 'done', 'player', 'ending_invalid', 'reward', 'mask', 'obs', 'fobs', 'final_obs', 'final_fobs']
+        layout, off = [], 0
+        for n in names:
+            t = getattr(vec, n)
+            if t is None:
+                continue
+            nbytes = t.numel() * t.element_size()
+            layout.append((n, off, nbytes, t.dtype, tuple(t.shape)))
+            off = (off + nbytes + 255) & ~255
+            if n in ('obs', 'fobs'):
+                self._step_bytes = off                      # everything a non-terminal step returns
+        self._slab = torch.zeros(off, dtype=torch.uint8, device=vec.device)
+        self._host = torch.zeros(off, dtype=torch.uint8).pin_memory()
+        self._host_np = self._host.numpy()
+        self._view = {}
+        for n, o, nbytes, dtype, shape in layout:
+            setattr(vec, n, self._slab[o:o + nbytes].view(dtype).view(shape))
+            self._view[n] = self._host_np[o:o + nbytes].view(_NP_DTYPES[dtype]).reshape(shape)
+        self._act_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._act_dev = torch.zeros(1, dtype=torch.int32, device=vec.device)
+
+    def _fetch(self, nbytes):
+        self._host[:nbytes].copy_(self._slab[:nbytes], non_blocking=True)
+        torch.cuda.current_stream(self._vec.device).synchronize()
+
+    def _obs_dict(self, obs_h, fobs_h, mask_h, player):
+        d = {_MASK: mask_h.astype(np.int64)}
         if self._want_p:
-            d[_POBS] = obs_t.cpu().numpy().copy()
+            d[_POBS] = obs_h.copy()
         if self._want_f:
-            d[_FOBS] = fobs_t.cpu().numpy().copy()
+            d[_FOBS] = fobs_h.copy()
         if self.observation_includes_internal_state:
             d[_ISTATE] = state_from_player_perspective(self.state, player)             # maenv:494-495
         return d
@@ -194,9 +227,10 @@ class StrategoMultiAgentEnv:
             self.player = int(first_player_override)
             self._vec.import_state(self.state[None], np.asarray([self.player], dtype=np.int8))
         self.episodes_completed += 1
-        obs_t, mask_t, _ = self._vec.observe()
-        fobs_t = self._vec.fobs
-        obs = {self.player: self._obs_dict(obs_t[0], fobs_t[0] if fobs_t is not None else None, mask_t[0], self.player)}
+        self._vec.observe()
+        self._fetch(self._step_bytes)
+        hv = self._view
+        obs = {self.player: self._obs_dict(hv['obs'][0], hv['fobs'][0] if self._want_f else None, hv['mask'][0], self.player)}
         if self.random_player_assignment:                                              # maenv:654-655
             obs = {self.player_map(k): val for k, val in obs.items()}
         return obs
@@ -213,27 +247,31 @@ class StrategoMultiAgentEnv:
         if not is_spatial_index:
             # a 1-D index in the mover's perspective (maenv:684-689): flip to absolute coordinates on the host
             action = int(ia.action_1d_from_player_perspective(self.rows, self.columns, action, self.player))
-            if not (-2 ** 31 <= action < 2 ** 31):
-                raise ValueError("Couldn't get the next state because the move wasn't valid.")
             flags |= _lib.STEP_ACTIONS_1D
-        vec.step(torch.tensor([action], dtype=torch.int32), flags=flags)
-        flags = torch.stack([vec.invalid_action.to(torch.float32), vec.done.to(torch.float32),
-                             vec.player.to(torch.float32), vec.ending_invalid.to(torch.float32)]).cpu().numpy()[:, 0]
+        if not (-2 ** 31 <= action < 2 ** 31):                                         # np.unravel_index raises (maenv:685)
+            raise ValueError("Couldn't get the next state because the move wasn't valid.")
+        self._act_host[0] = action
+        self._act_dev.copy_(self._act_host, non_blocking=True)
+        vec.step(self._act_dev, flags=flags)
+        self._fetch(self._step_bytes)
+        hv = self._view
+        flags = (int(hv['invalid_action'][0]), int(hv['done'][0]), int(hv['player'][0]), int(hv['ending_invalid'][0]))
         if flags[0]:
             raise ValueError("Couldn't get the next state because the move wasn't valid.")   # impl:902
         self.player = int(flags[2])
         if not flags[1]:                                                                # maenv:767-770
             dones = {self.player: False, "__all__": False}
-            obs = {self.player: self._obs_dict(vec.obs[0], vec.fobs[0] if self._want_f else None, vec.mask[0], self.player)}
+            obs = {self.player: self._obs_dict(hv['obs'][0], hv['fobs'][0] if self._want_f else None, hv['mask'][0], self.player)}
             rewards = {self.player: 0}
             infos = {}
         else:                                                                           # maenv:772-805
             dones = {1: True, -1: True, "__all__": True}
-            ff = vec.final_fobs
-            obs = {1: self._obs_dict(vec.final_obs[0, 0], ff[0, 0] if ff is not None else None, vec.mask[0], 1),
-                   -1: self._obs_dict(vec.final_obs[0, 1], ff[0, 1] if ff is not None else None, vec.mask[0], -1)}
+            self._fetch(self._host.numel())                                             # + the terminal observations
+            ff = hv.get('final_fobs')
+            obs = {1: self._obs_dict(hv['final_obs'][0, 0], ff[0, 0] if ff is not None else None, hv['mask'][0], 1),
+                   -1: self._obs_dict(hv['final_obs'][0, 1], ff[0, 1] if ff is not None else None, hv['mask'][0], -1)}
             infos = {1: {}, -1: {}}
-            rew = vec.reward[0].cpu().numpy()
+            rew = hv['reward'][0]
             if flags[3]:
                 rewards = {1: 0, -1: 0}
                 for p in (1, -1):
