@@ -66,6 +66,23 @@ def state_from_player_perspective(state, player):
     return out
 
 
+def load_curriculum_start_states(path):
+    """Curriculum start states (util.py:322-387): datasets 'state' [n,34,R,C] and 'winner' [n] (the likely winner, +1/-1).
+
+    `.npz` / `.npy`-archive files are read with numpy; anything else is opened as HDF5 like the reference does, which needs
+    `h5py` (absent from the MI355X image: convert with `np.savez(path, state=..., winner=...)`).  The reference re-opens the
+    file on every reset; the table is loaded once here (same draws from `np.random`)."""
+    if str(path).endswith('.npz'):
+        with np.load(path) as z:
+            return np.asarray(z['state']), np.asarray(z['winner'])
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError("curriculum_start_states_path %r is not an .npz file and h5py is not installed" % (path,)) from e
+    with h5py.File(path, 'r') as f:
+        return np.asarray(f['state']), np.asarray(f['winner'])
+
+
 class StrategoMultiAgentEnv:
 
     def __init__(self, env_config=None, device=0):
@@ -73,7 +90,7 @@ class StrategoMultiAgentEnv:
         cfg.update(env_config if env_config else {})
         self.variant = get_variant(cfg['version'])
         v = self.variant
-        for key in ('vs_human', 'vs_bot', 'curriculum_start_states_path'):
+        for key in ('vs_human', 'vs_bot'):
             if cfg[key]:
                 raise NotImplementedError("%s is outside the MI355X hot-path build (SURVEY.md section 8)" % key)
         if cfg['obs_channel_mode'] not in ('extended', 'original'):
@@ -89,6 +106,12 @@ class StrategoMultiAgentEnv:
         self._want_f = mode in (ObservationModes.FULLY_OBSERVABLE, ObservationModes.BOTH_OBSERVATIONS)
         self.penalize_ties = cfg['penalize_ties']
         self.random_player_assignment = cfg['random_player_assignment']
+        assert not (cfg['human_inits'] and cfg['curriculum_start_states_path'])           # maenv:332
+        self.use_curriculum_inits = False
+        if cfg['curriculum_start_states_path'] and not cfg['human_inits']:                  # maenv:341-346
+            self.use_curriculum_inits = True
+            self.random_player_assignment = True
+            self._curriculum = load_curriculum_start_states(cfg['curriculum_start_states_path'])
         self.repeat_games_from_other_side = cfg['repeat_games_from_other_side']
         assert not (self.random_player_assignment and self.repeat_games_from_other_side)   # maenv:358
         self.observation_includes_internal_state = cfg['observation_includes_internal_state']
@@ -110,9 +133,12 @@ class StrategoMultiAgentEnv:
         self.spatial_action_size = v.spatial_action_size
         self.action_size = v.action_size
 
-        self._fixed_maps = None
+        self._fixed_maps = self._fixed_curriculum = None
         if cfg['same_start_pos_everytime']:                       # maenv:352-354
-            self._fixed_maps = self._random_initial_maps()
+            if self.use_curriculum_inits:
+                self._fixed_curriculum = self._draw_curriculum_start()
+            else:
+                self._fixed_maps = self._random_initial_maps()
 
         self.episodes_completed = 0
         self.last_initial_state = None
@@ -196,9 +222,26 @@ class StrategoMultiAgentEnv:
             d[_ISTATE] = state_from_player_perspective(self.state, player)             # maenv:494-495
         return d
 
+    def _draw_curriculum_start(self):
+        """random_human_init of get_random_curriculum_init_fn (util.py:372-387): one np.random.randint draw."""
+        states, winners = self._curriculum
+        offset = np.random.randint(low=0, high=len(states))
+        st = np.squeeze(np.asarray(states[offset])).astype(np.int64)
+        st[5, 0, 0] = 0                                                                 # StateData.TURN_COUNT
+        st[5, 1, 0] = self.variant.max_turns                                            # StateData.MAX_TURNS
+        return st, int(np.squeeze(winners[offset]))
+
     # ---- reference API ----------------------------------------------------------------------------------------
     def reset(self, first_player_override=None, initial_state_override=None):
         v = self.variant
+        if self.use_curriculum_inits:                                                   # maenv:519-527, util.py:372-387
+            st, likely_winner = self._fixed_curriculum if self._fixed_curriculum is not None else self._draw_curriculum_start()
+            self.player = int(np.random.choice([-1, 1]))
+            self._vec.import_state(st[None], np.asarray([self.player], dtype=np.int8))
+            # player 1 gets the advantage of the curriculum start
+            self.player_map = lambda p: likely_winner if p == 1 else (-likely_winner if p == -1 else p)
+            self.reverse_player_map = lambda p: 1 if p == likely_winner else (-1 if p == -likely_winner else p)
+            return self._finish_reset(first_player_override, initial_state_override)
         if self.repeat_games_from_other_side and self.episodes_completed % 2 == 1:      # maenv:530-534
             initial_state = state_from_player_perspective(self.last_initial_state, -1)
             self._vec.import_state(initial_state[None], np.asarray([-1], dtype=np.int8))
@@ -216,6 +259,10 @@ class StrategoMultiAgentEnv:
             self.player = 1
             initial_state = self.state
         self.last_initial_state = initial_state
+        return self._finish_reset(first_player_override, initial_state_override)
+
+    def _finish_reset(self, first_player_override, initial_state_override):
+        v = self.variant
         if initial_state_override is not None:                                         # maenv:551-553
             st = np.asarray(initial_state_override, dtype=np.int64)
             if st.shape != (NUM_STATE_LAYERS, v.rows, v.columns):

@@ -99,12 +99,67 @@ class BatchedStrategoProceduralEnv:
         out = torch.gather(self._perspective_mask_ext(), 1, self._spatial_src[pi])
         return out.view(self.batch_size, *self.spatial_action_size)
 
-    def get_valid_moves_as_1d_mask(self, states, players):                                          # penv:74-80
-        """uint8 [N, action_size] in absolute coordinates, like impl:520-642 (last element = no-op)."""
+    def get_valid_moves_as_1d_mask(self, states, players, player_perspective=False):                # penv:74-80
+        """uint8 [N, action_size] in the coordinates of the given states, like impl:520-642 (last element = no-op).
+        player_perspective=True first flips the states of player -1 (penv:76-77) and then, like the reference, still
+        asks for player -1's moves on the flipped state."""
+        if player_perspective:
+            states = self.get_state_from_player_perspective(states, players)
         _, pl = self._load(states, players)
         self._vec.observe()
         pi = (pl < 0).to(torch.int64)
         return torch.gather(self._perspective_mask_ext(), 1, self._onedim_src[pi])
+
+    def get_dict_of_valid_moves_by_position(self, states, players):                                 # penv:82-85 / impl:1400-1429
+        """One dict per state: "start_r,start_c" -> [[end_r, end_c], ...] in ascending 1-D index order."""
+        masks = self.get_valid_moves_as_1d_mask(states, players).cpu().numpy()
+        out = []
+        for m in masks:
+            d = {}
+            for idx in np.flatnonzero(m):
+                if idx == self.action_size - 1:                                                      # impl:355-367
+                    raise ValueError("Action is a no-op so it doesn't translate to an actual action")
+                sr, sc, er, ec = (int(x) for x in ia.positions_from_1d(self.rows, self.columns, int(idx)))
+                d.setdefault("{},{}".format(sr, sc), []).append([er, ec])
+            out.append(d)
+        return out
+
+    def get_serializable_string_for_fully_observable_state(self, states):                           # penv:175-177
+        """pickle of the raw 33-channel observation from player 1's side, one bytes object per state."""
+        from pickle import dumps
+        obs = self.get_fully_observable_observation(states, np.ones(self.batch_size, dtype=np.int8)).cpu().numpy()
+        return [dumps(np.ascontiguousarray(o)) for o in obs]
+
+    def get_serializable_string_for_partially_observable_state(self, states):                       # penv:179-181
+        from pickle import dumps
+        obs = self.get_partially_observable_observation(states, np.ones(self.batch_size, dtype=np.int8)).cpu().numpy()
+        return [dumps(np.ascontiguousarray(o)) for o in obs]
+
+    @staticmethod
+    def print_board_to_console(state, partially_observable=False, hide_still_piece_markers=True):  # penv:183-214
+        """Text rendering of ONE state (int [34,R,C]): player 1's pieces as positive codes, player -1's (true or
+        partially-observable layer) as negative codes, "R" for obstacles; row and column 0 at the bottom right."""
+        st = state.cpu().numpy() if isinstance(state, torch.Tensor) else np.asarray(state)
+        _, rows, columns = st.shape
+        enemy_layer = 4 if partially_observable else 1
+        rule = "\n       " + "-" * (rows * 6 + 1)
+        lines = ["    COL" + "".join("  {}  ".format(str(c).rjust(2)) for c in range(columns - 1, -1, -1)) + rule]
+        for r in range(rows - 1, -1, -1):
+            cells = []
+            for c in range(columns - 1, -1, -1):
+                item = ""
+                if st[0, r, c] != 0:
+                    item = str(st[0, r, c])
+                elif st[enemy_layer, r, c] != 0:
+                    item = str(-1 * st[enemy_layer, r, c])
+                elif st[2, r, c] != 0:
+                    item = "R"
+                if not hide_still_piece_markers:
+                    item += "a" if st[32, r, c] == 1 else ""
+                    item += "b" if st[33, r, c] == 1 else ""
+                cells.append(item.rjust(4) + " |")
+            lines.append("Row {} |".format(str(r).rjust(2)) + "".join(cells) + rule)
+        print("\n".join(lines))
 
     # ---- observations (raw, as the reference's operator layer returns them; maenv normalises afterwards) -----------
     def get_partially_observable_observation_extended_channels(self, states, players):             # penv:171-173

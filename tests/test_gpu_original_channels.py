@@ -130,3 +130,78 @@ def test_procedural_original_observations_and_heuristic_rewards(name):
             want.append(float(rm[states[e][own, sr, sc], states[e][enemy, er, ec]]))
     got = penv.get_heuristic_rewards_from_move(states, players, np.asarray(acts), rm).cpu().numpy()
     assert np.array_equal(got, np.asarray(want, dtype=np.float32))
+
+
+def test_operator_debugging_aids_match_reference_goldens(capsys):
+    """print_board_to_console, get_dict_of_valid_moves_by_position, the serializable strings and the
+    player_perspective flag of get_valid_moves_as_1d_mask (penv:74-85, 175-214) vs outputs recorded from the reference
+    (tools/oracle/gen_golden_curriculum.py -> tests/golden/board_utils.json)."""
+    import hashlib
+    import json
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    with open(os.path.join(GOLDEN, 'board_utils.json')) as f:
+        recs = json.load(f)
+    cur = _load_npz(os.path.join(GOLDEN, 'curriculum_barrage.npz'))
+    states = np.stack([cur['state'][r['index']] for r in recs])
+    n = len(recs)
+    penv = BatchedStrategoProceduralEnv('barrage', n)
+    fo = penv.get_serializable_string_for_fully_observable_state(states)
+    po = penv.get_serializable_string_for_partially_observable_state(states)
+    for pl in (1, -1):
+        players = np.full(n, pl, dtype=np.int8)
+        dicts = penv.get_dict_of_valid_moves_by_position(states, players)
+        pp = penv.get_valid_moves_as_1d_mask(states, players, player_perspective=True).cpu().numpy().astype(np.uint8)
+        for i, r in enumerate(recs):
+            assert dicts[i] == r['moves_dict_%d' % pl], (i, pl)
+            assert hashlib.sha256(np.ascontiguousarray(pp[i]).tobytes()).hexdigest()[:16] == r['mask1d_pp_%d' % pl], (i, pl)
+    for i, r in enumerate(recs):
+        assert hashlib.sha256(fo[i]).hexdigest()[:16] == r['fo_string_sha']
+        assert hashlib.sha256(po[i]).hexdigest()[:16] == r['po_string_sha']
+        for po_flag, hide in ((False, True), (True, False)):
+            capsys.readouterr()
+            penv.print_board_to_console(states[i], partially_observable=po_flag, hide_still_piece_markers=hide)
+            assert capsys.readouterr().out == r['print_po%d_hide%d' % (po_flag, hide)]
+
+
+def test_facade_curriculum_start_states_replay_reference_goldens():
+    """curriculum_start_states_path (maenv:341-346, 519-527; util.py:372-387): same np.random consumption, start state,
+    first mover, player relabelling and per-step outputs as recorded from the reference."""
+    import hashlib
+    import json
+    import random
+    from stratego_env_amd.multiagent_env import StrategoMultiAgentEnv
+
+    def sha(a):
+        return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+    def obs_digest(obs):
+        h = hashlib.sha256()
+        for p in sorted(obs.keys()):
+            h.update(np.asarray(obs[p][MASK]).astype(np.uint8).tobytes())
+            h.update(np.ascontiguousarray(obs[p][POBS], dtype=np.float32).tobytes())
+        return h.hexdigest()[:16]
+
+    with open(os.path.join(GOLDEN, 'curriculum.json')) as f:
+        cases = json.load(f)
+    path = os.path.join(GOLDEN, 'curriculum_barrage.npz')
+    for case in cases:
+        np.random.seed(case['seed'])
+        random.seed(case['seed'])
+        env = StrategoMultiAgentEnv({'version': GameVersions.BARRAGE, 'observation_mode': ObservationModes.PARTIALLY_OBSERVABLE,
+                                     'curriculum_start_states_path': path,
+                                     'same_start_pos_everytime': case['same_start_pos_everytime']})
+        assert env.use_curriculum_inits and env.random_player_assignment
+        for g in case['games']:
+            obs = env.reset()
+            assert int(list(obs.keys())[0]) == g['first_key'] and env.player == g['player']
+            assert sha(env.state) == g['state'] and obs_digest(obs) == g['init']
+            for t, srec in enumerate(g['steps']):
+                k = list(obs.keys())[0]
+                valid = np.flatnonzero(obs[k][MASK].reshape(-1))
+                a = int(valid[(t * 7919) % len(valid)])
+                assert a == srec['action']
+                obs, rew, done, info = env.step({k: a})
+                assert sorted(int(x) for x in obs.keys()) == srec['keys'] and obs_digest(obs) == srec['digest']
+                assert bool(done['__all__']) == srec['done']
+                assert {str(kk): float(vv) for kk, vv in rew.items()} == srec['rewards']
+        env.close()
