@@ -154,8 +154,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        one_step()
+    if args.unfused:
+        for _ in range(args.steps):
+            one_step()
+    else:
+        env.rollout_steps(args.steps)    # the same K batched steps, enqueued by one C-ABI call (sgx_step_n)
     ev1.record()
     torch.cuda.synchronize()
     if dist:

@@ -142,6 +142,13 @@ int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, 
 /* One batched env.step(): see sgx_step_io. */
 int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);
 
+/* n_steps consecutive sgx_step calls with the same buffers, enqueued back to back without returning to the host language:
+ * the random-action game loop of examples/basic_game_loop.py:34-63 (sample a valid action, step, repeat) for N games.
+ * Requires io->next_actions_dev == io->actions_dev, so that every step plays the action the previous one drew; the
+ * output buffers hold the last step's results afterwards.  (Toy boards finish a batched step in tens of microseconds:
+ * driving them one call at a time from Python is launch-bound.) */
+int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void *stream);
+
 /* sample_random_valid_action (maenv:830-834) for a batch of masks laid out as mask_dev of sgx_step_io:
  * picks the k-th set byte, k drawn with the same counter RNG as next_actions_dev (identical results). */
 int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actions_dev, void *stream);

@@ -594,7 +594,7 @@ __device__ inline int fmod_(int a, int b) { int m = a % b; return m < 0 ? m + b 
 template <class G, int KIND>
 constexpr int waves_per_simd() {
     constexpr bool FULL = (KIND & 1) != 0;
-    constexpr int per_wg = WPB * (int)sizeof(Lds<G>) + 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0));
+    constexpr int per_wg = WPB * (int)sizeof(Lds<G>) + 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)) + SGX_MAX_CELLS;
     constexpr int wgs = (160 * 1024) / per_wg;
     constexpr int w = wgs * WPB / 4;
     // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
@@ -638,7 +638,8 @@ __device__ inline void write_record(Lds<G> &L, int8_t *rec_g, int rec_bytes, int
 
 // One game's env.step() by one wave (called with the wave's private LDS region).
 template <int R_, int C_, int KIND>
-__device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, const float *lut_s, const int64_t env, const int lane) {
+__device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, const float *lut_s, const uint8_t *obst_s, const int64_t env,
+                                         const int lane) {
     using G = Geo<R_, C_>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
@@ -646,24 +647,48 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     STAMP(0);
 
     int8_t *rec_g = P.boards + env * (int64_t)P.rec_bytes;
-    const int4 *scg = rec_scal<G>(P.boards, P.rec_bytes, env);
-    const int4 sc = scg[0], sc2 = scg[1];
+    // ---- stage.  Every global read of the step is issued up front -- the whole record (a few 128-byte lines) as one or
+    //      two int4 per lane, and the action -- so the wave pays ONE memory round trip.  The scalars, never-moved bitmaps
+    //      and capture events are then read from the LDS image of the record (L.tail has the record's layout from ST_OFF
+    //      on).  They used to be five dependent loads: a quarter of a toy game's lifetime.
+    constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + 63) / 64;
+    static_assert(G::TAIL_BYTES % 16 == 0 && NLOAD <= 2, "record image must fit two int4 per lane");
+    const int4 zero4 = make_int4(0, 0, 0, 0);
+    int4 rq0 = zero4, rq1 = zero4;
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(rec_g);
+        const int nq = min(P.rec_bytes >> 4, Q_REC);
+        if (lane < nq) rq0 = src[lane];
+        if constexpr (NLOAD > 1)
+            if (lane + 64 < nq) rq1 = src[lane + 64];
+    }
+    int a_raw = 0;
+    int4 pos_raw = zero4;
+    if (P.mode == 0) {
+        if (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) pos_raw = reinterpret_cast<const int4 *>(P.io.actions_dev)[env];
+        else a_raw = P.io.actions_dev[env];
+    }
+    {   // while the loads are in flight: clear the 28 rebuilt boards, copy the obstacle map (shared per workgroup)
+        int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
+        for (int i = Q_BOARDS + lane; i < G::LDS_BOARDS_BYTES / 16; i += 64) dst[i] = zero4;
+        for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(obst_s)[i];
+        int4 *tl = reinterpret_cast<int4 *>(L.tail);
+        if (lane < Q_BOARDS) dst[lane] = rq0;
+        else if (lane < Q_REC) tl[lane - Q_BOARDS] = rq0;
+        if constexpr (NLOAD > 1) {
+            if (lane + 64 < Q_BOARDS) dst[lane + 64] = rq1;
+            else if (lane + 64 < Q_REC) tl[lane + 64 - Q_BOARDS] = rq1;
+        }
+    }
+    wave_sync<G>();
+    const int4 sc = reinterpret_cast<const int4 *>(L.tail + 2 * G::SB)[0], sc2 = reinterpret_cast<const int4 *>(L.tail + 2 * G::SB)[1];
     int turn = uni(sc.x), flags = uni(sc.y), game_no = uni(sc.w);
     const int max_turns = uni(sc.z);
-    int n_events = uni(sc2.x);
+    int n_events = min(uni(sc2.x), (int)G::EVL_MAX);
     int rp0 = uni(sc2.y), rp1 = uni(sc2.z);   // recent-move pairs of player +1 / -1 (two named scalars: a runtime-indexed
                                               // array would live in scratch memory)
-    {   // ---- stage: the 4 dense boards -> LDS, the other 28 rebuilt (never-moved bitmaps, recent-move pairs, capture events)
-        const int4 *src = reinterpret_cast<const int4 *>(rec_g);
-        int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
-        for (int i = lane; i < G::LDS_BOARDS_BYTES / 16; i += 64) {
-            int4 v = make_int4(0, 0, 0, 0);
-            if (i < G::ST_OFF / 16) v = src[i];     // (a `cond ? src[i] : zero` select turns into a flat load from scratch)
-            dst[i] = v;
-        }
-        for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
-        wave_sync<G>();
-        const uint32_t *stb = reinterpret_cast<const uint32_t *>(rec_g + G::ST_OFF);
+    {   // ---- rebuild the 28 derived boards: never-moved bitmaps, recent-move pairs, capture events
+        const uint32_t *stb = reinterpret_cast<const uint32_t *>(L.tail);
 #pragma unroll
         for (int cc = 0; cc < G::CPL; ++cc) {
             const int i = lane + 64 * cc;
@@ -672,11 +697,9 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
                 L.b[B_STILL + 1][i] = (int8_t)((stb[G::SB / 4 + (i >> 5)] >> (i & 31)) & 1u);
             }
         }
-        const uint16_t *ev = reinterpret_cast<const uint16_t *>(rec_g + G::EVL_OFF);
-        uint16_t *evl = reinterpret_cast<uint16_t *>(L.tail + 2 * G::SB + 32);
+        const uint16_t *evl = reinterpret_cast<const uint16_t *>(L.tail + 2 * G::SB + 32);   // stays here for the write-back
         for (int i = lane; i < n_events; i += 64) {
-            const int evt = ev[i], byte = (B_CAP + (evt >> 8)) * S + (evt & 0xFF);   // event = (board - B_CAP) << 8 | cell
-            evl[i] = (uint16_t)evt;                                                  // kept for the whole-record write-back
+            const int evt = evl[i], byte = (B_CAP + (evt >> 8)) * S + (evt & 0xFF);  // event = (board - B_CAP) << 8 | cell
             atomicAdd(reinterpret_cast<unsigned int *>(&L.b[0][0]) + (byte >> 2), 1u << (8 * (byte & 3)));
         }
         if (lane < 4) {
@@ -698,13 +721,12 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
         // ------------------------------------------------------------------------------------------
         // decode (maenv:684-689): flat spatial index -> positions -> 1-D index -> absolute 1-D index
         // ------------------------------------------------------------------------------------------
-        const int a = (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) ? 0 : uni(P.io.actions_dev[env]);
+        const int a = uni(a_raw);
         int sr = 0, sc_ = 0, er = 0, ec = 0;
         bool valid = true;
         if (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) {
             // is_move_valid_by_position (penv:87-92): actions_dev is int32 [N][4] = (start_r, start_c, end_r, end_c), absolute
-            const int4 q = reinterpret_cast<const int4 *>(P.io.actions_dev)[env];
-            sr = uni(q.x); sc_ = uni(q.y); er = uni(q.z); ec = uni(q.w);
+            sr = uni(pos_raw.x); sc_ = uni(pos_raw.y); er = uni(pos_raw.z); ec = uni(pos_raw.w);
         } else if (P.io.flags & SGX_STEP_ACTIONS_1D) {
             // functional API (penv:148-155): the action already is an absolute-coordinate 1-D index (impl:262-277)
             if (a == AS - 1) {
@@ -934,6 +956,7 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) vo
     constexpr int ORIG4 = ObsKind<KIND>::ORIG ? 4 : 0;
     __shared__ Lds<G> LW[WPB];
     __shared__ alignas(16) float lut_s[OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)];
+    __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t env0 = group_of_block(P.map_mode) * WPB, env = env0 + wave;
 
@@ -947,8 +970,9 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) vo
         for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s + OBS_TAB_DWORDS)[i] = fsrc[i];
         build_quad_table<G, FS>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * WPB);
     }
+    for (int i = threadIdx.x; i < G::S / 4; i += 64 * WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
     __syncthreads();   // from here on every wave works on its own game
-    if (env < P.n_envs) env_step<R_, C_, KIND>(P, LW[wave], lut_s, env, lane);
+    if (env < P.n_envs) env_step<R_, C_, KIND>(P, LW[wave], lut_s, obst_s, env, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1462,6 +1486,20 @@ SGX_API int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream) {
     p.mode = 0;
     p.io = *io;
     return launch_step(h, p, stream);
+}
+
+SGX_API int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void *stream) {
+    if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
+    if (!io->actions_dev || io->next_actions_dev != io->actions_dev)
+        return fail(SGX_EINVAL, "sgx_step_n needs next_actions_dev == actions_dev (each step plays the action the previous one drew)%s");
+    if (n_steps < 0) return fail(SGX_EINVAL, "n_steps is negative%s");
+    HIP_TRY(hipSetDevice(h->device));
+    KParams p = make_params(h);
+    p.mode = 0;
+    p.io = *io;
+    for (int32_t i = 0; i < n_steps; ++i)
+        if (int rc = launch_step(h, p, stream)) return rc;
+    return SGX_OK;
 }
 
 SGX_API int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actions_dev, void *stream) {

@@ -171,6 +171,12 @@ class VecStrategoEnv:
         if a.dtype != torch.int32 or a.device != self.device or not a.is_contiguous():
             a = a.to(device=self.device, dtype=torch.int32).contiguous()
         assert a.numel() == self.num_envs * (4 if (flags & _lib.STEP_ACTIONS_POSITIONS) else 1)
+        io = self._fill_io(a, want_next_actions, emit_obs, emit_mask, flags)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_step(self._h, C.byref(io), self._stream()))
+        return self.obs, self.mask, self.reward, self.done, self.player
+
+    def _fill_io(self, a, want_next_actions, emit_obs, emit_mask, flags):
         io = self._io
         io.actions_dev = a.data_ptr()
         io.obs_dev = self.obs.data_ptr() if emit_obs else None
@@ -186,13 +192,19 @@ class VecStrategoEnv:
         io.next_actions_dev = self.next_actions.data_ptr() if want_next_actions else None
         io.auto_reset = 1 if self.auto_reset else 0
         io.flags = int(flags) | self._mode_flags
-        with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_step(self._h, C.byref(io), self._stream()))
-        return self.obs, self.mask, self.reward, self.done, self.player
+        return io
 
     def rollout_step(self):
         """Random-valid-action rollout step: plays `next_actions` (drawn by the previous call) and draws the next."""
         return self.step(self.next_actions, want_next_actions=True)
+
+    def rollout_steps(self, n_steps):
+        """`n_steps` rollout steps enqueued by one library call (sgx_step_n): same results as calling rollout_step()
+        n_steps times, without a Python round trip per step (toy boards are launch-bound otherwise)."""
+        io = self._fill_io(self.next_actions, True, True, True, 0)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_step_n(self._h, C.byref(io), int(n_steps), self._stream()))
+        return self.obs, self.mask, self.reward, self.done, self.player
 
     def sample_valid_actions(self, mask=None, out=None):
         """Uniformly random valid action per env from `mask` (default: the current one) -- maenv:830-834."""

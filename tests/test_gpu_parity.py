@@ -280,3 +280,34 @@ def test_tune_placement_keeps_outputs():
     env.rollout_step()
     assert int(env.invalid_action.sum()) == 0
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['micro', 'barrage'])
+def test_step_n_equals_n_single_steps(name):
+    """sgx_step_n (k rollout steps in one library call) leaves exactly the state and outputs of k sgx_step calls."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    from stratego_env_amd import _lib
+    import ctypes as C
+    k, n = 37, 512
+    envs = [VecStrategoEnv(name, n, seed=0xABCD, auto_reset=True) for _ in range(2)]
+    for e in envs:
+        e.reset()
+        e.sample_valid_actions()
+    for _ in range(k):
+        envs[0].rollout_step()
+    envs[1].rollout_steps(k)
+    torch.cuda.synchronize()
+    for attr in ('obs', 'mask', 'reward', 'done', 'player', 'invalid_action', 'ending_invalid', 'next_actions'):
+        assert torch.equal(getattr(envs[0], attr), getattr(envs[1], attr)), attr
+    s0, p0 = envs[0].export_state()
+    s1, p1 = envs[1].export_state()
+    assert torch.equal(s0, s1) and torch.equal(p0, p1)
+    assert torch.equal(envs[0].env_info(), envs[1].env_info())
+    # the call insists on the self-feeding configuration
+    io = envs[1]._fill_io(envs[1].next_actions, False, True, True, 0)
+    assert envs[1]._L.sgx_step_n(envs[1]._h, C.byref(io), 3, None) == -1
+    assert b'next_actions_dev' in envs[1]._L.sgx_last_error()
+    for e in envs:
+        e.close()
