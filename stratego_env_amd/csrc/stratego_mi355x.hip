@@ -100,8 +100,13 @@ struct Geo {
     static constexpr int MPA = R + C;
     static constexpr int AS = RC * MPA + 1;           // 1-D action size (impl:252-254)
     static constexpr int NOBS = RC * OBS_CH;          // floats per observation
-    static constexpr int CPL = (RC + 63) / 64;        // cells per lane
-    static constexpr int CNT_PAD = CPL * 64;
+    // Lanes per game.  A 64-lane wave is one game on boards of more than 32 cells; toy boards share a wave between 2 or 4
+    // games (each VALU instruction costs 4 cycles whether 12 or 64 lanes do useful work: one 3x4 game per wave ran the chip
+    // at the VALU issue limit with 80 % of the lanes idle).  Everything below that says `lane` means the lane inside the game.
+    static constexpr int LPG = RC <= 16 ? 16 : (RC <= 32 ? 32 : 64);
+    static constexpr int GPW = 64 / LPG;              // games per wave
+    static constexpr int CPL = (RC + LPG - 1) / LPG;  // cells per lane
+    static constexpr int CNT_PAD = CPL * LPG;
 };
 
 struct DevTables {
@@ -128,7 +133,6 @@ struct KParams {
     int64_t env_id_offset;
     sgx_step_io io;
     int32_t mode;  // 0 = step, 1 = observe
-    int32_t map_mode;  // experiment knob (env SGX_MAP_MODE): 0 = XCD-chunked game map, 1 = linear, 2 = XCD-chunked with interleaved sub-chunks
 #ifdef SGX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [N][16] s_memtime stamps per phase
 #endif
@@ -193,19 +197,25 @@ __device__ inline int4 *rec_scal(int8_t *boards, int rec_bytes, int64_t env) {
     return reinterpret_cast<int4 *>(boards + env * (int64_t)rec_bytes + G::SC_OFF);
 }
 
-__device__ inline int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// A value that is the same in every lane of a game: an SGPR when the game is the whole wave, left alone otherwise.
+template <class G>
+__device__ inline int uni(int x) {
+    if constexpr (G::LPG == 64) return __builtin_amdgcn_readfirstlane(x);
+    else return x;
+}
+// Ballot over the lanes of this lane's game (bit i = lane i of the game).
+template <class G>
+__device__ inline unsigned long long gballot(bool pred) {
+    const unsigned long long b = __ballot(pred);
+    if constexpr (G::LPG == 64) return b;
+    else return (b >> (__lane_id() & ~(G::LPG - 1))) & ((1ull << G::LPG) - 1ull);
+}
 
 // XCD-aware block -> env map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
 // range of envs so neighbouring envs' output lines meet in one L2.
-__device__ inline int64_t group_of_block(int map_mode) {
+__device__ inline int64_t group_of_block() {
     const int64_t nb = gridDim.x, b = blockIdx.x;
-    if ((map_mode & 15) == 1) return b;
-    const int64_t chunk = nb >> 3;  // grid is a multiple of 8
-    if ((map_mode & 15) == 2) {            // each XCD sweeps 64-group sub-chunks that interleave with the other XCDs' sub-chunks
-        const int64_t i = b >> 3, x = b & 7;
-        return ((i >> 6) * 8 + x) * 64 + (i & 63);
-    }
-    return (((b & 7) + (map_mode >> 4)) & 7) * chunk + (b >> 3);   // bits 4..6 of map_mode: rotate the XCD -> region assignment
+    return (b & 7) * (nb >> 3) + (b >> 3);   // grid is a multiple of 8
 }
 
 // Orders the LDS phases of ONE wave (each wave owns its game's LDS region; waves of a workgroup never exchange
@@ -330,11 +340,11 @@ __device__ void emit_obs(const Lds<G> &L, const float *tab, int qi, float *__res
     if constexpr (RC % 4 == 0) {
         constexpr int NQ = (RC / 4) * NCH;                                           // quads (16 B) of one observation
         const uint4 *qtab = reinterpret_cast<const uint4 *>(tab + LUT_DWORDS) + qi * NCH;
-        const int m0 = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 63);          // quads past a 1 KiB boundary
+        const int m0 = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & (G::LPG - 1));  // quads past a 1 KiB boundary (LPG = 64)
         f32x4 *base = reinterpret_cast<f32x4 *>(dst);
         const int gstep = qi ? -4 : 4;
 #pragma unroll SGX_OBS_UNROLL
-        for (int q0 = -m0; q0 < NQ; q0 += 64) {
+        for (int q0 = -m0; q0 < NQ; q0 += G::LPG) {
             const int q = q0 + lane;
             const bool in = (unsigned)q < (unsigned)NQ;
             const int qq = in ? q : 0, g = qq / NCH, qd = qq - g * NCH;
@@ -350,7 +360,7 @@ __device__ void emit_obs(const Lds<G> &L, const float *tab, int qi, float *__res
         }
     } else {
         // odd cell counts (5x5, 15x15): an env's observation is not 16-byte aligned; dword path
-        for (int f = lane; f < RC * NCH; f += 64) {
+        for (int f = lane; f < RC * NCH; f += G::LPG) {
             const int pcell = f / NCH, ch = f - pcell * NCH;
             const int cell = qi ? RC - 1 - pcell : pcell;
             dst[f] = lut[lut_row(ch) + Spec::bias(ch) + bb[Spec::board(ch, qi) * S + cell]];
@@ -371,8 +381,8 @@ __device__ void emit_obs(const Lds<G> &L, const float *tab, int qi, float *__res
 template <class G>
 __device__ __forceinline__ void mask_noop_only(Lds<G> &L, int lane) {
     const int4 z = make_int4(0, 0, 0, 0);
-    for (int i = lane; i < G::MB_WORDS / 4; i += 64) reinterpret_cast<int4 *>(L.mbits)[i] = z;
-    for (int i = lane; i < G::CNT_PAD / 4; i += 64) reinterpret_cast<int *>(L.cnt)[i] = 0;
+    for (int i = lane; i < G::MB_WORDS / 4; i += G::LPG) reinterpret_cast<int4 *>(L.mbits)[i] = z;
+    for (int i = lane; i < G::CNT_PAD / 4; i += G::LPG) reinterpret_cast<int *>(L.cnt)[i] = 0;
     wave_sync<G>();
     if (lane == 0) { L.mbits[(G::K - 1) >> 5] = 1u << ((G::K - 1) & 31); L.cnt[0] = 1; }
     wave_sync<G>();
@@ -385,8 +395,8 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G> &L, int qi, bool game_over, in
     const int8_t *own = L.b[B_PIECES + qi], *enemy = L.b[B_PIECES + 1 - qi], *rec = L.b[B_RECENT + qi], *obst = L.b[B_OBST];
     {
         const int4 z = make_int4(0, 0, 0, 0);
-        for (int i = lane; i < G::MB_WORDS / 4; i += 64) reinterpret_cast<int4 *>(L.mbits)[i] = z;
-        for (int i = lane; i < G::CNT_PAD / 4; i += 64) reinterpret_cast<int *>(L.cnt)[i] = 0;
+        for (int i = lane; i < G::MB_WORDS / 4; i += G::LPG) reinterpret_cast<int4 *>(L.mbits)[i] = z;
+        for (int i = lane; i < G::CNT_PAD / 4; i += G::LPG) reinterpret_cast<int *>(L.cnt)[i] = 0;
     }
     int total = 0;
     if (!game_over) {
@@ -394,7 +404,7 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G> &L, int qi, bool game_over, in
         int npieces = 0;
 #pragma unroll
         for (int cc = 0; cc < G::CPL; ++cc) {
-            const int i = lane + 64 * cc;
+            const int i = lane + G::LPG * cc;
             bool movable = false;
             if (i < RC) {
                 const int t = own[i];
@@ -402,7 +412,7 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G> &L, int qi, bool game_over, in
                 L.occ[i] = (uint8_t)((t != 0 ? OCC_OWN : 0) | (enemy[i] != 0 ? OCC_ENEMY : 0) | (obst[i] != 0 ? OCC_OBST : 0) |
                                      (rec[i] == 1 ? OCC_CAME_FROM : 0));
             }
-            const unsigned long long bm = __ballot(movable);
+            const unsigned long long bm = gballot<G>(movable);
             if (movable) L.plist[npieces + __popcll(bm & ((1ull << lane) - 1ull))] = (uint8_t)i;
             npieces += __popcll(bm);
         }
@@ -411,7 +421,7 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G> &L, int qi, bool game_over, in
         const int sgn = qi ? -1 : 1;  // perspective +r is absolute -r for player -1 (impl:678-695)
         const int nrays = 4 * npieces;
         int mine = 0;
-        for (int j0 = 0; j0 < nrays; j0 += 64) {
+        for (int j0 = 0; j0 < nrays; j0 += G::LPG) {
             const int j = j0 + lane;
             const bool act = j < nrays;
             const int i = act ? L.plist[j >> 2] : 0, d = j & 3;
@@ -447,8 +457,8 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G> &L, int qi, bool game_over, in
             if (act && d == 0) { L.cnt[pcell] = (uint8_t)n; mine += n; }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-        total = uni(mine);
+        for (int o = G::LPG / 2; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        total = uni<G>(mine);
     }
     if (total == 0 && lane == 0) {
         L.mbits[(K - 1) >> 5] = 1u << ((K - 1) & 31);  // valid_moves_mask[0, 0, -1] (impl:514-515); mbits was just zeroed
@@ -476,8 +486,8 @@ __device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) 
         const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
         const int nchunks = (A + G::NA + 15) >> 4;
         uint8_t *gbase = dst - A;                       // 16-byte aligned
-        const int shift = (int)((reinterpret_cast<uintptr_t>(gbase) >> 4) & 63);   // start the sweep on a 1 KiB boundary
-        for (int c0 = -shift; c0 < nchunks; c0 += 64) {
+        const int shift = (int)((reinterpret_cast<uintptr_t>(gbase) >> 4) & (G::LPG - 1));   // start the sweep on a 1 KiB boundary
+        for (int c0 = -shift; c0 < nchunks; c0 += G::LPG) {
             const int c = c0 + lane;
             if (c < 0 || c >= nchunks) continue;
             const int lo = 16 * c - A;                  // first mask byte of this chunk
@@ -494,7 +504,7 @@ __device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) 
             }
         }
     } else {
-        for (int i = lane; i < G::NA; i += 64) dst[i] = (uint8_t)((L.mbits[i >> 5] >> (i & 31)) & 1u);
+        for (int i = lane; i < G::NA; i += G::LPG) dst[i] = (uint8_t)((L.mbits[i >> 5] >> (i & 31)) & 1u);
     }
 }
 
@@ -506,26 +516,26 @@ __device__ int kth_valid(const Lds<G> &L, int k, int lane) {
     bool found = false;
 #pragma unroll
     for (int cc = 0; cc < G::CPL; ++cc) {
-        const int c0 = L.cnt[lane + 64 * cc];
+        const int c0 = L.cnt[lane + G::LPG * cc];
         int incl = c0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(incl, o);
+        for (int o = 1; o < G::LPG; o <<= 1) {
+            const int v = __shfl_up(incl, o, G::LPG);
             if (lane >= o) incl += v;
         }
-        const unsigned long long hit = __ballot(run + incl > k);
+        const unsigned long long hit = gballot<G>(run + incl > k);
         if (!found && hit) {
             const int l = __ffsll((long long)hit) - 1;
-            cell = 64 * cc + l;
-            before = run + __shfl(incl - c0, l);
+            cell = G::LPG * cc + l;
+            before = run + __shfl(incl - c0, l, G::LPG);
             found = true;
         }
-        run += __shfl(incl, 63);
+        run += __shfl(incl, G::LPG - 1, G::LPG);
     }
-    cell = uni(cell);
-    int kk = uni(k - before);
+    cell = uni<G>(cell);
+    int kk = uni<G>(k - before);
     const int p = cell * K + (lane < K ? lane : 0);
-    unsigned long long bits = __ballot(lane < K && ((L.mbits[p >> 5] >> (p & 31)) & 1u) != 0);
+    unsigned long long bits = gballot<G>(lane < K && ((L.mbits[p >> 5] >> (p & 31)) & 1u) != 0);
     for (int i = 0; i < kk; ++i) bits &= bits - 1;
     const int ch = __ffsll((long long)bits) - 1;
     return cell * K + ch;
@@ -538,7 +548,7 @@ __device__ int kth_valid(const Lds<G> &L, int k, int lane) {
 template <class G>
 __device__ void clear_boards(Lds<G> &L, int lane) {
     const int4 z = make_int4(0, 0, 0, 0);
-    for (int i = lane; i < G::LDS_BOARDS_BYTES / 16; i += 64) reinterpret_cast<int4 *>(&L.b[0][0])[i] = z;
+    for (int i = lane; i < G::LDS_BOARDS_BYTES / 16; i += G::LPG) reinterpret_cast<int4 *>(&L.b[0][0])[i] = z;
 }
 
 // place code `t` of player index pi at absolute cell
@@ -559,7 +569,7 @@ __device__ void sample_boards(Lds<G> &L, const KParams &P, uint64_t g, uint64_t 
         const uint32_t i1 = rng_below(sgx_rng(P.seed, g, j, STREAM_SETUP, 0), (uint32_t)P.n_setups);
         const uint32_t i2 = rng_below(sgx_rng(P.seed, g, j, STREAM_SETUP, 1), (uint32_t)P.n_setups);
         const uint8_t *s1 = P.setups + (int64_t)i1 * n, *s2 = P.setups + (int64_t)i2 * n;
-        for (int x = lane; x < n; x += 64) {
+        for (int x = lane; x < n; x += G::LPG) {
             const int r = x / C, c = x - r * C;
             place(L, 0, r * C + c, s1[(U - 1 - r) * C + c]);           // p1 own-side row r = string row U-1-r
             place(L, 1, RC - n + x, s2[x]);                            // absolute rows R-U.. = string rows 0..
@@ -594,7 +604,7 @@ __device__ inline int fmod_(int a, int b) { int m = a % b; return m < 0 ? m + b 
 template <class G, int KIND>
 constexpr int waves_per_simd() {
     constexpr bool FULL = (KIND & 1) != 0;
-    constexpr int per_wg = WPB * (int)sizeof(Lds<G>) + 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)) + SGX_MAX_CELLS;
+    constexpr int per_wg = WPB * G::GPW * (int)sizeof(Lds<G>) + 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)) + SGX_MAX_CELLS;
     constexpr int wgs = (160 * 1024) / per_wg;
     constexpr int w = wgs * WPB / 4;
     // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
@@ -612,7 +622,7 @@ __device__ inline void write_record(Lds<G> &L, int8_t *rec_g, int rec_bytes, int
 #pragma unroll
         for (int w = 0; w < G::SB / 8; ++w) {
             const int i = lane + 64 * w;
-            const unsigned long long m = __ballot(i < RC && L.b[B_STILL + pi][i < RC ? i : 0] != 0);
+            const unsigned long long m = gballot<G>(i < RC && L.b[B_STILL + pi][i < RC ? i : 0] != 0);
             if (lane == 0) reinterpret_cast<unsigned long long *>(L.tail + pi * G::SB)[w] = m;
         }
     if (lane == 0) {
@@ -623,7 +633,7 @@ __device__ inline void write_record(Lds<G> &L, int8_t *rec_g, int rec_bytes, int
     const int4 *bsrc = reinterpret_cast<const int4 *>(&L.b[0][0]), *tsrc = reinterpret_cast<const int4 *>(L.tail);
     int4 *dst = reinterpret_cast<int4 *>(rec_g);
     const int n_tail_q = (2 * G::SB + 32 + 2 * n_events + 15) >> 4;            // tail int4s that carry data
-    for (int i = lane; i < rec_bytes / 16; i += 64) {
+    for (int i = lane; i < rec_bytes / 16; i += G::LPG) {
         int4 v = make_int4(0, 0, 0, 0);
         if (i < G::ST_OFF / 16) {
             v = bsrc[i];
@@ -651,7 +661,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     //      two int4 per lane, and the action -- so the wave pays ONE memory round trip.  The scalars, never-moved bitmaps
     //      and capture events are then read from the LDS image of the record (L.tail has the record's layout from ST_OFF
     //      on).  They used to be five dependent loads: a quarter of a toy game's lifetime.
-    constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + 63) / 64;
+    constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + G::LPG - 1) / G::LPG;
     static_assert(G::TAIL_BYTES % 16 == 0 && NLOAD <= 2, "record image must fit two int4 per lane");
     const int4 zero4 = make_int4(0, 0, 0, 0);
     int4 rq0 = zero4, rq1 = zero4;
@@ -660,7 +670,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
         const int nq = min(P.rec_bytes >> 4, Q_REC);
         if (lane < nq) rq0 = src[lane];
         if constexpr (NLOAD > 1)
-            if (lane + 64 < nq) rq1 = src[lane + 64];
+            if (lane + G::LPG < nq) rq1 = src[lane + G::LPG];
     }
     int a_raw = 0;
     int4 pos_raw = zero4;
@@ -670,35 +680,35 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     }
     {   // while the loads are in flight: clear the 28 rebuilt boards, copy the obstacle map (shared per workgroup)
         int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
-        for (int i = Q_BOARDS + lane; i < G::LDS_BOARDS_BYTES / 16; i += 64) dst[i] = zero4;
-        for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(obst_s)[i];
+        for (int i = Q_BOARDS + lane; i < G::LDS_BOARDS_BYTES / 16; i += G::LPG) dst[i] = zero4;
+        for (int i = lane; i < S / 4; i += G::LPG) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(obst_s)[i];
         int4 *tl = reinterpret_cast<int4 *>(L.tail);
         if (lane < Q_BOARDS) dst[lane] = rq0;
         else if (lane < Q_REC) tl[lane - Q_BOARDS] = rq0;
         if constexpr (NLOAD > 1) {
-            if (lane + 64 < Q_BOARDS) dst[lane + 64] = rq1;
-            else if (lane + 64 < Q_REC) tl[lane + 64 - Q_BOARDS] = rq1;
+            if (lane + G::LPG < Q_BOARDS) dst[lane + G::LPG] = rq1;
+            else if (lane + G::LPG < Q_REC) tl[lane + G::LPG - Q_BOARDS] = rq1;
         }
     }
     wave_sync<G>();
     const int4 sc = reinterpret_cast<const int4 *>(L.tail + 2 * G::SB)[0], sc2 = reinterpret_cast<const int4 *>(L.tail + 2 * G::SB)[1];
-    int turn = uni(sc.x), flags = uni(sc.y), game_no = uni(sc.w);
-    const int max_turns = uni(sc.z);
-    int n_events = min(uni(sc2.x), (int)G::EVL_MAX);
-    int rp0 = uni(sc2.y), rp1 = uni(sc2.z);   // recent-move pairs of player +1 / -1 (two named scalars: a runtime-indexed
+    int turn = uni<G>(sc.x), flags = uni<G>(sc.y), game_no = uni<G>(sc.w);
+    const int max_turns = uni<G>(sc.z);
+    int n_events = min(uni<G>(sc2.x), (int)G::EVL_MAX);
+    int rp0 = uni<G>(sc2.y), rp1 = uni<G>(sc2.z);   // recent-move pairs of player +1 / -1 (two named scalars: a runtime-indexed
                                               // array would live in scratch memory)
     {   // ---- rebuild the 28 derived boards: never-moved bitmaps, recent-move pairs, capture events
         const uint32_t *stb = reinterpret_cast<const uint32_t *>(L.tail);
 #pragma unroll
         for (int cc = 0; cc < G::CPL; ++cc) {
-            const int i = lane + 64 * cc;
+            const int i = lane + G::LPG * cc;
             if (i < RC) {
                 L.b[B_STILL][i] = (int8_t)((stb[i >> 5] >> (i & 31)) & 1u);
                 L.b[B_STILL + 1][i] = (int8_t)((stb[G::SB / 4 + (i >> 5)] >> (i & 31)) & 1u);
             }
         }
         const uint16_t *evl = reinterpret_cast<const uint16_t *>(L.tail + 2 * G::SB + 32);   // stays here for the write-back
-        for (int i = lane; i < n_events; i += 64) {
+        for (int i = lane; i < n_events; i += G::LPG) {
             const int evt = evl[i], byte = (B_CAP + (evt >> 8)) * S + (evt & 0xFF);  // event = (board - B_CAP) << 8 | cell
             atomicAdd(reinterpret_cast<unsigned int *>(&L.b[0][0]) + (byte >> 2), 1u << (8 * (byte & 3)));
         }
@@ -721,12 +731,12 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
         // ------------------------------------------------------------------------------------------
         // decode (maenv:684-689): flat spatial index -> positions -> 1-D index -> absolute 1-D index
         // ------------------------------------------------------------------------------------------
-        const int a = uni(a_raw);
+        const int a = uni<G>(a_raw);
         int sr = 0, sc_ = 0, er = 0, ec = 0;
         bool valid = true;
         if (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) {
             // is_move_valid_by_position (penv:87-92): actions_dev is int32 [N][4] = (start_r, start_c, end_r, end_c), absolute
-            sr = uni(pos_raw.x); sc_ = uni(pos_raw.y); er = uni(pos_raw.z); ec = uni(pos_raw.w);
+            sr = uni<G>(pos_raw.x); sc_ = uni<G>(pos_raw.y); er = uni<G>(pos_raw.z); ec = uni<G>(pos_raw.w);
         } else if (P.io.flags & SGX_STEP_ACTIONS_1D) {
             // functional API (penv:148-155): the action already is an absolute-coordinate 1-D index (impl:262-277)
             if (a == AS - 1) {
@@ -782,8 +792,8 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
             const int s = s_in ? sr * C + sc_ : 0, e = e_in ? er * C + ec : 0;
             const int v_obst_s = obst[s], v_obst_e = obst[e], v_own_s = own[s], v_own_e = own[e], v_en_e = enemy[e];
             const int v_rec_s = recent[s], v_rec_e = recent[e], v_po_s = own_po[s];
-            const int obst_s = uni(v_obst_s), obst_e = uni(v_obst_e), t = uni(v_own_s), own_e = uni(v_own_e);
-            const int dest = uni(v_en_e), old_start = uni(v_rec_s), old_end = uni(v_rec_e), moved_po = uni(v_po_s);
+            const int obst_s = uni<G>(v_obst_s), obst_e = uni<G>(v_obst_e), t = uni<G>(v_own_s), own_e = uni<G>(v_own_e);
+            const int dest = uni<G>(v_en_e), old_start = uni<G>(v_rec_s), old_end = uni<G>(v_rec_e), moved_po = uni<G>(v_po_s);
             if (over) valid = false;
             if (!s_in || obst_s != 0) valid = false;
             if (!e_in || obst_e != 0) valid = false;
@@ -798,7 +808,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
                     const int k = lane + 1;  // lanes 0.. check the intermediate cells
                     bool blk = false;
                     if (k < dist) { const int m = s + k * stepc; blk = own[m] != 0 || enemy[m] != 0 || obst[m] != 0; }
-                    if (__ballot(blk) != 0ull) valid = false;
+                    if (gballot<G>(blk) != 0ull) valid = false;
                 } else if (dist > 1) valid = false;
             }
             if (valid) {
@@ -814,7 +824,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
                 }
                 wave_sync<G>();
                 // clear the mover's recent-moves board (np.zeros_like, impl:1014)
-                for (int i = lane; i < S / 4; i += 64) reinterpret_cast<int *>(recent)[i] = 0;
+                for (int i = lane; i < S / 4; i += G::LPG) reinterpret_cast<int *>(recent)[i] = 0;
                 wave_sync<G>();
                 if (lane == 0) {
                     own_still[s] = 0; own_still[e] = 0; enemy_still[e] = 0;  // impl:939-941
@@ -954,11 +964,11 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) vo
     using FS = typename ObsKind<KIND>::F;
     constexpr bool FULL = ObsKind<KIND>::FULL;
     constexpr int ORIG4 = ObsKind<KIND>::ORIG ? 4 : 0;
-    __shared__ Lds<G> LW[WPB];
+    __shared__ Lds<G> LW[WPB * G::GPW];
     __shared__ alignas(16) float lut_s[OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)];
     __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t env0 = group_of_block(P.map_mode) * WPB, env = env0 + wave;
+    const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;     // lane inside the game, game inside the workgroup
+    const int64_t env = group_of_block() * (WPB * G::GPW) + slot;
 
     // ---- the workgroup's shared normalisation LUT (L2-resident source)
     const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
@@ -972,7 +982,7 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) vo
     }
     for (int i = threadIdx.x; i < G::S / 4; i += 64 * WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
     __syncthreads();   // from here on every wave works on its own game
-    if (env < P.n_envs) env_step<R_, C_, KIND>(P, LW[wave], lut_s, obst_s, env, lane);
+    if (env < P.n_envs) env_step<R_, C_, KIND>(P, LW[slot], lut_s, obst_s, env, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -991,21 +1001,21 @@ __global__ __launch_bounds__(64) void reset_kernel(const ResetParams P) {
     __shared__ Lds<G> L;
     const int lane = threadIdx.x;
     const int64_t env = blockIdx.x;
-    if (env >= P.k.n_envs) return;
+    if (env >= P.k.n_envs || lane >= G::LPG) return;     // helpers work on the LPG lanes of one game
     if (P.select && P.select[env] == 0) return;
     int game_no;
     if (P.p1_maps) {
         clear_boards(L, lane);
         wave_sync<G>();
         const int8_t *m1 = P.p1_maps + env * (int64_t)RC, *m2 = P.p2_maps + env * (int64_t)RC;
-        for (int i = lane; i < RC; i += 64) {
+        for (int i = lane; i < RC; i += G::LPG) {
             place(L, 0, i, m1[i]);
             place(L, 1, i, m2[RC - 1 - i]);  // p2 map rotated 180 degrees (impl:221)
         }
         wave_sync<G>();
         game_no = 0;
     } else {
-        game_no = uni(rec_scal<G>(P.k.boards, P.k.rec_bytes, env)[0].w) + 1;
+        game_no = uni<G>(rec_scal<G>(P.k.boards, P.k.rec_bytes, env)[0].w) + 1;
         sample_boards(L, P.k, (uint64_t)(P.k.env_id_offset + env), (uint64_t)game_no, lane);
     }
     write_record(L, P.k.boards + env * (int64_t)P.k.rec_bytes, P.k.rec_bytes, make_int4(0, 0, P.k.max_turns, game_no),
@@ -1022,14 +1032,14 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
     __shared__ Lds<G> L;
     const int lane = threadIdx.x;
     const int64_t env = blockIdx.x;
-    if (env >= P.n_envs) return;
+    if (env >= P.n_envs || lane >= G::LPG) return;       // helpers work on the LPG lanes of one game
     const uint8_t *m = mask + env * (int64_t)NA;
-    for (int i = lane; i < G::MB_WORDS; i += 64) L.mbits[i] = 0;
+    for (int i = lane; i < G::MB_WORDS; i += G::LPG) L.mbits[i] = 0;
     wave_sync<G>();
     int mine = 0;
 #pragma unroll
     for (int cc = 0; cc < G::CPL; ++cc) {
-        const int cell = lane + 64 * cc;
+        const int cell = lane + G::LPG * cc;
         int n = 0;
         if (cell < RC)
             for (int c = 0; c < K; ++c)
@@ -1042,9 +1052,9 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
         mine += n;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    for (int o = G::LPG / 2; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     wave_sync<G>();
-    const int total = uni(mine);
+    const int total = uni<G>(mine);
     const int4 sc = rec_scal<G>(P.boards, P.rec_bytes, env)[0];
     int na = -1;
     if (total > 0) {
@@ -1238,7 +1248,6 @@ KParams make_params(const sgx_env *h) {
     p.n_envs = h->n_envs;
     p.seed = h->seed;
     p.env_id_offset = h->env_id_offset;
-    { const char *mm = getenv("SGX_MAP_MODE"); p.map_mode = mm ? atoi(mm) : 0; }
 #ifdef SGX_STAMPS
     p.stamps = h->stamps;
 #endif
@@ -1445,7 +1454,8 @@ SGX_API int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p
 }
 
 static int launch_step(sgx_env *h, const KParams &p, void *stream) {
-    const unsigned grid = grid_for((h->n_envs + WPB - 1) / WPB);
+    const int gpw = h->cfg.rows * h->cfg.cols <= 16 ? 4 : (h->cfg.rows * h->cfg.cols <= 32 ? 2 : 1);   // Geo::GPW
+    const unsigned grid = grid_for((h->n_envs + WPB * gpw - 1) / (WPB * gpw));
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
 #define CALL_STEP_KIND(R, C, KIND) step_kernel<R, C, KIND><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p)
 #define CALL_STEP0(R, C) CALL_STEP_KIND(R, C, 0)
