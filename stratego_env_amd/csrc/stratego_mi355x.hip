@@ -318,6 +318,15 @@ __device__ inline int clamp15(int v) { return min(max(v, 0), 15); }
 template <class G, class Spec>
 __device__ inline void build_quad_table(uint32_t *qtab, int tid, int nthreads) {
     constexpr int RC = G::RC, S = G::S, NCH = Spec::NCH;
+    if constexpr (RC % 4 != 0) {
+        // odd cell counts (5x5, 15x15): per-channel table instead -- entry (qi, ch) = LDS byte offset of the source board (low 16
+        // bits) and LUT index base (high 16 bits); emit_obs adds the cell
+        for (int i = tid; i < 2 * NCH; i += nthreads) {
+            const int qi = i / NCH, ch = i - qi * NCH;
+            qtab[i] = (uint32_t)(Spec::board(ch, qi) * S) | ((uint32_t)(lut_row(ch) + Spec::bias(ch)) << 16);
+        }
+        return;
+    }
     for (int i = tid; i < 2 * NCH * 4; i += nthreads) {
         const int qi = i / (NCH * 4), r = i - qi * (NCH * 4), f = r;            // f = 4*qd + j : float index inside a 4-cell group
         const int rc = f / NCH, ch = f - rc * NCH;
@@ -359,11 +368,39 @@ __device__ void emit_obs(const Lds<G> &L, const float *tab, int qi, float *__res
             if (in) stream_store(&base[q], o);
         }
     } else {
-        // odd cell counts (5x5, 15x15): an env's observation is not 16-byte aligned; dword path
-        for (int f = lane; f < RC * NCH; f += G::LPG) {
-            const int pcell = f / NCH, ch = f - pcell * NCH;
-            const int cell = qi ? RC - 1 - pcell : pcell;
-            dst[f] = lut[lut_row(ch) + Spec::bias(ch) + bb[Spec::board(ch, qi) * S + cell]];
+        // odd cell counts (5x5, 15x15): an env's observation is only 4-byte aligned.  Lanes own the 16-byte slots of the
+        // ADDRESS range (sweep started on a chunk boundary like above); a slot's four floats are looked up one by one
+        // through the per-channel table, whole slots leave as one 16-byte store, the partial first / last slot as dwords.
+        // (One dword per lane per store, the first version, reached 2.3 TB/s on 15x15.)
+        constexpr int NF = RC * NCH;
+        const uint32_t *ctab = reinterpret_cast<const uint32_t *>(tab + LUT_DWORDS) + qi * NCH;
+        const int a = (int)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3);             // floats past a 16-byte boundary
+        float *base = dst - a;
+        const int nslots = (a + NF + 3) >> 2;
+        const int m0 = (int)((reinterpret_cast<uintptr_t>(base) >> 4) & (G::LPG - 1));
+#pragma unroll 2
+        for (int k0 = -m0; k0 < nslots; k0 += G::LPG) {
+            const int k = k0 + lane;
+            const bool slot_in = k >= 0 && k < nslots;
+            const int f0 = 4 * (slot_in ? k : 0) - a;
+            float o[4];
+            bool in[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = f0 + j;
+                in[j] = slot_in && (unsigned)f < (unsigned)NF;
+                const int ff = in[j] ? f : 0, pcell = ff / NCH, ch = ff - pcell * NCH;
+                const uint32_t e = ctab[ch];
+                o[j] = lut[(e >> 16) + bb[(e & 0xFFFF) + (qi ? RC - 1 - pcell : pcell)]];
+            }
+            if (in[0] && in[3]) {
+                f32x4 q = {o[0], o[1], o[2], o[3]};
+                stream_store(&reinterpret_cast<f32x4 *>(base)[k], q);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (in[j]) base[4 * k + j] = o[j];
+            }
         }
     }
 }
@@ -477,34 +514,37 @@ __device__ inline uint32_t mask_bits(const Lds<G> &L, int p, int n) {
     return (uint32_t)(w >> (p & 31)) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
 }
 
-// LDS mask bits -> global uint8 [R,C,K].  An env's mask starts at env*NA bytes: 4-byte but not 16-byte aligned
-// (3700 = 4 mod 16); lanes own 16-byte-aligned chunks of the global range, so whole chunks leave as one 16-byte
-// store per lane and only the partial first / last chunks go out as dwords.
+// LDS mask bits -> global uint8 [R,C,K].  An env's mask starts at env*NA bytes: 4-byte but not 16-byte aligned at 10x10
+// (3700 = 4 mod 16), byte aligned when NA is odd (5x5, 15x15); lanes own 16-byte-aligned chunks of the global range, so
+// whole chunks leave as one 16-byte store per lane and only the partial first / last chunks go out as dwords (bytes when
+// the base is not 4-byte aligned).
 template <class G>
 __device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) {
-    if constexpr (G::NA % 4 == 0) {
-        const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
-        const int nchunks = (A + G::NA + 15) >> 4;
-        uint8_t *gbase = dst - A;                       // 16-byte aligned
-        const int shift = (int)((reinterpret_cast<uintptr_t>(gbase) >> 4) & (G::LPG - 1));   // start the sweep on a 1 KiB boundary
-        for (int c0 = -shift; c0 < nchunks; c0 += G::LPG) {
-            const int c = c0 + lane;
-            if (c < 0 || c >= nchunks) continue;
-            const int lo = 16 * c - A;                  // first mask byte of this chunk
-            if (lo >= 0 && lo + 16 <= G::NA) {
-                const uint32_t b16 = mask_bits(L, lo, 16);
-                i32x4 q4 = {(int)expand4(b16 & 15), (int)expand4((b16 >> 4) & 15), (int)expand4((b16 >> 8) & 15), (int)expand4(b16 >> 12)};
-                stream_store(&reinterpret_cast<i32x4 *>(gbase)[c], q4);
-            } else {
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int o = lo + 4 * w;
-                    if (o >= 0 && o < G::NA) *reinterpret_cast<uint32_t *>(dst + o) = expand4(mask_bits(L, o, 4));
-                }
-            }
-        }
-    } else {
+    if constexpr (G::NA % 4 != 0 && G::NA < 2048) {      // small byte-aligned masks (5x5: 425 bytes): plain byte stores measured faster
         for (int i = lane; i < G::NA; i += G::LPG) dst[i] = (uint8_t)((L.mbits[i >> 5] >> (i & 31)) & 1u);
+        return;
+    }
+    const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
+    const int nchunks = (A + G::NA + 15) >> 4;
+    uint8_t *gbase = dst - A;                       // 16-byte aligned
+    const int shift = (int)((reinterpret_cast<uintptr_t>(gbase) >> 4) & (G::LPG - 1));   // start the sweep on a 1 KiB boundary
+    for (int c0 = -shift; c0 < nchunks; c0 += G::LPG) {
+        const int c = c0 + lane;
+        if (c < 0 || c >= nchunks) continue;
+        const int lo = 16 * c - A;                  // first mask byte of this chunk
+        if (lo >= 0 && lo + 16 <= G::NA) {
+            const uint32_t b16 = mask_bits(L, lo, 16);
+            i32x4 q4 = {(int)expand4(b16 & 15), (int)expand4((b16 >> 4) & 15), (int)expand4((b16 >> 8) & 15), (int)expand4(b16 >> 12)};
+            stream_store(&reinterpret_cast<i32x4 *>(gbase)[c], q4);
+        } else if constexpr (G::NA % 4 == 0) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int o = lo + 4 * w;
+                if (o >= 0 && o < G::NA) *reinterpret_cast<uint32_t *>(dst + o) = expand4(mask_bits(L, o, 4));
+            }
+        } else {
+            for (int o = max(lo, 0); o < min(lo + 16, (int)G::NA); ++o) dst[o] = (uint8_t)((L.mbits[o >> 5] >> (o & 31)) & 1u);
+        }
     }
 }
 
