@@ -311,3 +311,42 @@ def test_step_n_equals_n_single_steps(name):
     assert b'next_actions_dev' in envs[1]._L.sgx_last_error()
     for e in envs:
         e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,N', [('micro', 65536 + 17), ('tiny', 40003), ('fives', 30001)])
+def test_toy_full_size_shared_waves_vs_oracle_digests(name, N):
+    """BASELINE config 4 size (65,536 Micro games) plus a ragged tail: toy boards share a wave (4 or 2 games per wave), so the
+    sampled envs include the first and last games of waves and of the partly filled last workgroup.  Micro games last ~11
+    moves: 64 steps are ~6 auto-resets per env."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    T, seed = 64, 0xD1CE
+    v = VARIANTS[name]
+    env = VecStrategoEnv(name, N, seed=seed, auto_reset=True)
+    env.reset()
+    env.sample_valid_actions()
+    ids = np.unique(np.concatenate([np.arange(0, 9), np.arange(28, 36), np.arange(N - 19, N),
+                                    np.linspace(0, N - 1, 24).astype(np.int64)]))
+    idx = torch.from_numpy(ids).to(env.device)
+    digs = [orc.FNV_OFFSET] * len(ids)
+    cells = v.rows * v.columns
+    for t in range(T):
+        env.rollout_step()
+        m = env.mask.view(N, -1)
+        assert int((m.sum(dim=1, dtype=torch.int32) == 0).sum()) == 0 and int((m > 1).sum()) == 0
+        o = env.obs.view(N, cells, 67)
+        assert bool(torch.isfinite(o).all()) and float(o.abs().max()) <= 1.0
+        assert int(env.invalid_action.sum()) == 0
+        mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
+        rw, dn, pl = env.reward[idx].cpu().numpy(), env.done[idx].cpu().numpy(), env.player[idx].cpu().numpy()
+        ei = env.ending_invalid[idx].cpu().numpy()
+        for i in range(len(ids)):
+            tail = np.asarray([dn[i], pl[i], ei[i], 0], dtype=np.int32)
+            digs[i] = orc.fnv1a(digs[i], mk[i].tobytes() + ob[i].tobytes() + rw[i].tobytes() + tail.tobytes())
+    cv = oracle_cvariant(name)
+    for i in range(len(ids)):
+        total, d, f = orc.rollout(cv, seed, int(ids[i]), 1, T, threads=1)
+        assert int(d[0]) == digs[i], (name, 'env', int(ids[i]))
+    assert int(env.env_info()[:, 1].sum()) > N          # games were finished and restarted everywhere
+    env.close()
