@@ -1443,15 +1443,21 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
         sgx_destroy(h);
         return fail(SGX_ENOMEM, "device allocation failed%s");
     }
-    HIP_TRY(hipMemset(h->boards, 0, (size_t)n_envs * h->rec_bytes));
-    HIP_TRY(hipMemcpy(h->tab, &host_tab, sizeof(DevTables), hipMemcpyHostToDevice));
+#define HIP_TRY_OR_DESTROY(expr)                                                             \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) { sgx_destroy(h); return fail(SGX_EDEVICE, #expr ": %s", hipGetErrorString(e_)); } \
+    } while (0)
+    HIP_TRY_OR_DESTROY(hipMemset(h->boards, 0, (size_t)n_envs * h->rec_bytes));
+    HIP_TRY_OR_DESTROY(hipMemcpy(h->tab, &host_tab, sizeof(DevTables), hipMemcpyHostToDevice));
 #ifdef SGX_STAMPS
-    HIP_TRY(hipMalloc((void **)&h->stamps, (size_t)n_envs * 16 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(h->stamps, 0, (size_t)n_envs * 16 * sizeof(unsigned long long)));
+    HIP_TRY_OR_DESTROY(hipMalloc((void **)&h->stamps, (size_t)n_envs * 16 * sizeof(unsigned long long)));
+    HIP_TRY_OR_DESTROY(hipMemset(h->stamps, 0, (size_t)n_envs * 16 * sizeof(unsigned long long)));
 #endif
     init_scal_kernel<<<(unsigned)((n_envs + 255) / 256), 256>>>(h->boards, h->rec_bytes, h->sc_off, n_envs, cfg->max_turns);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY_OR_DESTROY(hipGetLastError());
+    HIP_TRY_OR_DESTROY(hipDeviceSynchronize());
+#undef HIP_TRY_OR_DESTROY
     *out = h;
     return SGX_OK;
 }
