@@ -1161,36 +1161,74 @@ __global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t
 
 // Reachable states only: at most two non-zero recent-move cells per player (impl:1013-1028) and at most
 // max_events captured pieces; anything beyond that cannot come from play and is dropped.
+// One 256-thread block per state: a single coalesced pass over the 34 int64 layers scatters them into LDS (dense boards
+// straight into the record image, never-moved flags, recent-move codes and captured counts as bytes), the capture-event list
+// is laid out with a block-wide prefix sum, and the finished record leaves as whole 128-byte lines.  (The first version
+// walked the 24 captured layers with one thread: 4.6 ms per 65,536 states against 0.44 ms for the export.)
 template <int R_, int C_>
-__global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in) {
+__global__ __launch_bounds__(256) void import_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in) {
     using G = Geo<R_, C_>;
-    constexpr int RC = G::RC, C = G::C, S = G::S;
+    constexpr int RC = G::RC, C = G::C, S = G::S, NT = 256;
+    constexpr int IMG = (G::EVL_OFF + 2 * G::EVL_MAX + 127) & ~127;      // >= rec_bytes of any piece set on this board
+    constexpr int NE = 24 * RC, PER = (NE + NT - 1) / NT;
+    __shared__ alignas(16) uint8_t img[IMG];
+    __shared__ uint8_t cap[NE];
+    __shared__ int8_t recent[2 * RC];
+    __shared__ uint8_t still[2 * RC];
+    __shared__ int scan[NT];
+    const int tid = threadIdx.x;
     const int64_t env = blockIdx.x;
     if (env >= P.n_envs) return;
     int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
     const int64_t *s = in + env * (int64_t)(SGX_STATE_LAYERS * RC);
-    for (int x = threadIdx.x; x < P.rec_bytes; x += blockDim.x) {
-        if (x >= G::ST_OFF && x < G::EVL_OFF + 2 * P.max_events) continue;   // bitmaps, scalars and events are written below
-        const int b = x / S, cell = x - b * S;
-        int v = 0;
-        if (b < STORED_BOARDS && cell < RC) {
-            const int64_t raw = s[ref_layer_of_board(b) * RC + cell];
-            const int hi = b < 2 ? SP_BOMB : b < 4 ? SP_UNKNOWN : 1;     // legal range of the layer; anything else -> 0
-            v = (raw >= 0 && raw <= hi) ? (int)raw : 0;
-        }
-        rec[x] = (int8_t)v;
+    for (int i = tid; i < IMG / 4; i += NT) reinterpret_cast<uint32_t *>(img)[i] = 0;
+    __syncthreads();
+    for (int x = tid; x < SGX_STATE_LAYERS * RC; x += NT) {
+        const int l = x / RC, cell = x - l * RC;
+        if (l == 2 || l == 5) continue;                               // obstacles are the variant's; scalars below
+        const int64_t raw = s[x];
+        if (l < 2 || l == 3 || l == 4) {                              // legal range of the layer; anything else -> 0
+            const int b = l < 2 ? B_PIECES + l : B_PO + (l - 3), hi = l < 2 ? SP_BOMB : SP_UNKNOWN;
+            img[b * S + cell] = (uint8_t)((raw >= 0 && raw <= hi) ? (int)raw : 0);
+        } else if (l == 6 || l == 7) recent[(l - 6) * RC + cell] = (int8_t)((raw >= -3 && raw <= 1) ? (int)raw : 0);
+        else if (l < 32) cap[(l - 8) * RC + cell] = (uint8_t)(raw <= 0 ? 0 : (raw > 12 ? 12 : (int)raw));
+        else still[(l - 32) * RC + cell] = raw == 1 ? 1 : 0;
     }
     __syncthreads();
-    for (int w = threadIdx.x; w < 2 * (G::SB / 4); w += blockDim.x) {      // never-moved bitmaps from layers 32/33
+    for (int w = tid; w < 2 * (G::SB / 4); w += NT) {                  // never-moved bitmaps from layers 32/33
         const int pl = w / (G::SB / 4), w0 = w - pl * (G::SB / 4);
         uint32_t bits = 0;
         for (int k = 0; k < 32; ++k) {
             const int cell = 32 * w0 + k;
-            if (cell < RC && s[(32 + pl) * RC + cell] == 1) bits |= 1u << k;
+            if (cell < RC && still[pl * RC + cell]) bits |= 1u << k;
         }
-        reinterpret_cast<uint32_t *>(rec + G::ST_OFF)[w] = bits;
+        reinterpret_cast<uint32_t *>(img + G::ST_OFF)[w] = bits;
     }
-    if (threadIdx.x == 0) {
+    // capture events in (layer, cell) order: thread t owns entries [t*PER, (t+1)*PER) of the count table
+    int cnt = 0;
+    for (int k = 0; k < PER; ++k) {
+        const int e = tid * PER + k;
+        if (e < NE) cnt += cap[e];
+    }
+    scan[tid] = cnt;
+    __syncthreads();
+    for (int o = 1; o < NT; o <<= 1) {
+        const int v = tid >= o ? scan[tid - o] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    {
+        int at = scan[tid] - cnt;
+        uint16_t *ev = reinterpret_cast<uint16_t *>(img + G::EVL_OFF);
+        for (int k = 0; k < PER; ++k) {
+            const int e = tid * PER + k;
+            if (e < NE)
+                for (int q = cap[e]; q > 0; --q, ++at)
+                    if (at < P.max_events) ev[at] = (uint16_t)(((e / RC) << 8) | (e % RC));
+        }
+    }
+    if (tid == 0) {
         const int64_t *d = s + 5 * RC;
         int flags = 0;
         if (d[1] != 0) flags |= F_OVER;
@@ -1201,22 +1239,17 @@ __global__ void import_kernel(const KParams P, const int64_t *__restrict__ in, c
         for (int pl = 0; pl < 2; ++pl) {
             int k = 0;
             for (int cell = 0; cell < RC && k < 2; ++cell) {
-                const int64_t raw = s[(6 + pl) * RC + cell];
-                const int code = (raw >= -3 && raw <= 1) ? (int)raw : 0;
+                const int code = recent[pl * RC + cell];
                 if (code != 0) { pairs[pl] |= (cell | ((code & 0xFF) << 8)) << (16 * k); ++k; }
             }
         }
-        uint16_t *ev = reinterpret_cast<uint16_t *>(rec + G::EVL_OFF);
-        int n = 0;
-        for (int b = 0; b < 24; ++b)
-            for (int cell = 0; cell < RC; ++cell)
-                for (int64_t q = min((long long)s[(8 + b) * RC + cell], 12ll); q > 0 && n < P.max_events; --q) ev[n++] = (uint16_t)((b << 8) | cell);
-        for (int i = n; i < P.max_events; ++i) ev[i] = 0;
-        int4 *scg = rec_scal<G>(P.boards, P.rec_bytes, env);
-        const int old_game = scg[0].w;
+        const int old_game = rec_scal<G>(P.boards, P.rec_bytes, env)[0].w;
+        int4 *scg = reinterpret_cast<int4 *>(img + G::SC_OFF);
         scg[0] = make_int4((int)d[0], flags, (int)d[C], old_game < 0 ? 0 : old_game);
-        scg[1] = make_int4(n, pairs[0], pairs[1], 0);
+        scg[1] = make_int4(min(scan[NT - 1], P.max_events), pairs[0], pairs[1], 0);
     }
+    __syncthreads();
+    for (int i = tid; i < P.rec_bytes / 16; i += NT) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(img)[i];
 }
 
 __global__ void info_kernel(const int8_t *__restrict__ boards, int rec_bytes, int sc_off, int32_t *__restrict__ out, int64_t n) {

@@ -32,7 +32,7 @@ class BatchedStrategoProceduralEnv:
         self.batch_size = int(batch_size)
         self.action_size = v.action_size                                                            # penv:34
         self.spatial_action_size = v.spatial_action_size                                            # penv:35
-        self._vec = VecStrategoEnv(v.name, batch_size, device=device, human_inits=False, full_obs=True)
+        self._vec = VecStrategoEnv(v.name, batch_size, device=device, human_inits=False)
         self.device = self._vec.device
         sp, od = ia.gather_tables(v.rows, v.columns)
         self._spatial_src = torch.from_numpy(np.stack(sp)).to(self.device)                          # [2, NA]
@@ -94,7 +94,7 @@ class BatchedStrategoProceduralEnv:
     def get_valid_moves_as_spatial_mask(self, states, players):                                     # penv:127-128
         """uint8 [N,R,C,K] in the coordinates of the given states (no perspective flip), like impl:399-517."""
         _, pl = self._load(states, players)
-        self._vec.observe()
+        self._vec.observe(emit_obs=False)
         pi = (pl < 0).to(torch.int64)
         out = torch.gather(self._perspective_mask_ext(), 1, self._spatial_src[pi])
         return out.view(self.batch_size, *self.spatial_action_size)
@@ -106,7 +106,7 @@ class BatchedStrategoProceduralEnv:
         if player_perspective:
             states = self.get_state_from_player_perspective(states, players)
         _, pl = self._load(states, players)
-        self._vec.observe()
+        self._vec.observe(emit_obs=False)
         pi = (pl < 0).to(torch.int64)
         return torch.gather(self._perspective_mask_ext(), 1, self._onedim_src[pi])
 
@@ -163,32 +163,33 @@ class BatchedStrategoProceduralEnv:
 
     # ---- observations (raw, as the reference's operator layer returns them; maenv normalises afterwards) -----------
     def get_partially_observable_observation_extended_channels(self, states, players):             # penv:171-173
-        self._load(states, players)
-        self._vec.observe(raw=True)
-        return self._vec.obs.clone()
+        return self._observe_raw(states, players, full=False, original=False)
 
     def get_fully_observable_observation_extended_channels(self, states, players):                 # penv:166-169
-        self._load(states, players)
-        self._vec.observe(raw=True)
-        return self._vec.fobs.clone()
+        return self._observe_raw(states, players, full=True, original=False)
 
-    def _observe_original(self, states, players, full):
+    def _observe_raw(self, states, players, full, original):
+        """One raw (un-normalised) observation kind into a fresh tensor; nothing else is rendered."""
         vec = self._vec
         self._load(states, players)
-        ch = _lib.FO_OBS_CHANNELS_ORIGINAL if full else _lib.PO_OBS_CHANNELS_ORIGINAL
+        if original:
+            ch = _lib.FO_OBS_CHANNELS_ORIGINAL if full else _lib.PO_OBS_CHANNELS_ORIGINAL
+        else:
+            ch = _lib.FO_OBS_CHANNELS if full else _lib.PO_OBS_CHANNELS
         out = torch.empty((self.batch_size, self.rows, self.columns, ch), dtype=torch.float32, device=self.device)
+        flags = _lib.STEP_RAW_OBS | (_lib.STEP_ORIGINAL_CHANNELS if original else 0)
         with torch.cuda.device(self.device):
             _lib.check(vec._L.sgx_observe(vec._h, None if full else out.data_ptr(), out.data_ptr() if full else None, None, None,
-                                          _lib.STEP_RAW_OBS | _lib.STEP_ORIGINAL_CHANNELS, vec._stream()))
+                                          flags, vec._stream()))
         return out
 
     def get_partially_observable_observation(self, states, players):                               # penv:162-164
         """Deprecated 32-channel observation holding piece values (impl:1153-1197), raw."""
-        return self._observe_original(states, players, full=False)
+        return self._observe_raw(states, players, full=False, original=True)
 
     def get_fully_observable_observation(self, states, players):                                   # penv:157-160
         """Deprecated 33-channel observation (impl:1075-1123), raw."""
-        return self._observe_original(states, players, full=True)
+        return self._observe_raw(states, players, full=True, original=True)
 
     # ---- pure tensor functions (no kernel needed) -------------------------------------------------------------------
     def get_state_from_player_perspective(self, states, players):                                   # penv:101-103 / impl:645-675

@@ -117,9 +117,11 @@ class VecStrategoEnv:
             _lib.check(self._L.sgx_reset(self._h, _ptr(sel), _ptr(m1), _ptr(m2), self._stream()))
         return self.observe()
 
-    def observe(self, raw=False):
+    def observe(self, raw=False, emit_obs=True, emit_mask=True):
+        """_get_current_obs for every env (no state change); emit_obs / emit_mask = False skip those outputs."""
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_observe(self._h, _ptr(self.obs), _ptr(self.fobs), _ptr(self.mask), _ptr(self.player),
+            _lib.check(self._L.sgx_observe(self._h, _ptr(self.obs) if emit_obs else None, _ptr(self.fobs) if emit_obs else None,
+                                           _ptr(self.mask) if emit_mask else None, _ptr(self.player),
                                            (_lib.STEP_RAW_OBS if raw else 0) | self._mode_flags, self._stream()))
         return self.obs, self.mask, self.player
 
