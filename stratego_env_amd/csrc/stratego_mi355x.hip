@@ -1080,18 +1080,41 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
     const uint8_t *m = mask + env * (int64_t)NA;
     for (int i = lane; i < G::MB_WORDS; i += G::LPG) L.mbits[i] = 0;
     wave_sync<G>();
+    {   // mask bytes -> bits in LDS, read as 16-byte chunks of the address range (the mirror image of emit_mask)
+        const int A = (int)(reinterpret_cast<uintptr_t>(m) & 15);
+        const int nchunks = (A + NA + 15) >> 4;
+        const uint8_t *gbase = m - A;
+        for (int c = lane; c < nchunks; c += G::LPG) {
+            const int lo = 16 * c - A;
+            if (lo >= 0 && lo + 16 <= NA) {
+                const uint4 v = reinterpret_cast<const uint4 *>(gbase)[c];
+                uint32_t bits = 0;
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t nz = ((((w4[j] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w4[j]) >> 7) & 0x01010101u;   // byte != 0
+                    bits |= ((nz & 1u) | ((nz >> 7) & 2u) | ((nz >> 14) & 4u) | ((nz >> 21) & 8u)) << (4 * j);
+                }
+                if (bits) {
+                    atomicOr(&L.mbits[lo >> 5], bits << (lo & 31));
+                    if ((lo & 31) > 16) atomicOr(&L.mbits[(lo >> 5) + 1], bits >> (32 - (lo & 31)));
+                }
+            } else {
+                for (int o = max(lo, 0); o < min(lo + 16, (int)NA); ++o)
+                    if (m[o] != 0) atomicOr(&L.mbits[o >> 5], 1u << (o & 31));
+            }
+        }
+    }
+    wave_sync<G>();
     int mine = 0;
 #pragma unroll
     for (int cc = 0; cc < G::CPL; ++cc) {
         const int cell = lane + G::LPG * cc;
         int n = 0;
-        if (cell < RC)
-            for (int c = 0; c < K; ++c)
-                if (m[cell * K + c] != 0) {
-                    const int bit = cell * K + c;
-                    atomicOr(&L.mbits[bit >> 5], 1u << (bit & 31));
-                    ++n;
-                }
+        if (cell < RC) {
+            n = __popc(mask_bits(L, cell * K, K < 32 ? K : 32));
+            if constexpr (K > 32) n += __popc(mask_bits(L, cell * K + 32, K - 32));
+        }
         L.cnt[cell] = (uint8_t)n;
         mine += n;
     }
