@@ -1,8 +1,9 @@
 // stratego_mi355x.hip -- HIP kernels (gfx950 / CDNA4) and C-ABI of the batched Stratego env.
 //
-// One wavefront (64 lanes) per game.  A game's state record (32 int8 boards, absolute coordinates)
-// is staged in LDS, the move is applied there, the next mover's valid-actions mask is built in LDS
-// and its 67-channel normalised observation is rendered straight into 16-byte coalesced global stores.
+// One wavefront (64 lanes) per game; boards of <= 32 cells share a wave between 2 or 4 games (Geo::LPG lanes per game).
+// A game's compact state record (4 dense int8 boards + bitmaps + scalars + capture events, whole 128-byte lines) is expanded
+// to 32 boards in LDS, the move is applied there, the next mover's valid-actions mask is built in LDS as bits and its
+// 67-channel normalised observation is rendered straight into line-aligned 16-byte global stores.
 // HBM-bound integer/byte work: no MFMA.  See DESIGN.md for the data layout and byte accounting.
 //
 // Reference functions reproduced (paths relative to /root/reference/stratego_env):
@@ -54,7 +55,7 @@ constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 673 /* >= 20*33 (79 channels), = 1 m
 #ifndef SGX_MIN_WAVES
 #define SGX_MIN_WAVES 6
 #endif
-constexpr int WPB = SGX_WPB;  // waves (= games) per workgroup; they share the LUT
+constexpr int WPB = SGX_WPB;  // waves per workgroup (WPB * Geo::GPW games); they share the LUT
 // per observation kind in LDS: the LUT followed by the quad table (2 perspectives x NCH quads x 4 packed entries, see emit_obs)
 constexpr int QTAB_DWORDS = 2 * OBS_CH * 4, OBS_TAB_DWORDS = LUT_DWORDS + QTAB_DWORDS;   // partial kind; the full kind follows it
 constexpr int FOBS_TAB_DWORDS = LUT_DWORDS + 2 * FOBS_CH * 4;
