@@ -350,3 +350,31 @@ def test_toy_full_size_shared_waves_vs_oracle_digests(name, N):
         assert int(d[0]) == digs[i], (name, 'env', int(ids[i]))
     assert int(env.env_info()[:, 1].sum()) > N          # games were finished and restarted everywhere
     env.close()
+
+
+@pytest.mark.gpu
+def test_calls_run_on_the_callers_stream():
+    """Every entry point enqueues on the stream it is given (torch's current stream): a rollout issued inside a side-stream
+    context, with the default stream kept busy, equals the same rollout on the default stream."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    n, k = 2048, 25
+    a = VecStrategoEnv('barrage', n, seed=99, auto_reset=True)
+    b = VecStrategoEnv('barrage', n, seed=99, auto_reset=True)
+    a.reset(); a.sample_valid_actions()
+    for _ in range(k):
+        a.rollout_step()
+    side = torch.cuda.Stream()
+    busy = torch.empty(1 << 26, device='cuda')
+    with torch.cuda.stream(side):
+        b.reset(); b.sample_valid_actions()
+        for _ in range(k):
+            busy.fill_(1.0)                        # default-stream work that must not order b's launches
+            b.rollout_step()
+        st_b, pl_b = b.export_state()
+    side.synchronize()
+    torch.cuda.synchronize()
+    st_a, pl_a = a.export_state()
+    assert torch.equal(st_a, st_b) and torch.equal(pl_a, pl_b)
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.mask, b.mask) and torch.equal(a.next_actions, b.next_actions)
+    a.close(); b.close()
