@@ -378,3 +378,57 @@ def test_calls_run_on_the_callers_stream():
     assert torch.equal(st_a, st_b) and torch.equal(pl_a, pl_b)
     assert torch.equal(a.obs, b.obs) and torch.equal(a.mask, b.mask) and torch.equal(a.next_actions, b.next_actions)
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['barrage', 'standard', 'micro', 'fives'])
+def test_import_sanitises_unreachable_states(name):
+    """sgx_import_state accepts any int64 tensor: values outside a layer's legal range become 0, captured counts are
+    clamped, at most two recent-move cells per player and at most max_events captures survive (documented limits of the
+    packed record) -- and stepping such states afterwards stays in bounds (no invalid memory access, outputs finite)."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    v = VARIANTS[name]
+    R, C = v.rows, v.columns
+    n = 64
+    rng = np.random.RandomState(7)
+    st = rng.randint(-5, 40, size=(n, 34, R, C)).astype(np.int64)
+    st[:, 5] = 0
+    st[:, 5, 0, 0] = rng.randint(0, 10, size=n)           # turn count
+    st[:, 5, 1, 0] = v.max_turns
+    env = VecStrategoEnv(name, n, seed=1, auto_reset=True)
+    players = np.where(rng.rand(n) < 0.5, 1, -1).astype(np.int8)
+    env.import_state(torch.from_numpy(st), torch.from_numpy(players))
+    out, pl = env.export_state()
+    out = out.cpu().numpy()
+    assert np.array_equal(pl.cpu().numpy(), players)
+    max_events = 2 * sum(v.piece_counts)
+    for e in range(n):
+        for layer, hi in ((0, 12), (1, 12), (3, 13), (4, 13)):
+            want = np.where((st[e, layer] >= 0) & (st[e, layer] <= hi), st[e, layer], 0)
+            assert np.array_equal(out[e, layer], want), (name, e, layer)
+        for layer in (32, 33):
+            assert np.array_equal(out[e, layer], (st[e, layer] == 1).astype(np.int64))
+        for layer in (6, 7):                                # first two legal non-zero codes in cell order
+            codes = np.where((st[e, layer] >= -3) & (st[e, layer] <= 1), st[e, layer], 0).reshape(-1)
+            keep = np.flatnonzero(codes)[:2]
+            want = np.zeros(R * C, dtype=np.int64)
+            want[keep] = codes[keep]
+            assert np.array_equal(out[e, layer].reshape(-1), want), (name, e, layer)
+        caps = np.clip(st[e, 8:32], 0, 12).reshape(-1)      # (layer, cell) order, truncated at max_events
+        want = np.zeros_like(caps)
+        budget = max_events
+        for i in np.flatnonzero(caps):
+            take = min(int(caps[i]), budget)
+            want[i] = take
+            budget -= take
+            if budget == 0:
+                break
+        assert np.array_equal(out[e, 8:32].reshape(-1), want), (name, e, 'captured')
+        assert np.array_equal(out[e, 2], v.obstacle_map().astype(np.int64))
+    env.sample_valid_actions()
+    for _ in range(8):
+        env.rollout_step()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(env.obs).all()) and int((env.mask > 1).sum()) == 0
+    env.close()
