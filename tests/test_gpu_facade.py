@@ -155,3 +155,16 @@ def test_facade_1d_actions_and_oscillation_flag():
     obs, rew, done, info = env.step({1: flat}, allow_piece_oscillation=True)
     assert list(obs.keys()) == [-1]
     env.close()
+
+
+def test_batched_policy_loop_example_runs(capsys):
+    import sys
+    from stratego_env_amd.examples import batched_policy_loop as ex
+    argv = sys.argv
+    sys.argv = ['batched_policy_loop', '--games', '512', '--steps', '40', '--version', 'tiny']
+    try:
+        ex.main()
+    finally:
+        sys.argv = argv
+    out = capsys.readouterr().out
+    assert 'games finished' in out and '512 tiny games x 40 steps' in out
