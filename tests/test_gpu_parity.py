@@ -432,3 +432,37 @@ def test_import_sanitises_unreachable_states(name):
     torch.cuda.synchronize()
     assert bool(torch.isfinite(env.obs).all()) and int((env.mask > 1).sum()) == 0
     env.close()
+
+
+@pytest.mark.gpu
+def test_long_horizon_rollout_with_max_turn_endings():
+    """2,500 batched steps of 4,096 Barrage games: several auto-resets per env, games that run into max_turns = 1000
+    (ENDING_INVALID, impl:1040-1043) inside the batch, capture-event lists that fill up -- oracle digests of sampled envs."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    N, T, seed = 4096, 2500, 0xFEED5
+    env = VecStrategoEnv('barrage', N, seed=seed, auto_reset=True)
+    env.reset()
+    env.sample_valid_actions()
+    ids = np.asarray([0, 7, 1000, 2047, 4095], dtype=np.int64)
+    idx = torch.from_numpy(ids).to(env.device)
+    digs = [orc.FNV_OFFSET] * len(ids)
+    invalid_endings = torch.zeros((), dtype=torch.int64, device=env.device)
+    for t in range(T):
+        env.rollout_step()
+        invalid_endings += env.ending_invalid.sum()
+        mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
+        rw, dn, pl = env.reward[idx].cpu().numpy(), env.done[idx].cpu().numpy(), env.player[idx].cpu().numpy()
+        ei = env.ending_invalid[idx].cpu().numpy()
+        for i in range(len(ids)):
+            tail = np.asarray([dn[i], pl[i], ei[i], 0], dtype=np.int32)
+            digs[i] = orc.fnv1a(digs[i], mk[i].tobytes() + ob[i].tobytes() + rw[i].tobytes() + tail.tobytes())
+    assert int(env.invalid_action.sum()) == 0
+    assert int(invalid_endings) > 0                       # max-turn endings did occur
+    cv = oracle_cvariant('barrage', setups=S.load_setup_table('barrage'))
+    for i in range(len(ids)):
+        total, d, f = orc.rollout(cv, seed, int(ids[i]), 1, T, threads=1)
+        assert int(d[0]) == digs[i], ('env', int(ids[i]))
+    info = env.env_info().cpu().numpy()
+    assert info[:, 1].min() >= 2                          # every env finished at least two games
+    env.close()
