@@ -93,7 +93,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=512)
     ap.add_argument('--warmup', type=int, default=64)
-    ap.add_argument('--envs', type=int, default=65536, help='games per GPU')
+    ap.add_argument('--envs', type=int, default=65536, help='games per GPU (weak scaling: fixed as --gpus grows)')
+    ap.add_argument('--total-envs', type=int, default=0,
+                    help='strong scaling instead (SURVEY 8d config 5): this many games in total, split evenly over the ranks')
     ap.add_argument('--version', default='barrage')
     ap.add_argument('--unfused', action='store_true', help='sample actions with the standalone sampler kernel')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
@@ -132,7 +134,7 @@ def main():
     from stratego_env_amd.config import VARIANTS
     from stratego_env_amd.vec_env import VecStrategoEnv
     v = VARIANTS[args.version]
-    n = args.envs
+    n = args.envs if not args.total_envs else args.total_envs // world    # rank r owns global ids [r*n, (r+1)*n)
     env = VecStrategoEnv(args.version, n, device=local_rank, seed=BASE_SEED, env_id_offset=rank * n, auto_reset=True)
     env.reset()
     placement_us = env.tune_placement(args.placement_trials, max_memory_fraction=0.5) if args.placement_trials > 1 else None
@@ -186,7 +188,7 @@ def main():
         out = {
             "metric": "env steps/sec", "value": total_steps / elapsed, "unit": "env steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_envs else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%d concurrent %s games per GPU (%dx%d), random-valid-action rollout with auto-reset, "
                                    "%s step+sample" % (n, args.version, v.rows, v.columns,
