@@ -51,7 +51,7 @@ class BatchedStrategoProceduralEnv:
         pl = self._players(players)
         vec = self._vec
         with torch.cuda.device(self.device):
-            _lib.check(vec._L.sgx_import_state(vec._h, st.data_ptr(), pl.data_ptr(), vec._stream()))
+            _lib.check(vec._L.sgx_import_state(vec._h, st.data_ptr(), pl.data_ptr(), vec._stream()), vec._L)
         return st, pl
 
     def _perspective_mask_ext(self):
@@ -180,7 +180,7 @@ class BatchedStrategoProceduralEnv:
         flags = _lib.STEP_RAW_OBS | (_lib.STEP_ORIGINAL_CHANNELS if original else 0)
         with torch.cuda.device(self.device):
             _lib.check(vec._L.sgx_observe(vec._h, None if full else out.data_ptr(), out.data_ptr() if full else None, None, None,
-                                          flags, vec._stream()))
+                                          flags, vec._stream()), vec._L)
         return out
 
     def get_partially_observable_observation(self, states, players):                               # penv:162-164

@@ -58,7 +58,7 @@ class VecStrategoEnv:
         self._cfg = _lib.make_config(v)
         h = C.c_void_p()
         _lib.check(self._L.sgx_create(C.byref(self._cfg), self.num_envs, self.device.index, self.seed,
-                                      self.env_id_offset, C.byref(h)))
+                                      self.env_id_offset, C.byref(h)), self._L)
         self._h = h
         if human_inits is None:
             human_inits = bool(v.human_inits)
@@ -66,7 +66,7 @@ class VecStrategoEnv:
             if not v.human_inits:
                 raise ValueError("Human inits not supported with {} game version".format(v.name))  # util.py:310
             table = np.ascontiguousarray(load_setup_table(v.human_inits))
-            _lib.check(self._L.sgx_set_setup_table(self._h, table.ctypes.data_as(C.c_void_p), table.shape[0]))
+            _lib.check(self._L.sgx_set_setup_table(self._h, table.ctypes.data_as(C.c_void_p), table.shape[0]), self._L)
         self.human_inits = bool(human_inits)
         N, R, Cc, K, dev = self.num_envs, self.R, self.Cc, self.K, self.device
         self.obs = torch.empty((N, R, Cc, self.p_channels), dtype=torch.float32, device=dev)
@@ -114,7 +114,7 @@ class VecStrategoEnv:
             m2 = torch.as_tensor(p2_maps).to(device=self.device, dtype=torch.int8).contiguous().reshape(self.num_envs, -1)
             assert m1.shape[1] == self.R * self.Cc and m2.shape == m1.shape
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_reset(self._h, _ptr(sel), _ptr(m1), _ptr(m2), self._stream()))
+            _lib.check(self._L.sgx_reset(self._h, _ptr(sel), _ptr(m1), _ptr(m2), self._stream()), self._L)
         return self.observe()
 
     def observe(self, raw=False, emit_obs=True, emit_mask=True):
@@ -122,7 +122,7 @@ class VecStrategoEnv:
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_observe(self._h, _ptr(self.obs) if emit_obs else None, _ptr(self.fobs) if emit_obs else None,
                                            _ptr(self.mask) if emit_mask else None, _ptr(self.player),
-                                           (_lib.STEP_RAW_OBS if raw else 0) | self._mode_flags, self._stream()))
+                                           (_lib.STEP_RAW_OBS if raw else 0) | self._mode_flags, self._stream()), self._L)
         return self.obs, self.mask, self.player
 
     def tune_placement(self, trials=24, launches=6, mask_trials=None, max_memory_fraction=0.25):
@@ -175,7 +175,7 @@ class VecStrategoEnv:
         assert a.numel() == self.num_envs * (4 if (flags & _lib.STEP_ACTIONS_POSITIONS) else 1)
         io = self._fill_io(a, want_next_actions, emit_obs, emit_mask, flags)
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_step(self._h, C.byref(io), self._stream()))
+            _lib.check(self._L.sgx_step(self._h, C.byref(io), self._stream()), self._L)
         return self.obs, self.mask, self.reward, self.done, self.player
 
     def _fill_io(self, a, want_next_actions, emit_obs, emit_mask, flags):
@@ -205,7 +205,7 @@ class VecStrategoEnv:
         n_steps times, without a Python round trip per step (toy boards are launch-bound otherwise)."""
         io = self._fill_io(self.next_actions, True, True, True, 0)
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_step_n(self._h, C.byref(io), int(n_steps), self._stream()))
+            _lib.check(self._L.sgx_step_n(self._h, C.byref(io), int(n_steps), self._stream()), self._L)
         return self.obs, self.mask, self.reward, self.done, self.player
 
     def sample_valid_actions(self, mask=None, out=None):
@@ -213,7 +213,7 @@ class VecStrategoEnv:
         mask = self.mask if mask is None else mask
         out = self.next_actions if out is None else out
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_sample_valid(self._h, _ptr(mask), _ptr(out), self._stream()))
+            _lib.check(self._L.sgx_sample_valid(self._h, _ptr(mask), _ptr(out), self._stream()), self._L)
         return out
 
     def export_state(self):
@@ -221,7 +221,7 @@ class VecStrategoEnv:
         st = torch.empty((self.num_envs, NUM_STATE_LAYERS, self.R, self.Cc), dtype=torch.int64, device=self.device)
         pl = torch.empty((self.num_envs,), dtype=torch.int8, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_export_state(self._h, _ptr(st), _ptr(pl), self._stream()))
+            _lib.check(self._L.sgx_export_state(self._h, _ptr(st), _ptr(pl), self._stream()), self._L)
         return st, pl
 
     def import_state(self, state, player=None):
@@ -231,12 +231,12 @@ class VecStrategoEnv:
         if player is not None:
             pl = torch.as_tensor(player).to(device=self.device, dtype=torch.int8).contiguous()
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_import_state(self._h, _ptr(st), _ptr(pl), self._stream()))
+            _lib.check(self._L.sgx_import_state(self._h, _ptr(st), _ptr(pl), self._stream()), self._L)
         return self.observe()
 
     def env_info(self):
         """int32 [N,4]: turn count, game number, game_over, current player."""
         out = torch.empty((self.num_envs, 4), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_get_env_info(self._h, _ptr(out), self._stream()))
+            _lib.check(self._L.sgx_get_env_info(self._h, _ptr(out), self._stream()), self._L)
         return out
