@@ -21,6 +21,7 @@ from .config import FO_OBS_CHANNELS, PO_OBS_CHANNELS, NUM_STATE_LAYERS, get_vari
 from .enums import GameVersions, ObservationComponents, ObservationModes
 from .setups import load_setup_table, sample_initial_maps_like_reference
 from .spaces import Box, Dict, Discrete
+from .procedural_env import StrategoProceduralEnv
 from .vec_env import VecStrategoEnv
 
 _NP_DTYPES = {torch.uint8: np.uint8, torch.int8: np.int8, torch.int32: np.int32, torch.float32: np.float32}
@@ -129,6 +130,8 @@ class StrategoMultiAgentEnv:
         self._p_obs_ranges, self._p_obs_mids = obs_norm.ranges_mids(self._p_obs_highs, self._p_obs_lows)   # maenv:388-391
         self._f_obs_ranges, self._f_obs_mids = obs_norm.ranges_mids(self._f_obs_highs, self._f_obs_lows)   # maenv:393-396
         self._build_host_mirror()
+        # the operator-level object the reference exposes (maenv:329); its one-game handle is created on first use
+        self.base_env = StrategoProceduralEnv(v.rows, v.columns, version=v.name, device=device)
         self.rows, self.columns = v.rows, v.columns
         self.spatial_action_size = v.spatial_action_size
         self.action_size = v.action_size
@@ -352,6 +355,7 @@ class StrategoMultiAgentEnv:
 
     def close(self):
         self._vec.close()
+        self.base_env.close()
 
 
 def make_stratego_env(env_config):                                                     # maenv:837-838

@@ -265,5 +265,163 @@ class BatchedStrategoProceduralEnv:
     def get_action_1d_index_from_player_perspective(self, action_index, player):
         return ia.action_1d_from_player_perspective(self.rows, self.columns, action_index, player)
 
+    def get_action_spatial_index_from_1d_index(self, action_index):                                 # penv:135-139
+        sr, sc, er, ec = self.get_action_positions_from_1d_index(action_index)
+        return self.get_action_spatial_index_from_positions(sr, sc, er, ec)
+
     def close(self):
         self._vec.close()
+
+
+def _default_version(rows, columns):
+    """The reference's StrategoProceduralEnv is built from (rows, columns) only; pick the variant of that size with the most
+    pieces (its capture-event capacity covers the others; obstacles are checked per call)."""
+    from .config import VARIANTS
+    cands = [v for v in VARIANTS.values() if v.rows == rows and v.columns == columns]
+    if not cands:
+        raise ValueError("no game variant with a %dx%d board" % (rows, columns))
+    return max(cands, key=lambda v: sum(v.piece_counts)).name
+
+
+class StrategoProceduralEnv:
+    """The reference class of the same name (penv:20-214) for ONE state at a time: same constructor, method names,
+    argument meaning, return types (numpy int64 states and masks, float32 observations, Python scalars) and errors.  It is
+    what `StrategoMultiAgentEnv.base_env` is; every call runs the HIP kernels through a one-game
+    BatchedStrategoProceduralEnv (use that class directly for throughput)."""
+
+    def __init__(self, rows, columns, version=None, device=0):
+        if rows < 3 or columns < 3:
+            raise ValueError("Both rows and columns have to be at least 3 (you passed rows: {} columns: {})."
+                             .format(rows, columns))                                                # penv:28-30
+        self.rows, self.columns = np.int64(rows), np.int64(columns)
+        self.action_size = np.int64(ia.action_size(int(rows), int(columns)))                        # penv:34
+        k = ia.spatial_channels(int(rows), int(columns))
+        self.spatial_action_size = (np.int64(rows), np.int64(columns), np.int64(k))                 # penv:35
+        self._version = version if version is not None else _default_version(int(rows), int(columns))
+        self._device = device
+        self._batched = None
+
+    @property
+    def _b(self):
+        if self._batched is None:
+            self._batched = BatchedStrategoProceduralEnv(self._version, 1, device=self._device)
+        return self._batched
+
+    def _state(self, state):
+        st = np.asarray(state, dtype=np.int64)
+        if st.shape != (NUM_STATE_LAYERS, int(self.rows), int(self.columns)):
+            raise ValueError("state must have shape (34, rows, columns)")
+        if not np.array_equal(st[2] != 0, self._b.variant.obstacle_map() != 0):
+            raise ValueError("the state's obstacle layer differs from the %s variant's (a per-handle constant here)" % self._version)
+        return st[None]
+
+    @staticmethod
+    def _pl(player):
+        return np.asarray([int(player)], dtype=np.int8)
+
+    # ---- state construction / transition ---------------------------------------------------------------------------
+    def create_initial_state(self, obstacle_map, player_1_initial_piece_map, player_2_initial_piece_map, max_turns):
+        correct_shape = (int(self.rows), int(self.columns))
+        for name, m in (("obstacle map", obstacle_map), ("player_1_initial_piece_map map", player_1_initial_piece_map),
+                        ("player_2_initial_piece_map map", player_2_initial_piece_map)):
+            if tuple(np.shape(m)) != correct_shape:
+                raise ValueError("{} needs to be of shape {}, was {}".format(name, correct_shape, np.shape(m)))   # penv:44-55
+        if not np.array_equal(np.asarray(obstacle_map) != 0, self._b.variant.obstacle_map() != 0):
+            raise ValueError("obstacle_map differs from the %s variant's (a per-handle constant here)" % self._version)
+        st = self._b.create_initial_state(np.asarray(player_1_initial_piece_map, dtype=np.int8)[None],
+                                          np.asarray(player_2_initial_piece_map, dtype=np.int8)[None])[0].cpu().numpy()
+        st[5, 1, 0] = int(max_turns)                                                                # StateData.MAX_TURNS (impl:247)
+        return st
+
+    def get_next_state(self, state, player, action_index, allow_piece_oscillation=False):          # penv:148-155
+        ns, _, ok = self._b.get_next_state(self._state(state), self._pl(player), np.asarray([int(action_index)], dtype=np.int64),
+                                           allow_piece_oscillation=allow_piece_oscillation)
+        if not bool(ok[0]):
+            raise ValueError("Couldn't get the next state because the move wasn't valid.")          # impl:902
+        return ns[0].cpu().numpy(), player * -1
+
+    def is_move_valid_by_position(self, state, player, start_r, start_c, end_r, end_c, allow_piece_oscillation=False):
+        return bool(self._b.is_move_valid_by_position(self._state(state), self._pl(player), [int(start_r)], [int(start_c)],
+                                                      [int(end_r)], [int(end_c)], allow_piece_oscillation)[0])
+
+    def is_move_valid_by_1d_index(self, state, player, action_index, allow_piece_oscillation=False):
+        return bool(self._b.is_move_valid_by_1d_index(self._state(state), self._pl(player), [int(action_index)],
+                                                      allow_piece_oscillation)[0])
+
+    # ---- masks -------------------------------------------------------------------------------------------------------
+    def get_valid_moves_as_1d_mask(self, state, player, player_perspective=False):                  # penv:74-80
+        m = self._b.get_valid_moves_as_1d_mask(self._state(state), self._pl(player), player_perspective=player_perspective)
+        return m[0].cpu().numpy().astype(np.int64)
+
+    def get_valid_moves_as_spatial_mask(self, state, player):                                       # penv:127-128
+        return self._b.get_valid_moves_as_spatial_mask(self._state(state), self._pl(player))[0].cpu().numpy().astype(np.int64)
+
+    def get_dict_of_valid_moves_by_position(self, state, player):                                   # penv:82-85
+        return self._b.get_dict_of_valid_moves_by_position(self._state(state), self._pl(player))[0]
+
+    # ---- observations (raw) --------------------------------------------------------------------------------------------
+    def get_fully_observable_observation(self, state, player):                                      # penv:157-160
+        return self._b.get_fully_observable_observation(self._state(state), self._pl(player))[0].cpu().numpy()
+
+    def get_partially_observable_observation(self, state, player):                                  # penv:162-164
+        return self._b.get_partially_observable_observation(self._state(state), self._pl(player))[0].cpu().numpy()
+
+    def get_fully_observable_observation_extended_channels(self, state, player):                    # penv:166-169
+        return self._b.get_fully_observable_observation_extended_channels(self._state(state), self._pl(player))[0].cpu().numpy()
+
+    def get_partially_observable_observation_extended_channels(self, state, player):                # penv:171-173
+        return self._b.get_partially_observable_observation_extended_channels(self._state(state), self._pl(player))[0].cpu().numpy()
+
+    def get_serializable_string_for_fully_observable_state(self, state):                            # penv:175-177
+        return self._b.get_serializable_string_for_fully_observable_state(self._state(state))[0]
+
+    def get_serializable_string_for_partially_observable_state(self, state):                        # penv:179-181
+        return self._b.get_serializable_string_for_partially_observable_state(self._state(state))[0]
+
+    def print_board_to_console(self, state, partially_observable=False, hide_still_piece_markers=True):   # penv:183-214
+        BatchedStrategoProceduralEnv.print_board_to_console(state, partially_observable, hide_still_piece_markers)
+
+    # ---- state algebra -------------------------------------------------------------------------------------------------
+    def get_state_from_player_perspective(self, state, player):                                     # penv:101-103
+        st = np.asarray(state, dtype=np.int64)
+        return self._b.get_state_from_player_perspective(st[None], self._pl(player))[0].cpu().numpy()
+
+    def get_game_ended(self, state, player):                                                        # penv:141-143
+        return np.float32(self._b.get_game_ended(np.asarray(state, dtype=np.int64)[None], self._pl(player))[0].item())
+
+    def get_game_result_is_invalid(self, state):                                                    # penv:145-146
+        return bool(self._b.get_game_result_is_invalid(np.asarray(state, dtype=np.int64)[None])[0])
+
+    # ---- index converters (scalars, like the reference) ---------------------------------------------------------------
+    def get_action_1d_index_from_positions(self, start_r, start_c, end_r, end_c):                   # penv:62-66
+        return np.int64(self._b.get_action_1d_index_from_positions(int(start_r), int(start_c), int(end_r), int(end_c)))
+
+    def get_action_positions_from_1d_index(self, action_index):                                     # penv:68-72
+        return tuple(np.int64(x) for x in self._b.get_action_positions_from_1d_index(int(action_index)))
+
+    def get_action_positions_from_player_perspective(self, player, start_r, start_c, end_r, end_c):   # penv:105-108
+        return tuple(np.int64(x) for x in self._b.get_action_positions_from_player_perspective(
+            int(player), int(start_r), int(start_c), int(end_r), int(end_c)))
+
+    def get_action_1d_index_from_player_perspective(self, action_index, player):                    # penv:110-115
+        return np.int64(self._b.get_action_1d_index_from_player_perspective(int(action_index), int(player)))
+
+    def get_action_spatial_index_from_positions(self, start_r, start_c, end_r, end_c):              # penv:117-121
+        return tuple(np.int64(x) for x in self._b.get_action_spatial_index_from_positions(int(start_r), int(start_c),
+                                                                                          int(end_r), int(end_c)))
+
+    def get_action_positions_from_spatial_index(self, spatial_index):                               # penv:123-125
+        r, c, ch = (int(x) for x in spatial_index)
+        return tuple(np.int64(x) for x in self._b.get_action_positions_from_spatial_index((r, c, ch)))
+
+    def get_action_1d_index_from_spatial_index(self, spatial_index):                                # penv:130-133
+        r, c, ch = (int(x) for x in spatial_index)
+        return np.int64(self._b.get_action_1d_index_from_spatial_index((r, c, ch)))
+
+    def get_action_spatial_index_from_1d_index(self, action_index):                                 # penv:135-139
+        return tuple(np.int64(x) for x in self._b.get_action_spatial_index_from_1d_index(int(action_index)))
+
+    def close(self):
+        if self._batched is not None:
+            self._batched.close()
+            self._batched = None
