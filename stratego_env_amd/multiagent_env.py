@@ -24,6 +24,8 @@ from .spaces import Box, Dict, Discrete
 from .procedural_env import StrategoProceduralEnv
 from .vec_env import VecStrategoEnv
 
+SPATIAL_STRATEGO_ENV = 'SpatialStratego-v1'   # maenv:31
+
 _NP_DTYPES = {torch.uint8: np.uint8, torch.int8: np.int8, torch.int32: np.int32, torch.float32: np.float32}
 
 DEFAULT_CONFIG = {   # maenv:47-69

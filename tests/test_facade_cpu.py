@@ -34,3 +34,11 @@ def test_perspective_flip_matches_oracle():
     for st in g['final_states'][:16].astype(np.int64):
         assert np.array_equal(state_from_player_perspective(st, -1), ru.get_state_from_player_perspective(st, -1))
         assert state_from_player_perspective(st, 1) is st
+
+
+def test_package_exports_match_the_reference_package():
+    """stratego_env/__init__.py:1-2 exports these five names."""
+    import stratego_env_amd as pkg
+    for name in ('ObservationModes', 'ObservationComponents', 'GameVersions', 'StrategoMultiAgentEnv', 'SPATIAL_STRATEGO_ENV'):
+        assert getattr(pkg, name) is not None
+    assert pkg.SPATIAL_STRATEGO_ENV == 'SpatialStratego-v1'
