@@ -107,6 +107,7 @@ class StrategoMultiAgentEnv:
         self.observation_mode = mode
         self._want_p = mode in (ObservationModes.PARTIALLY_OBSERVABLE, ObservationModes.BOTH_OBSERVATIONS)
         self._want_f = mode in (ObservationModes.FULLY_OBSERVABLE, ObservationModes.BOTH_OBSERVATIONS)
+        self.vs_human = self.vs_bot = False                                                 # maenv:429, 436 (GUI / bot links are not built)
         self.penalize_ties = cfg['penalize_ties']
         self.random_player_assignment = cfg['random_player_assignment']
         assert not (cfg['human_inits'] and cfg['curriculum_start_states_path'])           # maenv:332
