@@ -73,6 +73,15 @@ class Variant:
             m[r, c] = 1
         return m
 
+    def as_reference_config(self) -> dict:
+        """The reference's `*_STRATEGO_CONFIG` dict for this variant (game/config.py:3-313): same keys, `piece_amounts`
+        keyed by the SP enum in SPY..BOMB order, obstacle cells as a list of (row, column) tuples."""
+        from .enums import SP
+        return {'rows': self.rows, 'columns': self.columns, 'max_turns': self.max_turns,
+                'obstacle_locations': [tuple(x) for x in self.obstacle_locations],
+                'piece_amounts': {SP(t): n for t, n in enumerate(self.piece_counts, start=1)},
+                'initial_state_usable_rows': self.initial_state_usable_rows}
+
     def captured_count_highs(self) -> Tuple[int, ...]:
         """Normalisation highs of the captured-count channels: count if > 1 else 8 (maenv:288-298)."""
         return tuple(n if n > 1 else 8 for n in self.piece_counts)
@@ -104,3 +113,18 @@ def get_variant(version) -> Variant:
     if version not in VARIANTS:
         raise ValueError("unknown game version {!r}".format(version))
     return VARIANTS[version]
+
+
+# The reference's module-level names (game/config.py, stratego_multiagent_env.py:33-45)
+VERSION_CONFIGS = {GameVersions(name): v.as_reference_config() for name, v in VARIANTS.items()}
+STANDARD_STRATEGO_CONFIG = VERSION_CONFIGS[GameVersions.STANDARD]
+MEDIUM_STANDARD_STRATEGO_CONFIG = VERSION_CONFIGS[GameVersions.MEDIUM_STANDARD]
+SHORT_STANDARD_STRATEGO_CONFIG = VERSION_CONFIGS[GameVersions.SHORT_STANDARD]
+STANDARD_STRATEGO_CONFIG2 = VERSION_CONFIGS[GameVersions.STANDARD2]
+BARRAGE_STRATEGO_CONFIG = VERSION_CONFIGS[GameVersions.BARRAGE]
+SHORT_BARRAGE_STRATEGO_CONFIG = VERSION_CONFIGS[GameVersions.SHORT_BARRAGE]
+OCTA_BARRAGE_STRATEGO_CONFIG = VERSION_CONFIGS[GameVersions.OCTA_BARRAGE]
+MEDIUM_STRATEGO_CONFIG = VERSION_CONFIGS[GameVersions.MEDIUM]
+FIVES_STRATEGO_CONFIG = VERSION_CONFIGS[GameVersions.FIVES]
+TINY_STRATEGO_CONFIG = VERSION_CONFIGS[GameVersions.TINY]
+MICRO_STRATEGO_CONFIG = VERSION_CONFIGS[GameVersions.MICRO]

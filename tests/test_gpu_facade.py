@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from stratego_env_amd import GameVersions, ObservationModes
+from stratego_env_amd.config import VARIANTS
 from tests.helpers import digest_obs, load_expanded, load_games
 
 pytestmark = pytest.mark.gpu
@@ -168,3 +169,49 @@ def test_batched_policy_loop_example_runs(capsys):
         sys.argv = argv
     out = capsys.readouterr().out
     assert 'games finished' in out and '512 tiny games x 40 steps' in out
+
+
+def test_reference_named_setup_helpers_reproduce_reference_resets():
+    """stratego_env_amd.util (create_game_from_data, get_random_human_init_fn, get_random_initial_state_fn: util.py:13-53,
+    241-319) with the reference-style config dicts: the states equal what the reference's reset() built from the same
+    np.random / random seeds (tests/golden/facade_reset.json)."""
+    import json
+    import os
+    import random
+    from stratego_env_amd import config as cfgmod, setups, util
+    from stratego_env_amd.procedural_env import StrategoProceduralEnv
+    from tests.helpers import GOLDEN
+    with open(os.path.join(GOLDEN, 'facade_reset.json')) as f:
+        cases = json.load(f)
+    done = set()
+    for case in cases:
+        key = (case['version'], case['human_inits'])
+        if key in done or case['version'] == 'standard':
+            continue
+        done.add(key)
+        cfg = cfgmod.VERSION_CONFIGS[GameVersions(case['version'])]
+        assert cfg['rows'] == VARIANTS[case['version']].rows and list(cfg['piece_amounts'].values()) == list(VARIANTS[case['version']].piece_counts)
+        penv = StrategoProceduralEnv(cfg['rows'], cfg['columns'], version=case['version'])
+        fn = (util.get_random_human_init_fn(GameVersions(case['version']), cfg, penv) if case['human_inits']
+              else util.get_random_initial_state_fn(penv, cfg))
+        np.random.seed(case['seed'])
+        random.seed(case['seed'])
+        for g in case['games']:
+            np.random.random()                                   # the golden env drew its player assignment first (maenv:538)
+            st = fn()
+            assert st.shape == (34, cfg['rows'], cfg['columns']) and st.dtype == np.int64
+            assert np.array_equal(st[0], np.asarray(g['p1_map'])) and np.array_equal(st[1][::-1, ::-1], np.asarray(g['p2_map']))
+            assert st[5, 1, 0] == cfg['max_turns'] and np.array_equal(st[3] != 0, st[0] != 0)
+        penv.close()
+    # strings and code arrays are interchangeable, and the no-argument procedural_env default works
+    inv = {v: k for k, v in setups.LETTER_TO_CODE.items()}
+    table = setups.load_setup_table('barrage')
+    s1, s2 = (''.join(inv[int(c)] for c in table[i]) for i in (0, 1))
+    cfg = cfgmod.BARRAGE_STRATEGO_CONFIG
+    a = util.create_game_from_data(s1, s2, cfg)
+    b = util.create_game_from_data(table[0], table[1], cfg)
+    assert s1 == 'AAAAALAAKAAAAAAEAACADAAAAAAAABDAAAAAAAAM' and np.array_equal(a, b)      # BARRAGE_INITS[0] (SURVEY 8c)
+    pos = util.create_initial_positions_from_human_data(s1, s2, cfg)
+    assert pos.shape == (2, 10, 10) and np.array_equal(pos[0], a[0]) and np.array_equal(pos[1], a[1][::-1, ::-1])
+    with pytest.raises(ValueError):
+        util.get_random_human_init_fn('tiny', cfgmod.TINY_STRATEGO_CONFIG)
