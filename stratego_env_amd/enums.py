@@ -1,50 +1,23 @@
-"""String-valued enums that are part of the drop-in API (reference: stratego_env/game/enums.py:4-29).
-
-Observation dict keys are the *values* of ObservationComponents; players are the ints 1 and -1.
+"""Enums of the drop-in API.  Member names and values are the reference's (stratego_env/game/enums.py:4-29; piece codes
+stratego_procedural_impl.py:145-163) because they are the interface: observation dicts are keyed by the *values* of
+ObservationComponents, `env_config['version']` takes a GameVersions member, `piece_amounts` is keyed by SP.
+Every string-valued member's value is its lower-cased name; piece codes count up from NOPIECE = 0.
 """
 from enum import Enum
 
 
-class ObservationModes(Enum):
-    PARTIALLY_OBSERVABLE = 'partially_observable'
-    FULLY_OBSERVABLE = 'fully_observable'
-    BOTH_OBSERVATIONS = 'both_observations'
+def _lowercase_enum(name, members):
+    return Enum(name, {m: m.lower() for m in members.split()}, module=__name__)
 
 
-class ObservationComponents(Enum):
-    PARTIAL_OBSERVATION = 'partial_observation'
-    FULL_OBSERVATION = 'full_observation'
-    VALID_ACTIONS_MASK = 'valid_actions_mask'
-    INTERNAL_STATE = 'internal_state'
+ObservationModes = _lowercase_enum('ObservationModes', 'PARTIALLY_OBSERVABLE FULLY_OBSERVABLE BOTH_OBSERVATIONS')
 
+ObservationComponents = _lowercase_enum('ObservationComponents',
+                                        'PARTIAL_OBSERVATION FULL_OBSERVATION VALID_ACTIONS_MASK INTERNAL_STATE')
 
-class GameVersions(Enum):
-    STANDARD = 'standard'
-    SHORT_STANDARD = 'short_standard'
-    MEDIUM_STANDARD = 'medium_standard'
-    STANDARD2 = 'standard2'
-    BARRAGE = 'barrage'
-    SHORT_BARRAGE = 'short_barrage'
-    OCTA_BARRAGE = 'octa_barrage'
-    MEDIUM = 'medium'
-    TINY = 'tiny'
-    MICRO = 'micro'
-    FIVES = 'fives'
+GameVersions = _lowercase_enum('GameVersions', 'STANDARD SHORT_STANDARD MEDIUM_STANDARD STANDARD2 BARRAGE SHORT_BARRAGE '
+                                               'OCTA_BARRAGE MEDIUM TINY MICRO FIVES')
 
-
-class SP(Enum):
-    """Piece codes (reference: stratego_procedural_impl.py:145-163)."""
-    NOPIECE = 0
-    SPY = 1
-    SCOUT = 2
-    MINER = 3
-    SERGEANT = 4
-    LIEUTENANT = 5
-    CAPTAIN = 6
-    MAJOR = 7
-    COLONEL = 8
-    GENERAL = 9
-    MARSHALL = 10
-    FLAG = 11
-    BOMB = 12
-    UNKNOWN = 13
+# Stratego pieces: ranks 1 (spy) .. 10 (marshal), then flag, bomb, and the "unknown" marker of the partially-observable layers
+SP = Enum('SP', 'NOPIECE SPY SCOUT MINER SERGEANT LIEUTENANT CAPTAIN MAJOR COLONEL GENERAL MARSHALL FLAG BOMB UNKNOWN',
+          start=0, module=__name__)
