@@ -135,8 +135,8 @@ class VecStrategoEnv:
         boxes the first dozen allocations are all in the slow class while later ones are fast.  So this allocates
         candidates (all held until the end, so that each one is different memory; at most `max_memory_fraction` of the
         free device memory), times a few `sgx_observe` launches (which write obs + mask and change no state) on each,
-        keeps the fastest and frees the rest.  Call after reset(); returns {'obs': [...], 'mask': [...]} per-candidate
-        launch times in microseconds."""
+        keeps the fastest and frees the rest.  Call after reset(); returns {'obs': [...], ('fobs': [...],) 'mask': [...]}
+        per-candidate launch times in microseconds."""
         def time_observe():
             self.observe()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -149,7 +149,8 @@ class VecStrategoEnv:
 
         report = {}
         mask_trials = min(trials, 8) if mask_trials is None else mask_trials
-        for name, n in (('obs', trials), ('mask', mask_trials)):   # the obs buffer matters most; then the mask
+        todo = [('obs', trials)] + ([('fobs', trials)] if self.fobs is not None else []) + [('mask', mask_trials)]
+        for name, n in todo:   # the observation buffers matter most; then the mask
             cur = getattr(self, name)
             free_b, _ = torch.cuda.mem_get_info(self.device)
             size_b = cur.numel() * cur.element_size()

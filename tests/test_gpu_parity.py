@@ -280,6 +280,12 @@ def test_tune_placement_keeps_outputs():
     env.rollout_step()
     assert int(env.invalid_action.sum()) == 0
     env.close()
+    env = VecStrategoEnv('tiny', 1024, seed=5, auto_reset=True, full_obs=True)       # BOTH mode: the full observation is placed too
+    env.reset()
+    fobs0 = env.fobs.clone()
+    rep = env.tune_placement(trials=2, launches=2)
+    assert sorted(rep) == ['fobs', 'mask', 'obs'] and np.array_equal(env.fobs.cpu().numpy(), fobs0.cpu().numpy())
+    env.close()
 
 
 @pytest.mark.gpu
