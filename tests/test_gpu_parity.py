@@ -33,16 +33,17 @@ def _oracle_batch(name, seed, g0, n):
     ('medium', 32, 300, 0.1), ('fives', 32, 200, 0.1), ('tiny', 64, 200, 0.1), ('micro', 64, 120, 0.1),
     ('short_barrage', 32, 250, 0.1), ('standard2', 4, 150, 0.05),
 ])
-def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage):
-    """Random-valid-action rollouts with auto-reset (+ injected garbage actions): every output of every step."""
+def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0):
+    """Random-valid-action rollouts with auto-reset (+ injected garbage actions): every output of every step.
+    (tools/soak_parity.py re-runs this with other seeds, batch sizes and garbage rates for minutes.)"""
     import torch
     from stratego_env_amd.vec_env import VecStrategoEnv
     v = VARIANTS[name]
-    seed, g0 = 0xABCDEF12345 + len(name), 1000
+    seed, g0 = 0xABCDEF12345 + len(name) + 7919 * seed_salt, 1000 + 31 * seed_salt
     env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True, final_obs=True)
     cv, oenvs = _oracle_batch(name, seed, g0, n_envs)
     NA = v.num_spatial_actions
-    rs = np.random.RandomState(7)
+    rs = np.random.RandomState(7 + seed_salt)
     obs, mask, player = env.reset()
     obs_h, mask_h, player_h = obs.cpu().numpy(), mask.cpu().numpy(), player.cpu().numpy()
     cur = []
@@ -100,7 +101,7 @@ def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage):
             st, pl = env.export_state()
             assert np.array_equal(st.cpu().numpy(), np.stack([oe.state for oe in oenvs])), (name, t, 'state export')
             assert np.array_equal(pl.cpu().numpy(), np.asarray([oe.player for oe in oenvs], dtype=np.int8))
-    assert games_done > 0 or name in ('standard', 'standard2')
+    assert games_done > 0 or name in ('standard', 'standard2', 'medium_standard')
     env.close()
 
 
