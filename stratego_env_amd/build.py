@@ -31,7 +31,7 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc not found: cannot build libstratego_mi355x.so")
     os.makedirs(OUT_DIR, exist_ok=True)
     cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-fvisibility=hidden',
-           '-Wno-unused-value', '-I', INCLUDE, SRC, '-o', LIB_PATH + '.tmp']
+           '-Wall', '-I', INCLUDE, SRC, '-o', LIB_PATH + '.tmp']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)

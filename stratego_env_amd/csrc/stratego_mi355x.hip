@@ -42,7 +42,6 @@ int fail(int code, const char *fmt, const char *detail = "") {
 // ---------------------------------------------------------------------------------------------
 constexpr int OBS_CH = SGX_PO_OBS_CHANNELS;  // 67
 constexpr int LUT_STRIDE = SGX_OBS_LUT_STRIDE;
-constexpr int LUT_SIZE = OBS_CH * LUT_STRIDE;
 // Device placement of the LUT rows.  A wave renders 64 consecutive float4 "quads", so the lanes of one LDS
 // access hold channels 4q+j (mod 67).  Rows are placed so that bank(row(ch)) = (ch/4 + {0,16,1,17}[ch%4]) mod 32:
 // the 32 lanes of an access group then hit 31-32 different banks (a dense ch*16 layout put them all on 2 banks:
@@ -305,7 +304,6 @@ struct ObsKind {
     using P = std::conditional_t<ORIG, OrigPartialObs, PartialObs>;
     using F = std::conditional_t<ORIG, OrigFullObs, FullObs>;
 };
-__device__ inline int clamp15(int v) { return min(max(v, 0), 15); }
 
 // ---------------------------------------------------------------------------------------------
 // Observation render: float32 [R][C][NCH], perspective of player index qi
@@ -344,7 +342,7 @@ __device__ inline void build_quad_table(uint32_t *qtab, int tid, int nthreads) {
 // 490 vs 333 us).  With address-aligned chunks a lane's quad changes every iteration, hence the quad table.
 template <class G, class Spec>
 __device__ void emit_obs(const Lds<G> &L, const float *tab, int qi, float *__restrict__ dst, int lane) {
-    constexpr int RC = G::RC, S = G::S, NCH = Spec::NCH;
+    constexpr int RC = G::RC, NCH = Spec::NCH;
     const int8_t *bb = &L.b[0][0];
     const float *lut = tab;
     if constexpr (RC % 4 == 0) {
@@ -1135,14 +1133,6 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
 // ---------------------------------------------------------------------------------------------
 // export / import in the reference's int64 [N,34,R,C] layout (impl:16-60)
 // ---------------------------------------------------------------------------------------------
-__device__ inline int ref_layer_of_board(int b) {  // internal board -> reference layer
-    if (b < 2) return b;                 // pieces      -> 0/1
-    if (b < 4) return 3 + (b - 2);       // PO pieces   -> 3/4
-    if (b < 6) return 32 + (b - 4);      // still       -> 32/33
-    if (b < 8) return 6 + (b - 6);       // recent      -> 6/7
-    return 8 + (b - 8);                  // captured    -> 8..31
-}
-
 template <int R_, int C_>
 __global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t *__restrict__ player_out) {
     using G = Geo<R_, C_>;
@@ -1521,12 +1511,13 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
 
 SGX_API int sgx_destroy(sgx_env *h) {
     if (!h) return SGX_OK;
-    hipSetDevice(h->device);
-    hipDeviceSynchronize();
-    if (h->boards) hipFree(h->boards);
-    if (h->tab) hipFree(h->tab);
-    if (h->setups) hipFree(h->setups);
-    if (h->stamps) hipFree(h->stamps);
+    // teardown is best effort: there is nobody to report a failed free to
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    if (h->boards) (void)hipFree(h->boards);
+    if (h->tab) (void)hipFree(h->tab);
+    if (h->setups) (void)hipFree(h->setups);
+    if (h->stamps) (void)hipFree(h->stamps);
     delete h;
     return SGX_OK;
 }
