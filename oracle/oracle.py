@@ -46,7 +46,8 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB_PATH)
+        # STRATEGO_ORACLE_LIB selects another build of the same source (the `make asan` library for sanitizer runs)
+        L = C.CDLL(os.environ.get('STRATEGO_ORACLE_LIB') or _LIB_PATH)
         L.so_action_size.restype = I64
         L.so_action_size.argtypes = [I64, I64]
         L.so_spatial_channels.restype = I64
