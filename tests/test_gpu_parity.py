@@ -473,3 +473,70 @@ def test_long_horizon_rollout_with_max_turn_endings():
     info = env.env_info().cpu().numpy()
     assert info[:, 1].min() >= 2                          # every env finished at least two games
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['tiny', 'barrage'])
+def test_manual_partial_resets_match_oracle(name):
+    """The non-auto-reset loop: finished envs stay finished (stepping them is an invalid action, state unchanged) until the
+    caller resets exactly those through `env_select`; a sampled reset starts the env's next game number, other envs are
+    untouched."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    n, T = 48, 260 if name == 'tiny' else 1300
+    seed, g0 = 0x51DE + len(name), 77
+    env = VecStrategoEnv(name, n, seed=seed, env_id_offset=g0, auto_reset=False)
+    cv, oenvs = _oracle_batch(name, seed, g0, n)
+    obs, mask, player = env.reset()
+    cur = [oe._obs(1) for oe in oenvs]
+    finished = np.zeros(n, dtype=bool)
+    resets = 0
+    for t in range(T):
+        acts = np.zeros(n, dtype=np.int32)
+        for e, oe in enumerate(oenvs):
+            acts[e] = orc.sample_action(cur[e][MASK].astype(np.uint8), seed, g0 + e, oe.game_no, int(oe.state[5, 0, 0]))
+        env.step(torch.from_numpy(acts))
+        done_h, inv_h = env.done.cpu().numpy(), env.invalid_action.cpu().numpy()
+        obs_h, mask_h, player_h = env.obs.cpu().numpy(), env.mask.cpu().numpy(), env.player.cpu().numpy()
+        for e, oe in enumerate(oenvs):
+            if finished[e]:
+                # a finished game offers only the no-op; whatever the reference does with it (the oracle is pinned to the
+                # reference on post-terminal steps too), the batched env does the same and the state stays where it was
+                assert int(mask_h[e].sum()) == 1 and mask_h[e][0, 0, -1] == 1
+                before = oe.state.copy()
+                try:
+                    oe.step({oe.player: int(acts[e])})
+                    assert inv_h[e] == 0
+                except ValueError:
+                    assert inv_h[e] == 1
+                assert np.array_equal(oe.state, before)
+                continue
+            o, rew, done, info = oe.step({oe.player: int(acts[e])})
+            assert inv_h[e] == 0 and bool(done_h[e]) == done['__all__']
+            if done['__all__']:
+                finished[e] = True
+                cur[e] = {MASK: o[oe.player][MASK] * 0}
+                cur[e][MASK][0, 0, -1] = 1
+            else:
+                p = oe.player
+                assert player_h[e] == p and np.array_equal(o[p][MASK], mask_h[e]) and o[p][POBS].tobytes() == obs_h[e].tobytes()
+                cur[e] = o[p]
+        if t % 40 == 39 and finished.any():
+            before, _ = env.export_state()
+            sel = torch.from_numpy(finished.astype(np.uint8))
+            obs, mask, player = env.reset(env_select=sel)
+            after, _ = env.export_state()
+            keep = torch.from_numpy(~finished).to(env.device)
+            assert torch.equal(before[keep], after[keep])                       # unselected envs untouched
+            obs_h, mask_h = obs.cpu().numpy(), mask.cpu().numpy()
+            for e in np.flatnonzero(finished):
+                oe = oenvs[e]
+                oe.game_no += 1
+                o = oe.reset(initial_state_override=orc.reset_state(cv, seed, g0 + e, oe.game_no))
+                assert np.array_equal(after[e].cpu().numpy(), oe.state)
+                assert np.array_equal(o[1][MASK], mask_h[e]) and o[1][POBS].tobytes() == obs_h[e].tobytes()
+                cur[e] = o[1]
+                resets += 1
+            finished[:] = False
+    assert resets > 0
+    env.close()
