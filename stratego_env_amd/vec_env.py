@@ -83,6 +83,7 @@ class VecStrategoEnv:
                            if (full_obs and final_obs) else None)
         self.next_actions = torch.zeros((N,), dtype=torch.int32, device=dev)
         self._io = _lib.SgxStepIO()
+        self._next_actions_fresh = False      # next_actions holds a draw for the CURRENT position of every env
 
     # ---- lifecycle -----------------------------------------------------------------------------------
     def close(self):
@@ -115,6 +116,7 @@ class VecStrategoEnv:
             assert m1.shape[1] == self.R * self.Cc and m2.shape == m1.shape
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_reset(self._h, _ptr(sel), _ptr(m1), _ptr(m2), self._stream()), self._L)
+        self._next_actions_fresh = False
         return self.observe()
 
     def observe(self, raw=False, emit_obs=True, emit_mask=True):
@@ -177,6 +179,7 @@ class VecStrategoEnv:
         io = self._fill_io(a, want_next_actions, emit_obs, emit_mask, flags)
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_step(self._h, C.byref(io), self._stream()), self._L)
+        self._next_actions_fresh = bool(want_next_actions)
         return self.obs, self.mask, self.reward, self.done, self.player
 
     def _fill_io(self, a, want_next_actions, emit_obs, emit_mask, flags):
@@ -198,12 +201,17 @@ class VecStrategoEnv:
         return io
 
     def rollout_step(self):
-        """Random-valid-action rollout step: plays `next_actions` (drawn by the previous call) and draws the next."""
+        """Random-valid-action rollout step: plays `next_actions` (drawn by the previous call, or now if there is no
+        current draw) and draws the next."""
+        if not self._next_actions_fresh:
+            self.sample_valid_actions()
         return self.step(self.next_actions, want_next_actions=True)
 
     def rollout_steps(self, n_steps):
         """`n_steps` rollout steps enqueued by one library call (sgx_step_n): same results as calling rollout_step()
         n_steps times, without a Python round trip per step (toy boards are launch-bound otherwise)."""
+        if not self._next_actions_fresh:
+            self.sample_valid_actions()
         io = self._fill_io(self.next_actions, True, True, True, 0)
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_step_n(self._h, C.byref(io), int(n_steps), self._stream()), self._L)
@@ -215,6 +223,8 @@ class VecStrategoEnv:
         out = self.next_actions if out is None else out
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_sample_valid(self._h, _ptr(mask), _ptr(out), self._stream()), self._L)
+        if mask is self.mask and out is self.next_actions:
+            self._next_actions_fresh = True
         return out
 
     def export_state(self):
@@ -233,6 +243,7 @@ class VecStrategoEnv:
             pl = torch.as_tensor(player).to(device=self.device, dtype=torch.int8).contiguous()
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_import_state(self._h, _ptr(st), _ptr(pl), self._stream()), self._L)
+        self._next_actions_fresh = False
         return self.observe()
 
     def env_info(self):

@@ -540,3 +540,22 @@ def test_manual_partial_resets_match_oracle(name):
             finished[:] = False
     assert resets > 0
     env.close()
+
+
+@pytest.mark.gpu
+def test_rollout_steps_draws_first_actions_itself():
+    """rollout_steps() right after reset() (no explicit sample_valid_actions) plays valid moves from the first step on and
+    equals the explicit sequence."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    a = VecStrategoEnv('micro', 300, seed=4, auto_reset=True)
+    b = VecStrategoEnv('micro', 300, seed=4, auto_reset=True)
+    a.reset(); a.rollout_steps(30)
+    b.reset(); b.sample_valid_actions()
+    for _ in range(30):
+        b.rollout_step()
+    assert int(a.invalid_action.sum()) == 0
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.next_actions, b.next_actions) and torch.equal(a.env_info(), b.env_info())
+    a.reset(); a.rollout_step()                     # a reset invalidates the pending draw
+    assert int(a.invalid_action.sum()) == 0
+    a.close(); b.close()
