@@ -1,4 +1,7 @@
-"""Placement sensitivity: several fresh output allocations x game->address map modes, one process, one binary."""
+"""NOTE: historical experiment record -- the SGX_MAP_MODE knob this script drives was removed from the library after the
+study (no game->address map changed the allocation classes); kept for the method, not runnable as is.
+
+Placement sensitivity: several fresh output allocations x game->address map modes, one process, one binary."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,3 +1,7 @@
+"""NOTE: historical experiment record -- the SGX_MAP_MODE knob this script drives was removed from the library after the
+study (no game->address map changed the allocation classes); kept for the method, not runnable as is.
+
+"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
