@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
     __shared__ uint8_t cap[NE];
     __shared__ int8_t recent[2 * RC];
     __shared__ uint8_t still[2 * RC];
-    __shared__ int scan[NT];
+    __shared__ int scan[NT / 64];
     const int tid = threadIdx.x;
     const int64_t env = blockIdx.x;
     if (env >= P.n_envs) return;
@@ -1224,16 +1224,20 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
         const int e = tid * PER + k;
         if (e < NE) cnt += cap[e];
     }
-    scan[tid] = cnt;
-    __syncthreads();
-    for (int o = 1; o < NT; o <<= 1) {
-        const int v = tid >= o ? scan[tid - o] : 0;
-        __syncthreads();
-        scan[tid] += v;
-        __syncthreads();
+    // block-wide inclusive scan: shuffle scan inside each wave, then the four wave totals through LDS
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += v;
     }
+    if ((tid & 63) == 63) scan[tid >> 6] = incl;
+    __syncthreads();
+    int wave_base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) wave_base += scan[w];
+    const int total_events = scan[0] + scan[1] + scan[2] + scan[3];
     {
-        int at = scan[tid] - cnt;
+        int at = wave_base + incl - cnt;
         uint16_t *ev = reinterpret_cast<uint16_t *>(img + G::EVL_OFF);
         for (int k = 0; k < PER; ++k) {
             const int e = tid * PER + k;
@@ -1260,7 +1264,7 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
         const int old_game = rec_scal<G>(P.boards, P.rec_bytes, env)[0].w;
         int4 *scg = reinterpret_cast<int4 *>(img + G::SC_OFF);
         scg[0] = make_int4((int)d[0], flags, (int)d[C], old_game < 0 ? 0 : old_game);
-        scg[1] = make_int4(min(scan[NT - 1], P.max_events), pairs[0], pairs[1], 0);
+        scg[1] = make_int4(min(total_events, P.max_events), pairs[0], pairs[1], 0);
     }
     __syncthreads();
     for (int i = tid; i < P.rec_bytes / 16; i += NT) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(img)[i];
