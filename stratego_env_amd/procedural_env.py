@@ -54,10 +54,16 @@ class BatchedStrategoProceduralEnv:
             _lib.check(vec._L.sgx_import_state(vec._h, st.data_ptr(), pl.data_ptr(), vec._stream()), vec._L)
         return st, pl
 
-    def _perspective_mask_ext(self):
-        """kernels' mask (mover perspective, flat) with one zero column appended."""
+    def _mask_in_state_coordinates(self, table, pl):
+        """The kernels' mask (mover's perspective, flat) re-indexed through `table` [2, M] (row = player index; an entry equal
+        to the number of spatial actions means "always 0"): one column gather per player instead of a per-row index tensor."""
         m = self._vec.mask.view(self.batch_size, -1)
-        return torch.cat([m, torch.zeros((self.batch_size, 1), dtype=m.dtype, device=self.device)], dim=1)
+        na = m.shape[1]
+        per_player = []
+        for k in (0, 1):
+            idx = table[k]
+            per_player.append(m.index_select(1, idx.clamp(max=na - 1)) * (idx < na).to(m.dtype))
+        return torch.where((pl < 0).view(-1, 1), per_player[1], per_player[0])
 
     # ---- state construction / transition -----------------------------------------------------------------------
     def create_initial_state(self, player_1_initial_piece_maps, player_2_initial_piece_maps):      # penv:38-60
@@ -95,9 +101,7 @@ class BatchedStrategoProceduralEnv:
         """uint8 [N,R,C,K] in the coordinates of the given states (no perspective flip), like impl:399-517."""
         _, pl = self._load(states, players)
         self._vec.observe(emit_obs=False)
-        pi = (pl < 0).to(torch.int64)
-        out = torch.gather(self._perspective_mask_ext(), 1, self._spatial_src[pi])
-        return out.view(self.batch_size, *self.spatial_action_size)
+        return self._mask_in_state_coordinates(self._spatial_src, pl).view(self.batch_size, *self.spatial_action_size)
 
     def get_valid_moves_as_1d_mask(self, states, players, player_perspective=False):                # penv:74-80
         """uint8 [N, action_size] in the coordinates of the given states, like impl:520-642 (last element = no-op).
@@ -107,8 +111,7 @@ class BatchedStrategoProceduralEnv:
             states = self.get_state_from_player_perspective(states, players)
         _, pl = self._load(states, players)
         self._vec.observe(emit_obs=False)
-        pi = (pl < 0).to(torch.int64)
-        return torch.gather(self._perspective_mask_ext(), 1, self._onedim_src[pi])
+        return self._mask_in_state_coordinates(self._onedim_src, pl)
 
     def get_dict_of_valid_moves_by_position(self, states, players):                                 # penv:82-85 / impl:1400-1429
         """One dict per state: "start_r,start_c" -> [[end_r, end_c], ...] in ascending 1-D index order."""
