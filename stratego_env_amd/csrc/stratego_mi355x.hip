@@ -1195,12 +1195,24 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
     if (env >= P.n_envs) return;
     int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
     const int64_t *s = in + env * (int64_t)(SGX_STATE_LAYERS * RC);
+    // all of the thread's loads first (the scatter below is branchy, the compiler would otherwise wait for each load in turn:
+    // 13 dependent round trips per block made the kernel latency-bound at 2.4 TB/s)
+    constexpr int NX = SGX_STATE_LAYERS * RC, ITER = (NX + NT - 1) / NT;
+    int64_t rawv[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const int x = tid + k * NT;
+        rawv[k] = x < NX ? s[x] : 0;
+    }
     for (int i = tid; i < IMG / 4; i += NT) reinterpret_cast<uint32_t *>(img)[i] = 0;
     __syncthreads();
-    for (int x = tid; x < SGX_STATE_LAYERS * RC; x += NT) {
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+        const int x = tid + k * NT;
+        if (x >= NX) continue;
         const int l = x / RC, cell = x - l * RC;
         if (l == 2 || l == 5) continue;                               // obstacles are the variant's; scalars below
-        const int64_t raw = s[x];
+        const int64_t raw = rawv[k];
         if (l < 2 || l == 3 || l == 4) {                              // legal range of the layer; anything else -> 0
             const int b = l < 2 ? B_PIECES + l : B_PO + (l - 3), hi = l < 2 ? SP_BOMB : SP_UNKNOWN;
             img[b * S + cell] = (uint8_t)((raw >= 0 && raw <= hi) ? (int)raw : 0);
