@@ -96,6 +96,13 @@ typedef struct sgx_step_io {
  * observations.  obs_dev / final_obs_dev then have 32 channels (impl:1126-1197) and fobs_dev / final_fobs_dev 33
  * (impl:1048-1123), normalised with the constants of maenv:87-199. */
 #define SGX_STEP_ORIGINAL_CHANNELS 16
+/* Masks of the functional API are indexed in the coordinates of the given STATE, not in the mover's perspective:
+ * SGX_STEP_MASK_1D: mask_dev is uint8 [N][R*C*(R+C)+1], get_valid_moves_as_1d_mask (penv:74-80, impl:520-642) of the current mover;
+ * SGX_STEP_MASK_STATE_COORDS: mask_dev is uint8 [N][R][C][K] as get_valid_moves_as_spatial_mask(state, player) returns it for
+ * the current mover WITHOUT the perspective flip (penv:127-128, impl:399-517; identical to the default for player +1).
+ * Both are also accepted by sgx_observe. */
+#define SGX_STEP_MASK_1D 32
+#define SGX_STEP_MASK_STATE_COORDS 64
 
 /* Library / geometry queries (penv:32-36: action_size, spatial_action_size). */
 int sgx_abi_version(void);
@@ -136,7 +143,7 @@ int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p1_maps_d
 
 /* _get_current_obs (maenv:447-497) for every env's current mover, no state change.
  * obs_dev, fobs_dev, mask_dev and player_dev are laid out as in sgx_step_io; each is nullable.
- * flags: 0 or any of SGX_STEP_RAW_OBS, SGX_STEP_ORIGINAL_CHANNELS. */
+ * flags: 0 or any of SGX_STEP_RAW_OBS, SGX_STEP_ORIGINAL_CHANNELS, SGX_STEP_MASK_1D, SGX_STEP_MASK_STATE_COORDS. */
 int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, int8_t *player_dev, int32_t flags, void *stream);
 
 /* One batched env.step(): see sgx_step_io. */

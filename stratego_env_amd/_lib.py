@@ -16,6 +16,7 @@ PO_OBS_CHANNELS_ORIGINAL = 32
 FO_OBS_CHANNELS_ORIGINAL = 33
 ABI_VERSION = 4
 STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, STEP_ORIGINAL_CHANNELS = 1, 2, 4, 8, 16
+STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
 
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (

@@ -547,6 +547,71 @@ __device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) 
     }
 }
 
+// The same mask in another index space: byte i of the output = mask bit src(i) (src(i) < 0: always 0).  Used for the
+// functional operator API, whose masks are indexed in the coordinates of the given STATE rather than in the mover's
+// perspective: the 1-D encoding (impl:520-642) and the spatial encoding for player -1 (impl:399-517 on an unflipped state).
+// 16-byte chunks of the address range like emit_mask; the source index is computed per byte (a handful of integer ops).
+template <class G, class F>
+__device__ void emit_mask_mapped(const Lds<G> &L, uint8_t *__restrict__ dst, int n_bytes, F src, int lane) {
+    const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
+    const int nchunks = (A + n_bytes + 15) >> 4;
+    uint8_t *gbase = dst - A;
+    for (int c = lane; c < nchunks; c += G::LPG) {
+        const int lo = 16 * c - A;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = lo + j;
+            if (i >= 0 && i < n_bytes) {
+                const int b = src(i);
+                if (b >= 0) w[j >> 2] |= ((L.mbits[b >> 5] >> (b & 31)) & 1u) << (8 * (j & 3));
+            }
+        }
+        if (lo >= 0 && lo + 16 <= n_bytes) {
+            i32x4 q4 = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+            stream_store(&reinterpret_cast<i32x4 *>(gbase)[c], q4);
+        } else {
+            for (int j = 0; j < 16; ++j)
+                if (lo + j >= 0 && lo + j < n_bytes) dst[lo + j] = (uint8_t)((w[j >> 2] >> (8 * (j & 3))) & 1u);
+        }
+    }
+}
+
+// perspective channel of the straight move (sr,sc)->(er,ec) given in the mover's perspective (impl:280-311)
+template <class G>
+__device__ inline int channel_of(int sr, int sc, int er, int ec) {
+    constexpr int R = G::R, C = G::C;
+    const int dr = er - sr, dc = ec - sc;
+    return dr > 0 ? dr - 1 : dr < 0 ? (R - 1) + (-dr - 1) : dc > 0 ? 2 * (R - 1) + dc - 1 : 2 * (R - 1) + (C - 1) + (-dc - 1);
+}
+// absolute 1-D action index (impl:262-277) -> bit of the perspective mask of player index qi
+template <class G>
+struct Src1D {
+    int qi;
+    __device__ int operator()(int i) const {
+        constexpr int R = G::R, C = G::C, K = G::K, MPA = G::MPA;
+        if (i == G::AS - 1) return K - 1;                                  // the no-op: [0,0,K-1] in any coordinates
+        const int q = i / MPA, off = i - q * MPA;
+        int sr = q / C, sc = q - sr * C, er, ec;
+        if (off >= R) { er = sr; ec = off - R; } else { er = off; ec = sc; }
+        if (er == sr && ec == sc) return -1;                              // the encoding's null moves
+        if (qi) { sr = R - 1 - sr; sc = C - 1 - sc; er = R - 1 - er; ec = C - 1 - ec; }
+        return (sr * C + sc) * K + channel_of<G>(sr, sc, er, ec);
+    }
+};
+// flat spatial index in the STATE's coordinates -> bit of player -1's perspective mask (cells and directions turn by 180 degrees;
+// the no-op stays at [0,0,K-1])
+template <class G>
+struct SrcSpatialFlipped {
+    __device__ int operator()(int i) const {
+        constexpr int R = G::R, C = G::C, K = G::K, RC = G::RC;
+        const int cell = i / K, ch = i - cell * K;
+        if (ch == K - 1) return cell == 0 ? K - 1 : -1;
+        const int pch = ch < R - 1 ? ch + (R - 1) : ch < 2 * (R - 1) ? ch - (R - 1) : ch < 2 * (R - 1) + (C - 1) ? ch + (C - 1) : ch - (C - 1);
+        return (RC - 1 - cell) * K + pch;
+    }
+};
+
 // k-th (0-based) valid action in ascending flat index order, from L.mbits / L.cnt
 template <class G>
 __device__ int kth_valid(const Lds<G> &L, int k, int lane) {
@@ -964,7 +1029,11 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     STAMP(4);   // results / terminal handling done
     // ---- outputs for the next mover
     if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
-    if (P.io.mask_dev) emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
+    if (P.io.mask_dev) {
+        if (P.io.flags & SGX_STEP_MASK_1D) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
+        else if ((P.io.flags & SGX_STEP_MASK_STATE_COORDS) && qi) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
+        else emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
+    }
     STAMP(5);   // mask stores issued
     // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
     if (P.io.obs_dev) emit_obs<G, PS>(L, lut, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH), lane);
@@ -1596,7 +1665,7 @@ SGX_API int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *ma
     p.mode = 1;
     p.io.obs_dev = obs_dev;
     p.io.fobs_dev = fobs_dev;
-    p.io.flags = flags & (SGX_STEP_RAW_OBS | SGX_STEP_ORIGINAL_CHANNELS);
+    p.io.flags = flags & (SGX_STEP_RAW_OBS | SGX_STEP_ORIGINAL_CHANNELS | SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS);
     p.io.mask_dev = mask_dev;
     p.io.player_dev = player_dev;
     return launch_step(h, p, stream);

@@ -62,38 +62,3 @@ def action_1d_from_player_perspective(R, C, idx, player):       # impl:698-720
         return idx
     flipped = action_1d_from_positions(R, C, *flip_positions(R, C, *positions_from_1d(R, C, idx)))
     return np.where(idx == action_size(R, C) - 1, idx, flipped)
-
-
-def gather_tables(R, C):
-    """Index tables turning the kernels' mover-perspective spatial mask (flat, + one appended zero column at index NA)
-    into the reference's absolute-coordinate masks for each player:
-        spatial_src[pi][a]  : source column for absolute spatial flat index a          (impl:399-517 on the given state)
-        onedim_src[pi][i]   : source column for absolute 1-D index i                   (impl:520-642)
-    pi = 0 for player +1, 1 for player -1."""
-    K, RC, AS = spatial_channels(R, C), R * C, action_size(R, C)
-    NA = RC * K
-    a = np.arange(NA, dtype=np.int64)
-    cell, ch = a // K, a % K
-    r, c = cell // C, cell % C
-    # absolute spatial (r, c, ch) seen from player -1's perspective: cell rotated 180 degrees, opposite direction blocks
-    mr, mc = R - 1, C - 1
-    ch_f = np.where(ch < mr, ch + mr, np.where(ch < 2 * mr, ch - mr, np.where(ch < 2 * mr + mc, ch + mc, np.where(ch < K - 1, ch - mc, ch))))
-    src_m1 = ((R - 1 - r) * C + (C - 1 - c)) * K + ch_f
-    src_m1[ch == K - 1] = NA                     # the no-op channel is never a move ...
-    src_m1[K - 1] = K - 1                        # ... except [0, 0, K-1], which is not flipped (impl:514-515)
-    spatial_src = [a.copy(), src_m1]
-    onedim_src = []
-    i = np.arange(AS - 1, dtype=np.int64)
-    sr, sc, er, ec = positions_from_1d(R, C, i)
-    _, _, chs = spatial_from_positions(R, C, sr, sc, er, ec)
-    ok = (chs >= 0) & (er >= 0) & (er < R) & (ec >= 0) & (ec < C)
-    abs_flat = (sr * C + sc) * K + np.where(ok, chs, 0)
-    for pi in range(2):
-        src = np.where(ok, spatial_src[pi][abs_flat] if pi == 0 else _inverse_lookup(spatial_src[1], abs_flat, NA), NA)
-        onedim_src.append(np.concatenate([src, [K - 1]]).astype(np.int64))     # 1-D no-op <- spatial no-op bit
-    return [t.astype(np.int64) for t in spatial_src], onedim_src
-
-
-def _inverse_lookup(src_table, abs_flat, NA):
-    """perspective column holding absolute spatial index abs_flat (src_table maps absolute -> perspective column)."""
-    return src_table[abs_flat]

@@ -34,9 +34,6 @@ class BatchedStrategoProceduralEnv:
         self.spatial_action_size = v.spatial_action_size                                            # penv:35
         self._vec = VecStrategoEnv(v.name, batch_size, device=device, human_inits=False)
         self.device = self._vec.device
-        sp, od = ia.gather_tables(v.rows, v.columns)
-        self._spatial_src = torch.from_numpy(np.stack(sp)).to(self.device)                          # [2, NA]
-        self._onedim_src = torch.from_numpy(np.stack(od)).to(self.device)                           # [2, AS]
         self._obstacles = torch.from_numpy(v.obstacle_map().astype(np.int64)).to(self.device)
 
     # ---- helpers ---------------------------------------------------------------------------------------------
@@ -54,16 +51,16 @@ class BatchedStrategoProceduralEnv:
             _lib.check(vec._L.sgx_import_state(vec._h, st.data_ptr(), pl.data_ptr(), vec._stream()), vec._L)
         return st, pl
 
-    def _mask_in_state_coordinates(self, table, pl):
-        """The kernels' mask (mover's perspective, flat) re-indexed through `table` [2, M] (row = player index; an entry equal
-        to the number of spatial actions means "always 0"): one column gather per player instead of a per-row index tensor."""
-        m = self._vec.mask.view(self.batch_size, -1)
-        na = m.shape[1]
-        per_player = []
-        for k in (0, 1):
-            idx = table[k]
-            per_player.append(m.index_select(1, idx.clamp(max=na - 1)) * (idx < na).to(m.dtype))
-        return torch.where((pl < 0).view(-1, 1), per_player[1], per_player[0])
+    def _mask_in_state_coordinates(self, one_dim):
+        """Mask of the loaded states' movers, indexed in the states' own coordinates (no perspective flip), rendered by the
+        kernel: SGX_STEP_MASK_1D -> uint8 [N, action_size], SGX_STEP_MASK_STATE_COORDS -> uint8 [N, R, C, K]."""
+        vec = self._vec
+        shape = (self.batch_size, self.action_size) if one_dim else (self.batch_size,) + tuple(self.spatial_action_size)
+        out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(vec._L.sgx_observe(vec._h, None, None, out.data_ptr(), None,
+                                          _lib.STEP_MASK_1D if one_dim else _lib.STEP_MASK_STATE_COORDS, vec._stream()), vec._L)
+        return out
 
     # ---- state construction / transition -----------------------------------------------------------------------
     def create_initial_state(self, player_1_initial_piece_maps, player_2_initial_piece_maps):      # penv:38-60
@@ -99,9 +96,8 @@ class BatchedStrategoProceduralEnv:
     # ---- masks ---------------------------------------------------------------------------------------------------
     def get_valid_moves_as_spatial_mask(self, states, players):                                     # penv:127-128
         """uint8 [N,R,C,K] in the coordinates of the given states (no perspective flip), like impl:399-517."""
-        _, pl = self._load(states, players)
-        self._vec.observe(emit_obs=False)
-        return self._mask_in_state_coordinates(self._spatial_src, pl).view(self.batch_size, *self.spatial_action_size)
+        self._load(states, players)
+        return self._mask_in_state_coordinates(one_dim=False)
 
     def get_valid_moves_as_1d_mask(self, states, players, player_perspective=False):                # penv:74-80
         """uint8 [N, action_size] in the coordinates of the given states, like impl:520-642 (last element = no-op).
@@ -109,9 +105,8 @@ class BatchedStrategoProceduralEnv:
         asks for player -1's moves on the flipped state."""
         if player_perspective:
             states = self.get_state_from_player_perspective(states, players)
-        _, pl = self._load(states, players)
-        self._vec.observe(emit_obs=False)
-        return self._mask_in_state_coordinates(self._onedim_src, pl)
+        self._load(states, players)
+        return self._mask_in_state_coordinates(one_dim=True)
 
     def get_dict_of_valid_moves_by_position(self, states, players):                                 # penv:82-85 / impl:1400-1429
         """One dict per state: "start_r,start_c" -> [[end_r, end_c], ...] in ascending 1-D index order."""
