@@ -10,6 +10,8 @@ their states on the device.  Where the reference raises ValueError for an invali
 Limits (documented in DESIGN.md): states must be reachable ones -- at most two non-zero recent-move cells per player and
 no more captured pieces than pieces exist; the obstacle layer must equal the variant's (it is a per-handle constant).
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -34,6 +36,7 @@ class BatchedStrategoProceduralEnv:
         self.spatial_action_size = v.spatial_action_size                                            # penv:35
         self._vec = VecStrategoEnv(v.name, batch_size, device=device, human_inits=False)
         self.device = self._vec.device
+        self._loaded_key = self._loaded_refs = None     # identity of the states currently imported into the scratch handle
         self._obstacles = torch.from_numpy(v.obstacle_map().astype(np.int64)).to(self.device)
 
     # ---- helpers ---------------------------------------------------------------------------------------------
@@ -47,8 +50,20 @@ class BatchedStrategoProceduralEnv:
             raise ValueError("states must have shape (batch, 34, rows, columns)")
         pl = self._players(players)
         vec = self._vec
-        with torch.cuda.device(self.device):
-            _lib.check(vec._L.sgx_import_state(vec._h, st.data_ptr(), pl.data_ptr(), vec._stream()), vec._L)
+        # consecutive queries on the very same device tensor OBJECTS (mask, then observation, then ... of one batch of search
+        # nodes) import once: same objects (held weakly, so a recycled address cannot alias) and unchanged in-place
+        # modification counters
+        key = None
+        if isinstance(states, torch.Tensor) and isinstance(players, torch.Tensor) and st.data_ptr() == states.data_ptr() \
+                and pl.data_ptr() == players.data_ptr():
+            key = (states._version, players._version)
+        hit = (key is not None and key == self._loaded_key and self._loaded_refs is not None
+               and self._loaded_refs[0]() is states and self._loaded_refs[1]() is players)
+        if not hit:
+            with torch.cuda.device(self.device):
+                _lib.check(vec._L.sgx_import_state(vec._h, st.data_ptr(), pl.data_ptr(), vec._stream()), vec._L)
+            self._loaded_key = key
+            self._loaded_refs = (weakref.ref(states), weakref.ref(players)) if key is not None else None
         return st, pl
 
     def _mask_in_state_coordinates(self, one_dim):
@@ -66,6 +81,7 @@ class BatchedStrategoProceduralEnv:
     def create_initial_state(self, player_1_initial_piece_maps, player_2_initial_piece_maps):      # penv:38-60
         """own-side piece maps int [N,R,C] -> states (obstacle map and max_turns come from the variant)."""
         self._vec.reset(player_1_initial_piece_maps, player_2_initial_piece_maps)
+        self._loaded_key = None
         st, _ = self._vec.export_state()
         return st
 
@@ -75,6 +91,7 @@ class BatchedStrategoProceduralEnv:
         flags = _lib.STEP_ACTIONS_1D | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
         a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.batch_size)
         self._vec.step(a, emit_obs=False, emit_mask=False, flags=flags)
+        self._loaded_key = None
         new_states, new_players = self._vec.export_state()
         return new_states, new_players, self._vec.invalid_action == 0
 
@@ -83,6 +100,7 @@ class BatchedStrategoProceduralEnv:
         flags = _lib.STEP_ACTIONS_1D | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
         a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.batch_size)
         self._vec.step(a, emit_obs=False, emit_mask=False, flags=flags)
+        self._loaded_key = None
         return self._vec.invalid_action == 0
 
     def is_move_valid_by_position(self, states, players, start_r, start_c, end_r, end_c, allow_piece_oscillation=False):  # penv:87-92
@@ -91,6 +109,7 @@ class BatchedStrategoProceduralEnv:
                            for x in (start_r, start_c, end_r, end_c)], dim=1).contiguous()
         flags = _lib.STEP_ACTIONS_POSITIONS | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
         self._vec.step(pos.view(-1), emit_obs=False, emit_mask=False, flags=flags)
+        self._loaded_key = None
         return self._vec.invalid_action == 0
 
     # ---- masks ---------------------------------------------------------------------------------------------------

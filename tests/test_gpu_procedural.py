@@ -180,3 +180,34 @@ def test_facade_exposes_base_env():
     mask = be.get_valid_moves_as_spatial_mask(pp, 1)                                    # maenv:452-454
     assert np.array_equal(mask, obs[env.player]['valid_actions_mask'])
     env.close()
+
+
+def test_repeated_queries_on_the_same_tensors_import_once_and_see_modifications():
+    import torch
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    n = 64
+    env = VecStrategoEnv('barrage', n, seed=12, auto_reset=True)
+    env.reset()
+    env.rollout_steps(40)
+    states, players = env.export_state()
+    penv = BatchedStrategoProceduralEnv('barrage', n)
+    m1 = penv.get_valid_moves_as_1d_mask(states, players)
+    key = penv._loaded_key
+    assert key is not None
+    m2 = penv.get_valid_moves_as_1d_mask(states, players)                 # cached import
+    po = penv.get_partially_observable_observation_extended_channels(states, players)
+    assert torch.equal(m1, m2) and penv._loaded_key == key
+    # an in-place change of the tensor is seen (torch bumps its version counter)
+    env.rollout_steps(7)
+    s2, p2 = env.export_state()
+    states.copy_(s2); players.copy_(p2)
+    m3 = penv.get_valid_moves_as_1d_mask(states, players)
+    fresh = BatchedStrategoProceduralEnv('barrage', n)
+    assert torch.equal(m3, fresh.get_valid_moves_as_1d_mask(s2, p2)) and not torch.equal(m3, m1)
+    # a transition invalidates the cache
+    a = torch.argmax((m3 != 0).to(torch.int8), dim=1)
+    penv.get_next_state(states, players, a)
+    assert penv._loaded_key is None
+    assert torch.equal(penv.get_valid_moves_as_1d_mask(states, players), m3)
+    env.close(); penv.close(); fresh.close()
