@@ -559,3 +559,32 @@ def test_rollout_steps_draws_first_actions_itself():
     a.reset(); a.rollout_step()                     # a reset invalidates the pending draw
     assert int(a.invalid_action.sum()) == 0
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_cabi_error_returns_on_device():
+    """Negative return codes + sgx_last_error text instead of exceptions or crashes; nothing is created on failure."""
+    import ctypes as C
+    from stratego_env_amd import _lib
+    L = _lib.load()
+    cfg = _lib.make_config(VARIANTS['barrage'])
+    h = C.c_void_p()
+    assert L.sgx_create(C.byref(cfg), 0, 0, 1, 0, C.byref(h)) == -1 and not h.value and b'n_envs' in L.sgx_last_error()
+    assert L.sgx_create(C.byref(cfg), 16, 99, 1, 0, C.byref(h)) == -1 and not h.value and b'device' in L.sgx_last_error()
+    bad = _lib.make_config(VARIANTS['barrage'])
+    bad.rows, bad.cols = 7, 7                                   # a size no reference variant uses: not built
+    bad.usable_rows = 2
+    assert L.sgx_create(C.byref(bad), 16, 0, 1, 0, C.byref(h)) == -1 and not h.value and b'unsupported board size' in L.sgx_last_error()
+    assert L.sgx_create(C.byref(cfg), 16, 0, 1, 0, None) == -1
+    assert L.sgx_create(C.byref(cfg), 16, 0, 1, 0, C.byref(h)) == 0 and h.value
+    assert L.sgx_step(h, None, None) == -1
+    io = _lib.SgxStepIO()
+    assert L.sgx_step(h, C.byref(io), None) == -1 and b'actions_dev' in L.sgx_last_error()
+    assert L.sgx_reset(h, None, C.c_void_p(1), None, None) == -1 and b'both piece maps' in L.sgx_last_error()
+    assert L.sgx_sample_valid(h, None, None, None) == -1
+    assert L.sgx_export_state(h, None, None, None) == -1 and L.sgx_import_state(h, None, None, None) == -1
+    tab = (C.c_uint8 * 40)(*([13] + [0] * 39))                   # piece code 13 is not a piece
+    assert L.sgx_set_setup_table(h, tab, 1) == -1 and b'piece code' in L.sgx_last_error()
+    assert L.sgx_num_envs(h) == 16 and L.sgx_spatial_channels(h) == 37 and L.sgx_num_spatial_actions(h) == 3700
+    assert L.sgx_action_size_1d(h) == 2001
+    assert L.sgx_destroy(h) == 0 and L.sgx_destroy(None) == 0
