@@ -100,7 +100,7 @@ typedef struct sgx_step_io {
  * SGX_STEP_MASK_1D: mask_dev is uint8 [N][R*C*(R+C)+1], get_valid_moves_as_1d_mask (penv:74-80, impl:520-642) of the current mover;
  * SGX_STEP_MASK_STATE_COORDS: mask_dev is uint8 [N][R][C][K] as get_valid_moves_as_spatial_mask(state, player) returns it for
  * the current mover WITHOUT the perspective flip (penv:127-128, impl:399-517; identical to the default for player +1).
- * Both are also accepted by sgx_observe. */
+ * Both are also accepted by sgx_observe; they cannot be combined with fobs_dev / final_fobs_dev or SGX_STEP_ORIGINAL_CHANNELS. */
 #define SGX_STEP_MASK_1D 32
 #define SGX_STEP_MASK_STATE_COORDS 64
 

@@ -571,6 +571,7 @@ __device__ void emit_mask_mapped(const Lds<G> &L, uint8_t *__restrict__ dst, int
             i32x4 q4 = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
             stream_store(&reinterpret_cast<i32x4 *>(gbase)[c], q4);
         } else {
+#pragma unroll                                   // (a rolled loop would index w[] dynamically: scratch memory for the whole kernel)
             for (int j = 0; j < 16; ++j)
                 if (lo + j >= 0 && lo + j < n_bytes) dst[lo + j] = (uint8_t)((w[j >> 2] >> (8 * (j & 3))) & 1u);
         }
@@ -755,7 +756,7 @@ __device__ inline void write_record(Lds<G> &L, int8_t *rec_g, int rec_bytes, int
 }
 
 // One game's env.step() by one wave (called with the wave's private LDS region).
-template <int R_, int C_, int KIND>
+template <int R_, int C_, int KIND, bool MAPPED>
 __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, const float *lut_s, const uint8_t *obst_s, const int64_t env,
                                          const int lane) {
     using G = Geo<R_, C_>;
@@ -1030,8 +1031,10 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     // ---- outputs for the next mover
     if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
     if (P.io.mask_dev) {
-        if (P.io.flags & SGX_STEP_MASK_1D) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
-        else if ((P.io.flags & SGX_STEP_MASK_STATE_COORDS) && qi) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
+        // MAPPED: the separate instantiation behind SGX_STEP_MASK_1D / SGX_STEP_MASK_STATE_COORDS (kept out of the hot kernel: its
+        // 16 index computations per lane cost 30 VGPRs)
+        if (MAPPED && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
+        else if (MAPPED && qi) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
         else emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
     }
     STAMP(5);   // mask stores issued
@@ -1069,7 +1072,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
 
 // KIND bit 0: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492);
 // KIND bit 1: obs_channel_mode 'original' (32/33 value channels) instead of 'extended' (67/79 one-hot channels)
-template <int R_, int C_, int KIND>
+template <int R_, int C_, int KIND, bool MAPPED = false>
 __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) void step_kernel(const KParams P) {
     using G = Geo<R_, C_>;
     using PS = typename ObsKind<KIND>::P;
@@ -1094,7 +1097,7 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) vo
     }
     for (int i = threadIdx.x; i < G::S / 4; i += 64 * WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
     __syncthreads();   // from here on every wave works on its own game
-    if (env < P.n_envs) env_step<R_, C_, KIND>(P, LW[slot], lut_s, obst_s, env, lane);
+    if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], lut_s, obst_s, env, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1645,7 +1648,12 @@ static int launch_step(sgx_env *h, const KParams &p, void *stream) {
 #define CALL_STEP1(R, C) CALL_STEP_KIND(R, C, 1)
 #define CALL_STEP2(R, C) CALL_STEP_KIND(R, C, 2)
 #define CALL_STEP3(R, C) CALL_STEP_KIND(R, C, 3)
-    if (!original && !full) DISPATCH_GEOMETRY(h, CALL_STEP0);
+    if (p.io.flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) {
+        if (full || original) return fail(SGX_EINVAL, "state-coordinate masks come with the 67-channel partial observation only%s");
+#define CALL_STEP_MAPPED(R, C) step_kernel<R, C, 0, true><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p)
+        DISPATCH_GEOMETRY(h, CALL_STEP_MAPPED);
+#undef CALL_STEP_MAPPED
+    } else if (!original && !full) DISPATCH_GEOMETRY(h, CALL_STEP0);
     else if (!original) DISPATCH_GEOMETRY(h, CALL_STEP1);
     else if (!full) DISPATCH_GEOMETRY(h, CALL_STEP2);
     else DISPATCH_GEOMETRY(h, CALL_STEP3);

@@ -160,3 +160,26 @@ def test_product_package_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), f
                 assert 'stratego_oracle' not in src or f == 'stratego_mi355x.hip', f
+
+
+def test_hot_kernels_use_no_scratch_memory(tmp_path):
+    """Resource guard for the kernels bench.py measures: the gfx950 ISA of step_kernel<R,C,0,false> (partial observation,
+    perspective mask) must not spill (scratch = 0) and must fit the register budget of its occupancy target.  (A helper that
+    is only reachable through a rare flag once cost the hot kernel 30 VGPRs and scratch: such paths get their own instantiation.)"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    out = tmp_path / 'k.s'
+    subprocess.check_call([hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '--cuda-device-only', '-S', '-I', hip_build.INCLUDE,
+                           hip_build.SRC, '-o', str(out)], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    seen = 0
+    for m in re.finditer(r'\.name:\s+(\S*step_kernelILi(\d+)ELi(\d+)ELi0ELb0E\S*)', text):
+        blk = text[max(0, m.start() - 1500):m.end() + 800]
+        scratch = int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk).group(1))
+        vgpr = int(re.search(r'\.vgpr_count:\s+(\d+)', blk).group(1))
+        cells = int(m.group(2)) * int(m.group(3))
+        assert scratch == 0, (m.group(1), scratch)
+        assert vgpr <= (64 if cells <= 64 else 80), (m.group(1), vgpr)      # 8 waves/SIMD on small boards, 6 on the others
+        seen += 1
+    assert seen == 7
