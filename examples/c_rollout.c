@@ -6,7 +6,10 @@
  *   gcc -std=c11 -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_rollout.c \
  *       -Lstratego_env_amd/_build -lstratego_mi355x -L/opt/rocm/lib -lamdhip64 \
  *       -Wl,-rpath,$PWD/stratego_env_amd/_build -Wl,-rpath,/opt/rocm/lib -o examples/c_rollout
- *   examples/c_rollout stratego_env_amd/inits/barrage_setups.npy [n_envs] [steps] [seed]
+ *   examples/c_rollout stratego_env_amd/inits/barrage_setups.npy [n_envs] [steps] [seed] [bench]
+ *
+ * With a fifth argument the steps are enqueued by one sgx_step_n call, nothing is copied to the host, and the program
+ * prints env steps per second measured with HIP events (the bench.py figure, from C).
  *
  * Prints games finished, invalid actions (must be 0) and the rolling FNV-1a digest of env 0's outputs
  * (mask, observation, rewards, done/player/ending_invalid), which tests/test_gpu_c_example.py compares with the oracle.
@@ -102,6 +105,30 @@ int main(int argc, char **argv) {
     io.next_actions_dev = actions;      /* the step draws each env's next action itself */
     io.auto_reset = 1;
 
+    if (argc > 5) {
+        /* the observation buffer's allocation decides 312 vs 400 us per step: try a few, keep the fastest */
+        float best_us = 0.f;
+        SGX_TRY(sgx_time_observe(h, obs, mask, 4, stream, &best_us));
+        for (int c = 0; c < 23; c++) {
+            float *cand, us;
+            if (hipMalloc((void **)&cand, N * obs_n * sizeof(float)) != hipSuccess) break;
+            SGX_TRY(sgx_time_observe(h, cand, mask, 4, stream, &us));
+            if (us < best_us) { best_us = us; io.obs_dev = cand; }         /* (rejected candidates are kept until exit, */
+        }                                                                  /*  so that every candidate is different memory) */
+        hipEvent_t e0, e1;
+        HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+        SGX_TRY(sgx_step_n(h, &io, 32, stream));                           /* warm-up */
+        HIP_OK(hipEventRecord(e0, stream));
+        SGX_TRY(sgx_step_n(h, &io, steps, stream));
+        HIP_OK(hipEventRecord(e1, stream));
+        HIP_OK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        printf("envs %lld steps %d: %.1f us per batched step, %.1f M env steps/s\n", (long long)N, steps, ms / steps * 1e3,
+               (double)N * steps / ms / 1e3);
+        SGX_TRY(sgx_destroy(h));
+        return 0;
+    }
     float *obs_h = (float *)malloc(obs_n * sizeof(float));
     uint8_t *mask_h = (uint8_t *)malloc(mask_n), *done_h = (uint8_t *)malloc((size_t)N), *inv_h = (uint8_t *)malloc((size_t)N);
     uint64_t digest = 0xCBF29CE484222325ull;

@@ -146,6 +146,13 @@ int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p1_maps_d
  * flags: 0 or any of SGX_STEP_RAW_OBS, SGX_STEP_ORIGINAL_CHANNELS, SGX_STEP_MASK_1D, SGX_STEP_MASK_STATE_COORDS. */
 int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, int8_t *player_dev, int32_t flags, void *stream);
 
+/* Average duration in microseconds of `launches` sgx_observe calls writing obs_dev / mask_dev (either may be NULL), measured
+ * with HIP events on `stream`; synchronises that stream.  The caller owns the output buffers, and on MI355X the same kernel
+ * runs 312-400 us depending on WHICH allocation the observation buffer is: a host allocates a few
+ * candidates, times each with this call and keeps the fastest (what VecStrategoEnv.tune_placement does from Python).
+ * No reference counterpart. */
+int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int32_t launches, void *stream, float *microseconds);
+
 /* One batched env.step(): see sgx_step_io. */
 int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);
 

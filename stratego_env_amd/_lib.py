@@ -22,7 +22,7 @@ STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
     'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
-    'sgx_observe', 'sgx_step', 'sgx_step_n', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_get_env_info',
+    'sgx_observe', 'sgx_time_observe', 'sgx_step', 'sgx_step_n', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_get_env_info',
 )
 
 
@@ -76,6 +76,8 @@ def _bind(L):
     L.sgx_reset.argtypes = [vp, vp, vp, vp, vp]
     L.sgx_observe.restype = C.c_int
     L.sgx_observe.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp]
+    L.sgx_time_observe.restype = C.c_int
+    L.sgx_time_observe.argtypes = [vp, vp, vp, C.c_int32, vp, C.POINTER(C.c_float)]
     L.sgx_step.restype = C.c_int
     L.sgx_step.argtypes = [vp, C.POINTER(SgxStepIO), vp]
     L.sgx_step_n.restype = C.c_int

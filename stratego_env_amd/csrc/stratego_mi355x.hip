@@ -1679,6 +1679,28 @@ SGX_API int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *ma
     return launch_step(h, p, stream);
 }
 
+SGX_API int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int32_t launches, void *stream, float *microseconds) {
+    if (!h || !microseconds || launches <= 0) return fail(SGX_EINVAL, "bad argument%s");
+    HIP_TRY(hipSetDevice(h->device));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = sgx_observe(h, obs_dev, nullptr, mask_dev, nullptr, 0, stream);       // untimed first touch
+    if (rc == SGX_OK) {
+        hipError_t e = hipEventRecord(e0, (hipStream_t)stream);
+        for (int32_t i = 0; i < launches && rc == SGX_OK; ++i) rc = sgx_observe(h, obs_dev, nullptr, mask_dev, nullptr, 0, stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (rc == SGX_OK && e != hipSuccess) rc = fail(SGX_EDEVICE, "timing events: %s", hipGetErrorString(e));
+        *microseconds = ms * 1000.f / (float)launches;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 SGX_API int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream) {
     if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
     if (!io->actions_dev) return fail(SGX_EINVAL, "actions_dev is NULL%s");
