@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 4
+#define SGX_ABI_VERSION 5
 #define SGX_MAX_CELLS 256        /* rows*cols <= 256 (largest reference variant: 15x15) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
 #define SGX_FO_OBS_CHANNELS 79   /* impl:1227 */
