@@ -51,3 +51,61 @@ def digest_obs(obs):
         h.update(np.ascontiguousarray(obs[p]['valid_actions_mask']).astype(np.uint8).tobytes())
         h.update(np.ascontiguousarray(obs[p]['partial_observation'], dtype=np.float32).tobytes())
     return int.from_bytes(h.digest()[:8], 'little')
+
+
+def _blank_state(R, C, max_turns, turn=0):
+    st = np.zeros((34, R, C), dtype=np.int64)
+    st[5, 0, 0] = turn
+    st[5, 1, 0] = max_turns
+    return st
+
+
+def _put(st, player, r, c, t, known=False, moved=False):
+    pi = 0 if player == 1 else 1
+    st[pi, r, c] = t
+    st[3 + pi, r, c] = t if known else 13
+    st[32 + pi, r, c] = 0 if moved else 1
+
+
+def directed_positions():
+    """Constructed 4x4 positions for the SURVEY A.8 quirks: every (attacker, defender) pair for both players as the attacker,
+    at an ordinary turn and on the last allowed turn (flag capture there still wins, anything else ends the game as invalid),
+    scout moves with and without reveal, and the no-op of a stuck mover.  -> (states int64 [n,34,4,4], players int8, legal
+    1-D actions).  Used by tests/test_gpu_procedural.py (GPU vs oracle) and tools/oracle/check_directed_vs_reference.py
+    (oracle vs the reference, build container)."""
+    R = C = 4
+    max_turns = VARIANTS['tiny'].max_turns
+    ru = orc.OracleRules(R, C)
+    states, players, actions = [], [], []
+    for mover in (1, -1):
+        for turn in (3, max_turns - 1):
+            for att in range(1, 11):                                   # spy .. marshal (flag and bomb cannot move)
+                for dfn in range(1, 13):
+                    st = _blank_state(R, C, max_turns, turn)
+                    _put(st, mover, 1, 1, att)
+                    _put(st, -mover, 2, 1, dfn)
+                    _put(st, mover, 0, 3, 11)                          # both flags somewhere out of the way
+                    if dfn != 11:
+                        _put(st, -mover, 3, 3, 11)
+                    _put(st, -mover, 3, 0, 5, moved=True)              # a spare mover so "opponent has no move" is not the result
+                    states.append(st); players.append(mover)
+                    actions.append(ru.get_action_1d_index_from_positions(1, 1, 2, 1))
+    # scout moves: long move over empty cells reveals it, a one-cell move does not; a long move that attacks reveals the survivor
+    for mover in (1, -1):
+        for (er, ec, dfn) in ((3, 1, 0), (2, 1, 0), (3, 1, 4), (3, 1, 1)):
+            st = _blank_state(R, C, max_turns, 5)
+            _put(st, mover, 1, 1, 2)
+            if dfn:
+                _put(st, -mover, er, ec, dfn)
+            _put(st, mover, 0, 3, 11); _put(st, -mover, 3, 3, 11); _put(st, -mover, 0, 0, 5, moved=True)
+            states.append(st); players.append(mover)
+            actions.append(ru.get_action_1d_index_from_positions(1, 1, er, ec))
+    # the no-op: only legal when the mover is stuck; it ends the game at once, even on the last turn (no max-turn check)
+    for mover in (1, -1):
+        for turn in (2, max_turns - 1):
+            st = _blank_state(R, C, max_turns, turn)
+            _put(st, mover, 0, 0, 11); _put(st, mover, 0, 1, 12)        # flag + bomb: nothing can move
+            _put(st, -mover, 3, 3, 11); _put(st, -mover, 3, 2, 6)
+            states.append(st); players.append(mover)
+            actions.append(ru.action_size - 1)
+    return np.stack(states), np.asarray(players, dtype=np.int8), np.asarray(actions, dtype=np.int64)

@@ -211,3 +211,34 @@ def test_repeated_queries_on_the_same_tensors_import_once_and_see_modifications(
     assert penv._loaded_key is None
     assert torch.equal(penv.get_valid_moves_as_1d_mask(states, players), m3)
     env.close(); penv.close(); fresh.close()
+
+
+def test_directed_combat_matrix_and_quirks_vs_oracle():
+    """SURVEY A.8 quirks on constructed positions (tests.helpers.directed_positions): next state, next mover, validity, game
+    result and both observations against the oracle (which tools/oracle/check_directed_vs_reference.py pins to the reference
+    on the same positions)."""
+    import torch
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    from tests.helpers import directed_positions
+    ru = orc.OracleRules(4, 4)
+    states, players, actions = directed_positions()
+    n = len(states)
+    penv = BatchedStrategoProceduralEnv('tiny', n)
+    ns, npl, ok = penv.get_next_state(states, players, actions)
+    ns, npl, ok = ns.cpu().numpy(), npl.cpu().numpy(), ok.cpu().numpy()
+    ended = penv.get_game_ended(torch.from_numpy(ns), torch.from_numpy(npl)).cpu().numpy()
+    po = penv.get_partially_observable_observation_extended_channels(torch.from_numpy(ns), torch.from_numpy(npl)).cpu().numpy()
+    fo = penv.get_fully_observable_observation_extended_channels(torch.from_numpy(ns), torch.from_numpy(npl)).cpu().numpy()
+    wins = invalid_endings = 0
+    for i in range(n):
+        want, wpl = ru.get_next_state(states[i], int(players[i]), int(actions[i]))       # every constructed move is legal
+        assert ok[i], i
+        assert np.array_equal(ns[i], want), (i, int(players[i]), int(actions[i]))
+        assert npl[i] == wpl
+        assert np.float32(ended[i]) == np.float32(ru.get_game_ended(want, wpl)), i
+        assert po[i].tobytes() == ru.get_partially_observable_observation_extended_channels(want, wpl).tobytes(), i
+        assert fo[i].tobytes() == ru.get_fully_observable_observation_extended_channels(want, wpl).tobytes(), i
+        wins += int(want[5, 0, 1] == 1 and want[5, 0, 2] != 0)
+        invalid_endings += int(want[5, 1, 1] == 1)
+    assert wins > 0 and invalid_endings > 0
+    penv.close()
