@@ -183,3 +183,10 @@ def test_hot_kernels_use_no_scratch_memory(tmp_path):
         assert vgpr <= (64 if cells <= 64 else 80), (m.group(1), vgpr)      # 8 waves/SIMD on small boards, 6 on the others
         seen += 1
     assert seen == 7
+
+
+def test_missing_library_fails_loudly():
+    """No fallback path: a missing .so is an error at load time, and the env class propagates it."""
+    with pytest.raises(_lib.SgxError) as ei:
+        _lib.load('/nonexistent/libstratego_mi355x.so')
+    assert 'no CPU fallback' in str(ei.value)
