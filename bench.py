@@ -83,7 +83,12 @@ def cpu_baseline(version, seed, target_seconds):
     t0 = time.perf_counter()
     total, _, _ = orc.rollout(cv, seed, 0, n_envs, n_steps, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": total / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+    # SURVEY 8d also asks for the one-thread figure: ~2 s of the same workload on one core
+    n1 = max(8, int(rate / cores * 2.0 / n_steps))
+    t1 = time.perf_counter()
+    total1, _, _ = orc.rollout(cv, seed, 0, n1, n_steps, threads=1)
+    one_thread = total1 / (time.perf_counter() - t1)
+    return {"value": total / dt, "unit": "env steps/s", "cores": cores, "kind": "port", "value_1_thread": one_thread,
             "sample": "%d %s games x %d steps (envs 0..%d of the same seeded workload), oracle C port with OpenMP over "
                       "games on %d threads, %.1f s" % (n_envs, version, n_steps, n_envs - 1, cores, dt)}
 
