@@ -226,6 +226,17 @@ def test_full_size_rollout_properties_and_oracle_digests():
             tail = np.asarray([dn[i], pl[i], ei[i], 0], dtype=np.int32)
             digs[i] = orc.fnv1a(digs[i], mk[i].tobytes() + ob[i].tobytes() + rw[i].tobytes() + tail.tobytes())
             fin[i] += int(dn[i])
+    # piece conservation on every one of the 65,536 exported states: pieces on the board + captured pieces = the variant's set;
+    # what the opponent knows is the truth or UNKNOWN exactly where pieces stand; nothing overlaps
+    st, _ = env.export_state()
+    counts = torch.tensor(VARIANTS['barrage'].piece_counts, device=env.device)
+    for pi, cap0 in ((0, 8), (1, 20)):
+        on_board = torch.stack([(st[:, pi] == t).sum(dim=(1, 2)) for t in range(1, 13)], dim=1)
+        captured = st[:, cap0:cap0 + 12].sum(dim=(2, 3))
+        assert bool((on_board + captured == counts).all())
+        known = st[:, 3 + pi]
+        assert bool(((known != 0) == (st[:, pi] != 0)).all()) and bool(((known == st[:, pi]) | (known == 13)).all())
+    assert not bool(((st[:, 0] != 0) & (st[:, 1] != 0)).any())
     cv = oracle_cvariant('barrage', setups=S.load_setup_table('barrage'))
     for i in range(n_chk):
         total, d, f = orc.rollout(cv, seed, int(ids[i]), 1, T, threads=1)
