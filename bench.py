@@ -200,8 +200,9 @@ def main():
                                                        "separate" if args.unfused else "fused"),
                        "games_per_gpu": n, "version": args.version, "seed": BASE_SEED,
                        "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns),
-                       # per-candidate launch times of the start-up placement trial: the fastest is kept
-                       "placement_trial_us": ({k: {"candidates": len(t), "min": round(min(t), 1),
+                       # per-candidate sgx_observe times of the start-up placement trial: the fastest is kept;
+                       # "first" is the allocation the env would have used without the trial
+                       "placement_trial_us": ({k: {"candidates": len(t), "first": round(t[0], 1), "min": round(min(t), 1),
                                                    "median": round(sorted(t)[len(t) // 2], 1), "max": round(max(t), 1)}
                                                for k, t in placement_us.items()} if placement_us else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
