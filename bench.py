@@ -211,7 +211,7 @@ def main():
                          "kernel": "step_kernel<%d,%d>" % (v.rows, v.columns),
                          "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:            # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
