@@ -155,6 +155,8 @@ class StrategoMultiAgentEnv:
         if self._want_f:
             spaces[_FOBS] = Box(np.float32(-1.0), np.float32(1.0), (v.rows, v.columns, self._f_obs_num_layers))
         if self.observation_includes_internal_state:
+            if not self.use_curriculum_inits:
+                self._random_initial_maps()      # the reference samples a state here just for its shape (maenv:419-425): same draws
             spaces[_ISTATE] = Box(np.float32(-np.inf), np.float32(np.inf), (NUM_STATE_LAYERS, v.rows, v.columns))
         self.observation_space = Dict(spaces)
         self.player = 1

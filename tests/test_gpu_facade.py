@@ -215,3 +215,52 @@ def test_reference_named_setup_helpers_reproduce_reference_resets():
     assert pos.shape == (2, 10, 10) and np.array_equal(pos[0], a[0]) and np.array_equal(pos[1], a[1][::-1, ::-1])
     with pytest.raises(ValueError):
         util.get_random_human_init_fn('tiny', cfgmod.TINY_STRATEGO_CONFIG)
+
+
+def test_facade_options_replay_reference_goldens():
+    """repeat_games_from_other_side, penalize_ties, observation_includes_internal_state, same_start_pos_everytime,
+    reset(first_player_override=...) -- every reset and step against outputs recorded from the reference
+    (tools/oracle/gen_golden_facade_options.py)."""
+    import hashlib
+    import json
+    import os
+    from stratego_env_amd.multiagent_env import StrategoMultiAgentEnv
+    from tests.helpers import GOLDEN
+
+    def obs_digest(obs):
+        h = hashlib.sha256()
+        for p in sorted(obs.keys()):
+            for comp in sorted(obs[p].keys()):
+                a = np.asarray(obs[p][comp])
+                a = a.astype(np.uint8) if comp == 'valid_actions_mask' else a.astype(np.int64) if comp == 'internal_state' else a
+                h.update(comp.encode())
+                h.update(np.ascontiguousarray(a).tobytes())
+        return h.hexdigest()[:16]
+
+    with open(os.path.join(GOLDEN, 'facade_options.json')) as f:
+        cases = json.load(f)
+    tied = 0
+    for case in cases:
+        cfg = dict(case['cfg'])
+        cfg['version'] = GameVersions(cfg['version'])
+        cfg['observation_mode'] = ObservationModes(cfg.get('observation_mode', 'partially_observable'))
+        np.random.seed(case['seed'])
+        random.seed(case['seed'])
+        env = StrategoMultiAgentEnv(cfg)
+        for ep in case['episodes']:
+            obs = env.reset(first_player_override=case['first_player_override'])
+            assert sorted(int(k) for k in obs) == ep['keys'] and sorted(list(obs.values())[0].keys()) == ep['comps'], case['name']
+            assert env.player == ep['player'] and obs_digest(obs) == ep['init'], case['name']
+            for t, srec in enumerate(ep['steps']):
+                k = list(obs.keys())[0]
+                valid = np.flatnonzero(obs[k]['valid_actions_mask'].reshape(-1))
+                a = int(valid[(7919 * t) % len(valid)])
+                assert a == srec['a']
+                obs, rew, done, info = env.step({k: a})
+                assert sorted(int(x) for x in obs) == srec['keys'] and obs_digest(obs) == srec['d'], (case['name'], t)
+                assert bool(done['__all__']) == srec['done']
+                assert {str(kk): float(vv) for kk, vv in rew.items()} == srec['rew'], (case['name'], t)
+                assert {str(kk): vv for kk, vv in info.items()} == srec['info'], (case['name'], t)
+                tied += int(srec['done'] and case['name'] == 'penalize_ties' and srec['rew'].get('1') == -0.5)
+        env.close()
+    assert tied > 0                      # the -0.5 / -0.5 ending was exercised
