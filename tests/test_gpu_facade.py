@@ -247,8 +247,12 @@ def test_facade_options_replay_reference_goldens():
         np.random.seed(case['seed'])
         random.seed(case['seed'])
         env = StrategoMultiAgentEnv(cfg)
-        for ep in case['episodes']:
-            obs = env.reset(first_player_override=case['first_player_override'])
+        first_state = None
+        for e_i, ep in enumerate(case['episodes']):
+            override = first_state if (case.get('override_second_reset') and e_i == 1) else None
+            obs = env.reset(first_player_override=case['first_player_override'], initial_state_override=override)
+            if first_state is None:
+                first_state = np.array(env.state, copy=True)
             assert sorted(int(k) for k in obs) == ep['keys'] and sorted(list(obs.values())[0].keys()) == ep['comps'], case['name']
             assert env.player == ep['player'] and obs_digest(obs) == ep['init'], case['name']
             for t, srec in enumerate(ep['steps']):
@@ -256,7 +260,11 @@ def test_facade_options_replay_reference_goldens():
                 valid = np.flatnonzero(obs[k]['valid_actions_mask'].reshape(-1))
                 a = int(valid[(7919 * t) % len(valid)])
                 assert a == srec['a']
-                obs, rew, done, info = env.step({k: a})
+                if case.get('one_dim'):
+                    a1 = int(env.base_env.get_action_1d_index_from_spatial_index(np.unravel_index(a, env.base_env.spatial_action_size)))
+                    obs, rew, done, info = env.step({k: a1}, is_spatial_index=False, allow_piece_oscillation=True)
+                else:
+                    obs, rew, done, info = env.step({k: a})
                 assert sorted(int(x) for x in obs) == srec['keys'] and obs_digest(obs) == srec['d'], (case['name'], t)
                 assert bool(done['__all__']) == srec['done']
                 assert {str(kk): float(vv) for kk, vv in rew.items()} == srec['rew'], (case['name'], t)
