@@ -160,7 +160,10 @@ class VecStrategoEnv:
             cands, times = [cur], []
             for i in range(n):
                 if i:
-                    cands.append(torch.empty(tuple(cur.shape), dtype=cur.dtype, device=self.device))
+                    try:
+                        cands.append(torch.empty(tuple(cur.shape), dtype=cur.dtype, device=self.device))
+                    except torch.cuda.OutOfMemoryError:      # somebody else holds the memory: settle for the candidates so far
+                        break
                 setattr(self, name, cands[i])
                 times.append(time_observe())
             setattr(self, name, cands[min(range(len(cands)), key=lambda i: times[i])])
