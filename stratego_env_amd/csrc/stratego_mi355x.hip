@@ -679,21 +679,22 @@ __device__ void sample_boards(Lds<G> &L, const KParams &P, uint64_t g, uint64_t 
             place(L, 0, r * C + c, s1[(U - 1 - r) * C + c]);           // p1 own-side row r = string row U-1-r
             place(L, 1, RC - n + x, s2[x]);                            // absolute rows R-U.. = string rows 0..
         }
-    } else if (lane == 0) {
-        uint8_t *loc = L.cnt;  // scratch, n <= CNT_PAD
-        for (int pl = 0; pl < 2; ++pl) {
-            for (int i = 0; i < n; ++i) loc[i] = (uint8_t)i;
-            for (int i = n - 1; i > 0; --i) {
-                const uint32_t k = rng_below(sgx_rng(P.seed, g, j, pl ? STREAM_SHUFFLE_P2 : STREAM_SHUFFLE_P1, (uint32_t)i), (uint32_t)(i + 1));
-                const uint8_t t = loc[i]; loc[i] = loc[k]; loc[k] = t;
-            }
-            int at = 0;
-            for (int t = 1; t <= 12; ++t)
-                for (int q = 0; q < P.piece_counts[t - 1]; ++q) {
-                    const int own_cell = loc[at++];                        // own-side (r, c), r < U
-                    place(L, pl, pl ? RC - 1 - own_cell : own_cell, t);    // p2 map rotated 180 degrees (impl:221)
-                }
+    } else if (lane < 2) {
+        // the two players' Fisher-Yates shuffles are independent (own RNG stream, own boards): lane 0 places player +1,
+        // lane 1 player -1, each in its own half of the scratch (2n <= cells <= CNT_PAD)
+        const int pl = lane;
+        uint8_t *loc = L.cnt + pl * n;
+        for (int i = 0; i < n; ++i) loc[i] = (uint8_t)i;
+        for (int i = n - 1; i > 0; --i) {
+            const uint32_t k = rng_below(sgx_rng(P.seed, g, j, pl ? STREAM_SHUFFLE_P2 : STREAM_SHUFFLE_P1, (uint32_t)i), (uint32_t)(i + 1));
+            const uint8_t t = loc[i]; loc[i] = loc[k]; loc[k] = t;
         }
+        int at = 0;
+        for (int t = 1; t <= 12; ++t)
+            for (int q = 0; q < P.piece_counts[t - 1]; ++q) {
+                const int own_cell = loc[at++];                        // own-side (r, c), r < U
+                place(L, pl, pl ? RC - 1 - own_cell : own_cell, t);    // p2 map rotated 180 degrees (impl:221)
+            }
     }
     wave_sync<G>();
 }
