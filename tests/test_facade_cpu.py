@@ -42,3 +42,24 @@ def test_package_exports_match_the_reference_package():
     for name in ('ObservationModes', 'ObservationComponents', 'GameVersions', 'StrategoMultiAgentEnv', 'SPATIAL_STRATEGO_ENV'):
         assert getattr(pkg, name) is not None
     assert pkg.SPATIAL_STRATEGO_ENV == 'SpatialStratego-v1'
+
+
+def test_curriculum_init_fn_draws_like_the_reference():
+    """util.get_random_curriculum_init_fn (util.py:372-387): the first draw after np.random.seed(s) is the start state the
+    reference's reset() produced for that seed (tests/golden/curriculum.json), turn count cleared and max_turns patched."""
+    import hashlib
+    import json
+    import os
+    from stratego_env_amd import util
+    from stratego_env_amd.config import VARIANTS
+    from tests.helpers import GOLDEN
+    with open(os.path.join(GOLDEN, 'curriculum.json')) as f:
+        cases = json.load(f)
+    fn = util.get_random_curriculum_init_fn(os.path.join(GOLDEN, 'curriculum_barrage.npz'), VARIANTS['barrage'].max_turns)
+    for case in cases:
+        if case['same_start_pos_everytime']:
+            continue
+        np.random.seed(case['seed'])
+        state, winner = fn()
+        assert hashlib.sha256(np.ascontiguousarray(state).tobytes()).hexdigest()[:16] == case['games'][0]['state']
+        assert winner in (1, -1) and state[5, 0, 0] == 0 and state[5, 1, 0] == VARIANTS['barrage'].max_turns
