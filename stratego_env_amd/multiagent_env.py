@@ -93,6 +93,12 @@ class StrategoMultiAgentEnv:
         cfg.update(env_config if env_config else {})
         self.variant = get_variant(cfg['version'])
         v = self.variant
+        # the reference merges env_config over the version's config dict (maenv:323), so a caller could override single variant
+        # fields (and only some code paths would honour them); variants are compiled-in constants here: refuse instead of diverging
+        overridden = [k for k in ('rows', 'columns', 'max_turns', 'obstacle_locations', 'piece_amounts', 'initial_state_usable_rows')
+                      if env_config and k in env_config and env_config[k] != self.variant.as_reference_config()[k]]
+        if overridden:
+            raise NotImplementedError("env_config overrides variant fields %s; pick one of the built game versions" % overridden)
         for key in ('vs_human', 'vs_bot'):
             if cfg[key]:
                 raise NotImplementedError("%s is outside the MI355X hot-path build (SURVEY.md section 8)" % key)

@@ -4,6 +4,7 @@ import os
 import random
 
 import numpy as np
+import pytest
 
 from stratego_env_amd import setups as S
 from stratego_env_amd.config import VARIANTS
@@ -63,3 +64,10 @@ def test_curriculum_init_fn_draws_like_the_reference():
         state, winner = fn()
         assert hashlib.sha256(np.ascontiguousarray(state).tobytes()).hexdigest()[:16] == case['games'][0]['state']
         assert winner in (1, -1) and state[5, 0, 0] == 0 and state[5, 1, 0] == VARIANTS['barrage'].max_turns
+
+
+def test_facade_refuses_per_env_variant_overrides():
+    from stratego_env_amd import GameVersions
+    from stratego_env_amd.multiagent_env import StrategoMultiAgentEnv
+    with pytest.raises(NotImplementedError):
+        StrategoMultiAgentEnv({'version': GameVersions.BARRAGE, 'max_turns': 50})
