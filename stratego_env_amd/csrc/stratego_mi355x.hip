@@ -1073,8 +1073,8 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
 
 // KIND bit 0: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492);
 // KIND bit 1: obs_channel_mode 'original' (32/33 value channels) instead of 'extended' (67/79 one-hot channels)
-template <int R_, int C_, int KIND, bool MAPPED = false>
-__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) void step_kernel(const KParams P) {
+template <int R_, int C_, int KIND, bool MAPPED>
+__device__ __forceinline__ void game_kernel_body(const KParams &P) {
     using G = Geo<R_, C_>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
@@ -1099,6 +1099,18 @@ __global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) vo
     for (int i = threadIdx.x; i < G::S / 4; i += 64 * WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
     __syncthreads();   // from here on every wave works on its own game
     if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], lut_s, obst_s, env, lane);
+}
+
+// sgx_step and sgx_observe run the same body (P.mode tells them apart at run time: specialising the body on the mode changed the
+// step kernel's schedule and cost 3.7 % on Barrage); two kernel symbols, so that a kernel trace keeps the env.step() launches
+// apart from the state-preserving observe launches (placement trials, reset())
+template <int R_, int C_, int KIND, bool MAPPED = false>
+__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) void step_kernel(const KParams P) {
+    game_kernel_body<R_, C_, KIND, MAPPED>(P);
+}
+template <int R_, int C_, int KIND, bool MAPPED = false>
+__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) void observe_kernel(const KParams P) {
+    game_kernel_body<R_, C_, KIND, MAPPED>(P);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1644,14 +1656,22 @@ static int launch_step(sgx_env *h, const KParams &p, void *stream) {
     const int gpw = h->cfg.rows * h->cfg.cols <= 16 ? 4 : (h->cfg.rows * h->cfg.cols <= 32 ? 2 : 1);   // Geo::GPW
     const unsigned grid = grid_for((h->n_envs + WPB * gpw - 1) / (WPB * gpw));
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
-#define CALL_STEP_KIND(R, C, KIND) step_kernel<R, C, KIND><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p)
+#define CALL_STEP_KIND(R, C, KIND)                                                                 \
+    do {                                                                                           \
+        if (p.mode) observe_kernel<R, C, KIND><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p);     \
+        else step_kernel<R, C, KIND><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p);               \
+    } while (0)
 #define CALL_STEP0(R, C) CALL_STEP_KIND(R, C, 0)
 #define CALL_STEP1(R, C) CALL_STEP_KIND(R, C, 1)
 #define CALL_STEP2(R, C) CALL_STEP_KIND(R, C, 2)
 #define CALL_STEP3(R, C) CALL_STEP_KIND(R, C, 3)
     if (p.io.flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) {
         if (full || original) return fail(SGX_EINVAL, "state-coordinate masks come with the 67-channel partial observation only%s");
-#define CALL_STEP_MAPPED(R, C) step_kernel<R, C, 0, true><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p)
+#define CALL_STEP_MAPPED(R, C)                                                                     \
+    do {                                                                                           \
+        if (p.mode) observe_kernel<R, C, 0, true><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p);  \
+        else step_kernel<R, C, 0, true><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p);            \
+    } while (0)
         DISPATCH_GEOMETRY(h, CALL_STEP_MAPPED);
 #undef CALL_STEP_MAPPED
     } else if (!original && !full) DISPATCH_GEOMETRY(h, CALL_STEP0);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel stats + PMC passes of bench.py, results under gpurun_out/prof_<tag>/.
-# (bench.py runs with --placement-trials 1 here: the placement trial launches sgx_observe, which is the same kernel symbol as
-# sgx_step and would otherwise be averaged into the step kernel's statistics.)
+# (bench.py runs with --placement-trials 1 here to keep the profiled runs short; sgx_observe launches -- placement trials, reset() --
+# have their own kernel symbol, observe_kernel, and do not mix into step_kernel's statistics.)
 # usage: tools/gpu_profile.sh <tag> [extra bench args]
 TAG=$1; shift
 export TMPDIR=/tmp
