@@ -18,7 +18,9 @@ LIB_PATH = os.path.join(OUT_DIR, 'libstratego_mi355x.so')
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
-    newest = max(os.path.getmtime(SRC), os.path.getmtime(os.path.join(INCLUDE, 'stratego_mi355x.h')))
+    csrc = os.path.dirname(SRC)
+    deps = [SRC, os.path.join(INCLUDE, 'stratego_mi355x.h')] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.h')]
+    newest = max(os.path.getmtime(f) for f in deps)
     return os.path.getmtime(LIB_PATH) < newest
 
 

@@ -1,0 +1,275 @@
+// sgx_layout.h -- geometry, HBM record / LDS layout, kernel parameters, counter RNG, per-game wave helpers, observation channel specs
+// Part of libstratego_mi355x.so; included by stratego_mi355x.hip in this order (one translation unit).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Geometry and layout
+// ---------------------------------------------------------------------------------------------
+constexpr int OBS_CH = SGX_PO_OBS_CHANNELS;  // 67
+constexpr int LUT_STRIDE = SGX_OBS_LUT_STRIDE;
+// Device placement of the LUT rows.  A wave renders 64 consecutive float4 "quads", so the lanes of one LDS
+// access hold channels 4q+j (mod 67).  Rows are placed so that bank(row(ch)) = (ch/4 + {0,16,1,17}[ch%4]) mod 32:
+// the 32 lanes of an access group then hit 31-32 different banks (a dense ch*16 layout put them all on 2 banks:
+// 78 % of LDS cycles were bank conflicts, profiles/r01_v1_*).  Two 16-entry rows share each 33-dword pitch.
+constexpr int FOBS_CH = SGX_FO_OBS_CHANNELS;  // 79
+constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 673 /* >= 20*33 (79 channels), = 1 mod 32 */, LUT_DWORDS = 2 * LUT_BLK + 2;  // 1348
+#ifndef SGX_WPB
+#define SGX_WPB 8
+#endif
+#ifndef SGX_MIN_WAVES
+#define SGX_MIN_WAVES 6
+#endif
+constexpr int WPB = SGX_WPB;  // waves per workgroup (WPB * Geo::GPW games); they share the LUT
+// per observation kind in LDS: the LUT followed by the quad table (2 perspectives x NCH quads x 4 packed entries, see emit_obs)
+constexpr int QTAB_DWORDS = 2 * OBS_CH * 4, OBS_TAB_DWORDS = LUT_DWORDS + QTAB_DWORDS;   // partial kind; the full kind follows it
+constexpr int FOBS_TAB_DWORDS = LUT_DWORDS + 2 * FOBS_CH * 4;
+__host__ __device__ constexpr int lut_row(int ch) { return ((ch >> 1) & 1) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH + (ch & 1) * 16; }
+
+// internal board indices inside an env record (each board is S bytes, absolute coordinates)
+constexpr int B_PIECES = 0;   // +pi : true pieces of player index pi (0 = player +1, 1 = player -1)   impl layers 0/1
+constexpr int B_PO = 2;       // +pi : what the opponent knows of pi's pieces                           impl layers 3/4
+constexpr int B_STILL = 4;    // +pi : never-moved flags                                                impl layers 32/33
+constexpr int B_RECENT = 6;   // +pi : two-square bookkeeping (LDS only, rebuilt from scal)             impl layers 6/7
+constexpr int B_CAP = 8;      // +12*pi + (type-1) : captured counts (LDS only, rebuilt from events)    impl layers 8-19 / 20-31
+constexpr int N_BOARDS = 32;
+constexpr int STORED_BOARDS = 4;  // boards 0..3 live in HBM as bytes; never-moved flags as bitmaps; the rest sparsely:
+//   recent moves: at most two non-zero cells per player (impl:1013-1028)  -> two (cell, code) pairs per player in scal
+//   captured counts: one event (board - B_CAP, cell) per captured piece   -> uint16 list, <= 2 * pieces per side entries
+constexpr int B_OBST = 32;    // LDS only: per-variant obstacle map (impl layer 2)
+
+// record scalars (32 B at SC_OFF): {turn, flags, max_turns, game_no} {n_events, recent pairs of +1, recent pairs of -1, 0}
+// a recent pair is cell | (code & 0xFF) << 8, two pairs per int (low / high half); code 0 = empty
+constexpr int F_OVER = 1, F_WIN_P1 = 2, F_WIN_M1 = 4, F_END_INVALID = 8, F_PLAYER_M1 = 16;
+
+enum { SP_SPY = 1, SP_SCOUT = 2, SP_MINER = 3, SP_MARSHALL = 10, SP_FLAG = 11, SP_BOMB = 12, SP_UNKNOWN = 13 };
+
+template <int R_, int C_>
+struct Geo {
+    static constexpr int R = R_, C = C_;
+    static constexpr int RC = R * C;
+    static constexpr int S = (RC + 3) & ~3;           // board stride (bytes)
+    static constexpr int LDS_BOARDS_BYTES = N_BOARDS * S;            // bytes of the 32 LDS boards (multiple of 128)
+    // HBM record (a multiple of 128 B, so every record is read and written as whole cache lines):
+    //   [0, 4S) four dense boards (true pieces, PO pieces) | zero padding to 16 | ST_OFF: never-moved bitmaps 2 x SB |
+    //   SC_OFF: 32 B scalars | EVL_OFF: capture events uint16[max_events] | zero padding
+    //   10x10: Barrage 512 B (4 lines), Standard 640 B (5 lines)
+    static constexpr int ST_OFF = (STORED_BOARDS * S + 15) & ~15;
+    static constexpr int SB = (((RC + 7) / 8) + 15) & ~15;           // bytes of one never-moved bitmap (bit i = cell i)
+    static constexpr int SC_OFF = ST_OFF + 2 * SB, EVL_OFF = SC_OFF + 32;
+    static constexpr int EVL_MAX = RC;                               // 2 * pieces per side <= cells
+    static constexpr int TAIL_BYTES = 2 * SB + 32 + ((2 * EVL_MAX + 15) & ~15);   // LDS image of the record from ST_OFF on
+    static constexpr int K = 2 * (R - 1) + 2 * (C - 1) + 1;
+    static constexpr int NA = RC * K;                 // spatial actions
+    static constexpr int NA_PAD = (NA + 15) & ~15;
+    static constexpr int MB_WORDS = (((NA + 31) / 32 + 1) + 3) & ~3;  // mask as bits in LDS (+1 slack word), multiple of 4
+    static constexpr int MPA = R + C;
+    static constexpr int AS = RC * MPA + 1;           // 1-D action size (impl:252-254)
+    static constexpr int NOBS = RC * OBS_CH;          // floats per observation
+    // Lanes per game.  A 64-lane wave is one game on boards of more than 32 cells; toy boards share a wave between 2 or 4
+    // games (each VALU instruction costs 4 cycles whether 12 or 64 lanes do useful work: one 3x4 game per wave ran the chip
+    // at the VALU issue limit with 80 % of the lanes idle).  Everything below that says `lane` means the lane inside the game.
+    static constexpr int LPG = RC <= 16 ? 16 : (RC <= 32 ? 32 : 64);   // (6x6 with two games per wave measured 5 % slower)
+    static constexpr int GPW = 64 / LPG;              // games per wave
+    static constexpr int CPL = (RC + LPG - 1) / LPG;  // cells per lane
+    static constexpr int CNT_PAD = CPL * LPG;
+};
+
+struct DevTables {
+    // observation LUTs, rows at lut_row(ch); index = 4 * original + 2 * raw + full:
+    //   original: obs_channel_mode 'original' (32/33 channels) instead of 'extended' (67/79)
+    //   raw: SGX_STEP_RAW_OBS, un-normalised channel values (penv:157-173 return raw observations)
+    //   full: the fully-observable observation instead of the partial one
+    float lut[8][LUT_DWORDS];
+    uint8_t obstacles[SGX_MAX_CELLS];
+};
+
+struct KParams {
+    int8_t *boards;
+    const DevTables *tab;
+    const uint8_t *setups;
+    int32_t n_setups;
+    int32_t max_turns;
+    int32_t usable_rows;
+    int32_t piece_counts[12];
+    int32_t rec_bytes;   // bytes of one env record in HBM: EVL_OFF + 2 * max_events rounded up to 128
+    int32_t max_events;
+    int64_t n_envs;
+    uint64_t seed;
+    int64_t env_id_offset;
+    sgx_step_io io;
+    int32_t mode;  // 0 = step, 1 = observe
+#ifdef SGX_STAMPS
+    unsigned long long *stamps;  // diagnostic build only: [N][16] s_memtime stamps per phase
+#endif
+};
+
+#ifdef SGX_STAMPS
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        unsigned long long t_;                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (lane == 0 && P.stamps) P.stamps[env * 16 + (i)] = t_;                                  \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// streaming stores of the big outputs (written once per step, read by a later kernel)
+#ifdef SGX_NT_STORES
+template <class T> __device__ inline void stream_store(T *p, T v) { __builtin_nontemporal_store(v, p); }
+#else
+template <class T> __device__ inline void stream_store(T *p, T v) { *p = v; }
+#endif
+
+// per-wave LDS: one game
+template <class G>
+struct alignas(16) Lds {
+    int8_t b[N_BOARDS + 1][G::S];
+    alignas(16) uint32_t mbits[G::MB_WORDS];           // valid-actions mask of the next mover, one BIT per action
+    alignas(16) uint8_t cnt[G::CNT_PAD];               // valid moves per perspective cell (also setup-shuffle scratch)
+    alignas(16) uint8_t occ[G::S];                     // gen_mask scratch: combined occupancy byte per cell
+    alignas(16) uint8_t plist[G::CNT_PAD];             // gen_mask scratch: compacted list of movable cells
+    alignas(16) uint8_t tail[G::TAIL_BYTES];           // record image from ST_OFF on: bitmaps, 32 B scalars, capture-event list
+};
+
+// ---------------------------------------------------------------------------------------------
+// Counter RNG of the synthetic-rollout harness; restated in oracle/stratego_oracle.c
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t sm_fin(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__host__ __device__ inline uint64_t sgx_rng(uint64_t seed, uint64_t g, uint64_t j, uint32_t stream, uint32_t t) {
+    uint64_t h = sm_fin(seed + 0x9E3779B97F4A7C15ull * (g + 1));
+    uint64_t ctr = ((uint64_t)stream << 32) | t;
+    return sm_fin(h ^ (j * 0xD1B54A32D192ED03ull + ctr * 0x8CB92BA72F3D8DD7ull + 0x2545F4914F6CDD1Dull));
+}
+__host__ __device__ inline uint32_t rng_below(uint64_t r, uint32_t n) { return (uint32_t)(((r >> 32) * (uint64_t)n) >> 32); }
+enum { STREAM_SETUP = 0, STREAM_ACTION = 1, STREAM_SHUFFLE_P1 = 2, STREAM_SHUFFLE_P2 = 3 };
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+template <class G>
+__device__ inline int4 *rec_scal(int8_t *boards, int rec_bytes, int64_t env) {
+    return reinterpret_cast<int4 *>(boards + env * (int64_t)rec_bytes + G::SC_OFF);
+}
+
+// A value that is the same in every lane of a game: an SGPR when the game is the whole wave, left alone otherwise.
+template <class G>
+__device__ inline int uni(int x) {
+    if constexpr (G::LPG == 64) return __builtin_amdgcn_readfirstlane(x);
+    else return x;
+}
+// Ballot over the lanes of this lane's game (bit i = lane i of the game).
+template <class G>
+__device__ inline unsigned long long gballot(bool pred) {
+    const unsigned long long b = __ballot(pred);
+    if constexpr (G::LPG == 64) return b;
+    else return (b >> (__lane_id() & ~(G::LPG - 1))) & ((1ull << G::LPG) - 1ull);
+}
+
+// XCD-aware block -> env map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+// range of envs so neighbouring envs' output lines meet in one L2.
+__device__ inline int64_t group_of_block() {
+    const int64_t nb = gridDim.x, b = blockIdx.x;
+    return (b & 7) * (nb >> 3) + (b >> 3);   // grid is a multiple of 8
+}
+
+// Orders the LDS phases of ONE wave (each wave owns its game's LDS region; waves of a workgroup never exchange
+// data after the LUT is staged).  DS operations of a wave execute in issue order, so only the compiler has to be
+// kept from moving LDS accesses across the phase boundary.
+template <class G>
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Observation channel specs: board holding channel `ch` for perspective player index qi, and the LUT index bias
+// (recent-moves codes are -3..1).  Partial: impl:1306-1332; full: impl:1200-1227; perspective swap impl:645-675.
+struct PartialObs {
+    static constexpr int NCH = OBS_CH;
+    __device__ static inline int board(int ch, int qi) {
+        if (ch < 12) return B_PIECES + qi;
+        if (ch < 25) return B_PO + qi;
+        if (ch < 38) return B_PO + (1 - qi);
+        if (ch == 38) return B_OBST;
+        if (ch == 39) return B_RECENT + qi;
+        if (ch == 40) return B_RECENT + (1 - qi);
+        if (ch < 53) return B_CAP + 12 * qi + (ch - 41);
+        if (ch < 65) return B_CAP + 12 * (1 - qi) + (ch - 53);
+        if (ch == 65) return B_STILL + qi;
+        return B_STILL + (1 - qi);
+    }
+    __device__ static inline int bias(int ch) { return (ch == 39 || ch == 40) ? 3 : 0; }
+};
+struct FullObs {
+    static constexpr int NCH = FOBS_CH;
+    __device__ static inline int board(int ch, int qi) {
+        if (ch < 12) return B_PIECES + qi;
+        if (ch < 24) return B_PIECES + (1 - qi);
+        if (ch < 37) return B_PO + qi;
+        if (ch < 50) return B_PO + (1 - qi);
+        if (ch == 50) return B_OBST;
+        if (ch == 51) return B_RECENT + qi;
+        if (ch == 52) return B_RECENT + (1 - qi);
+        if (ch < 65) return B_CAP + 12 * qi + (ch - 53);
+        if (ch < 77) return B_CAP + 12 * (1 - qi) + (ch - 65);
+        if (ch == 77) return B_STILL + qi;
+        return B_STILL + (1 - qi);
+    }
+    __device__ static inline int bias(int ch) { return (ch == 51 || ch == 52) ? 3 : 0; }
+};
+// obs_channel_mode='original' (maenv:368-375): channels hold piece VALUES; partial impl:1126-1148, full impl:1048-1070
+struct OrigPartialObs {
+    static constexpr int NCH = SGX_PO_OBS_CHANNELS_ORIGINAL;
+    __device__ static inline int board(int ch, int qi) {
+        if (ch == 0) return B_PIECES + qi;
+        if (ch == 1) return B_PO + qi;
+        if (ch == 2) return B_PO + (1 - qi);
+        if (ch == 3) return B_OBST;
+        if (ch == 4) return B_RECENT + qi;
+        if (ch == 5) return B_RECENT + (1 - qi);
+        if (ch < 18) return B_CAP + 12 * qi + (ch - 6);
+        if (ch < 30) return B_CAP + 12 * (1 - qi) + (ch - 18);
+        if (ch == 30) return B_STILL + qi;
+        return B_STILL + (1 - qi);
+    }
+    __device__ static inline int bias(int ch) { return (ch == 4 || ch == 5) ? 3 : 0; }
+};
+struct OrigFullObs {
+    static constexpr int NCH = SGX_FO_OBS_CHANNELS_ORIGINAL;
+    __device__ static inline int board(int ch, int qi) {
+        if (ch == 0) return B_PIECES + qi;
+        if (ch == 1) return B_PIECES + (1 - qi);
+        if (ch == 2) return B_OBST;
+        if (ch == 3) return B_RECENT + qi;
+        if (ch == 4) return B_RECENT + (1 - qi);
+        if (ch == 5) return B_PO + qi;
+        if (ch == 6) return B_PO + (1 - qi);
+        if (ch < 19) return B_CAP + 12 * qi + (ch - 7);
+        if (ch < 31) return B_CAP + 12 * (1 - qi) + (ch - 19);
+        if (ch == 31) return B_STILL + qi;
+        return B_STILL + (1 - qi);
+    }
+    __device__ static inline int bias(int ch) { return (ch == 3 || ch == 4) ? 3 : 0; }
+};
+// step-kernel observation kind: bit 0 = also render the fully-observable observation, bit 1 = 'original' channels
+template <int KIND>
+struct ObsKind {
+    static constexpr bool FULL = (KIND & 1) != 0, ORIG = (KIND & 2) != 0;
+    using P = std::conditional_t<ORIG, OrigPartialObs, PartialObs>;
+    using F = std::conditional_t<ORIG, OrigFullObs, FullObs>;
+};
+
+}  // namespace

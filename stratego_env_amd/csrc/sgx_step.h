@@ -1,0 +1,417 @@
+// sgx_step.h -- the step / observe kernels: one env.step() per game
+// Part of libstratego_mi355x.so; included by stratego_mi355x.hip in this order (one translation unit).
+#pragma once
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// The step kernel: env.step() of N games (maenv:659-828), one wave per game
+// ---------------------------------------------------------------------------------------------
+// waves per SIMD this geometry can reach: LDS per workgroup = WPB game regions + the shared LUT, 160 KiB per CU
+template <class G, int KIND>
+constexpr int waves_per_simd() {
+    constexpr bool FULL = (KIND & 1) != 0;
+    constexpr int per_wg = WPB * G::GPW * (int)sizeof(Lds<G>) + 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)) + SGX_MAX_CELLS;
+    constexpr int wgs = (160 * 1024) / per_wg;
+    constexpr int w = wgs * WPB / 4;
+    // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
+    constexpr int want = G::RC <= 64 ? 8 : SGX_MIN_WAVES;
+    return w > want ? want : (w < 1 ? 1 : w);
+}
+
+// Builds the record image from ST_OFF on in L.tail (never-moved bitmaps from the LDS still boards, the two scalar int4s,
+// the event list already kept in L.tail) and writes the whole record to HBM as 16-byte stores over whole 128-byte lines.
+template <class G>
+__device__ inline void write_record(Lds<G> &L, int8_t *rec_g, int rec_bytes, int4 sc0, int4 sc1, int n_events, int lane) {
+    constexpr int S = G::S, RC = G::RC;
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int w = 0; w < G::SB / 8; ++w) {
+            unsigned long long m = 0;
+#pragma unroll
+            for (int h = 0; h < G::GPW; ++h) {          // a game's ballot covers LPG cells
+                const int i = 64 * w + G::LPG * h + lane;
+                if (64 * w + G::LPG * h < RC) m |= gballot<G>(i < RC && L.b[B_STILL + pi][i < RC ? i : 0] != 0) << (G::LPG * h);
+            }
+            if (lane == 0) reinterpret_cast<unsigned long long *>(L.tail + pi * G::SB)[w] = m;
+        }
+    if (lane == 0) {
+        reinterpret_cast<int4 *>(L.tail + 2 * G::SB)[0] = sc0;
+        reinterpret_cast<int4 *>(L.tail + 2 * G::SB)[1] = sc1;
+    }
+    wave_sync<G>();
+    const int4 *bsrc = reinterpret_cast<const int4 *>(&L.b[0][0]), *tsrc = reinterpret_cast<const int4 *>(L.tail);
+    int4 *dst = reinterpret_cast<int4 *>(rec_g);
+    const int n_tail_q = (2 * G::SB + 32 + 2 * n_events + 15) >> 4;            // tail int4s that carry data
+    for (int i = lane; i < rec_bytes / 16; i += G::LPG) {
+        int4 v = make_int4(0, 0, 0, 0);
+        if (i < G::ST_OFF / 16) {
+            v = bsrc[i];
+            const int keep = STORED_BOARDS * S - 16 * i;                       // bytes of this int4 that belong to the stored boards
+            if (keep < 16) { if (keep <= 12) v.w = 0; if (keep <= 8) v.z = 0; if (keep <= 4) v.y = 0; if (keep <= 0) v.x = 0; }
+        } else if (i < G::ST_OFF / 16 + n_tail_q) {
+            v = tsrc[i - G::ST_OFF / 16];
+        }
+        dst[i] = v;
+    }
+}
+
+// One game's env.step() by one wave (called with the wave's private LDS region).
+template <int R_, int C_, int KIND, bool MAPPED>
+__device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, const float *lut_s, const uint8_t *obst_s, const int64_t env,
+                                         const int lane) {
+    using G = Geo<R_, C_>;
+    using PS = typename ObsKind<KIND>::P;
+    using FS = typename ObsKind<KIND>::F;
+    constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
+    STAMP(0);
+
+    int8_t *rec_g = P.boards + env * (int64_t)P.rec_bytes;
+    // ---- stage.  Every global read of the step is issued up front -- the whole record (a few 128-byte lines) as one or
+    //      two int4 per lane, and the action -- so the wave pays ONE memory round trip.  The scalars, never-moved bitmaps
+    //      and capture events are then read from the LDS image of the record (L.tail has the record's layout from ST_OFF
+    //      on).  They used to be five dependent loads: a quarter of a toy game's lifetime.
+    constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + G::LPG - 1) / G::LPG;
+    static_assert(G::TAIL_BYTES % 16 == 0 && NLOAD <= 2, "record image must fit two int4 per lane");
+    const int4 zero4 = make_int4(0, 0, 0, 0);
+    int4 rq0 = zero4, rq1 = zero4;
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(rec_g);
+        const int nq = min(P.rec_bytes >> 4, Q_REC);
+        if (lane < nq) rq0 = src[lane];
+        if constexpr (NLOAD > 1)
+            if (lane + G::LPG < nq) rq1 = src[lane + G::LPG];
+    }
+    int a_raw = 0;
+    int4 pos_raw = zero4;
+    if (P.mode == 0) {
+        if (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) pos_raw = reinterpret_cast<const int4 *>(P.io.actions_dev)[env];
+        else a_raw = P.io.actions_dev[env];
+    }
+    {   // while the loads are in flight: clear the 28 rebuilt boards, copy the obstacle map (shared per workgroup)
+        int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
+        for (int i = Q_BOARDS + lane; i < G::LDS_BOARDS_BYTES / 16; i += G::LPG) dst[i] = zero4;
+        for (int i = lane; i < S / 4; i += G::LPG) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(obst_s)[i];
+        int4 *tl = reinterpret_cast<int4 *>(L.tail);
+        if (lane < Q_BOARDS) dst[lane] = rq0;
+        else if (lane < Q_REC) tl[lane - Q_BOARDS] = rq0;
+        if constexpr (NLOAD > 1) {
+            if (lane + G::LPG < Q_BOARDS) dst[lane + G::LPG] = rq1;
+            else if (lane + G::LPG < Q_REC) tl[lane + G::LPG - Q_BOARDS] = rq1;
+        }
+    }
+    wave_sync<G>();
+    const int4 sc = reinterpret_cast<const int4 *>(L.tail + 2 * G::SB)[0], sc2 = reinterpret_cast<const int4 *>(L.tail + 2 * G::SB)[1];
+    int turn = uni<G>(sc.x), flags = uni<G>(sc.y), game_no = uni<G>(sc.w);
+    const int max_turns = uni<G>(sc.z);
+    int n_events = min(uni<G>(sc2.x), (int)G::EVL_MAX);
+    int rp0 = uni<G>(sc2.y), rp1 = uni<G>(sc2.z);   // recent-move pairs of player +1 / -1 (two named scalars: a runtime-indexed
+                                              // array would live in scratch memory)
+    {   // ---- rebuild the 28 derived boards: never-moved bitmaps, recent-move pairs, capture events
+        const uint32_t *stb = reinterpret_cast<const uint32_t *>(L.tail);
+#pragma unroll
+        for (int cc = 0; cc < G::CPL; ++cc) {
+            const int i = lane + G::LPG * cc;
+            if (i < RC) {
+                L.b[B_STILL][i] = (int8_t)((stb[i >> 5] >> (i & 31)) & 1u);
+                L.b[B_STILL + 1][i] = (int8_t)((stb[G::SB / 4 + (i >> 5)] >> (i & 31)) & 1u);
+            }
+        }
+        const uint16_t *evl = reinterpret_cast<const uint16_t *>(L.tail + 2 * G::SB + 32);   // stays here for the write-back
+        for (int i = lane; i < n_events; i += G::LPG) {
+            const int evt = evl[i], byte = (B_CAP + (evt >> 8)) * S + (evt & 0xFF);  // event = (board - B_CAP) << 8 | cell
+            atomicAdd(reinterpret_cast<unsigned int *>(&L.b[0][0]) + (byte >> 2), 1u << (8 * (byte & 3)));
+        }
+        if (lane < 4) {
+            const int pr = (((lane >> 1) ? rp1 : rp0) >> (16 * (lane & 1))) & 0xFFFF;
+            if (pr >> 8) L.b[B_RECENT + (lane >> 1)][pr & 0xFF] = (int8_t)(pr >> 8);
+        }
+    }
+    const float *lut = lut_s;
+    wave_sync<G>();
+    STAMP(1);   // state staged
+
+    int player = (flags & F_PLAYER_M1) ? -1 : 1;
+    bool over = (flags & F_OVER) != 0;
+    bool applied = false, invalid_action = false, noop_path = false;
+    int mover = player;
+    int dirty_s = -1, dirty_e = -1, dirty_cap_a = -1, dirty_cap_b = -1;   // cells / boards touched by the move
+
+    if (P.mode == 0) {
+        // ------------------------------------------------------------------------------------------
+        // decode (maenv:684-689): flat spatial index -> positions -> 1-D index -> absolute 1-D index
+        // ------------------------------------------------------------------------------------------
+        const int a = uni<G>(a_raw);
+        int sr = 0, sc_ = 0, er = 0, ec = 0;
+        bool valid = true;
+        if (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) {
+            // is_move_valid_by_position (penv:87-92): actions_dev is int32 [N][4] = (start_r, start_c, end_r, end_c), absolute
+            sr = uni<G>(pos_raw.x); sc_ = uni<G>(pos_raw.y); er = uni<G>(pos_raw.z); ec = uni<G>(pos_raw.w);
+        } else if (P.io.flags & SGX_STEP_ACTIONS_1D) {
+            // functional API (penv:148-155): the action already is an absolute-coordinate 1-D index (impl:262-277)
+            if (a == AS - 1) {
+                noop_path = true;
+            } else {                                                                         // impl:369-383
+                const int q = fdiv_(a, MPA), off = fmod_(a, MPA);
+                sr = fdiv_(q, C); sc_ = fmod_(q, C);
+                if (off >= R) { ec = off - R; er = sr; } else { er = off; ec = sc_; }
+            }
+        } else if (a < 0 || a >= NA) {
+            valid = false;  // np.unravel_index raises
+        } else {
+            const int cell = a / K, ch = a - cell * K;
+            sr = cell / C; sc_ = cell - sr * C;
+            if (ch < R - 1) { er = sr + ch + 1; ec = sc_; }                                   // impl:322-324
+            else if (ch < 2 * (R - 1)) { er = sr - (ch - (R - 1) + 1); ec = sc_; }
+            else if (ch < 2 * (R - 1) + (C - 1)) { er = sr; ec = sc_ + (ch - 2 * (R - 1) + 1); }
+            else { er = sr; ec = sc_ - (ch - (2 * (R - 1) + (C - 1)) + 1); }                   // also the no-op channel
+            int idx = (sr * C + sc_) * MPA + ((er != sr) ? er : R + ec);                     // impl:268-277
+            if (player == -1 && idx != AS - 1) {                                             // impl:698-720
+                const int q = fdiv_(idx, MPA), off = fmod_(idx, MPA);
+                int r0 = fdiv_(q, C), c0 = fmod_(q, C), r1, c1;
+                if (off >= R) { c1 = off - R; r1 = r0; } else { r1 = off; c1 = c0; }
+                r0 = R - 1 - r0; r1 = R - 1 - r1; c0 = C - 1 - c0; c1 = C - 1 - c1;
+                idx = (r0 * C + c0) * MPA + ((r1 != r0) ? r1 : R + c1);
+            }
+            if (idx == AS - 1) {
+                noop_path = true;                                                            // impl:809-814
+            } else {                                                                         // impl:369-383
+                const int q = fdiv_(idx, MPA), off = fmod_(idx, MPA);
+                sr = fdiv_(q, C); sc_ = fmod_(q, C);
+                if (off >= R) { ec = off - R; er = sr; } else { er = off; ec = sc_; }
+            }
+        }
+        const int pi = player == 1 ? 0 : 1;
+        int8_t *own = L.b[B_PIECES + pi], *enemy = L.b[B_PIECES + 1 - pi];
+        int8_t *own_po = L.b[B_PO + pi], *enemy_po = L.b[B_PO + 1 - pi];
+        int8_t *own_still = L.b[B_STILL + pi], *enemy_still = L.b[B_STILL + 1 - pi];
+        int8_t *recent = L.b[B_RECENT + pi];
+        const int8_t *obst = L.b[B_OBST];
+
+        if (valid && noop_path) {
+            // no-op is legal only if the mover has no move (or the game is over); finished games stay unchanged
+            if (!over) {
+                const int nmoves = gen_mask(L, pi, false, lane);
+                if (nmoves != 0) valid = false;
+                else { turn += 1; over = true; flags |= F_OVER | (player == 1 ? F_WIN_M1 : F_WIN_P1); }  // impl:916-920
+            }
+        } else if (valid) {
+            // ---- _is_move_valid_by_position (impl:723-798).  All board bytes the checks (and the move) need are read
+            //      up front from clamped cell indices, so the wave pays one LDS round trip instead of ten dependent ones.
+            const bool s_in = !(sc_ < 0 || sc_ >= C || sr < 0 || sr >= R), e_in = !(ec < 0 || ec >= C || er < 0 || er >= R);
+            const int s = s_in ? sr * C + sc_ : 0, e = e_in ? er * C + ec : 0;
+            const int v_obst_s = obst[s], v_obst_e = obst[e], v_own_s = own[s], v_own_e = own[e], v_en_e = enemy[e];
+            const int v_rec_s = recent[s], v_rec_e = recent[e], v_po_s = own_po[s];
+            const int obst_s = uni<G>(v_obst_s), obst_e = uni<G>(v_obst_e), t = uni<G>(v_own_s), own_e = uni<G>(v_own_e);
+            const int dest = uni<G>(v_en_e), old_start = uni<G>(v_rec_s), old_end = uni<G>(v_rec_e), moved_po = uni<G>(v_po_s);
+            if (over) valid = false;
+            if (!s_in || obst_s != 0) valid = false;
+            if (!e_in || obst_e != 0) valid = false;
+            if (t == 0 || t == SP_FLAG || t == SP_BOMB) valid = false;
+            if (own_e != 0) valid = false;
+            if (er != sr && ec != sc_) valid = false;
+            if (old_start == -3 && old_end == 1 && dest == 0 && !(P.io.flags & SGX_STEP_ALLOW_OSCILLATION)) valid = false;   // impl:771-777
+            if (valid) {
+                const int dist = (er != sr) ? abs(er - sr) : abs(ec - sc_);
+                if (t == SP_SCOUT) {
+                    const int stepc = (er != sr) ? ((er > sr) ? C : -C) : ((ec > sc_) ? 1 : -1);
+                    const int k = lane + 1;  // lanes 0.. check the intermediate cells
+                    bool blk = false;
+                    if (k < dist) { const int m = s + k * stepc; blk = own[m] != 0 || enemy[m] != 0 || obst[m] != 0; }
+                    if (gballot<G>(blk) != 0ull) valid = false;
+                } else if (dist > 1) valid = false;
+            }
+            if (valid) {
+                // ---- _get_next_state (impl:905-1028)
+                const int moved = t;
+                turn += 1;
+                bool wins = false, tied = false;
+                if (dest != 0) {
+                    if (moved == SP_MINER && dest == SP_BOMB) wins = true;
+                    else if (moved == SP_SPY && dest == SP_MARSHALL) wins = true;
+                    else if (dest == SP_FLAG) { wins = true; over = true; flags |= F_OVER | (player == 1 ? F_WIN_P1 : F_WIN_M1); }
+                    else if (dest != SP_BOMB) { if (moved == dest) tied = true; else if (moved > dest) wins = true; }
+                }
+                wave_sync<G>();
+                // clear the mover's recent-moves board (np.zeros_like, impl:1014)
+                for (int i = lane; i < S / 4; i += G::LPG) reinterpret_cast<int *>(recent)[i] = 0;
+                wave_sync<G>();
+                if (lane == 0) {
+                    own_still[s] = 0; own_still[e] = 0; enemy_still[e] = 0;  // impl:939-941
+                    own[s] = 0; own_po[s] = 0;                               // impl:950-951
+                    if (dest == 0) {
+                        own[e] = (int8_t)moved;
+                        const int far = (abs(er - sr) > 1 || abs(ec - sc_) > 1);
+                        own_po[e] = (int8_t)(far ? SP_SCOUT : moved_po);      // impl:960-964
+                        recent[s] = 1;                                       // impl:1019-1026
+                        recent[e] = (int8_t)(old_end == 1 ? (old_start == -2 ? -3 : -2) : -1);
+                    } else {
+                        if (tied || wins) { enemy[e] = 0; enemy_po[e] = 0; }
+                        if (wins) { own[e] = (int8_t)moved; own_po[e] = (int8_t)moved; }
+                        if (!wins && !tied) enemy_po[e] = (int8_t)dest;
+                        if (!wins) L.b[B_CAP + 12 * pi + moved - 1][e] += 1;               // impl:1001-1004
+                        if (wins || tied) L.b[B_CAP + 12 * (1 - pi) + dest - 1][e] += 1;   // impl:1006-1009
+                    }
+                }
+                dirty_s = s; dirty_e = e;
+                if (dest != 0) {
+                    if (!wins) dirty_cap_a = B_CAP + 12 * pi + moved - 1;
+                    if (wins || tied) dirty_cap_b = B_CAP + 12 * (1 - pi) + dest - 1;
+                    if (pi) rp1 = 0; else rp0 = 0;                                       // an attack wipes the mover's layer
+                } else {
+                    const int code = old_end == 1 ? (old_start == -2 ? -3 : -2) : -1;
+                    const int pr = (s | (1 << 8)) | ((e | ((code & 0xFF) << 8)) << 16);
+                    if (pi) rp1 = pr; else rp0 = pr;
+                }
+                wave_sync<G>();
+            }
+        }
+        if (valid) { applied = true; player = -player; } else invalid_action = true;
+    }
+
+    STAMP(2);   // move applied
+    // ---- next mover's mask; opponent-stuck and max-turn endings (impl:1031-1043)
+    int qi = player == 1 ? 0 : 1;
+    int nvalid = gen_mask(L, qi, over, lane);
+    bool ended_now = false;
+    if (applied && !noop_path) {
+        const bool was_over = over;
+        if (nvalid == 0) { over = true; flags = (flags & ~(F_WIN_P1 | F_WIN_M1)) | F_OVER | (mover == 1 ? F_WIN_P1 : F_WIN_M1); }
+        if (turn >= max_turns && !over) { over = true; flags |= F_OVER | F_END_INVALID; }
+        if (over && !was_over && nvalid != 0) { mask_noop_only(L, lane); nvalid = 0; }  // finished: the no-op only
+        ended_now = over;
+    } else if (applied && noop_path) {
+        ended_now = over;
+        if (nvalid != 0) { mask_noop_only(L, lane); nvalid = 0; }
+    }
+    flags = (flags & ~F_PLAYER_M1) | (player == -1 ? F_PLAYER_M1 : 0);
+    STAMP(3);   // mask generated
+
+    // ---- rewards / dones (maenv:699-805)
+    const bool done = over;
+    const bool end_invalid = over && (flags & F_END_INVALID);
+    float rew_p1 = 0.f, rew_m1 = 0.f;
+    if (over && !end_invalid) {
+        const int w = (flags & F_WIN_P1) ? 1 : (flags & F_WIN_M1) ? -1 : 0;
+        rew_p1 = w == 0 ? 1e-4f : (float)w;     // impl:838-840
+        rew_m1 = w == 0 ? 1e-4f : (float)-w;
+    }
+    if (P.mode == 0) {
+        // one store instruction for the rewards (lanes 0/1) and one for the three byte flags (lanes 0..2)
+        if (lane < 2 && P.io.reward_dev) P.io.reward_dev[2 * env + lane] = lane ? rew_m1 : rew_p1;
+        uint8_t *fp = lane == 0 ? P.io.done_dev : lane == 1 ? P.io.invalid_action_dev : lane == 2 ? P.io.ending_invalid_dev : nullptr;
+        const uint8_t fv = lane == 0 ? (done ? 1 : 0) : lane == 1 ? (invalid_action ? 1 : 0) : (end_invalid ? 1 : 0);
+        if (fp) fp[env] = fv;
+    }
+
+    // ---- terminal observations of both players (maenv:772-773)
+    if (P.mode == 0 && ended_now && P.io.final_obs_dev) {
+        float *fo = P.io.final_obs_dev + env * (int64_t)(2 * RC * PS::NCH);
+        emit_obs<G, PS>(L, lut, 0, fo, lane);
+        emit_obs<G, PS>(L, lut, 1, fo + RC * PS::NCH, lane);
+    }
+    if constexpr (ObsKind<KIND>::FULL)
+        if (P.mode == 0 && ended_now && P.io.final_fobs_dev) {
+            float *fo = P.io.final_fobs_dev + env * (int64_t)(2 * RC * FS::NCH);
+            emit_obs<G, FS>(L, lut + OBS_TAB_DWORDS, 0, fo, lane);
+            emit_obs<G, FS>(L, lut + OBS_TAB_DWORDS, 1, fo + RC * FS::NCH, lane);
+        }
+
+    // ---- auto-reset: the finished env starts its next game now
+    bool wrote_reset = false;
+    if (P.mode == 0 && ended_now && P.io.auto_reset) {
+        game_no += 1;
+        sample_boards(L, P, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, lane);
+        turn = 0; flags = 0; player = 1; qi = 0; over = false;
+        n_events = 0; rp0 = rp1 = 0;
+        nvalid = gen_mask(L, 0, false, lane);
+        wrote_reset = true;
+    }
+
+    STAMP(4);   // results / terminal handling done
+    // ---- outputs for the next mover
+    if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
+    if (P.io.mask_dev) {
+        // MAPPED: the separate instantiation behind SGX_STEP_MASK_1D / SGX_STEP_MASK_STATE_COORDS (kept out of the hot kernel: its
+        // 16 index computations per lane cost 30 VGPRs)
+        if (MAPPED && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
+        else if (MAPPED && qi) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
+        else emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
+    }
+    STAMP(5);   // mask stores issued
+    // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
+    if (P.io.obs_dev) emit_obs<G, PS>(L, lut, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH), lane);
+    if constexpr (ObsKind<KIND>::FULL)
+        if (P.io.fobs_dev) emit_obs<G, FS>(L, lut + OBS_TAB_DWORDS, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH), lane);
+    STAMP(6);   // obs stores issued
+    if (P.mode == 0 && P.io.next_actions_dev) {
+        const int total = nvalid == 0 ? 1 : nvalid;
+        const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, STREAM_ACTION, (uint32_t)turn), (uint32_t)total);
+        const int na = kth_valid(L, (int)k, lane);
+        if (lane == 0) P.io.next_actions_dev[env] = na;
+    }
+
+    STAMP(7);   // next action sampled
+    // ---- write the record back as whole 128-byte lines: dense boards, scalars, capture events.  (Scattered stores
+    //      of only the <= 9 touched bytes + 32 B of scalars are partial-line writes: measured 7 % slower.)
+    if (applied || wrote_reset) {
+        uint16_t *evl = reinterpret_cast<uint16_t *>(L.tail + 2 * G::SB + 32);
+        if (!wrote_reset && dirty_s >= 0) {
+            const int na = dirty_cap_a >= 0 ? 1 : 0, nb = dirty_cap_b >= 0 ? 1 : 0;
+            if (lane == 0 && na && n_events < P.max_events) evl[n_events] = (uint16_t)(((dirty_cap_a - B_CAP) << 8) | dirty_e);
+            if (lane == 1 && nb && n_events + na < P.max_events) evl[n_events + na] = (uint16_t)(((dirty_cap_b - B_CAP) << 8) | dirty_e);
+            n_events = min(n_events + na + nb, P.max_events);
+        }
+        write_record(L, rec_g, P.rec_bytes, make_int4(turn, flags, max_turns, game_no), make_int4(n_events, rp0, rp1, 0), n_events, lane);
+    }
+    STAMP(8);   // write-back issued
+#ifdef SGX_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(9);   // all stores acknowledged
+#endif
+}
+
+// KIND bit 0: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492);
+// KIND bit 1: obs_channel_mode 'original' (32/33 value channels) instead of 'extended' (67/79 one-hot channels)
+template <int R_, int C_, int KIND, bool MAPPED>
+__device__ __forceinline__ void game_kernel_body(const KParams &P) {
+    using G = Geo<R_, C_>;
+    using PS = typename ObsKind<KIND>::P;
+    using FS = typename ObsKind<KIND>::F;
+    constexpr bool FULL = ObsKind<KIND>::FULL;
+    constexpr int ORIG4 = ObsKind<KIND>::ORIG ? 4 : 0;
+    __shared__ Lds<G> LW[WPB * G::GPW];
+    __shared__ alignas(16) float lut_s[OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)];
+    __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS];
+    const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;     // lane inside the game, game inside the workgroup
+    const int64_t env = group_of_block() * (WPB * G::GPW) + slot;
+
+    // ---- the workgroup's shared normalisation LUT (L2-resident source)
+    const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
+    const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[ORIG4 + (raw ? 2 : 0)]);
+    for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
+    build_quad_table<G, PS>(reinterpret_cast<uint32_t *>(lut_s + LUT_DWORDS), threadIdx.x, 64 * WPB);
+    if constexpr (FULL) {
+        const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[ORIG4 + (raw ? 2 : 0) + 1]);
+        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s + OBS_TAB_DWORDS)[i] = fsrc[i];
+        build_quad_table<G, FS>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * WPB);
+    }
+    for (int i = threadIdx.x; i < G::S / 4; i += 64 * WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
+    __syncthreads();   // from here on every wave works on its own game
+    if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], lut_s, obst_s, env, lane);
+}
+
+// sgx_step and sgx_observe run the same body (P.mode tells them apart at run time: specialising the body on the mode changed the
+// step kernel's schedule and cost 3.7 % on Barrage); two kernel symbols, so that a kernel trace keeps the env.step() launches
+// apart from the state-preserving observe launches (placement trials, reset())
+template <int R_, int C_, int KIND, bool MAPPED = false>
+__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) void step_kernel(const KParams P) {
+    game_kernel_body<R_, C_, KIND, MAPPED>(P);
+}
+template <int R_, int C_, int KIND, bool MAPPED = false>
+__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) void observe_kernel(const KParams P) {
+    game_kernel_body<R_, C_, KIND, MAPPED>(P);
+}
+
+}  // namespace
