@@ -242,3 +242,19 @@ def test_directed_combat_matrix_and_quirks_vs_oracle():
         invalid_endings += int(want[5, 1, 1] == 1)
     assert wins > 0 and invalid_endings > 0
     penv.close()
+
+
+def test_heuristic_rewards_match_reference_golden():
+    """get_heuristic_rewards_from_move vs values recorded from the reference's _get_heuristic_rewards_from_move (impl:852-891)."""
+    import json
+    import os
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    from tests.helpers import GOLDEN, directed_positions
+    with open(os.path.join(GOLDEN, 'heuristic_rewards.json')) as f:
+        g = json.load(f)
+    states, players, actions = directed_positions()
+    rm = np.random.RandomState(g['matrix_seed']).rand(14, 14).astype(np.float32)
+    penv = BatchedStrategoProceduralEnv('tiny', len(states))
+    got = penv.get_heuristic_rewards_from_move(states, players, actions, rm).cpu().numpy()
+    assert np.array_equal(got, np.asarray(g['rewards'], dtype=np.float32))
+    penv.close()
