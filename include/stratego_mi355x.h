@@ -8,7 +8,8 @@
  *   - plain C, no C++/torch types; every *_dev pointer is a DEVICE pointer owned by the caller
  *     (e.g. a torch tensor's data_ptr()); the library owns only its internal state tensor;
  *   - all device work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream)
- *     and is asynchronous; no entry point synchronises the device except sgx_destroy;
+ *     and is asynchronous; the entry points that wait for the device are sgx_create, sgx_destroy,
+ *     sgx_set_setup_table, sgx_time_observe, sgx_alloc_outputs and sgx_free_outputs;
  *   - return 0 on success, a negative SGX_E* code on failure (sgx_last_error() has the text);
  *     nothing throws across the ABI; invalid *actions* are not API errors: they are reported per env
  *     in invalid_action[] with that env's state left unchanged (the reference raises ValueError,
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 5
+#define SGX_ABI_VERSION 6
 #define SGX_MAX_CELLS 256        /* rows*cols <= 256 (largest reference variant: 15x15) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
 #define SGX_FO_OBS_CHANNELS 79   /* impl:1227 */
@@ -152,6 +153,31 @@ int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, 
  * candidates, times each with this call and keeps the fastest (what VecStrategoEnv.tune_placement does from Python).
  * No reference counterpart. */
 int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int32_t launches, void *stream, float *microseconds);
+
+/* Library-owned output buffers with a bounded placement trial.  On MI355X the same launch takes
+ * 313-400 us depending on which physical memory backs the big observation buffer: device memory comes in regions of two
+ * kinds, a buffer lying inside one region runs at that region's rate (~350 or ~380-395 us for 65,536 Barrage games), and
+ * only a buffer whose pages MIX both kinds reaches the fast class (313-325 us).  Which one a plain allocation gets depends
+ * on what was allocated before it.  sgx_alloc_outputs allocates the mask buffer, then tries up to `max_trials` candidate
+ * allocations of the observation buffer (and of the fully-observable one with SGX_OUT_FULL_OBS): before each candidate a
+ * padding allocation of growing size is made and released again afterwards, which moves the candidate to other buddy blocks;
+ * each candidate is timed with a few sgx_observe launches (no state change) and only the fastest so far is kept.  At no
+ * time does the trial hold more than `max_extra_bytes` beyond the buffers it returns (0 or max_trials <= 1: no trial, first
+ * allocation).  Channel counts follow `flags` (SGX_STEP_ORIGINAL_CHANNELS).  Waits for the device.  No reference counterpart. */
+#define SGX_OUT_FULL_OBS 1024         /* also allocate fobs_dev [N,R,C,79] (or 33) */
+#define SGX_OUT_MAX_TRIALS 64
+typedef struct sgx_outputs {
+    float *obs_dev;                /* [N,R,C,67] (32 with SGX_STEP_ORIGINAL_CHANNELS) */
+    float *fobs_dev;               /* [N,R,C,79] (33) or NULL */
+    uint8_t *mask_dev;             /* [N,R,C,K] */
+    int64_t obs_bytes, fobs_bytes, mask_bytes;
+    int64_t peak_extra_bytes;      /* most memory the trial held beyond the returned buffers */
+    int32_t n_trials, n_ftrials;   /* candidates timed for obs_dev / fobs_dev */
+    float trial_us[SGX_OUT_MAX_TRIALS];    /* sgx_observe launch time with each obs candidate; [0] = the plain first allocation */
+    float ftrial_us[SGX_OUT_MAX_TRIALS];   /* the same for fobs_dev */
+} sgx_outputs;
+int sgx_alloc_outputs(sgx_env *h, int32_t flags, int64_t max_extra_bytes, int32_t max_trials, void *stream, sgx_outputs *out);
+int sgx_free_outputs(sgx_env *h, sgx_outputs *out);
 
 /* One batched env.step(): see sgx_step_io. */
 int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);

@@ -14,15 +14,16 @@ PO_OBS_CHANNELS = 67
 FO_OBS_CHANNELS = 79
 PO_OBS_CHANNELS_ORIGINAL = 32
 FO_OBS_CHANNELS_ORIGINAL = 33
-ABI_VERSION = 5
+ABI_VERSION = 6
 STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, STEP_ORIGINAL_CHANNELS = 1, 2, 4, 8, 16
 STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
+OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
 
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
     'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
-    'sgx_observe', 'sgx_time_observe', 'sgx_step', 'sgx_step_n', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_get_env_info',
+    'sgx_observe', 'sgx_time_observe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_step_n', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_get_env_info',
 )
 
 
@@ -37,6 +38,13 @@ class SgxStepIO(C.Structure):
                 ('invalid_action_dev', C.c_void_p), ('ending_invalid_dev', C.c_void_p), ('final_obs_dev', C.c_void_p),
                 ('final_fobs_dev', C.c_void_p), ('next_actions_dev', C.c_void_p), ('auto_reset', C.c_int32),
                 ('flags', C.c_int32)]
+
+
+class SgxOutputs(C.Structure):
+    _fields_ = [('obs_dev', C.c_void_p), ('fobs_dev', C.c_void_p), ('mask_dev', C.c_void_p),
+                ('obs_bytes', C.c_int64), ('fobs_bytes', C.c_int64), ('mask_bytes', C.c_int64), ('peak_extra_bytes', C.c_int64),
+                ('n_trials', C.c_int32), ('n_ftrials', C.c_int32),
+                ('trial_us', C.c_float * OUT_MAX_TRIALS), ('ftrial_us', C.c_float * OUT_MAX_TRIALS)]
 
 
 class SgxError(RuntimeError):
@@ -78,6 +86,10 @@ def _bind(L):
     L.sgx_observe.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp]
     L.sgx_time_observe.restype = C.c_int
     L.sgx_time_observe.argtypes = [vp, vp, vp, C.c_int32, vp, C.POINTER(C.c_float)]
+    L.sgx_alloc_outputs.restype = C.c_int
+    L.sgx_alloc_outputs.argtypes = [vp, C.c_int32, i64, C.c_int32, vp, C.POINTER(SgxOutputs)]
+    L.sgx_free_outputs.restype = C.c_int
+    L.sgx_free_outputs.argtypes = [vp, C.POINTER(SgxOutputs)]
     L.sgx_step.restype = C.c_int
     L.sgx_step.argtypes = [vp, C.POINTER(SgxStepIO), vp]
     L.sgx_step_n.restype = C.c_int
@@ -103,8 +115,17 @@ def load(path=None):
     if not os.path.exists(path):
         raise SgxError("libstratego_mi355x.so is not built (%s missing). Run `python -m stratego_env_amd.build` "
                        "or __graft_entry__.build(); there is no CPU fallback." % path)
-    _libs[path] = _bind(C.CDLL(path))
-    return _libs[path]
+    L = C.CDLL(path)
+    missing = [sym for sym in EXPORTED_SYMBOLS if not hasattr(L, sym)]
+    if missing:
+        raise SgxError("%s does not export %s: it was built from other sources; rebuild with `python -m stratego_env_amd.build`"
+                       % (path, ', '.join(missing)))
+    L = _bind(L)
+    if L.sgx_abi_version() != ABI_VERSION:       # struct layouts differ between ABI versions: never bind a stale library
+        raise SgxError("%s has ABI version %d, this package needs %d; rebuild with `python -m stratego_env_amd.build`"
+                       % (path, L.sgx_abi_version(), ABI_VERSION))
+    _libs[path] = L
+    return L
 
 
 def check(rc, lib=None):

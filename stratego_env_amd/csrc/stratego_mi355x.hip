@@ -386,6 +386,117 @@ SGX_API int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int3
     return rc;
 }
 
+// ---- library-owned output buffers with a bounded placement trial
+namespace {
+
+struct TrialCtx {
+    sgx_env *h;
+    void *stream;
+    int32_t flags;
+    hipEvent_t e0, e1;
+};
+
+// average launch time of 6 sgx_observe launches writing the given buffers (one untimed first touch)
+int time_candidate(TrialCtx &c, float *obs, float *fobs, uint8_t *mask, float *us) {
+    const int launches = 6;
+    int rc = sgx_observe(c.h, obs, fobs, mask, nullptr, c.flags, c.stream);
+    if (rc != SGX_OK) return rc;
+    HIP_TRY(hipEventRecord(c.e0, (hipStream_t)c.stream));
+    for (int i = 0; i < launches && rc == SGX_OK; ++i) rc = sgx_observe(c.h, obs, fobs, mask, nullptr, c.flags, c.stream);
+    if (rc != SGX_OK) return rc;
+    HIP_TRY(hipEventRecord(c.e1, (hipStream_t)c.stream));
+    HIP_TRY(hipEventSynchronize(c.e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c.e0, c.e1));
+    *us = ms * 1000.f / (float)launches;
+    return SGX_OK;
+}
+
+// Picks the fastest of up to max_trials allocations of `bytes`.  Candidate k > 0 is allocated behind a padding allocation of
+// k * step bytes, which is released again before the candidate is timed, so that at most (candidate + padding) is held beyond
+// the buffer that is kept.  `which` = 0: the candidate is the partial observation buffer, 1: the fully-observable one.
+int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t *mask, int64_t max_extra, int32_t max_trials,
+                float **best_out, float *trial_us, int32_t *n_trials, int64_t *peak_extra) {
+    float *best = nullptr;
+    if (hipMalloc((void **)&best, bytes) != hipSuccess) return fail(SGX_ENOMEM, "device allocation failed (output buffer)%s");
+    *best_out = best;
+    *n_trials = 0;
+    const bool can_try = max_trials > 1 && max_extra >= (int64_t)bytes;
+    if (!can_try) return SGX_OK;
+    float best_us = 0.f;
+    int rc = time_candidate(c, which ? obs_fixed : best, which ? best : nullptr, mask, &best_us);
+    if (rc != SGX_OK) return rc;
+    trial_us[0] = best_us;
+    *n_trials = 1;
+    const size_t room = (size_t)max_extra - bytes;                        // what the padding may take
+    size_t step = bytes / 8;
+    step = (step + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    for (int k = 1; k < max_trials && k < SGX_OUT_MAX_TRIALS; ++k) {
+        const size_t pad_bytes = (size_t)k * step;
+        if (pad_bytes > room) break;
+        void *pad = nullptr;
+        float *cand = nullptr;
+        if (hipMalloc(&pad, pad_bytes) != hipSuccess) { (void)hipGetLastError(); break; }         // memory is short: settle
+        if (hipMalloc((void **)&cand, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(pad); break; }
+        if ((int64_t)(pad_bytes + bytes) > *peak_extra) *peak_extra = (int64_t)(pad_bytes + bytes);
+        (void)hipFree(pad);
+        float us = 0.f;
+        rc = time_candidate(c, which ? obs_fixed : cand, which ? cand : nullptr, mask, &us);
+        if (rc != SGX_OK) { (void)hipFree(cand); return rc; }
+        trial_us[k] = us;
+        *n_trials = k + 1;
+        if (us < best_us) { (void)hipFree(best); best = cand; best_us = us; *best_out = best; }
+        else (void)hipFree(cand);
+    }
+    return SGX_OK;
+}
+
+}  // namespace
+
+SGX_API int sgx_free_outputs(sgx_env *h, sgx_outputs *out) {
+    if (!h || !out) return fail(SGX_EINVAL, "NULL argument%s");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (out->obs_dev) (void)hipFree(out->obs_dev);
+    if (out->fobs_dev) (void)hipFree(out->fobs_dev);
+    if (out->mask_dev) (void)hipFree(out->mask_dev);
+    out->obs_dev = out->fobs_dev = nullptr;
+    out->mask_dev = nullptr;
+    return SGX_OK;
+}
+
+SGX_API int sgx_alloc_outputs(sgx_env *h, int32_t flags, int64_t max_extra_bytes, int32_t max_trials, void *stream, sgx_outputs *out) {
+    if (!h || !out) return fail(SGX_EINVAL, "NULL argument%s");
+    if (flags & ~(SGX_OUT_FULL_OBS | SGX_STEP_ORIGINAL_CHANNELS)) return fail(SGX_EINVAL, "sgx_alloc_outputs: unknown flag%s");
+    memset(out, 0, sizeof(*out));
+    HIP_TRY(hipSetDevice(h->device));
+    const bool original = (flags & SGX_STEP_ORIGINAL_CHANNELS) != 0, full = (flags & SGX_OUT_FULL_OBS) != 0;
+    const int64_t cells = (int64_t)h->cfg.rows * h->cfg.cols;
+    out->obs_bytes = h->n_envs * cells * lut_channels(false, original) * 4;
+    out->fobs_bytes = full ? h->n_envs * cells * lut_channels(true, original) * 4 : 0;
+    out->mask_bytes = h->n_envs * cells * h->K;
+    if (hipMalloc((void **)&out->mask_dev, (size_t)out->mask_bytes) != hipSuccess) return fail(SGX_ENOMEM, "device allocation failed (mask buffer)%s");
+    TrialCtx c{h, stream, flags & SGX_STEP_ORIGINAL_CHANNELS, nullptr, nullptr};
+    int rc = SGX_OK;
+    if (hipEventCreate(&c.e0) != hipSuccess || hipEventCreate(&c.e1) != hipSuccess) rc = fail(SGX_EDEVICE, "hipEventCreate failed%s");
+    if (rc == SGX_OK)
+        rc = pick_buffer(c, 0, (size_t)out->obs_bytes, nullptr, out->mask_dev, max_extra_bytes, max_trials, &out->obs_dev, out->trial_us,
+                         &out->n_trials, &out->peak_extra_bytes);
+    if (rc == SGX_OK && full)
+        rc = pick_buffer(c, 1, (size_t)out->fobs_bytes, out->obs_dev, out->mask_dev, max_extra_bytes, max_trials, &out->fobs_dev, out->ftrial_us,
+                         &out->n_ftrials, &out->peak_extra_bytes);
+    if (c.e0) (void)hipEventDestroy(c.e0);
+    if (c.e1) (void)hipEventDestroy(c.e1);
+    if (rc != SGX_OK) {
+        const std::string keep = g_last_error;
+        (void)sgx_free_outputs(h, out);
+        g_last_error = keep;
+        return rc;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return SGX_OK;
+}
+
 SGX_API int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream) {
     if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
     if (!io->actions_dev) return fail(SGX_EINVAL, "actions_dev is NULL%s");

@@ -31,6 +31,21 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _DeviceBuffer:
+    """A library-owned device allocation seen through __cuda_array_interface__ (zero-copy into a torch tensor)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2,
+                                         'strides': None}
+
+
+def _wrap_device(ptr, shape, dtype, device):
+    typestr = {torch.float32: '<f4', torch.uint8: '|u1'}[dtype]
+    t = torch.as_tensor(_DeviceBuffer(ptr, shape, typestr), device=device)
+    assert t.data_ptr() == int(ptr) and t.dtype == dtype
+    return t
+
+
 class VecStrategoEnv:
     def __init__(self, version='barrage', num_envs=1, device=0, seed=0, env_id_offset=0, human_inits=None,
                  auto_reset=False, final_obs=False, full_obs=False, lib_path=None, obs_channel_mode='extended'):
@@ -88,6 +103,7 @@ class VecStrategoEnv:
     # ---- lifecycle -----------------------------------------------------------------------------------
     def close(self):
         if getattr(self, '_h', None):
+            self._release_outputs()
             self._L.sgx_destroy(self._h)
             self._h = None
 
@@ -127,51 +143,41 @@ class VecStrategoEnv:
                                            (_lib.STEP_RAW_OBS if raw else 0) | self._mode_flags, self._stream()), self._L)
         return self.obs, self.mask, self.player
 
-    def tune_placement(self, trials=24, launches=6, mask_trials=None, max_memory_fraction=0.25):
-        """Pick the fastest of up to `trials` candidate allocations for the big output tensors (obs, then mask).
+    def tune_placement(self, trials=None, max_extra_bytes=8 << 30):
+        """Move the big output tensors (obs, fobs, mask) into library-owned buffers picked by a bounded placement trial
+        (sgx_alloc_outputs).
 
-        Measured on MI355X (tools/tlb_probe.py): device allocations come in speed classes -- the same
-        kernel writing the same bytes takes e.g. 332 / 355 / 380 / 400 us depending on which allocation `obs` is.  The class
-        is a property of the physical backing (offsets inside an allocation are equivalent, a sequential fill is equally
-        fast everywhere, a random scatter over the buffer shows the same ranking); it cannot be requested, and on some
-        boxes the first dozen allocations are all in the slow class while later ones are fast.  So this allocates
-        candidates (all held until the end, so that each one is different memory; at most `max_memory_fraction` of the
-        free device memory), times a few `sgx_observe` launches (which write obs + mask and change no state) on each,
-        keeps the fastest and frees the rest.  Call after reset(); returns {'obs': [...], ('fobs': [...],) 'mask': [...]}
-        per-candidate launch times in microseconds."""
-        def time_observe():
-            self.observe()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream(self.device))
-            for _ in range(launches):
-                self.observe()
-            e1.record(torch.cuda.current_stream(self.device))
-            e1.synchronize()
-            return e0.elapsed_time(e1) / launches * 1e3
-
-        report = {}
-        mask_trials = min(trials, 8) if mask_trials is None else mask_trials
-        todo = [('obs', trials)] + ([('fobs', trials)] if self.fobs is not None else []) + [('mask', mask_trials)]
-        for name, n in todo:   # the observation buffers matter most; then the mask
-            cur = getattr(self, name)
-            free_b, _ = torch.cuda.mem_get_info(self.device)
-            size_b = cur.numel() * cur.element_size()
-            n = max(1, min(n, 1 + int(free_b * max_memory_fraction) // max(size_b, 1)))
-            cands, times = [cur], []
-            for i in range(n):
-                if i:
-                    try:
-                        cands.append(torch.empty(tuple(cur.shape), dtype=cur.dtype, device=self.device))
-                    except torch.cuda.OutOfMemoryError:      # somebody else holds the memory: settle for the candidates so far
-                        break
-                setattr(self, name, cands[i])
-                times.append(time_observe())
-            setattr(self, name, cands[min(range(len(cands)), key=lambda i: times[i])])
-            del cands
-            report[name] = times
-        torch.cuda.empty_cache()     # give the rejected candidates back to the device
+        Measured on MI355X: device memory comes in regions of two kinds; an observation buffer lying inside one region runs at
+        that region's rate (about 350 or 380-395 us per launch of 65,536 Barrage games), one whose pages mix both kinds at
+        313-325 us, and which of these a plain allocation gets depends on what was allocated before it.  The library tries
+        up to `trials` candidate allocations, each behind a padding allocation of growing size that is released again, times a
+        few state-preserving sgx_observe launches on each and keeps the fastest; it never holds more than `max_extra_bytes`
+        beyond the buffers it returns.  Call after reset().  Returns the per-candidate launch times in microseconds:
+        {'obs': [...], ('fobs': [...])}; [0] is the plain first allocation."""
+        out = _lib.SgxOutputs()
+        flags = self._mode_flags | (_lib.OUT_FULL_OBS if self.fobs is not None else 0)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_alloc_outputs(self._h, flags, int(max_extra_bytes), int(trials or _lib.OUT_MAX_TRIALS),
+                                                 self._stream(), C.byref(out)), self._L)
+        self._release_outputs()
+        self._outputs = out
+        N, R, Cc, K = self.num_envs, self.R, self.Cc, self.K
+        self.obs = _wrap_device(out.obs_dev, (N, R, Cc, self.p_channels), torch.float32, self.device)
+        self.mask = _wrap_device(out.mask_dev, (N, R, Cc, K), torch.uint8, self.device)
+        report = {'obs': [float(x) for x in out.trial_us[:out.n_trials]]}
+        if out.fobs_dev:
+            self.fobs = _wrap_device(out.fobs_dev, (N, R, Cc, self.f_channels), torch.float32, self.device)
+            report['fobs'] = [float(x) for x in out.ftrial_us[:out.n_ftrials]]
+        self.placement_peak_extra_bytes = int(out.peak_extra_bytes)
         self.observe()
         return report
+
+    def _release_outputs(self):
+        """Frees library-owned output buffers (tensors wrapping them must not be used afterwards)."""
+        out = getattr(self, '_outputs', None)
+        if out is not None and getattr(self, '_h', None):
+            self._L.sgx_free_outputs(self._h, C.byref(out))
+        self._outputs = None
 
     def step(self, actions, want_next_actions=False, emit_obs=True, emit_mask=True, flags=0):
         """One env.step() for every env.  actions: int32 [N] flat (R,C,K) indices in each mover's perspective."""

@@ -1,0 +1,94 @@
+"""bench.py's own multi-rank path on CPU: `python bench.py --gpus N --dry-run` must start N ranks itself (fresh child
+processes, gloo rendezvous on 127.0.0.1), shard the global env ids with sharding.shard_range, reduce over all ranks and print
+ONE line with n_gpus == N.  The dry run swaps the env for a stub (no GPU here) but runs the same Rank / shard_of /
+timed_steps / reduce code the measured run uses.  A launcher that silently falls back to one rank fails these tests."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, 'bench.py')
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'TORCHELASTIC_RUN_ID', 'SGX_BENCH_LAUNCHER')}
+    env.update(extra)
+    return env
+
+
+def _run(args, env=None, timeout=240):
+    p = subprocess.run([sys.executable, BENCH] + args, env=env or _clean_env(), capture_output=True, text=True, timeout=timeout)
+    return p
+
+
+def _json_lines(stdout):
+    return [json.loads(l) for l in stdout.splitlines() if l.startswith('{')]
+
+
+def test_self_launch_two_ranks():
+    p = _run(['--gpus', '2', '--dry-run', '--steps', '5', '--warmup', '2', '--envs', '1000'])
+    assert p.returncode == 0, p.stderr
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1                                    # rank 0 only
+    d = lines[0]
+    assert d['n_gpus'] == 2 and d['dry_run'] is True and d['value'] is None
+    assert d['launched_by'] == 'bench.py' and d['scaling'] == 'weak'
+    assert d['config']['total_games'] == 2000 and d['config']['games_covered_by_ranks'] == 2000
+    assert d['config']['stub_steps_x_games'] == 5 * 2000      # the SUM all-reduce saw both ranks' timed steps
+
+
+def test_self_launch_strong_scaling_keeps_the_remainder():
+    # 1001 games over 3 ranks: shard_range gives 334 + 334 + 333; an integer division would drop two games
+    p = _run(['--gpus', '3', '--dry-run', '--steps', '4', '--warmup', '1', '--total-envs', '1001'])
+    assert p.returncode == 0, p.stderr
+    d = _json_lines(p.stdout)[0]
+    assert d['n_gpus'] == 3 and d['scaling'] == 'strong'
+    assert d['config']['games_covered_by_ranks'] == 1001 and d['config']['stub_steps_x_games'] == 4 * 1001
+
+
+def test_external_launcher_world_size_must_match_gpus():
+    # a launcher that started ONE rank for --gpus 2 is an error, not a 1-GPU run
+    p = _run(['--gpus', '2', '--dry-run', '--steps', '2', '--warmup', '1'], env=_clean_env(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0'))
+    assert p.returncode != 0 and 'WORLD_SIZE=1' in (p.stderr + p.stdout)
+    # and the other way round: --gpus 1 inside a 2-rank job
+    p = _run(['--gpus', '1', '--dry-run', '--steps', '2', '--warmup', '1'], env=_clean_env(RANK='0', WORLD_SIZE='2', LOCAL_RANK='0'))
+    assert p.returncode != 0 and 'WORLD_SIZE=2' in (p.stderr + p.stdout)
+
+
+def test_under_torch_distributed_run():
+    """The driver's launch form: python -m torch.distributed.run ... bench.py --gpus N (ranks from the environment)."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), BENCH, '--gpus', '2', '--dry-run', '--steps', '3', '--warmup', '1',
+                        '--envs', '64'], env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1 and lines[0]['n_gpus'] == 2 and lines[0]['launched_by'] == 'external'
+    assert lines[0]['config']['games_covered_by_ranks'] == 128
+
+
+def test_single_rank_dry_run_and_failing_rank_stops_the_job():
+    p = _run(['--gpus', '1', '--dry-run', '--steps', '3', '--warmup', '1', '--envs', '10'])
+    assert p.returncode == 0, p.stderr
+    assert _json_lines(p.stdout)[0]['n_gpus'] == 1
+    # rank 1 of 2 gets no games (1 game in total): every rank must exit non-zero instead of hanging in the barrier
+    p = _run(['--gpus', '2', '--dry-run', '--steps', '3', '--warmup', '1', '--total-envs', '1'], timeout=120)
+    assert p.returncode != 0 and not _json_lines(p.stdout)
+
+
+def test_measured_run_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = _run(['--gpus', '1', '--steps', '2', '--warmup', '1'])
+    assert p.returncode != 0 and 'no CPU fallback' in (p.stderr + p.stdout)
+    p = _run(['--gpus', '2', '--steps', '2', '--warmup', '1'])          # the launcher counts devices before starting ranks
+    assert p.returncode != 0 and 'GPU(s) are visible' in (p.stderr + p.stdout)

@@ -105,11 +105,12 @@ def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0):
     env.close()
 
 
-@pytest.mark.parametrize('name,limit', [('barrage', 96), ('standard', 12), ('octa_barrage', 48), ('medium', 64),
-                                        ('fives', 64), ('tiny', 128), ('micro', 128), ('short_barrage', 32)])
-def test_replay_reference_golden_games(name, limit):
-    """Golden games recorded from the REFERENCE (tests/golden, tools/oracle/gen_golden.py): the GPU must reproduce
-    every per-step digest, reward, done flag, error flag and the final internal state."""
+@pytest.mark.parametrize('name', ['barrage', 'standard', 'octa_barrage', 'medium', 'fives', 'tiny', 'micro', 'short_barrage',
+                                  'short_standard', 'standard2'])
+def test_replay_reference_golden_games(name, limit=1 << 30):
+    """Golden games recorded from the REFERENCE (tests/golden, tools/oracle/gen_golden.py) -- ALL of them: 256 Barrage, 24
+    Standard, every toy and short variant: the GPU must reproduce every per-step digest, reward, done flag, error flag and the
+    final internal state."""
     import torch
     from stratego_env_amd.vec_env import VecStrategoEnv
     g = load_games(name)
@@ -285,8 +286,9 @@ def test_tune_placement_keeps_outputs():
     env = VecStrategoEnv('barrage', 4096, seed=5, auto_reset=True)
     env.reset()
     obs0, mask0 = env.obs.clone(), env.mask.clone()
-    rep = env.tune_placement(trials=3, launches=2)
-    assert len(rep['obs']) == 3 and len(rep['mask']) == 3
+    rep = env.tune_placement(trials=3)
+    assert len(rep['obs']) == 3 and env.placement_peak_extra_bytes <= 8 << 30
+    assert env.obs.data_ptr() == env._outputs.obs_dev and env.mask.data_ptr() == env._outputs.mask_dev     # library-owned buffers
     assert np.array_equal(env.obs.cpu().numpy(), obs0.cpu().numpy()) and np.array_equal(env.mask.cpu().numpy(), mask0.cpu().numpy())
     env.sample_valid_actions()
     env.rollout_step()
@@ -295,8 +297,13 @@ def test_tune_placement_keeps_outputs():
     env = VecStrategoEnv('tiny', 1024, seed=5, auto_reset=True, full_obs=True)       # BOTH mode: the full observation is placed too
     env.reset()
     fobs0 = env.fobs.clone()
-    rep = env.tune_placement(trials=2, launches=2)
-    assert sorted(rep) == ['fobs', 'mask', 'obs'] and np.array_equal(env.fobs.cpu().numpy(), fobs0.cpu().numpy())
+    rep = env.tune_placement(trials=2)
+    assert sorted(rep) == ['fobs', 'obs'] and len(rep['fobs']) == 2 and np.array_equal(env.fobs.cpu().numpy(), fobs0.cpu().numpy())
+    rep = env.tune_placement(trials=4, max_extra_bytes=0)                   # no budget: plain first allocation, nothing timed
+    assert rep['obs'] == [] and np.array_equal(env.fobs.cpu().numpy(), fobs0.cpu().numpy())
+    env.sample_valid_actions()
+    env.rollout_step()
+    assert int(env.invalid_action.sum()) == 0
     env.close()
 
 

@@ -14,7 +14,7 @@ from stratego_env_amd.vec_env import VecStrategoEnv  # noqa: E402
 def run(version, n, steps, full, mode):
     env = VecStrategoEnv(version, n, seed=7, auto_reset=True, full_obs=full, obs_channel_mode=mode)
     env.reset()
-    env.tune_placement(8)
+    env.tune_placement()
     env.sample_valid_actions()
     env.rollout_steps(16)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
