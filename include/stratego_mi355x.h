@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 6
+#define SGX_ABI_VERSION 7
 #define SGX_MAX_CELLS 256        /* rows*cols <= 256 (largest reference variant: 15x15) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
 #define SGX_FO_OBS_CHANNELS 79   /* impl:1227 */
@@ -198,6 +198,23 @@ int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actions_dev, 
  * (absolute coordinates).  player_dev int8 [N] = current mover (nullable on export; NULL on import = +1). */
 int sgx_export_state(sgx_env *h, int64_t *state_dev, int8_t *player_dev, void *stream);
 int sgx_import_state(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, void *stream);
+/* The same import with a report: the reference's pure functions accept ANY int64 [34,R,C] (impl:399-517, 894-1045), the packed
+ * record only what play can produce.  sanitised_dev uint8 [N] (nullable) is set to 1 for every state the import had to alter:
+ * a value outside its layer's range (-> 0), more than two non-zero recent-move cells of one player (the rest dropped), more
+ * captured pieces than 2 x pieces per side (the surplus dropped), an obstacle layer that differs from the variant's (the
+ * variant's is used), a player that is not +1 / -1; 0 otherwise -- results for flagged states may differ from the reference's. */
+int sgx_import_state_checked(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, uint8_t *sanitised_dev, void *stream);
+
+/* Search callers (MCTS on get_next_state, penv:148-155) keep their nodes in the packed records instead of paying the 27 KB
+ * int64 import / export per state: handles of the same variant on the same device act as node pools.
+ * sgx_copy_envs: records src[src_index[i]] -> dst[dst_index[i]] for i < n (an index array may be NULL = identity).
+ * sgx_expand: one env.step() per env i of `dst`, reading the game from record src_index[i] of `src` (i when NULL) and writing
+ * the successor to record i of `dst`; where the action is invalid (invalid_action[i] = 1) record i becomes a copy of the
+ * parent.  `io` as in sgx_step (flags SGX_STEP_ACTIONS_1D / _POSITIONS / _ALLOW_OSCILLATION / _RAW_OBS / _MASK_*; no auto_reset,
+ * no fully-observable / original-channel outputs); src == dst with a NULL index is sgx_step.  No reference counterpart beyond
+ * get_next_state itself. */
+int sgx_copy_envs(sgx_env *dst, const int32_t *dst_index_dev, sgx_env *src, const int32_t *src_index_dev, int64_t n, void *stream);
+int sgx_expand(sgx_env *dst, sgx_env *src, const int32_t *src_index_dev, const sgx_step_io *io, void *stream);
 
 /* Per-env bookkeeping: int32 [N][4] = {turn count, game number, game_over, current player}. */
 int sgx_get_env_info(sgx_env *h, int32_t *info_dev, void *stream);

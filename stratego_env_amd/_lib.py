@@ -14,7 +14,7 @@ PO_OBS_CHANNELS = 67
 FO_OBS_CHANNELS = 79
 PO_OBS_CHANNELS_ORIGINAL = 32
 FO_OBS_CHANNELS_ORIGINAL = 33
-ABI_VERSION = 6
+ABI_VERSION = 7
 STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, STEP_ORIGINAL_CHANNELS = 1, 2, 4, 8, 16
 STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
 OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
@@ -23,7 +23,7 @@ OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
     'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
-    'sgx_observe', 'sgx_time_observe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_step_n', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_get_env_info',
+    'sgx_observe', 'sgx_time_observe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_step_n', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
 )
 
 
@@ -100,6 +100,12 @@ def _bind(L):
     L.sgx_export_state.argtypes = [vp, vp, vp, vp]
     L.sgx_import_state.restype = C.c_int
     L.sgx_import_state.argtypes = [vp, vp, vp, vp]
+    L.sgx_import_state_checked.restype = C.c_int
+    L.sgx_import_state_checked.argtypes = [vp, vp, vp, vp, vp]
+    L.sgx_copy_envs.restype = C.c_int
+    L.sgx_copy_envs.argtypes = [vp, vp, vp, vp, i64, vp]
+    L.sgx_expand.restype = C.c_int
+    L.sgx_expand.argtypes = [vp, vp, vp, C.POINTER(SgxStepIO), vp]
     L.sgx_get_env_info.restype = C.c_int
     L.sgx_get_env_info.argtypes = [vp, vp, vp]
     return L

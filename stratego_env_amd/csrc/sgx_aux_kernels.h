@@ -156,7 +156,8 @@ __global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t
 // is laid out with a block-wide prefix sum, and the finished record leaves as whole 128-byte lines.  (The first version
 // walked the 24 captured layers with one thread: 4.6 ms per 65,536 states against 0.44 ms for the export.)
 template <int R_, int C_>
-__global__ __launch_bounds__(256) void import_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in) {
+__global__ __launch_bounds__(256) void import_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in,
+                                                     uint8_t *__restrict__ sanitised) {
     using G = Geo<R_, C_>;
     constexpr int RC = G::RC, C = G::C, S = G::S, NT = 256;
     constexpr int IMG = (G::EVL_OFF + 2 * G::EVL_MAX + 127) & ~127;      // >= rec_bytes of any piece set on this board
@@ -166,9 +167,11 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
     __shared__ int8_t recent[2 * RC];
     __shared__ uint8_t still[2 * RC];
     __shared__ int scan[NT / 64];
+    __shared__ int altered;       // the state held something the packed record cannot carry: reported through sanitised[]
     const int tid = threadIdx.x;
     const int64_t env = blockIdx.x;
     if (env >= P.n_envs) return;
+    if (tid == 0) altered = 0;
     int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
     const int64_t *s = in + env * (int64_t)(SGX_STATE_LAYERS * RC);
     // all of the thread's loads first (the scatter below is branchy, the compiler would otherwise wait for each load in turn:
@@ -187,14 +190,18 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
         const int x = tid + k * NT;
         if (x >= NX) continue;
         const int l = x / RC, cell = x - l * RC;
-        if (l == 2 || l == 5) continue;                               // obstacles are the variant's; scalars below
+        if (l == 5) continue;                                         // scalars below
         const int64_t raw = rawv[k];
-        if (l < 2 || l == 3 || l == 4) {                              // legal range of the layer; anything else -> 0
+        bool ok = true;
+        if (l == 2) ok = raw == (int64_t)P.tab->obstacles[cell];      // obstacles are the variant's (a per-handle constant)
+        else if (l < 2 || l == 3 || l == 4) {                         // legal range of the layer; anything else -> 0
             const int b = l < 2 ? B_PIECES + l : B_PO + (l - 3), hi = l < 2 ? SP_BOMB : SP_UNKNOWN;
-            img[b * S + cell] = (uint8_t)((raw >= 0 && raw <= hi) ? (int)raw : 0);
-        } else if (l == 6 || l == 7) recent[(l - 6) * RC + cell] = (int8_t)((raw >= -3 && raw <= 1) ? (int)raw : 0);
-        else if (l < 32) cap[(l - 8) * RC + cell] = (uint8_t)(raw <= 0 ? 0 : (raw > 12 ? 12 : (int)raw));
-        else still[(l - 32) * RC + cell] = raw == 1 ? 1 : 0;
+            ok = raw >= 0 && raw <= hi;
+            img[b * S + cell] = (uint8_t)(ok ? (int)raw : 0);
+        } else if (l == 6 || l == 7) { ok = raw >= -3 && raw <= 1; recent[(l - 6) * RC + cell] = (int8_t)(ok ? (int)raw : 0); }
+        else if (l < 32) { ok = raw >= 0 && raw <= 12; cap[(l - 8) * RC + cell] = (uint8_t)(raw <= 0 ? 0 : (raw > 12 ? 12 : (int)raw)); }
+        else { ok = raw == 0 || raw == 1; still[(l - 32) * RC + cell] = raw == 1 ? 1 : 0; }
+        if (!ok) altered = 1;
     }
     __syncthreads();
     for (int w = tid; w < 2 * (G::SB / 4); w += NT) {                  // never-moved bitmaps from layers 32/33
@@ -242,13 +249,19 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
         if (d[C + 1] != 0) flags |= F_END_INVALID;
         if (player_in && player_in[env] < 0) flags |= F_PLAYER_M1;
         int pairs[2] = {0, 0};
+        bool dropped = total_events > P.max_events;
         for (int pl = 0; pl < 2; ++pl) {
             int k = 0;
-            for (int cell = 0; cell < RC && k < 2; ++cell) {
+            for (int cell = 0; cell < RC; ++cell) {
                 const int code = recent[pl * RC + cell];
-                if (code != 0) { pairs[pl] |= (cell | ((code & 0xFF) << 8)) << (16 * k); ++k; }
+                if (code == 0) continue;
+                if (k < 2) pairs[pl] |= (cell | ((code & 0xFF) << 8)) << (16 * k);
+                else dropped = true;                                  // more than two recent-move cells cannot come from play
+                ++k;
             }
         }
+        if (player_in && player_in[env] != 1 && player_in[env] != -1) dropped = true;
+        if (sanitised) sanitised[env] = (altered || dropped) ? 1 : 0;
         const int old_game = rec_scal<G>(P.boards, P.rec_bytes, env)[0].w;
         int4 *scg = reinterpret_cast<int4 *>(img + G::SC_OFF);
         scg[0] = make_int4((int)d[0], flags, (int)d[C], old_game < 0 ? 0 : old_game);
@@ -256,6 +269,17 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
     }
     __syncthreads();
     for (int i = tid; i < P.rec_bytes / 16; i += NT) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(img)[i];
+}
+
+// sgx_copy_envs: packed records between two handles of the same variant, one wave per record
+__global__ __launch_bounds__(256) void copy_records_kernel(int8_t *__restrict__ dst, const int32_t *__restrict__ dst_idx, const int8_t *__restrict__ src,
+                                                           const int32_t *__restrict__ src_idx, int rec_bytes, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)(blockDim.x / 64) + threadIdx.x / 64;
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int4 *s = reinterpret_cast<const int4 *>(src + (int64_t)(src_idx ? src_idx[i] : i) * rec_bytes);
+    int4 *d = reinterpret_cast<int4 *>(dst + (int64_t)(dst_idx ? dst_idx[i] : i) * rec_bytes);
+    for (int q = lane; q < rec_bytes / 16; q += 64) d[q] = s[q];
 }
 
 __global__ void info_kernel(const int8_t *__restrict__ boards, int rec_bytes, int sc_off, int32_t *__restrict__ out, int64_t n) {

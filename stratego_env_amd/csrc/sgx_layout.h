@@ -100,6 +100,10 @@ struct KParams {
     int64_t env_id_offset;
     sgx_step_io io;
     int32_t mode;  // 0 = step, 1 = observe
+    // functional-API instantiation only (sgx_expand): game i is read from record src_index[i] (i when NULL) of ANOTHER handle's
+    // records and written to record i of this one, whether or not the move was valid
+    const int8_t *src_boards;
+    const int32_t *src_index;
 #ifdef SGX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [N][16] s_memtime stamps per phase
 #endif

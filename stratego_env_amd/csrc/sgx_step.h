@@ -68,6 +68,9 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     STAMP(0);
 
     int8_t *rec_g = P.boards + env * (int64_t)P.rec_bytes;
+    const int8_t *rec_src = rec_g;
+    if constexpr (MAPPED)        // sgx_expand: the game comes from another handle's records (functional-API instantiation only)
+        if (P.src_boards) rec_src = P.src_boards + (int64_t)(P.src_index ? P.src_index[env] : env) * (int64_t)P.rec_bytes;
     // ---- stage.  Every global read of the step is issued up front -- the whole record (a few 128-byte lines) as one or
     //      two int4 per lane, and the action -- so the wave pays ONE memory round trip.  The scalars, never-moved bitmaps
     //      and capture events are then read from the LDS image of the record (L.tail has the record's layout from ST_OFF
@@ -77,7 +80,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     const int4 zero4 = make_int4(0, 0, 0, 0);
     int4 rq0 = zero4, rq1 = zero4;
     {
-        const int4 *src = reinterpret_cast<const int4 *>(rec_g);
+        const int4 *src = reinterpret_cast<const int4 *>(rec_src);
         const int nq = min(P.rec_bytes >> 4, Q_REC);
         if (lane < nq) rq0 = src[lane];
         if constexpr (NLOAD > 1)
@@ -355,7 +358,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     STAMP(7);   // next action sampled
     // ---- write the record back as whole 128-byte lines: dense boards, scalars, capture events.  (Scattered stores
     //      of only the <= 9 touched bytes + 32 B of scalars are partial-line writes: measured 7 % slower.)
-    if (applied || wrote_reset) {
+    if (applied || wrote_reset || (MAPPED && P.src_boards)) {
         uint16_t *evl = reinterpret_cast<uint16_t *>(L.tail + 2 * G::SB + 32);
         if (!wrote_reset && dirty_s >= 0) {
             const int na = dirty_cap_a >= 0 ? 1 : 0, nb = dirty_cap_b >= 0 ? 1 : 0;

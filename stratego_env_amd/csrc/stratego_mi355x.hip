@@ -329,8 +329,8 @@ static int launch_step(sgx_env *h, const KParams &p, void *stream) {
 #define CALL_STEP1(R, C) CALL_STEP_KIND(R, C, 1)
 #define CALL_STEP2(R, C) CALL_STEP_KIND(R, C, 2)
 #define CALL_STEP3(R, C) CALL_STEP_KIND(R, C, 3)
-    if (p.io.flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) {
-        if (full || original) return fail(SGX_EINVAL, "state-coordinate masks come with the 67-channel partial observation only%s");
+    if ((p.io.flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) || p.src_boards) {
+        if (full || original) return fail(SGX_EINVAL, "state-coordinate masks and sgx_expand come with the 67-channel partial observation only%s");
 #define CALL_STEP_MAPPED(R, C)                                                                     \
     do {                                                                                           \
         if (p.mode) observe_kernel<R, C, 0, true><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p);  \
@@ -543,15 +543,56 @@ SGX_API int sgx_export_state(sgx_env *h, int64_t *state_dev, int8_t *player_dev,
     return SGX_OK;
 }
 
-SGX_API int sgx_import_state(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, void *stream) {
+SGX_API int sgx_import_state_checked(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, uint8_t *sanitised_dev, void *stream) {
     if (!h || !state_dev) return fail(SGX_EINVAL, "NULL argument%s");
     HIP_TRY(hipSetDevice(h->device));
     KParams p = make_params(h);
-#define CALL_IMPORT(R, C) import_kernel<R, C><<<(unsigned)h->n_envs, 256, 0, (hipStream_t)stream>>>(p, state_dev, player_dev)
+#define CALL_IMPORT(R, C) import_kernel<R, C><<<(unsigned)h->n_envs, 256, 0, (hipStream_t)stream>>>(p, state_dev, player_dev, sanitised_dev)
     DISPATCH_GEOMETRY(h, CALL_IMPORT);
 #undef CALL_IMPORT
     HIP_TRY(hipGetLastError());
     return SGX_OK;
+}
+
+SGX_API int sgx_import_state(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, void *stream) {
+    return sgx_import_state_checked(h, state_dev, player_dev, nullptr, stream);
+}
+
+namespace {
+int same_variant(const sgx_env *a, const sgx_env *b) {
+    if (a->device != b->device) return fail(SGX_EINVAL, "the two handles live on different devices%s");
+    if (memcmp(&a->cfg, &b->cfg, sizeof(sgx_config)) != 0 || a->rec_bytes != b->rec_bytes)
+        return fail(SGX_EINVAL, "the two handles were created for different variants%s");
+    return SGX_OK;
+}
+}  // namespace
+
+SGX_API int sgx_copy_envs(sgx_env *dst, const int32_t *dst_index_dev, sgx_env *src, const int32_t *src_index_dev, int64_t n, void *stream) {
+    if (!dst || !src) return fail(SGX_EINVAL, "handle is NULL%s");
+    if (int rc = same_variant(dst, src)) return rc;
+    if (n < 0 || (!dst_index_dev && n > dst->n_envs) || (!src_index_dev && n > src->n_envs)) return fail(SGX_EINVAL, "n out of range%s");
+    if (n == 0) return SGX_OK;
+    HIP_TRY(hipSetDevice(dst->device));
+    copy_records_kernel<<<(unsigned)((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(dst->boards, dst_index_dev, src->boards, src_index_dev, dst->rec_bytes, n);
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}
+
+SGX_API int sgx_expand(sgx_env *dst, sgx_env *src, const int32_t *src_index_dev, const sgx_step_io *io, void *stream) {
+    if (!dst || !src || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
+    if (!io->actions_dev) return fail(SGX_EINVAL, "actions_dev is NULL%s");
+    if (int rc = same_variant(dst, src)) return rc;
+    if (!src_index_dev && src->n_envs < dst->n_envs) return fail(SGX_EINVAL, "without src_index_dev the source handle needs at least as many envs%s");
+    if (io->auto_reset) return fail(SGX_EINVAL, "sgx_expand does not auto-reset%s");
+    if (io->fobs_dev || io->final_fobs_dev || (io->flags & SGX_STEP_ORIGINAL_CHANNELS))
+        return fail(SGX_EINVAL, "sgx_expand renders the 67-channel partial observation only%s");
+    HIP_TRY(hipSetDevice(dst->device));
+    KParams p = make_params(dst);
+    p.mode = 0;
+    p.io = *io;
+    p.src_boards = src->boards;
+    p.src_index = src_index_dev;
+    return launch_step(dst, p, stream);
 }
 
 SGX_API int sgx_get_env_info(sgx_env *h, int32_t *info_dev, void *stream) {

@@ -33,17 +33,33 @@ def nnet_choose_action_example(current_player, obs_from_env):
     return np.random.choice(p.shape[0], p=p)
 
 
-def play_one_game(env):
-    """-> (steps, rewards dict of the terminal step)."""
+def play_one_game(env, trace=None):
+    """-> (steps, rewards dict of the terminal step).  `trace`: optional list that receives the reset observation and then
+    one (action, obs, rewards, dones, infos) tuple per step (the parity tests compare it with the reference's own loop)."""
     obs, steps = env.reset(), 0
+    if trace is not None:
+        trace.append(obs)
     while True:
         (mover,) = obs.keys()                             # exactly one agent is asked to act
         assert mover in (1, -1)
-        obs, rewards, dones, infos = env.step(action_dict={mover: nnet_choose_action_example(mover, obs)})
+        action = nnet_choose_action_example(mover, obs)
+        obs, rewards, dones, infos = env.step(action_dict={mover: action})
         steps += 1
+        if trace is not None:
+            trace.append((int(action), obs, rewards, dones, infos))
         if dones["__all__"]:
             return steps, rewards
         assert all(r == 0.0 for r in rewards.values())
+
+
+def make_env(version='standard', observation_mode=ObservationModes.PARTIALLY_OBSERVABLE):
+    """The env of the reference's __main__ block (basic_game_loop.py:34-42): STANDARD, human setups, random player assignment."""
+    return StrategoMultiAgentEnv(env_config={
+        'version': GameVersions(version),
+        'random_player_assignment': True,
+        'human_inits': version in HUMAN_INIT_VERSIONS,
+        'observation_mode': observation_mode,
+    })
 
 
 def main():
@@ -51,12 +67,7 @@ def main():
     ap.add_argument('--games', type=int, default=1)
     ap.add_argument('--version', default='standard')
     args = ap.parse_args()
-    env = StrategoMultiAgentEnv(env_config={
-        'version': GameVersions(args.version),
-        'random_player_assignment': True,
-        'human_inits': args.version in HUMAN_INIT_VERSIONS,
-        'observation_mode': ObservationModes.PARTIALLY_OBSERVABLE,
-    })
+    env = make_env(args.version)
     for g in range(args.games):
         steps, rewards = play_one_game(env)
         print("game %d: %d steps, reward of player 1: %s, of player -1: %s" % (g, steps, rewards[1], rewards[-1]))

@@ -8,9 +8,19 @@ their states on the device.  Where the reference raises ValueError for an invali
 `valid` mask and leaves that state unchanged.
 
 Limits (documented in DESIGN.md): states must be reachable ones -- at most two non-zero recent-move cells per player and
-no more captured pieces than pieces exist; the obstacle layer must equal the variant's (it is a per-handle constant).
+no more captured pieces than pieces exist; the obstacle layer must equal the variant's (it is a per-handle constant).  Every
+import reports which states it had to alter (`last_sanitised`, uint8 [N]; `strict=True` raises ValueError instead).
+
+Every call imports the states it is given.  A caller that asks several questions about the SAME batch can hold it loaded:
+
+    with env.loaded(states, players):
+        mask = env.get_valid_moves_as_1d_mask(states, players)
+        obs = env.get_partially_observable_observation_extended_channels(states, players)
+
+(inside the scope, calls given the same tensor OBJECTS skip the import; the caller promises not to write to them meanwhile).
+Search callers avoid the 27 KB int64 layout altogether with PackedStates (pack / expand / unpack below).
 """
-import weakref
+import contextlib
 
 import numpy as np
 import torch
@@ -36,7 +46,10 @@ class BatchedStrategoProceduralEnv:
         self.spatial_action_size = v.spatial_action_size                                            # penv:35
         self._vec = VecStrategoEnv(v.name, batch_size, device=device, human_inits=False)
         self.device = self._vec.device
-        self._loaded_key = self._loaded_refs = None     # identity of the states currently imported into the scratch handle
+        self._held = None            # (states, players) objects held loaded by a `with env.loaded(...)` scope
+        self._scratch_is_held = False
+        self.strict = False          # True: ValueError when an import had to alter a state (sanitised)
+        self.last_sanitised = torch.zeros((self.batch_size,), dtype=torch.uint8, device=self.device)
         self._obstacles = torch.from_numpy(v.obstacle_map().astype(np.int64)).to(self.device)
 
     # ---- helpers ---------------------------------------------------------------------------------------------
@@ -50,21 +63,34 @@ class BatchedStrategoProceduralEnv:
             raise ValueError("states must have shape (batch, 34, rows, columns)")
         pl = self._players(players)
         vec = self._vec
-        # consecutive queries on the very same device tensor OBJECTS (mask, then observation, then ... of one batch of search
-        # nodes) import once: same objects (held weakly, so a recycled address cannot alias) and unchanged in-place
-        # modification counters
-        key = None
-        if isinstance(states, torch.Tensor) and isinstance(players, torch.Tensor) and st.data_ptr() == states.data_ptr() \
-                and pl.data_ptr() == players.data_ptr():
-            key = (states._version, players._version)
-        hit = (key is not None and key == self._loaded_key and self._loaded_refs is not None
-               and self._loaded_refs[0]() is states and self._loaded_refs[1]() is players)
-        if not hit:
-            with torch.cuda.device(self.device):
-                _lib.check(vec._L.sgx_import_state(vec._h, st.data_ptr(), pl.data_ptr(), vec._stream()), vec._L)
-            self._loaded_key = key
-            self._loaded_refs = (weakref.ref(states), weakref.ref(players)) if key is not None else None
+        if self._held is not None and self._scratch_is_held and states is self._held[0] and players is self._held[1]:
+            return st, pl                                   # inside `with env.loaded(states, players)`: already in the scratch handle
+        with torch.cuda.device(self.device):
+            _lib.check(vec._L.sgx_import_state_checked(vec._h, st.data_ptr(), pl.data_ptr(), self.last_sanitised.data_ptr(),
+                                                       vec._stream()), vec._L)
+        self._scratch_is_held = self._held is not None and states is self._held[0] and players is self._held[1]
+        if self.strict and bool(self.last_sanitised.any()):
+            raise ValueError("state is not one the packed record can carry (unreachable by play): see sgx_import_state_checked")
         return st, pl
+
+    def _scratch_changed(self):
+        """The scratch handle no longer holds the states of an enclosing `loaded` scope (a move was applied to it)."""
+        self._scratch_is_held = False
+
+    @contextlib.contextmanager
+    def loaded(self, states, players):
+        """Opt-in: import `states` once and let the calls inside the scope that are given the same tensor objects reuse the
+        import.  The caller promises not to modify the tensors inside the scope (writes through other libraries or streams
+        are invisible to this class); outside a scope every call imports."""
+        prev = self._held
+        self._held = (states, players)
+        self._scratch_is_held = False
+        try:
+            self._load(states, players)
+            yield self
+        finally:
+            self._held = prev
+            self._scratch_is_held = False
 
     def _mask_in_state_coordinates(self, one_dim):
         """Mask of the loaded states' movers, indexed in the states' own coordinates (no perspective flip), rendered by the
@@ -81,7 +107,7 @@ class BatchedStrategoProceduralEnv:
     def create_initial_state(self, player_1_initial_piece_maps, player_2_initial_piece_maps):      # penv:38-60
         """own-side piece maps int [N,R,C] -> states (obstacle map and max_turns come from the variant)."""
         self._vec.reset(player_1_initial_piece_maps, player_2_initial_piece_maps)
-        self._loaded_key = None
+        self._scratch_changed()
         st, _ = self._vec.export_state()
         return st
 
@@ -91,7 +117,7 @@ class BatchedStrategoProceduralEnv:
         flags = _lib.STEP_ACTIONS_1D | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
         a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.batch_size)
         self._vec.step(a, emit_obs=False, emit_mask=False, flags=flags)
-        self._loaded_key = None
+        self._scratch_changed()
         new_states, new_players = self._vec.export_state()
         return new_states, new_players, self._vec.invalid_action == 0
 
@@ -100,7 +126,7 @@ class BatchedStrategoProceduralEnv:
         flags = _lib.STEP_ACTIONS_1D | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
         a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.batch_size)
         self._vec.step(a, emit_obs=False, emit_mask=False, flags=flags)
-        self._loaded_key = None
+        self._scratch_changed()
         return self._vec.invalid_action == 0
 
     def is_move_valid_by_position(self, states, players, start_r, start_c, end_r, end_c, allow_piece_oscillation=False):  # penv:87-92
@@ -109,7 +135,7 @@ class BatchedStrategoProceduralEnv:
                            for x in (start_r, start_c, end_r, end_c)], dim=1).contiguous()
         flags = _lib.STEP_ACTIONS_POSITIONS | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
         self._vec.step(pos.view(-1), emit_obs=False, emit_mask=False, flags=flags)
-        self._loaded_key = None
+        self._scratch_changed()
         return self._vec.invalid_action == 0
 
     # ---- masks ---------------------------------------------------------------------------------------------------
@@ -286,6 +312,78 @@ class BatchedStrategoProceduralEnv:
         sr, sc, er, ec = self.get_action_positions_from_1d_index(action_index)
         return self.get_action_spatial_index_from_positions(sr, sc, er, ec)
 
+    # ---- packed states: search nodes kept in the library's records (no int64 import / export per call) ---------------
+    def new_packed(self, n=None):
+        """An empty pool of `n` packed states of this variant (default: batch_size)."""
+        return PackedStates(self.variant.name, self.batch_size if n is None else n, self.device)
+
+    def pack(self, states, players, out=None):
+        """int64 [n,34,R,C] + players -> PackedStates (`out` or a new pool); `sanitised` uint8 [n] reports altered states."""
+        st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64).contiguous()
+        out = out if out is not None else self.new_packed(st.shape[0])
+        out._vec.import_state_checked(st, players, out.sanitised)
+        if self.strict and bool(out.sanitised.any()):
+            raise ValueError("state is not one the packed record can carry (unreachable by play)")
+        return out
+
+    def close(self):
+        self._vec.close()
+
+
+class PackedStates:
+    """A pool of n game states in the library's packed records (0.5 KB each for Barrage against 27 KB in the reference's int64
+    layout), for tree-search callers of get_next_state (penv:148-155): nodes are expanded pool-to-pool with `expand`, copied with
+    `copy_from`, and only converted to the reference layout when somebody wants to look at them (`unpack`)."""
+
+    def __init__(self, version, n, device=0):
+        self._vec = VecStrategoEnv(version, n, device=device, human_inits=False)
+        self.n = int(n)
+        self.device = self._vec.device
+        self.sanitised = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)
+
+    def unpack(self):
+        """-> (states int64 [n,34,R,C], players int8 [n])."""
+        return self._vec.export_state()
+
+    def copy_from(self, src, src_index=None, dst_index=None, n=None):
+        """records src[src_index[i]] -> self[dst_index[i]] (index tensors int32 on the device, None = identity)."""
+        vec = self._vec
+        si = None if src_index is None else torch.as_tensor(src_index).to(device=self.device, dtype=torch.int32).contiguous()
+        di = None if dst_index is None else torch.as_tensor(dst_index).to(device=self.device, dtype=torch.int32).contiguous()
+        if n is None:
+            n = si.numel() if si is not None else di.numel() if di is not None else min(self.n, src.n)
+        with torch.cuda.device(self.device):
+            _lib.check(vec._L.sgx_copy_envs(vec._h, None if di is None else di.data_ptr(), src._vec._h,
+                                            None if si is None else si.data_ptr(), int(n), vec._stream()), vec._L)
+        return self
+
+    def expand(self, parents, action_indices, parent_index=None, allow_piece_oscillation=False, mask_1d_out=None):
+        """get_next_state for every slot i of this pool: self[i] = next_state(parents[parent_index[i]], action_indices[i])
+        (absolute 1-D actions, impl:262-277).  -> (valid bool [n], players int8 [n] of the successors); where the move is invalid
+        the slot holds a copy of the parent.  mask_1d_out: optional uint8 [n, action_size] receiving the successors'
+        get_valid_moves_as_1d_mask in the same launch."""
+        vec = self._vec
+        a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.n).contiguous()
+        pi = None if parent_index is None else torch.as_tensor(parent_index).to(device=self.device, dtype=torch.int32).reshape(self.n).contiguous()
+        flags = _lib.STEP_ACTIONS_1D | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
+        if mask_1d_out is not None:
+            assert mask_1d_out.dtype == torch.uint8 and mask_1d_out.is_contiguous() and mask_1d_out.shape[0] == self.n
+            flags |= _lib.STEP_MASK_1D
+        io = vec._fill_io(a, False, False, False, flags)
+        io.auto_reset = 0
+        io.mask_dev = mask_1d_out.data_ptr() if mask_1d_out is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(vec._L.sgx_expand(vec._h, parents._vec._h, None if pi is None else pi.data_ptr(), io, vec._stream()), vec._L)
+        vec._next_actions_fresh = False
+        return vec.invalid_action == 0, vec.player
+
+    def valid_moves_as_1d_mask(self):
+        out = torch.empty((self.n, self._vec.variant.action_size), dtype=torch.uint8, device=self.device)
+        vec = self._vec
+        with torch.cuda.device(self.device):
+            _lib.check(vec._L.sgx_observe(vec._h, None, None, out.data_ptr(), None, _lib.STEP_MASK_1D, vec._stream()), vec._L)
+        return out
+
     def close(self):
         self._vec.close()
 
@@ -322,6 +420,7 @@ class StrategoProceduralEnv:
     def _b(self):
         if self._batched is None:
             self._batched = BatchedStrategoProceduralEnv(self._version, 1, device=self._device)
+            self._batched.strict = True      # a state the packed record cannot carry is an error here, never silently altered
         return self._batched
 
     def _state(self, state):

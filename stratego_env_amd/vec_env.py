@@ -130,6 +130,9 @@ class VecStrategoEnv:
             m1 = torch.as_tensor(p1_maps).to(device=self.device, dtype=torch.int8).contiguous().reshape(self.num_envs, -1)
             m2 = torch.as_tensor(p2_maps).to(device=self.device, dtype=torch.int8).contiguous().reshape(self.num_envs, -1)
             assert m1.shape[1] == self.R * self.Cc and m2.shape == m1.shape
+            pieces = sum(self.variant.piece_counts)      # the record's capture-event list holds 2 x pieces entries
+            if int(torch.maximum((m1 != 0).sum(1).max(), (m2 != 0).sum(1).max())) > pieces:
+                raise ValueError("a piece map holds more pieces than the %s variant has (%d per side)" % (self.variant.name, pieces))
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_reset(self._h, _ptr(sel), _ptr(m1), _ptr(m2), self._stream()), self._L)
         self._next_actions_fresh = False
@@ -254,6 +257,15 @@ class VecStrategoEnv:
             _lib.check(self._L.sgx_import_state(self._h, _ptr(st), _ptr(pl), self._stream()), self._L)
         self._next_actions_fresh = False
         return self.observe()
+
+    def import_state_checked(self, state, player, sanitised):
+        """import_state without the observe, reporting altered states in `sanitised` (uint8 [N], see sgx_import_state_checked)."""
+        st = torch.as_tensor(state).to(device=self.device, dtype=torch.int64).contiguous()
+        assert tuple(st.shape) == (self.num_envs, NUM_STATE_LAYERS, self.R, self.Cc)
+        pl = None if player is None else torch.as_tensor(player).to(device=self.device, dtype=torch.int8).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_import_state_checked(self._h, _ptr(st), _ptr(pl), _ptr(sanitised), self._stream()), self._L)
+        self._next_actions_fresh = False
 
     def env_info(self):
         """int32 [N,4]: turn count, game number, game_over, current player."""

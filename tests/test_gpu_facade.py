@@ -30,7 +30,7 @@ def _state_from_maps(name, m1, m2):
     return orc.OracleRules(v.rows, v.columns).create_initial_state(ob, m1.astype(np.int64), m2.astype(np.int64), v.max_turns)
 
 
-@pytest.mark.parametrize('name', ['barrage', 'tiny', 'micro', 'octa_barrage'])
+@pytest.mark.parametrize('name', ['barrage', 'standard', 'tiny', 'micro', 'octa_barrage'])
 def test_facade_replays_reference_games(name):
     """reset(initial_state_override=...) + step({player: action}) reproduce the reference's dict outputs: keys, dtypes,
     digests, rewards, dones, infos; invalid actions raise ValueError and leave the env unchanged."""
@@ -115,6 +115,57 @@ def test_basic_game_loop_example_runs():
         assert all(r == 0.0 for r in rew.values())
     assert 1 <= n <= 20 and set(rew.keys()) == {1, -1}
     env.close()
+
+
+def _loop_digest(obs, keys):
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(obs.keys()):
+        for k in keys:
+            if k in obs[p]:
+                a = np.ascontiguousarray(obs[p][k])
+                h.update((a.astype(np.uint8) if k == MASK else a.astype(np.float32)).tobytes())
+    return int.from_bytes(h.digest()[:8], 'little')
+
+
+def test_basic_game_loop_reproduces_the_reference_loop_end_to_end():
+    """tests/golden/game_loop.json was recorded by running the REFERENCE's examples/basic_game_loop.py __main__ configuration
+    (STANDARD, human_inits, random_player_assignment, PARTIALLY_OBSERVABLE) with its own nnet_choose_action_example after
+    np.random.seed(s); random.seed(s).  This package's example, seeded the same way, must choose the same actions, return
+    the same observation dicts (keys after relabelling, mask and observation bytes), rewards and infos, to the last step."""
+    import json
+    import os
+    from tests.helpers import GOLDEN
+    from stratego_env_amd.examples import basic_game_loop as ex
+    gold = json.load(open(os.path.join(GOLDEN, 'game_loop.json')))
+    keys = (MASK, POBS)
+    for g in gold['main_config']:
+        np.random.seed(g['seed'])
+        random.seed(g['seed'])
+        env = ex.make_env('standard')                     # constructed after seeding, like the reference's __main__
+        trace = []
+        steps, rewards = ex.play_one_game(env, trace)
+        assert list(trace[0].keys()) == [g['first_key']] and _loop_digest(trace[0], keys) == g['init_digest']
+        assert steps == len(g['actions']) and [t[0] for t in trace[1:]] == g['actions'], g['seed']
+        assert [_loop_digest(t[1], keys) for t in trace[1:]] == g['digests'], g['seed']
+        assert {str(k): float(v) for k, v in rewards.items()} == g['rewards']
+        infos = trace[-1][4]
+        assert {str(k): dict(v) for k, v in infos.items()} == g['infos']
+        env.close()
+    # the reference's DEFAULT observation mode (BOTH_OBSERVATIONS, maenv:53) through the same loop
+    both = (MASK, POBS, 'full_observation')
+    for g in gold['default_mode']:
+        np.random.seed(g['seed'])
+        random.seed(g['seed'])
+        from stratego_env_amd.multiagent_env import StrategoMultiAgentEnv
+        env = StrategoMultiAgentEnv(env_config={'version': GameVersions(g['version']), 'random_player_assignment': True,
+                                                'human_inits': True})
+        trace = []
+        steps, rewards = ex.play_one_game(env, trace)
+        assert _loop_digest(trace[0], both) == g['init_digest'] and [t[0] for t in trace[1:]] == g['actions']
+        assert [_loop_digest(t[1], both) for t in trace[1:]] == g['digests'], (g['version'], g['seed'])
+        assert {str(k): float(v) for k, v in rewards.items()} == g['rewards']
+        env.close()
 
 
 def test_facade_1d_actions_and_oscillation_flag():

@@ -105,6 +105,81 @@ def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0):
     env.close()
 
 
+def test_config2_256_heldout_seeds_to_termination():
+    """BASELINE config 2's bit-exact check, literally: 256 held-out seeds bench_seed+1 .. bench_seed+256, env id 0,
+    each played with the workload's own action rule (k-th valid action, k from the counter RNG) until its first game ends, on
+    the GPU (one handle per seed -- the seed belongs to the handle -- writing into slices of shared output tensors) and on the
+    CPU oracle; compared per step on (drawn action, mask, observation, reward, done, player, invalid-ending) and on the final
+    state."""
+    import torch
+    from bench import BASE_SEED
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    name, n = 'barrage', 256
+    v = VARIANTS[name]
+    cv = oracle_cvariant(name, setups=_table(name))
+    dev = torch.device('cuda', 0)
+    R, Cc, K = v.rows, v.columns, v.spatial_channels
+    obs_all = torch.empty((n, R, Cc, 67), dtype=torch.float32, device=dev)
+    mask_all = torch.empty((n, R, Cc, K), dtype=torch.uint8, device=dev)
+    rew_all = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+    done_all = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    player_all = torch.zeros((n,), dtype=torch.int8, device=dev)
+    inv_all = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    einv_all = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    next_all = torch.zeros((n,), dtype=torch.int32, device=dev)
+    envs, oenvs, cur = [], [], []
+    for i in range(n):
+        seed = BASE_SEED + 1 + i
+        e = VecStrategoEnv(name, 1, seed=seed, env_id_offset=0, auto_reset=False)
+        e.obs, e.mask, e.reward, e.done = obs_all[i:i + 1], mask_all[i:i + 1], rew_all[i:i + 1], done_all[i:i + 1]
+        e.player, e.invalid_action, e.ending_invalid, e.next_actions = player_all[i:i + 1], inv_all[i:i + 1], einv_all[i:i + 1], next_all[i:i + 1]
+        e.reset()
+        e.sample_valid_actions()
+        envs.append(e)
+        oe = oracle_env(name)
+        oe.reset(initial_state_override=orc.reset_state(cv, seed, 0, 0))
+        oenvs.append(oe)
+    obs_h, mask_h, nxt_h = obs_all.cpu().numpy(), mask_all.cpu().numpy(), next_all.cpu().numpy()
+    for i, oe in enumerate(oenvs):
+        o = oe._obs(1)
+        assert np.array_equal(o[MASK], mask_h[i]) and o[POBS].tobytes() == obs_h[i].tobytes(), ('reset', i)
+        cur.append(o)
+    live = list(range(n))
+    steps = 0
+    while live:
+        acts = {}
+        for i in live:
+            oe = oenvs[i]
+            a = orc.sample_action(cur[i][MASK].astype(np.uint8), BASE_SEED + 1 + i, 0, 0, int(oe.state[5, 0, 0]))
+            assert nxt_h[i] == a, (i, steps, 'drawn action')
+            acts[i] = a
+            envs[i].rollout_step()
+        obs_h, mask_h, nxt_h = obs_all.cpu().numpy(), mask_all.cpu().numpy(), next_all.cpu().numpy()
+        rew_h, done_h, player_h = rew_all.cpu().numpy(), done_all.cpu().numpy(), player_all.cpu().numpy()
+        inv_h, einv_h = inv_all.cpu().numpy(), einv_all.cpu().numpy()
+        still = []
+        for i in live:
+            oe = oenvs[i]
+            o, rew, done, info = oe.step({oe.player: acts[i]})
+            assert inv_h[i] == 0 and bool(done_h[i]) == done['__all__'], (i, steps)
+            if done['__all__']:
+                assert (rew_h[i, 0], rew_h[i, 1]) == (rew[1], rew[-1]) and bool(einv_h[i]) == info[1]['game_result_was_invalid']
+                assert int(mask_h[i].sum()) == 1 and mask_h[i][0, 0, -1] == 1
+                st, pl = envs[i].export_state()
+                assert np.array_equal(st.cpu().numpy()[0], oe.state), (i, 'final state')
+            else:
+                p = oe.player
+                assert player_h[i] == p and np.array_equal(o[p][MASK], mask_h[i]) and o[p][POBS].tobytes() == obs_h[i].tobytes(), (i, steps)
+                assert rew_h[i, 0] == 0 and rew_h[i, 1] == 0
+                cur[i] = o[p]
+                still.append(i)
+        live = still
+        steps += 1
+        assert steps <= v.max_turns
+    for e in envs:
+        e.close()
+
+
 @pytest.mark.parametrize('name', ['barrage', 'standard', 'octa_barrage', 'medium', 'fives', 'tiny', 'micro', 'short_barrage',
                                   'short_standard', 'standard2'])
 def test_replay_reference_golden_games(name, limit=1 << 30):

@@ -182,7 +182,9 @@ def test_facade_exposes_base_env():
     env.close()
 
 
-def test_repeated_queries_on_the_same_tensors_import_once_and_see_modifications():
+def test_every_call_imports_and_the_loaded_scope_is_opt_in():
+    """Default: every query imports the states it is given, so writes that torch cannot see (another library writing through
+    data_ptr, `.data` assignments) are never missed.  `with penv.loaded(states, players)` is the opt-in to import once."""
     import torch
     from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
     from stratego_env_amd.vec_env import VecStrategoEnv
@@ -192,25 +194,125 @@ def test_repeated_queries_on_the_same_tensors_import_once_and_see_modifications(
     env.rollout_steps(40)
     states, players = env.export_state()
     penv = BatchedStrategoProceduralEnv('barrage', n)
+    fresh = BatchedStrategoProceduralEnv('barrage', n)
     m1 = penv.get_valid_moves_as_1d_mask(states, players)
-    key = penv._loaded_key
-    assert key is not None
-    m2 = penv.get_valid_moves_as_1d_mask(states, players)                 # cached import
-    po = penv.get_partially_observable_observation_extended_channels(states, players)
-    assert torch.equal(m1, m2) and penv._loaded_key == key
-    # an in-place change of the tensor is seen (torch bumps its version counter)
+    # a write that does not bump torch's version counter (what a foreign kernel writing through data_ptr() looks like)
     env.rollout_steps(7)
     s2, p2 = env.export_state()
-    states.copy_(s2); players.copy_(p2)
+    v0 = states._version
+    states.data.copy_(s2); players.data.copy_(p2)
+    assert states._version == v0
     m3 = penv.get_valid_moves_as_1d_mask(states, players)
-    fresh = BatchedStrategoProceduralEnv('barrage', n)
     assert torch.equal(m3, fresh.get_valid_moves_as_1d_mask(s2, p2)) and not torch.equal(m3, m1)
-    # a transition invalidates the cache
-    a = torch.argmax((m3 != 0).to(torch.int8), dim=1)
-    penv.get_next_state(states, players, a)
-    assert penv._loaded_key is None
-    assert torch.equal(penv.get_valid_moves_as_1d_mask(states, players), m3)
+    # opt-in scope: one import for several questions about the same objects; a transition inside the scope re-imports
+    calls = []
+    real = penv._vec._L.sgx_import_state_checked
+
+    class Counting:
+        def __getattr__(self, k):
+            if k == 'sgx_import_state_checked':
+                return lambda *a: (calls.append(1), real(*a))[1]
+            return getattr(penv_L, k)
+    penv_L = penv._vec._L
+    penv._vec._L = Counting()
+    with penv.loaded(states, players):
+        ma = penv.get_valid_moves_as_1d_mask(states, players)
+        po = penv.get_partially_observable_observation_extended_channels(states, players)
+        assert len(calls) == 1 and torch.equal(ma, m3)
+        a = torch.argmax((m3 != 0).to(torch.int8), dim=1)
+        penv.get_next_state(states, players, a)                           # uses the held import, then dirties the scratch handle
+        assert len(calls) == 1
+        assert torch.equal(penv.get_valid_moves_as_1d_mask(states, players), m3) and len(calls) == 2
+        other = states.clone()
+        penv.get_valid_moves_as_1d_mask(other, players)                   # other objects: imported, and the held ones again afterwards
+        assert torch.equal(penv.get_valid_moves_as_1d_mask(states, players), m3) and len(calls) == 4
+    penv.get_valid_moves_as_1d_mask(states, players)
+    penv.get_valid_moves_as_1d_mask(states, players)
+    assert len(calls) == 6                                                # outside the scope: always
+    penv._vec._L = penv_L
+    assert torch.equal(po, fresh.get_partially_observable_observation_extended_channels(s2, p2))
     env.close(); penv.close(); fresh.close()
+
+
+def test_import_reports_sanitised_states_and_strict_mode_raises():
+    """The packed record carries reachable states only; sgx_import_state_checked flags every state it had to alter, the
+    batched API exposes the flags and the single-state class raises ValueError."""
+    import torch
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv, StrategoProceduralEnv
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    n = 16
+    env = VecStrategoEnv('barrage', n, seed=3, auto_reset=True)
+    env.reset()
+    env.rollout_steps(30)
+    states, players = env.export_state()
+    bad = states.clone()
+    bad[1, 0, 0, 0] = 99                 # piece code out of range
+    bad[2, 6, 3, 3] = 1; bad[2, 6, 3, 4] = -1; bad[2, 6, 3, 5] = -2      # three recent-move cells of one player
+    bad[3, 2, 0, 0] = 1                  # an obstacle the variant does not have
+    bad[4, 10] = 3                       # 300 captured pieces
+    bad[5, 33, 2, 2] = 7                 # never-moved flag that is not 0 / 1
+    penv = BatchedStrategoProceduralEnv('barrage', n)
+    penv.get_valid_moves_as_1d_mask(bad, players)
+    flags = penv.last_sanitised.cpu().numpy()
+    assert flags.tolist() == [0, 1, 1, 1, 1, 1] + [0] * (n - 6)
+    penv.get_valid_moves_as_1d_mask(states, players)
+    assert int(penv.last_sanitised.sum()) == 0
+    packed = penv.pack(bad, players)
+    assert packed.sanitised.cpu().numpy().tolist() == flags.tolist()
+    penv.strict = True
+    with pytest.raises(ValueError):
+        penv.get_valid_moves_as_1d_mask(bad, players)
+    single = StrategoProceduralEnv(10, 10)
+    single.get_valid_moves_as_1d_mask(states[0].cpu().numpy(), int(players[0]))
+    with pytest.raises(ValueError):
+        single.get_valid_moves_as_1d_mask(bad[1].cpu().numpy(), int(players[1]))
+    with pytest.raises(ValueError):                                       # more pieces than the variant has
+        env.reset(torch.ones((n, 10, 10), dtype=torch.int8), torch.ones((n, 10, 10), dtype=torch.int8))
+    env.close(); penv.close(); packed.close()
+
+
+@pytest.mark.parametrize('name', ['barrage', 'tiny', 'fives'])
+def test_packed_states_expand_equals_get_next_state(name):
+    """Search on packed records: pool-to-pool expansion (sgx_expand) with a parent index gives exactly the successors the
+    int64 get_next_state gives (which the other tests pin to the oracle); invalid actions leave a copy of the parent."""
+    import torch
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    n_par, n = 48, 192
+    env = VecStrategoEnv(name, n_par, seed=21, auto_reset=True)
+    env.reset()
+    env.rollout_steps(9)
+    states, players = env.export_state()
+    ppar = BatchedStrategoProceduralEnv(name, n_par)
+    parents = ppar.pack(states, players)
+    assert int(parents.sanitised.sum()) == 0
+    rs = np.random.RandomState(3)
+    pidx = torch.from_numpy(rs.randint(0, n_par, size=n).astype(np.int32)).cuda()
+    masks = ppar.get_valid_moves_as_1d_mask(states, players)[pidx.long()]
+    # a random valid action for most children, garbage for some
+    pick = torch.multinomial((masks != 0).float(), 1).squeeze(1).to(torch.int32)
+    garbage = torch.from_numpy(rs.rand(n) < 0.2).cuda()
+    acts = torch.where(garbage, torch.randint(0, masks.shape[1], (n,), device='cuda', dtype=torch.int32), pick)
+    pch = BatchedStrategoProceduralEnv(name, n)
+    children = pch.new_packed()
+    mask_out = torch.empty((n, masks.shape[1]), dtype=torch.uint8, device='cuda')
+    valid, child_players = children.expand(parents, acts, parent_index=pidx, mask_1d_out=mask_out)
+    want_states, want_players, want_valid = pch.get_next_state(states[pidx.long()], players[pidx.long()], acts)
+    got_states, got_players = children.unpack()
+    assert torch.equal(valid, want_valid) and bool((~valid).any()) and bool(valid.any())
+    assert torch.equal(got_states, want_states) and torch.equal(got_players, want_players) and torch.equal(child_players, want_players)
+    assert torch.equal(mask_out, pch.get_valid_moves_as_1d_mask(want_states, want_players))
+    assert torch.equal(children.valid_moves_as_1d_mask(), mask_out)
+    # the parents are untouched; copy_from scatters records between pools
+    ps, pp = parents.unpack()
+    assert torch.equal(ps, states) and torch.equal(pp, players)
+    pool = pch.new_packed()
+    dst = torch.arange(n - 1, -1, -1, dtype=torch.int32, device='cuda')
+    pool.copy_from(children, dst_index=dst)
+    cs, cp = pool.unpack()
+    assert torch.equal(cs.flip(0), got_states) and torch.equal(cp.flip(0), got_players)
+    for x in (env, ppar, pch, parents, children, pool):
+        x.close()
 
 
 def test_directed_combat_matrix_and_quirks_vs_oracle():

@@ -32,14 +32,20 @@ def main():
     m1 = penv.get_valid_moves_as_1d_mask(states, players)
     # first valid 1-D action of every state
     acts = torch.argmax((m1 != 0).to(torch.int8), dim=1).to(torch.int32)
-    for name, fn in (('export_state', lambda: env.export_state()),
+    parents = penv.pack(states, players)
+    children = penv.new_packed()
+    mask_out = torch.empty((n, m1.shape[1]), dtype=torch.uint8, device='cuda')
+    for name, fn in (('packed: expand (get_next_state)', lambda: children.expand(parents, acts)),
+                     ('packed: expand + 1-D mask', lambda: children.expand(parents, acts, mask_1d_out=mask_out)),
+                     ('packed: copy_from', lambda: children.copy_from(parents)),
+                     ('export_state', lambda: env.export_state()),
                      ('import_state', lambda: penv._load(states, players)),
                      ('get_next_state', lambda: penv.get_next_state(states, players, acts)),
                      ('is_move_valid_by_1d_index', lambda: penv.is_move_valid_by_1d_index(states, players, acts)),
                      ('get_valid_moves_as_1d_mask', lambda: penv.get_valid_moves_as_1d_mask(states, players)),
                      ('partial obs (raw)', lambda: penv.get_partially_observable_observation_extended_channels(states, players))):
         t = timed(fn)
-        print("%-28s %9.1f us per batch of %d  -> %8.1f M states/s" % (name, t * 1e6, n, n / t / 1e6), flush=True)
+        print("%-32s %9.1f us per batch of %d  -> %8.1f M states/s" % (name, t * 1e6, n, n / t / 1e6), flush=True)
 
 
 if __name__ == '__main__':
