@@ -144,13 +144,13 @@ __global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t
                 if (pr >> 8) o[(6 + pl) * RC + (pr & 0xFF)] = (int8_t)(pr >> 8);
             }
         const uint16_t *ev = reinterpret_cast<const uint16_t *>(rec + G::EVL_OFF);
-        for (int i = 0; i < sc2.x; ++i) o[(8 + (ev[i] >> 8)) * RC + (ev[i] & 0xFF)] += 1;
+        for (int i = 0; i < sc2.x; ++i) o[(8 + ((ev[i] >> 8) & 31)) * RC + (ev[i] & 0xFF)] += (ev[i] >> EV_COUNT_SHIFT) + 1;
         if (player_out) player_out[env] = (sc.y & F_PLAYER_M1) ? -1 : 1;
     }
 }
 
-// Reachable states only: at most two non-zero recent-move cells per player (impl:1013-1028) and at most
-// max_events captured pieces; anything beyond that cannot come from play and is dropped.
+// Reachable states only: at most two non-zero recent-move cells per player (impl:1013-1028), at most max_events (layer, cell)
+// pairs with captured pieces and at most 8 of them on one pair; anything beyond that cannot come from play and is dropped.
 // One 256-thread block per state: a single coalesced pass over the 34 int64 layers scatters them into LDS (dense boards
 // straight into the record image, never-moved flags, recent-move codes and captured counts as bytes), the capture-event list
 // is laid out with a block-wide prefix sum, and the finished record leaves as whole 128-byte lines.  (The first version
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
             ok = raw >= 0 && raw <= hi;
             img[b * S + cell] = (uint8_t)(ok ? (int)raw : 0);
         } else if (l == 6 || l == 7) { ok = raw >= -3 && raw <= 1; recent[(l - 6) * RC + cell] = (int8_t)(ok ? (int)raw : 0); }
-        else if (l < 32) { ok = raw >= 0 && raw <= 12; cap[(l - 8) * RC + cell] = (uint8_t)(raw <= 0 ? 0 : (raw > 12 ? 12 : (int)raw)); }
+        else if (l < 32) { ok = raw >= 0 && raw <= EV_COUNT_MAX; cap[(l - 8) * RC + cell] = (uint8_t)(raw <= 0 ? 0 : (raw > EV_COUNT_MAX ? EV_COUNT_MAX : (int)raw)); }
         else { ok = raw == 0 || raw == 1; still[(l - 32) * RC + cell] = raw == 1 ? 1 : 0; }
         if (!ok) altered = 1;
     }
@@ -213,11 +213,11 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
         }
         reinterpret_cast<uint32_t *>(img + G::ST_OFF)[w] = bits;
     }
-    // capture events in (layer, cell) order: thread t owns entries [t*PER, (t+1)*PER) of the count table
+    // capture events (one per non-zero count) in (layer, cell) order: thread t owns entries [t*PER, (t+1)*PER) of the count table
     int cnt = 0;
     for (int k = 0; k < PER; ++k) {
         const int e = tid * PER + k;
-        if (e < NE) cnt += cap[e];
+        if (e < NE) cnt += cap[e] != 0;
     }
     // block-wide inclusive scan: shuffle scan inside each wave, then the four wave totals through LDS
     int incl = cnt;
@@ -236,9 +236,10 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
         uint16_t *ev = reinterpret_cast<uint16_t *>(img + G::EVL_OFF);
         for (int k = 0; k < PER; ++k) {
             const int e = tid * PER + k;
-            if (e < NE)
-                for (int q = cap[e]; q > 0; --q, ++at)
-                    if (at < P.max_events) ev[at] = (uint16_t)(((e / RC) << 8) | (e % RC));
+            if (e < NE && cap[e] != 0) {
+                if (at < P.max_events) ev[at] = (uint16_t)(((cap[e] - 1) << EV_COUNT_SHIFT) | ((e / RC) << 8) | (e % RC));
+                ++at;
+            }
         }
     }
     if (tid == 0) {

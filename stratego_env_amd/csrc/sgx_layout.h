@@ -22,9 +22,16 @@ constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 673 /* >= 20*33 (79 channels), = 1 m
 #define SGX_MIN_WAVES 6
 #endif
 constexpr int WPB = SGX_WPB;  // waves per workgroup (WPB * Geo::GPW games); they share the LUT
-// per observation kind in LDS: the LUT followed by the quad table (2 perspectives x NCH quads x 4 packed entries, see emit_obs)
+// 'original' channel mode only -- per observation kind in LDS: the LUT followed by the quad table (2 perspectives x NCH quads x 4
+// packed entries, see emit_obs_lut)
 constexpr int QTAB_DWORDS = 2 * OBS_CH * 4, OBS_TAB_DWORDS = LUT_DWORDS + QTAB_DWORDS;   // partial kind; the full kind follows it
 constexpr int FOBS_TAB_DWORDS = LUT_DWORDS + 2 * FOBS_CH * 4;
+// 'extended' channel mode: an observation is rendered from 4-bit codes, one per float, decoded by v_cvt_off_f32_i4 (x 4):
+// 0 -> 0.0, 2 -> 0.5, 4 -> 1.0, 12 -> -1.0.  Every channel has a default code (one-hot / obstacle / never-moved: 0; recent
+// moves: 0.5 normalised, 0 raw; captured counts: -1 normalised, 0 raw) held in a per-variant template; the few entries that are
+// neither default nor 1.0 (captured counts >= 1, non-zero recent-move codes) are patched into the output afterwards.
+constexpr int NIB_ONE = 4, CODE_NONE = 0xFF, CODETAB_REC = 192, CODETAB_BYTES = 208;
+constexpr int TMPL_MAX_BYTES = ((SGX_MAX_CELLS * FOBS_CH / 2) + 15) & ~15;   // 10,112
 __host__ __device__ constexpr int lut_row(int ch) { return ((ch >> 1) & 1) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH + (ch & 1) * 16; }
 
 // internal board indices inside an env record (each board is S bytes, absolute coordinates)
@@ -32,12 +39,16 @@ constexpr int B_PIECES = 0;   // +pi : true pieces of player index pi (0 = playe
 constexpr int B_PO = 2;       // +pi : what the opponent knows of pi's pieces                           impl layers 3/4
 constexpr int B_STILL = 4;    // +pi : never-moved flags                                                impl layers 32/33
 constexpr int B_RECENT = 6;   // +pi : two-square bookkeeping (LDS only, rebuilt from scal)             impl layers 6/7
-constexpr int B_CAP = 8;      // +12*pi + (type-1) : captured counts (LDS only, rebuilt from events)    impl layers 8-19 / 20-31
-constexpr int N_BOARDS = 32;
+constexpr int N_BOARDS = 8;   // boards that make up a game in LDS (cleared by a reset)
 constexpr int STORED_BOARDS = 4;  // boards 0..3 live in HBM as bytes; never-moved flags as bitmaps; the rest sparsely:
 //   recent moves: at most two non-zero cells per player (impl:1013-1028)  -> two (cell, code) pairs per player in scal
-//   captured counts: one event (board - B_CAP, cell) per captured piece   -> uint16 list, <= 2 * pieces per side entries
-constexpr int B_OBST = 32;    // LDS only: per-variant obstacle map (impl layer 2)
+//   captured counts (impl layers 8-19 / 20-31): never dense, not even in LDS -- one EVENT per (layer, cell) with a non-zero
+//   count: uint16 = (count - 1) << 13 | (12 * pi + type - 1) << 8 | cell, <= 2 * pieces per side entries; a count cannot
+//   exceed the 8 pieces of the most numerous type
+constexpr int B_OBST = 8;     // LDS only: per-variant obstacle map (impl layer 2)
+constexpr int B_ZERO = 9;     // LDS only: all zero ('original' channel mode reads the captured-count channels' defaults from it)
+constexpr int N_LDS_BOARDS = 10;
+constexpr int EV_KEY_MASK = 0x1FFF, EV_COUNT_SHIFT = 13, EV_COUNT_MAX = 8;
 
 // record scalars (32 B at SC_OFF): {turn, flags, max_turns, game_no} {n_events, recent pairs of +1, recent pairs of -1, 0}
 // a recent pair is cell | (code & 0xFF) << 8, two pairs per int (low / high half); code 0 = empty
@@ -50,7 +61,7 @@ struct Geo {
     static constexpr int R = R_, C = C_;
     static constexpr int RC = R * C;
     static constexpr int S = (RC + 3) & ~3;           // board stride (bytes)
-    static constexpr int LDS_BOARDS_BYTES = N_BOARDS * S;            // bytes of the 32 LDS boards (multiple of 128)
+    static constexpr int LDS_BOARDS_BYTES = N_BOARDS * S;            // bytes of the 8 boards of a game in LDS (multiple of 16)
     // HBM record (a multiple of 128 B, so every record is read and written as whole cache lines):
     //   [0, 4S) four dense boards (true pieces, PO pieces) | zero padding to 16 | ST_OFF: never-moved bitmaps 2 x SB |
     //   SC_OFF: 32 B scalars | EVL_OFF: capture events uint16[max_events] | zero padding
@@ -83,6 +94,13 @@ struct DevTables {
     //   full: the fully-observable observation instead of the partial one
     float lut[8][LUT_DWORDS];
     uint8_t obstacles[SGX_MAX_CELLS];
+    // 'extended' mode code templates, index = 2 * raw + full: nibble e (entry e = cell * NCH + ch of one observation, low nibble
+    // first) = the default code of channel ch
+    alignas(16) uint8_t tmpl[4][TMPL_MAX_BYTES];
+    // codes of the values that are not channel defaults, index = raw: [16 * (type - 1) + count] for a captured count (the own and
+    // the enemy block of a piece type share their normalisation), [CODETAB_REC + code + 3] for a recent-move code; CODE_NONE where
+    // the float is not one of the 16 decodable values (such entries are patched into the output as floats)
+    alignas(16) uint8_t codetab[2][CODETAB_BYTES];
 };
 
 struct KParams {
@@ -132,10 +150,14 @@ template <class T> __device__ inline void stream_store(T *p, T v) { __builtin_no
 template <class T> __device__ inline void stream_store(T *p, T v) { *p = v; }
 #endif
 
-// per-wave LDS: one game
-template <class G>
+// per-wave LDS: one game.  NIB_CH = channels of the widest observation rendered from codes by this kernel instantiation
+// (0: 'original' channel mode, no code buffer).
+template <class G, int NIB_CH = OBS_CH>
 struct alignas(16) Lds {
-    int8_t b[N_BOARDS + 1][G::S];
+    static constexpr int NIB_BYTES = ((G::RC * NIB_CH + 1) / 2 + 15) & ~15;
+    int8_t b[N_LDS_BOARDS][G::S];
+    alignas(16) uint8_t nib_lead[16];                  // emit_obs_codes reads up to one halfword in front of the codes (odd boards)
+    alignas(16) uint8_t nib[NIB_BYTES + 16];           // 4-bit code of every float of the observation being rendered
     alignas(16) uint32_t mbits[G::MB_WORDS];           // valid-actions mask of the next mover, one BIT per action
     alignas(16) uint8_t cnt[G::CNT_PAD];               // valid moves per perspective cell (also setup-shuffle scratch)
     alignas(16) uint8_t occ[G::S];                     // gen_mask scratch: combined occupancy byte per cell
@@ -201,42 +223,24 @@ __device__ inline void wave_sync() {
 
 // Observation channel specs: board holding channel `ch` for perspective player index qi, and the LUT index bias
 // (recent-moves codes are -3..1).  Partial: impl:1306-1332; full: impl:1200-1227; perspective swap impl:645-675.
+// 'extended' kinds are rendered from codes (sgx_obs.h): first channel of each block
 struct PartialObs {
     static constexpr int NCH = OBS_CH;
-    __device__ static inline int board(int ch, int qi) {
-        if (ch < 12) return B_PIECES + qi;
-        if (ch < 25) return B_PO + qi;
-        if (ch < 38) return B_PO + (1 - qi);
-        if (ch == 38) return B_OBST;
-        if (ch == 39) return B_RECENT + qi;
-        if (ch == 40) return B_RECENT + (1 - qi);
-        if (ch < 53) return B_CAP + 12 * qi + (ch - 41);
-        if (ch < 65) return B_CAP + 12 * (1 - qi) + (ch - 53);
-        if (ch == 65) return B_STILL + qi;
-        return B_STILL + (1 - qi);
-    }
-    __device__ static inline int bias(int ch) { return (ch == 39 || ch == 40) ? 3 : 0; }
+    static constexpr bool CODES = true;
+    static constexpr int OWN0 = 0, ENEMY0 = -1 /* no enemy true pieces */, OWN_PO0 = 12, ENEMY_PO0 = 25, OBST = 38, REC0 = 39, CAP0 = 41,
+                         STILL0 = 65;
 };
 struct FullObs {
     static constexpr int NCH = FOBS_CH;
-    __device__ static inline int board(int ch, int qi) {
-        if (ch < 12) return B_PIECES + qi;
-        if (ch < 24) return B_PIECES + (1 - qi);
-        if (ch < 37) return B_PO + qi;
-        if (ch < 50) return B_PO + (1 - qi);
-        if (ch == 50) return B_OBST;
-        if (ch == 51) return B_RECENT + qi;
-        if (ch == 52) return B_RECENT + (1 - qi);
-        if (ch < 65) return B_CAP + 12 * qi + (ch - 53);
-        if (ch < 77) return B_CAP + 12 * (1 - qi) + (ch - 65);
-        if (ch == 77) return B_STILL + qi;
-        return B_STILL + (1 - qi);
-    }
-    __device__ static inline int bias(int ch) { return (ch == 51 || ch == 52) ? 3 : 0; }
+    static constexpr bool CODES = true;
+    static constexpr int OWN0 = 0, ENEMY0 = 12, OWN_PO0 = 24, ENEMY_PO0 = 37, OBST = 50, REC0 = 51, CAP0 = 53, STILL0 = 77;
 };
 // obs_channel_mode='original' (maenv:368-375): channels hold piece VALUES; partial impl:1126-1148, full impl:1048-1070
+// ('original' kinds go through (board byte, LUT row); their captured-count channels read the all-zero board and are patched)
 struct OrigPartialObs {
     static constexpr int NCH = SGX_PO_OBS_CHANNELS_ORIGINAL;
+    static constexpr bool CODES = false;
+    static constexpr int REC0 = 4, CAP0 = 6;
     __device__ static inline int board(int ch, int qi) {
         if (ch == 0) return B_PIECES + qi;
         if (ch == 1) return B_PO + qi;
@@ -244,8 +248,7 @@ struct OrigPartialObs {
         if (ch == 3) return B_OBST;
         if (ch == 4) return B_RECENT + qi;
         if (ch == 5) return B_RECENT + (1 - qi);
-        if (ch < 18) return B_CAP + 12 * qi + (ch - 6);
-        if (ch < 30) return B_CAP + 12 * (1 - qi) + (ch - 18);
+        if (ch < 30) return B_ZERO;
         if (ch == 30) return B_STILL + qi;
         return B_STILL + (1 - qi);
     }
@@ -253,6 +256,8 @@ struct OrigPartialObs {
 };
 struct OrigFullObs {
     static constexpr int NCH = SGX_FO_OBS_CHANNELS_ORIGINAL;
+    static constexpr bool CODES = false;
+    static constexpr int REC0 = 3, CAP0 = 7;
     __device__ static inline int board(int ch, int qi) {
         if (ch == 0) return B_PIECES + qi;
         if (ch == 1) return B_PIECES + (1 - qi);
@@ -261,8 +266,7 @@ struct OrigFullObs {
         if (ch == 4) return B_RECENT + (1 - qi);
         if (ch == 5) return B_PO + qi;
         if (ch == 6) return B_PO + (1 - qi);
-        if (ch < 19) return B_CAP + 12 * qi + (ch - 7);
-        if (ch < 31) return B_CAP + 12 * (1 - qi) + (ch - 19);
+        if (ch < 31) return B_ZERO;
         if (ch == 31) return B_STILL + qi;
         return B_STILL + (1 - qi);
     }
@@ -272,6 +276,7 @@ struct OrigFullObs {
 template <int KIND>
 struct ObsKind {
     static constexpr bool FULL = (KIND & 1) != 0, ORIG = (KIND & 2) != 0;
+    static constexpr int NIB_CH = ORIG ? 0 : (FULL ? FOBS_CH : OBS_CH);     // code buffer of the game's Lds
     using P = std::conditional_t<ORIG, OrigPartialObs, PartialObs>;
     using F = std::conditional_t<ORIG, OrigFullObs, FullObs>;
 };

@@ -14,8 +14,8 @@ namespace {
 #define SGX_GENMASK_INLINE __forceinline__
 #endif
 // finished game: only the no-op bit [0,0,K-1] (impl:414, 514-515)
-template <class G>
-__device__ __forceinline__ void mask_noop_only(Lds<G> &L, int lane) {
+template <class G, int NB>
+__device__ __forceinline__ void mask_noop_only(Lds<G, NB> &L, int lane) {
     const int4 z = make_int4(0, 0, 0, 0);
     for (int i = lane; i < G::MB_WORDS / 4; i += G::LPG) reinterpret_cast<int4 *>(L.mbits)[i] = z;
     for (int i = lane; i < G::CNT_PAD / 4; i += G::LPG) reinterpret_cast<int *>(L.cnt)[i] = 0;
@@ -24,8 +24,8 @@ __device__ __forceinline__ void mask_noop_only(Lds<G> &L, int lane) {
     wave_sync<G>();
 }
 
-template <class G>
-__device__ SGX_GENMASK_INLINE int gen_mask(Lds<G> &L, int qi, bool game_over, int lane) {
+template <class G, int NB>
+__device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over, int lane) {
     constexpr int R = G::R, C = G::C, RC = G::RC, K = G::K;
     constexpr int OCC_OWN = 1, OCC_ENEMY = 2, OCC_OBST = 4, OCC_CAME_FROM = 8;
     const int8_t *own = L.b[B_PIECES + qi], *enemy = L.b[B_PIECES + 1 - qi], *rec = L.b[B_RECENT + qi], *obst = L.b[B_OBST];
@@ -107,8 +107,8 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G> &L, int qi, bool game_over, in
 // 4 mask bits -> 4 mask bytes
 __device__ inline uint32_t expand4(uint32_t nib) { return (nib * 0x00204081u) & 0x01010101u; }
 // `n` (<= 32) mask bits starting at bit position p
-template <class G>
-__device__ inline uint32_t mask_bits(const Lds<G> &L, int p, int n) {
+template <class G, int NB>
+__device__ inline uint32_t mask_bits(const Lds<G, NB> &L, int p, int n) {
     const unsigned long long w = (unsigned long long)L.mbits[p >> 5] | ((unsigned long long)L.mbits[(p >> 5) + 1] << 32);
     return (uint32_t)(w >> (p & 31)) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u));
 }
@@ -117,8 +117,8 @@ __device__ inline uint32_t mask_bits(const Lds<G> &L, int p, int n) {
 // (3700 = 4 mod 16), byte aligned when NA is odd (5x5, 15x15); lanes own 16-byte-aligned chunks of the global range, so
 // whole chunks leave as one 16-byte store per lane and only the partial first / last chunks go out as dwords (bytes when
 // the base is not 4-byte aligned).
-template <class G>
-__device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) {
+template <class G, int NB>
+__device__ void emit_mask(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int lane) {
     if constexpr (G::NA % 4 != 0 && G::NA < 2048) {      // small byte-aligned masks (5x5: 425 bytes): plain byte stores measured faster
         for (int i = lane; i < G::NA; i += G::LPG) dst[i] = (uint8_t)((L.mbits[i >> 5] >> (i & 31)) & 1u);
         return;
@@ -151,8 +151,8 @@ __device__ void emit_mask(const Lds<G> &L, uint8_t *__restrict__ dst, int lane) 
 // functional operator API, whose masks are indexed in the coordinates of the given STATE rather than in the mover's
 // perspective: the 1-D encoding (impl:520-642) and the spatial encoding for player -1 (impl:399-517 on an unflipped state).
 // 16-byte chunks of the address range like emit_mask; the source index is computed per byte (a handful of integer ops).
-template <class G, class F>
-__device__ void emit_mask_mapped(const Lds<G> &L, uint8_t *__restrict__ dst, int n_bytes, F src, int lane) {
+template <class G, int NB, class F>
+__device__ void emit_mask_mapped(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int n_bytes, F src, int lane) {
     const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
     const int nchunks = (A + n_bytes + 15) >> 4;
     uint8_t *gbase = dst - A;
@@ -214,8 +214,8 @@ struct SrcSpatialFlipped {
 };
 
 // k-th (0-based) valid action in ascending flat index order, from L.mbits / L.cnt
-template <class G>
-__device__ int kth_valid(const Lds<G> &L, int k, int lane) {
+template <class G, int NB>
+__device__ int kth_valid(const Lds<G, NB> &L, int k, int lane) {
     constexpr int K = G::K;
     int cell = 0, before = 0, run = 0;
     bool found = false;

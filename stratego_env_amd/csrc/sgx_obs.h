@@ -1,4 +1,4 @@
-// sgx_obs.h -- observation rendering: quad / channel tables and the line-aligned LUT emission
+// sgx_obs.h -- observation rendering: 4-bit code buffer + line-aligned emission ('extended' channels), LUT emission ('original')
 // Part of libstratego_mi355x.so; included by stratego_mi355x.hip in this order (one translation unit).
 #pragma once
 
@@ -6,11 +6,166 @@ namespace {
 
 // ---------------------------------------------------------------------------------------------
 // Observation render: float32 [R][C][NCH], perspective of player index qi
-// (partial: impl:1335-1397, full: impl:1230-1303; normalisation maenv:499-508 through the LUT)
+// (partial: impl:1335-1397, full: impl:1230-1303; normalisation maenv:499-508)
 // ---------------------------------------------------------------------------------------------
 #ifndef SGX_OBS_UNROLL
 #define SGX_OBS_UNROLL 4
 #endif
+
+// ---- 'extended' channels (67 / 79): rendered from 4-bit codes -------------------------------------------------------------
+// 41 of the 67 partial channels (53 of 79) are 0 / 1 indicators of one board byte (piece one-hots, obstacle, never-moved), and
+// the others are almost always at their default (captured counts 0, recent-move code 0).  The first version looked every float
+// up through (board byte, LUT row): 9 LDS + 27 VALU instructions per 16-byte store, the kernel's largest phase on every board
+// size.  Now: (1) the game's code buffer L.nib is filled from the variant's template of channel defaults (whole 16-byte copies);
+// (2) the lane owning a cell ORs the code of 1.0 into the <= 8 indicator entries that are set; (3) a quad of the output is ONE
+// 16-bit LDS read and four v_cvt_off_f32_i4 (x 4) -- 1-2 LDS + ~18 VALU per store; (4) the few entries that are neither default
+// nor 1.0 (a captured count >= 1, a non-zero recent-move code) are written afterwards as single floats (emit_obs_patches),
+// after the wave has waited for its bulk stores.
+
+// 4-bit code -> float: v_cvt_off_f32_i4 gives sext(code) / 16
+__device__ inline float code_to_float(unsigned x) { return __builtin_amdgcn_cvt_off_f32_i4((int)x) * 4.0f; }
+
+template <class G, int NB>
+__device__ inline void set_code_one(Lds<G, NB> &L, int entry) {
+    atomicOr(reinterpret_cast<unsigned int *>(L.nib) + (entry >> 3), (unsigned)NIB_ONE << ((entry & 7) * 4));
+}
+// replaces the default code `was` of an entry by `now`
+template <class G, int NB>
+__device__ inline void swap_code(Lds<G, NB> &L, int entry, int was, int now) {
+    atomicXor(reinterpret_cast<unsigned int *>(L.nib) + (entry >> 3), (unsigned)(was ^ now) << ((entry & 7) * 4));
+}
+
+// entry (cell, channel, LUT value index) of capture event / recent-move pair number i (events first, then the four pairs) in
+// Spec's observation from perspective qi; false for an empty pair
+template <class G, class Spec, int NB>
+__device__ inline bool special_entry(const Lds<G, NB> &L, int i, int n_events, int rp0, int rp1, int qi, int &entry, int &ch, int &v, int &tab_idx) {
+    const uint16_t *evl = reinterpret_cast<const uint16_t *>(L.tail + 2 * G::SB + 32);
+    int cell;
+    if (i < n_events) {
+        const int ev = evl[i], b = (ev >> 8) & 31, pi = b >= 12 ? 1 : 0, t = b - 12 * pi;
+        cell = ev & 0xFF;
+        ch = Spec::CAP0 + (pi == qi ? 0 : 12) + t;
+        v = (ev >> EV_COUNT_SHIFT) + 1;
+        tab_idx = 16 * t + v;
+    } else {
+        const int k = i - n_events, pl = k >> 1, pr = (((pl ? rp1 : rp0) >> (16 * (k & 1))) & 0xFFFF);
+        const int code = (int)(int8_t)(pr >> 8);
+        if (code == 0) return false;
+        cell = pr & 0xFF;
+        ch = Spec::REC0 + (pl == qi ? 0 : 1);
+        v = code + 3;
+        tab_idx = CODETAB_REC + v;
+    }
+    entry = (qi ? G::RC - 1 - cell : cell) * Spec::NCH + ch;
+    return true;
+}
+
+// Fills L.nib with the codes of Spec's observation from player index qi's perspective.  tmpl = the variant's default codes,
+// codetab = codes of captured counts / recent-move codes (both workgroup-shared LDS copies).  Returns (per game) whether some
+// entry's value has no code and must be patched into the output (emit_obs_patches).
+template <class G, class Spec, int NB>
+__device__ inline bool build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uint8_t *codetab, int qi, int n_events, int rp0, int rp1, int lane) {
+    constexpr int RC = G::RC, NCH = Spec::NCH, NBYTES = ((RC * NCH + 1) / 2 + 15) & ~15;
+    static_assert(NBYTES <= Lds<G, NB>::NIB_BYTES, "code buffer too small for this observation kind");
+    for (int i = lane; i < NBYTES / 16; i += G::LPG) reinterpret_cast<int4 *>(L.nib)[i] = reinterpret_cast<const int4 *>(tmpl)[i];
+    wave_sync<G>();
+#pragma unroll
+    for (int cc = 0; cc < G::CPL; ++cc) {
+        const int i = lane + G::LPG * cc;
+        if (i < RC) {
+            const int base = (qi ? RC - 1 - i : i) * NCH;
+            const int own = L.b[B_PIECES + qi][i], en = L.b[B_PIECES + 1 - qi][i];
+            const int own_po = L.b[B_PO + qi][i], en_po = L.b[B_PO + 1 - qi][i];
+            if (own) set_code_one(L, base + Spec::OWN0 + own - 1);
+            if constexpr (Spec::ENEMY0 >= 0)
+                if (en) set_code_one(L, base + Spec::ENEMY0 + en - 1);
+            if (own_po) set_code_one(L, base + Spec::OWN_PO0 + own_po - 1);
+            if (en_po) set_code_one(L, base + Spec::ENEMY_PO0 + en_po - 1);
+            if (L.b[B_OBST][i]) set_code_one(L, base + Spec::OBST);
+            if (L.b[B_STILL + qi][i]) set_code_one(L, base + Spec::STILL0);
+            if (L.b[B_STILL + 1 - qi][i]) set_code_one(L, base + Spec::STILL0 + 1);
+        }
+    }
+    bool uncoded = false;
+    for (int i = lane; i < n_events + 4; i += G::LPG) {
+        int entry, ch, v, ti;
+        if (special_entry<G, Spec>(L, i, n_events, rp0, rp1, qi, entry, ch, v, ti)) {
+            const int now = codetab[ti], was = codetab[i < n_events ? (ti & ~15) : CODETAB_REC + 3];   // default: count 0 / code 0
+            if (now == CODE_NONE) uncoded = true;
+            else swap_code(L, entry, was, now);
+        }
+    }
+    wave_sync<G>();
+    return gballot<G>(uncoded) != 0ull;
+}
+
+// L.nib -> global.  The observation is written in 1 KiB chunks aligned to 1 KiB ADDRESS boundaries (whole 128-byte lines per
+// store instruction; chunking by cell group left two partial lines per store and ran 1.5x slower in the store-pattern probe).
+template <class G, class Spec, int NB>
+__device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, int lane) {
+    constexpr int RC = G::RC, NCH = Spec::NCH;
+    const uint16_t *n16 = reinterpret_cast<const uint16_t *>(L.nib);
+    if constexpr (RC % 4 == 0) {
+        constexpr int NQ = (RC / 4) * NCH;                                           // quads (16 B) of one observation
+        const int m0 = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & (G::LPG - 1));  // quads past a chunk boundary
+        f32x4 *base = reinterpret_cast<f32x4 *>(dst);
+#pragma unroll SGX_OBS_UNROLL
+        for (int q0 = -m0; q0 < NQ; q0 += G::LPG) {
+            const int q = q0 + lane;
+            const bool in = (unsigned)q < (unsigned)NQ;
+            const unsigned x = n16[in ? q : 0];
+            f32x4 o = {code_to_float(x), code_to_float(x >> 4), code_to_float(x >> 8), code_to_float(x >> 12)};
+            if (in) stream_store(&base[q], o);
+        }
+    } else {
+        // odd cell counts (5x5, 15x15): an env's observation is only 4-byte aligned.  Lanes own the 16-byte slots of the
+        // ADDRESS range; slot k holds floats 4k-a .. 4k-a+3 (a = floats past a 16-byte boundary), i.e. 16 code bits that start
+        // (4-a) nibbles into halfword k-1: two halfword reads and a shift.  Whole slots leave as one 16-byte store, the partial
+        // first / last slot as dwords.
+        constexpr int NF = RC * NCH;
+        const int a = (int)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3);
+        float *base = dst - a;
+        const int nslots = (a + NF + 3) >> 2;
+        const int m0 = (int)((reinterpret_cast<uintptr_t>(base) >> 4) & (G::LPG - 1));
+        const int sh = a ? (4 - a) * 4 : 0, back = a ? 1 : 0;
+#pragma unroll 2
+        for (int k0 = -m0; k0 < nslots; k0 += G::LPG) {
+            const int k = k0 + lane;
+            const bool slot_in = k >= 0 && k < nslots;
+            const int kk = slot_in ? k : 0;
+            // halfword -1 is L.nib_lead (its value never reaches a stored float)
+            const unsigned w = (unsigned)n16[kk - back] | ((unsigned)n16[kk - back + 1] << 16);
+            const unsigned x = w >> sh;
+            const float o[4] = {code_to_float(x), code_to_float(x >> 4), code_to_float(x >> 8), code_to_float(x >> 12)};
+            const int f0 = 4 * kk - a;
+            if (slot_in && f0 >= 0 && f0 + 3 < NF) {
+                f32x4 qv = {o[0], o[1], o[2], o[3]};
+                stream_store(&reinterpret_cast<f32x4 *>(base)[k], qv);
+            } else if (slot_in) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((unsigned)(f0 + j) < (unsigned)NF) base[4 * k + j] = o[j];
+            }
+        }
+    }
+}
+
+// The entries of Spec's observation (perspective qi) whose value has no code (CODES kinds: codetab says CODE_NONE) or that the LUT
+// path leaves at the default ('original' kinds: every capture event): written as single floats.  `lut` = this kind's LUT in
+// GLOBAL memory (L2-resident; a handful of lanes read it once per step), codetab may be NULL for 'original' kinds.  The caller
+// has waited for the bulk stores of `dst` (s_waitcnt vmcnt(0)): these stores hit addresses other lanes have just written.
+template <class G, class Spec, int NB>
+__device__ inline void emit_obs_patches(const Lds<G, NB> &L, const float *__restrict__ lut, const uint8_t *codetab, int qi, float *__restrict__ dst,
+                                        int n_events, int rp0, int rp1, int lane) {
+    const int n = n_events + (Spec::CODES ? 4 : 0);     // ('original' kinds render the recent-move channels through the LUT)
+    for (int i = lane; i < n; i += G::LPG) {
+        int entry, ch, v, ti;
+        if (special_entry<G, Spec>(L, i, n_events, rp0, rp1, qi, entry, ch, v, ti))
+            if (!Spec::CODES || codetab[ti] == CODE_NONE) dst[entry] = lut[lut_row(ch) + v];
+    }
+}
+
+// ---- 'original' channels (32 / 33 value channels): every float through (board byte, LUT row) -----------------------------------
 // quad table entry of (perspective qi, quad qd, element j): LDS byte offset of the source board at the first 4-cell group
 // (low 16 bits) and LUT index base (high 16 bits); built once per workgroup (build_quad_table)
 template <class G, class Spec>
@@ -18,7 +173,7 @@ __device__ inline void build_quad_table(uint32_t *qtab, int tid, int nthreads) {
     constexpr int RC = G::RC, S = G::S, NCH = Spec::NCH;
     if constexpr (RC % 4 != 0) {
         // odd cell counts (5x5, 15x15): per-channel table instead -- entry (qi, ch) = LDS byte offset of the source board (low 16
-        // bits) and LUT index base (high 16 bits); emit_obs adds the cell
+        // bits) and LUT index base (high 16 bits); emit_obs_lut adds the cell
         for (int i = tid; i < 2 * NCH; i += nthreads) {
             const int qi = i / NCH, ch = i - qi * NCH;
             qtab[i] = (uint32_t)(Spec::board(ch, qi) * S) | ((uint32_t)(lut_row(ch) + Spec::bias(ch)) << 16);
@@ -34,13 +189,11 @@ __device__ inline void build_quad_table(uint32_t *qtab, int tid, int nthreads) {
     }
 }
 
-// `tab` = this observation kind's LUT followed by its quad table.
-// The observation is written in 1 KiB chunks aligned to 1 KiB ADDRESS boundaries (whole 128-byte lines per store
-// instruction).  Chunking by 4-cell group instead (64 of a group's 67 quads per store, every store 48 bytes further off a
-// line) left two partial lines per store and ran 1.5x slower in the store-pattern probe (tools/microbench/aligned_alloc.hip:
-// 490 vs 333 us).  With address-aligned chunks a lane's quad changes every iteration, hence the quad table.
-template <class G, class Spec>
-__device__ void emit_obs(const Lds<G> &L, const float *tab, int qi, float *__restrict__ dst, int lane) {
+// `tab` = this observation kind's LUT followed by its quad table (workgroup-shared LDS).  Same chunking as emit_codes; a lane's
+// quad changes every iteration, hence the quad table.  The captured-count channels read the all-zero board (their default);
+// emit_obs_patches writes the counts that are not zero.
+template <class G, class Spec, int NB>
+__device__ void emit_obs_lut(const Lds<G, NB> &L, const float *tab, int qi, float *__restrict__ dst, int lane) {
     constexpr int RC = G::RC, NCH = Spec::NCH;
     const int8_t *bb = &L.b[0][0];
     const float *lut = tab;
@@ -66,10 +219,6 @@ __device__ void emit_obs(const Lds<G> &L, const float *tab, int qi, float *__res
             if (in) stream_store(&base[q], o);
         }
     } else {
-        // odd cell counts (5x5, 15x15): an env's observation is only 4-byte aligned.  Lanes own the 16-byte slots of the
-        // ADDRESS range (sweep started on a chunk boundary like above); a slot's four floats are looked up one by one
-        // through the per-channel table, whole slots leave as one 16-byte store, the partial first / last slot as dwords.
-        // (One dword per lane per store, the first version, reached 2.3 TB/s on 15x15.)
         constexpr int NF = RC * NCH;
         const uint32_t *ctab = reinterpret_cast<const uint32_t *>(tab + LUT_DWORDS) + qi * NCH;
         const int a = (int)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3);             // floats past a 16-byte boundary

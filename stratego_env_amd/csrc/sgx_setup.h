@@ -8,22 +8,22 @@ namespace {
 // Fresh game into LDS boards: _create_initial_state (impl:211-249) from own-side maps (explicit, from the
 // human-setup table: util:241-275 net effect, or random back-row placement: util:13-30)
 // ---------------------------------------------------------------------------------------------
-template <class G>
-__device__ void clear_boards(Lds<G> &L, int lane) {
+template <class G, int NB>
+__device__ void clear_boards(Lds<G, NB> &L, int lane) {
     const int4 z = make_int4(0, 0, 0, 0);
     for (int i = lane; i < G::LDS_BOARDS_BYTES / 16; i += G::LPG) reinterpret_cast<int4 *>(&L.b[0][0])[i] = z;
 }
 
 // place code `t` of player index pi at absolute cell
-template <class G>
-__device__ inline void place(Lds<G> &L, int pi, int cell, int t) {
+template <class G, int NB>
+__device__ inline void place(Lds<G, NB> &L, int pi, int cell, int t) {
     L.b[B_PIECES + pi][cell] = (int8_t)t;
     L.b[B_PO + pi][cell] = t ? SP_UNKNOWN : 0;
     L.b[B_STILL + pi][cell] = t ? 1 : 0;
 }
 
-template <class G>
-__device__ void sample_boards(Lds<G> &L, const KParams &P, uint64_t g, uint64_t j, int lane) {
+template <class G, int NB>
+__device__ void sample_boards(Lds<G, NB> &L, const KParams &P, uint64_t g, uint64_t j, int lane) {
     constexpr int C = G::C, RC = G::RC;
     const int U = P.usable_rows, n = U * C;
     clear_boards(L, lane);

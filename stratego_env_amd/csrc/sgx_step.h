@@ -7,11 +7,20 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // The step kernel: env.step() of N games (maenv:659-828), one wave per game
 // ---------------------------------------------------------------------------------------------
+// workgroup-shared tables: 'extended' kinds -- default-code templates (+ the small code table); 'original' kinds -- LUT + quad table
+template <class G, int KIND>
+constexpr int tmpl_bytes(bool full) { return ((G::RC * (full ? FOBS_CH : OBS_CH) + 1) / 2 + 15) & ~15; }
+template <class G, int KIND>
+constexpr int shared_table_bytes() {
+    constexpr bool FULL = (KIND & 1) != 0, ORIG = (KIND & 2) != 0;
+    if (ORIG) return 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0));
+    return tmpl_bytes<G, KIND>(false) + (FULL ? tmpl_bytes<G, KIND>(true) : 0) + CODETAB_BYTES;
+}
+
 // waves per SIMD this geometry can reach: LDS per workgroup = WPB game regions + the shared LUT, 160 KiB per CU
 template <class G, int KIND>
 constexpr int waves_per_simd() {
-    constexpr bool FULL = (KIND & 1) != 0;
-    constexpr int per_wg = WPB * G::GPW * (int)sizeof(Lds<G>) + 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)) + SGX_MAX_CELLS;
+    constexpr int per_wg = WPB * G::GPW * (int)sizeof(Lds<G, ObsKind<KIND>::NIB_CH>) + shared_table_bytes<G, KIND>() + SGX_MAX_CELLS;
     constexpr int wgs = (160 * 1024) / per_wg;
     constexpr int w = wgs * WPB / 4;
     // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
@@ -19,10 +28,30 @@ constexpr int waves_per_simd() {
     return w > want ? want : (w < 1 ? 1 : w);
 }
 
+// One more captured piece on layer / cell `key` ((12 * pi + type - 1) << 8 | cell): the count of its event goes up, or a new event
+// is appended.  Returns the new number of events.
+template <class G, int NB>
+__device__ inline int add_capture(Lds<G, NB> &L, int n_events, int max_events, int key, int lane) {
+    uint16_t *evl = reinterpret_cast<uint16_t *>(L.tail + 2 * G::SB + 32);
+    bool found = false;
+    for (int i0 = 0; i0 < n_events; i0 += G::LPG) {                    // (wave-uniform bound for a 64-lane game)
+        const int i = i0 + lane;
+        const bool hit = i < n_events && (evl[i] & EV_KEY_MASK) == key;
+        if (hit && (evl[i] >> EV_COUNT_SHIFT) < EV_COUNT_MAX - 1) evl[i] = (uint16_t)(evl[i] + (1 << EV_COUNT_SHIFT));
+        found = found || gballot<G>(hit) != 0ull;
+    }
+    if (!found && n_events < max_events) {
+        if (lane == 0) evl[n_events] = (uint16_t)key;
+        n_events += 1;
+    }
+    wave_sync<G>();
+    return n_events;
+}
+
 // Builds the record image from ST_OFF on in L.tail (never-moved bitmaps from the LDS still boards, the two scalar int4s,
 // the event list already kept in L.tail) and writes the whole record to HBM as 16-byte stores over whole 128-byte lines.
-template <class G>
-__device__ inline void write_record(Lds<G> &L, int8_t *rec_g, int rec_bytes, int4 sc0, int4 sc1, int n_events, int lane) {
+template <class G, int NB>
+__device__ inline void write_record(Lds<G, NB> &L, int8_t *rec_g, int rec_bytes, int4 sc0, int4 sc1, int n_events, int lane) {
     constexpr int S = G::S, RC = G::RC;
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi)
@@ -58,12 +87,14 @@ __device__ inline void write_record(Lds<G> &L, int8_t *rec_g, int rec_bytes, int
 }
 
 // One game's env.step() by one wave (called with the wave's private LDS region).
+// `shared` = the workgroup's tables (shared_table_bytes): templates + code table, or LUTs + quad tables
 template <int R_, int C_, int KIND, bool MAPPED>
-__device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, const float *lut_s, const uint8_t *obst_s, const int64_t env,
-                                         const int lane) {
+__device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsKind<KIND>::NIB_CH> &L, const uint8_t *shared, const uint8_t *obst_s,
+                                         const int64_t env, const int lane) {
     using G = Geo<R_, C_>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
+    constexpr bool ORIG = ObsKind<KIND>::ORIG, FULL = ObsKind<KIND>::FULL;
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     STAMP(0);
 
@@ -92,10 +123,16 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
         if (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) pos_raw = reinterpret_cast<const int4 *>(P.io.actions_dev)[env];
         else a_raw = P.io.actions_dev[env];
     }
-    {   // while the loads are in flight: clear the 28 rebuilt boards, copy the obstacle map (shared per workgroup)
+    {   // while the loads are in flight: clear the recent-move boards and the zero board, copy the obstacle map (shared per
+        // workgroup).  (The never-moved boards are written cell by cell below; captured counts are never dense.)
         int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
-        for (int i = Q_BOARDS + lane; i < G::LDS_BOARDS_BYTES / 16; i += G::LPG) dst[i] = zero4;
-        for (int i = lane; i < S / 4; i += G::LPG) reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(obst_s)[i];
+        static_assert((B_RECENT * S) % 16 == 0 || true, "");
+        for (int i = lane; i < S / 4; i += G::LPG) {
+            reinterpret_cast<int *>(L.b[B_RECENT])[i] = 0;
+            reinterpret_cast<int *>(L.b[B_RECENT + 1])[i] = 0;
+            if constexpr (ORIG) reinterpret_cast<int *>(L.b[B_ZERO])[i] = 0;
+            reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(obst_s)[i];
+        }
         int4 *tl = reinterpret_cast<int4 *>(L.tail);
         if (lane < Q_BOARDS) dst[lane] = rq0;
         else if (lane < Q_REC) tl[lane - Q_BOARDS] = rq0;
@@ -111,7 +148,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     int n_events = min(uni<G>(sc2.x), (int)G::EVL_MAX);
     int rp0 = uni<G>(sc2.y), rp1 = uni<G>(sc2.z);   // recent-move pairs of player +1 / -1 (two named scalars: a runtime-indexed
                                               // array would live in scratch memory)
-    {   // ---- rebuild the 28 derived boards: never-moved bitmaps, recent-move pairs, capture events
+    {   // ---- rebuild the derived boards: never-moved bitmaps, recent-move pairs (capture events stay a list)
         const uint32_t *stb = reinterpret_cast<const uint32_t *>(L.tail);
 #pragma unroll
         for (int cc = 0; cc < G::CPL; ++cc) {
@@ -121,17 +158,11 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
                 L.b[B_STILL + 1][i] = (int8_t)((stb[G::SB / 4 + (i >> 5)] >> (i & 31)) & 1u);
             }
         }
-        const uint16_t *evl = reinterpret_cast<const uint16_t *>(L.tail + 2 * G::SB + 32);   // stays here for the write-back
-        for (int i = lane; i < n_events; i += G::LPG) {
-            const int evt = evl[i], byte = (B_CAP + (evt >> 8)) * S + (evt & 0xFF);  // event = (board - B_CAP) << 8 | cell
-            atomicAdd(reinterpret_cast<unsigned int *>(&L.b[0][0]) + (byte >> 2), 1u << (8 * (byte & 3)));
-        }
         if (lane < 4) {
             const int pr = (((lane >> 1) ? rp1 : rp0) >> (16 * (lane & 1))) & 0xFFFF;
             if (pr >> 8) L.b[B_RECENT + (lane >> 1)][pr & 0xFF] = (int8_t)(pr >> 8);
         }
     }
-    const float *lut = lut_s;
     wave_sync<G>();
     STAMP(1);   // state staged
 
@@ -139,7 +170,6 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     bool over = (flags & F_OVER) != 0;
     bool applied = false, invalid_action = false, noop_path = false;
     int mover = player;
-    int dirty_s = -1, dirty_e = -1, dirty_cap_a = -1, dirty_cap_b = -1;   // cells / boards touched by the move
 
     if (P.mode == 0) {
         // ------------------------------------------------------------------------------------------
@@ -253,14 +283,12 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
                         if (tied || wins) { enemy[e] = 0; enemy_po[e] = 0; }
                         if (wins) { own[e] = (int8_t)moved; own_po[e] = (int8_t)moved; }
                         if (!wins && !tied) enemy_po[e] = (int8_t)dest;
-                        if (!wins) L.b[B_CAP + 12 * pi + moved - 1][e] += 1;               // impl:1001-1004
-                        if (wins || tied) L.b[B_CAP + 12 * (1 - pi) + dest - 1][e] += 1;   // impl:1006-1009
                     }
                 }
-                dirty_s = s; dirty_e = e;
                 if (dest != 0) {
-                    if (!wins) dirty_cap_a = B_CAP + 12 * pi + moved - 1;
-                    if (wins || tied) dirty_cap_b = B_CAP + 12 * (1 - pi) + dest - 1;
+                    // captured counts (impl:999-1009): the attacker's own layer unless it won, the defender's if it lost or tied
+                    if (!wins) n_events = add_capture(L, n_events, P.max_events, ((12 * pi + moved - 1) << 8) | e, lane);
+                    if (wins || tied) n_events = add_capture(L, n_events, P.max_events, ((12 * (1 - pi) + dest - 1) << 8) | e, lane);
                     if (pi) rp1 = 0; else rp0 = 0;                                       // an attack wipes the mover's layer
                 } else {
                     const int code = old_end == 1 ? (old_start == -2 ? -3 : -2) : -1;
@@ -308,18 +336,43 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
         if (fp) fp[env] = fv;
     }
 
-    // ---- terminal observations of both players (maenv:772-773)
-    if (P.mode == 0 && ended_now && P.io.final_obs_dev) {
-        float *fo = P.io.final_obs_dev + env * (int64_t)(2 * RC * PS::NCH);
-        emit_obs<G, PS>(L, lut, 0, fo, lane);
-        emit_obs<G, PS>(L, lut, 1, fo + RC * PS::NCH, lane);
-    }
-    if constexpr (ObsKind<KIND>::FULL)
-        if (P.mode == 0 && ended_now && P.io.final_fobs_dev) {
-            float *fo = P.io.final_fobs_dev + env * (int64_t)(2 * RC * FS::NCH);
-            emit_obs<G, FS>(L, lut + OBS_TAB_DWORDS, 0, fo, lane);
-            emit_obs<G, FS>(L, lut + OBS_TAB_DWORDS, 1, fo + RC * FS::NCH, lane);
+    // ---- observation rendering (sgx_obs.h).  render(): the bulk stores of one observation; returns whether single entries
+    //      remain to be written as floats (no code for the value / 'original' kinds' non-zero captured counts): patch() does that
+    //      once the wave has waited for its bulk stores -- the entries lie inside lines other lanes have just stored.
+    const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
+    const float *glut_p = P.tab->lut[(ORIG ? 4 : 0) + (raw ? 2 : 0)], *glut_f = P.tab->lut[(ORIG ? 4 : 0) + (raw ? 2 : 0) + 1];
+    const uint8_t *codetab = ORIG ? nullptr : shared + tmpl_bytes<G, KIND>(false) + (FULL ? tmpl_bytes<G, KIND>(true) : 0);
+    auto render = [&](auto spec, bool full, int q, float *dst) -> bool {
+        using Spec = decltype(spec);
+        if constexpr (Spec::CODES) {
+            const bool uncoded = build_codes<G, Spec>(L, full ? shared + tmpl_bytes<G, KIND>(false) : shared, codetab, q, n_events, rp0, rp1, lane);
+            emit_codes<G, Spec>(L, dst, lane);
+            return uncoded;
+        } else {
+            emit_obs_lut<G, Spec>(L, reinterpret_cast<const float *>(shared) + (full ? OBS_TAB_DWORDS : 0), q, dst, lane);
+            return n_events > 0;
         }
+    };
+    auto patch = [&](auto spec, bool full, int q, float *dst) {
+        using Spec = decltype(spec);
+        emit_obs_patches<G, Spec>(L, full ? glut_f : glut_p, codetab, q, dst, n_events, rp0, rp1, lane);
+    };
+
+    // ---- terminal observations of both players (maenv:772-773); patched at once (rare step, and an auto-reset empties the events)
+    if (P.mode == 0 && ended_now && (P.io.final_obs_dev || (FULL && P.io.final_fobs_dev))) {
+        float *fo = P.io.final_obs_dev ? P.io.final_obs_dev + env * (int64_t)(2 * RC * PS::NCH) : nullptr;
+        float *ffo = (FULL && P.io.final_fobs_dev) ? P.io.final_fobs_dev + env * (int64_t)(2 * RC * FS::NCH) : nullptr;
+        bool todo = false;
+        if (fo) { todo |= render(PS{}, false, 0, fo); todo |= render(PS{}, false, 1, fo + RC * PS::NCH); }
+        if constexpr (FULL)
+            if (ffo) { todo |= render(FS{}, true, 0, ffo); todo |= render(FS{}, true, 1, ffo + RC * FS::NCH); }
+        if (todo) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (fo) { patch(PS{}, false, 0, fo); patch(PS{}, false, 1, fo + RC * PS::NCH); }
+            if constexpr (FULL)
+                if (ffo) { patch(FS{}, true, 0, ffo); patch(FS{}, true, 1, ffo + RC * FS::NCH); }
+        }
+    }
 
     // ---- auto-reset: the finished env starts its next game now
     bool wrote_reset = false;
@@ -344,9 +397,10 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     }
     STAMP(5);   // mask stores issued
     // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
-    if (P.io.obs_dev) emit_obs<G, PS>(L, lut, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH), lane);
-    if constexpr (ObsKind<KIND>::FULL)
-        if (P.io.fobs_dev) emit_obs<G, FS>(L, lut + OBS_TAB_DWORDS, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH), lane);
+    bool patch_p = false, patch_f = false;
+    if (P.io.obs_dev) patch_p = render(PS{}, false, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH));
+    if constexpr (FULL)
+        if (P.io.fobs_dev) patch_f = render(FS{}, true, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH));
     STAMP(6);   // obs stores issued
     if (P.mode == 0 && P.io.next_actions_dev) {
         const int total = nvalid == 0 ? 1 : nvalid;
@@ -358,15 +412,13 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>> &L, 
     STAMP(7);   // next action sampled
     // ---- write the record back as whole 128-byte lines: dense boards, scalars, capture events.  (Scattered stores
     //      of only the <= 9 touched bytes + 32 B of scalars are partial-line writes: measured 7 % slower.)
-    if (applied || wrote_reset || (MAPPED && P.src_boards)) {
-        uint16_t *evl = reinterpret_cast<uint16_t *>(L.tail + 2 * G::SB + 32);
-        if (!wrote_reset && dirty_s >= 0) {
-            const int na = dirty_cap_a >= 0 ? 1 : 0, nb = dirty_cap_b >= 0 ? 1 : 0;
-            if (lane == 0 && na && n_events < P.max_events) evl[n_events] = (uint16_t)(((dirty_cap_a - B_CAP) << 8) | dirty_e);
-            if (lane == 1 && nb && n_events + na < P.max_events) evl[n_events + na] = (uint16_t)(((dirty_cap_b - B_CAP) << 8) | dirty_e);
-            n_events = min(n_events + na + nb, P.max_events);
-        }
+    if (applied || wrote_reset || (MAPPED && P.src_boards))
         write_record(L, rec_g, P.rec_bytes, make_int4(turn, flags, max_turns, game_no), make_int4(n_events, rp0, rp1, 0), n_events, lane);
+    if (patch_p || patch_f) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (patch_p) patch(PS{}, false, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH));
+        if constexpr (FULL)
+            if (patch_f) patch(FS{}, true, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH));
     }
     STAMP(8);   // write-back issued
 #ifdef SGX_STAMPS
@@ -382,27 +434,39 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     using G = Geo<R_, C_>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
-    constexpr bool FULL = ObsKind<KIND>::FULL;
-    constexpr int ORIG4 = ObsKind<KIND>::ORIG ? 4 : 0;
-    __shared__ Lds<G> LW[WPB * G::GPW];
-    __shared__ alignas(16) float lut_s[OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0)];
+    constexpr bool FULL = ObsKind<KIND>::FULL, ORIG = ObsKind<KIND>::ORIG;
+    __shared__ Lds<G, ObsKind<KIND>::NIB_CH> LW[WPB * G::GPW];
+    __shared__ alignas(16) uint8_t shared[shared_table_bytes<G, KIND>()];
     __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS];
     const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;     // lane inside the game, game inside the workgroup
     const int64_t env = group_of_block() * (WPB * G::GPW) + slot;
 
-    // ---- the workgroup's shared normalisation LUT (L2-resident source)
+    // ---- the workgroup's shared tables (L2-resident sources)
     const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
-    const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[ORIG4 + (raw ? 2 : 0)]);
-    for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
-    build_quad_table<G, PS>(reinterpret_cast<uint32_t *>(lut_s + LUT_DWORDS), threadIdx.x, 64 * WPB);
-    if constexpr (FULL) {
-        const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[ORIG4 + (raw ? 2 : 0) + 1]);
-        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s + OBS_TAB_DWORDS)[i] = fsrc[i];
-        build_quad_table<G, FS>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * WPB);
+    if constexpr (ORIG) {
+        float *lut_s = reinterpret_cast<float *>(shared);
+        const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[4 + (raw ? 2 : 0)]);
+        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
+        build_quad_table<G, PS>(reinterpret_cast<uint32_t *>(lut_s + LUT_DWORDS), threadIdx.x, 64 * WPB);
+        if constexpr (FULL) {
+            const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[4 + (raw ? 2 : 0) + 1]);
+            for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s + OBS_TAB_DWORDS)[i] = fsrc[i];
+            build_quad_table<G, FS>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * WPB);
+        }
+    } else {
+        constexpr int NP = tmpl_bytes<G, KIND>(false), NF = FULL ? tmpl_bytes<G, KIND>(true) : 0;
+        const int4 *tp = reinterpret_cast<const int4 *>(P.tab->tmpl[raw ? 2 : 0]);
+        for (int i = threadIdx.x; i < NP / 16; i += 64 * WPB) reinterpret_cast<int4 *>(shared)[i] = tp[i];
+        if constexpr (FULL) {
+            const int4 *tf = reinterpret_cast<const int4 *>(P.tab->tmpl[(raw ? 2 : 0) + 1]);
+            for (int i = threadIdx.x; i < NF / 16; i += 64 * WPB) reinterpret_cast<int4 *>(shared + NP)[i] = tf[i];
+        }
+        const int4 *ct = reinterpret_cast<const int4 *>(P.tab->codetab[raw ? 1 : 0]);
+        for (int i = threadIdx.x; i < CODETAB_BYTES / 16; i += 64 * WPB) reinterpret_cast<int4 *>(shared + NP + NF)[i] = ct[i];
     }
     for (int i = threadIdx.x; i < G::S / 4; i += 64 * WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
     __syncthreads();   // from here on every wave works on its own game
-    if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], lut_s, obst_s, env, lane);
+    if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], shared, obst_s, env, lane);
 }
 
 // sgx_step and sgx_observe run the same body (P.mode tells them apart at run time: specialising the body on the mode changed the

@@ -188,6 +188,60 @@ static void build_lut(const sgx_config *cfg, bool full, float *lut, bool raw_val
     }
 }
 
+// 'extended' observations are rendered from 4-bit codes (sgx_obs.h): code c decodes to sext(c) / 4.  Templates of the channel
+// defaults and the codes of captured counts / recent-move codes, derived from the LUTs themselves.
+static int float_code(float f) {
+    for (int c = 0; c < 16; ++c)
+        if ((float)(c < 8 ? c : c - 16) / 4.0f == f) return c;
+    return CODE_NONE;
+}
+static int build_code_tables(const sgx_config *cfg, DevTables *tab) {
+    const int rc_cells = cfg->rows * cfg->cols;
+    float dense[2][FOBS_CH * LUT_STRIDE];
+    for (int raw = 0; raw < 2; ++raw) {
+        for (int full = 0; full < 2; ++full) {
+            build_lut(cfg, full != 0, dense[full], raw != 0, false);
+            const int nch = full ? FOBS_CH : OBS_CH, rec0 = full ? 51 : 39;
+            uint8_t *t = tab->tmpl[2 * raw + full];
+            memset(t, 0, TMPL_MAX_BYTES);
+            for (int ch = 0; ch < nch; ++ch) {
+                const bool rec = ch == rec0 || ch == rec0 + 1;
+                const int code = float_code(dense[full][ch * LUT_STRIDE + (rec ? 3 : 0)]);
+                if (code == CODE_NONE) return fail(SGX_EINVAL, "a channel default has no 4-bit code%s");
+                // indicator channels (one-hot blocks, obstacle, never-moved): the value of a set entry must decode from NIB_ONE
+                const int n_true = full ? 24 : 12, po_end = n_true + 26;
+                int set_index = -1;
+                if (ch < n_true) set_index = ch % 12 + 1;
+                else if (ch < po_end) set_index = (ch - n_true) % 13 + 1;
+                else if (ch == po_end || ch >= nch - 2) set_index = 1;
+                if (set_index >= 0 && float_code(dense[full][ch * LUT_STRIDE + set_index]) != NIB_ONE)
+                    return fail(SGX_EINVAL, "an indicator channel's set value is not 1.0%s");
+                for (int cell = 0; cell < rc_cells; ++cell) {
+                    const int e = cell * nch + ch;
+                    t[e >> 1] |= (uint8_t)(code << (4 * (e & 1)));
+                }
+            }
+        }
+        uint8_t *ct = tab->codetab[raw];
+        memset(ct, CODE_NONE, CODETAB_BYTES);
+        for (int t = 0; t < 12; ++t)
+            for (int v = 0; v < LUT_STRIDE; ++v) {
+                // own and enemy block, partial and full kind: the same normalisation per piece type (maenv:288-298 / 229-239)
+                const float f = dense[0][(41 + t) * LUT_STRIDE + v];
+                if (f != dense[0][(53 + t) * LUT_STRIDE + v] || f != dense[1][(53 + t) * LUT_STRIDE + v] || f != dense[1][(65 + t) * LUT_STRIDE + v])
+                    return fail(SGX_EINVAL, "captured-count channels of one piece type are normalised differently%s");
+                ct[16 * t + v] = (uint8_t)float_code(f);
+            }
+        for (int v = 0; v < 5; ++v) {
+            const float f = dense[0][39 * LUT_STRIDE + v];
+            if (f != dense[0][40 * LUT_STRIDE + v] || f != dense[1][51 * LUT_STRIDE + v] || f != dense[1][52 * LUT_STRIDE + v])
+                return fail(SGX_EINVAL, "recent-move channels are normalised differently%s");
+            ct[CODETAB_REC + v] = (uint8_t)float_code(f);
+        }
+    }
+    return SGX_OK;
+}
+
 SGX_API int sgx_build_obs_lut(const sgx_config *cfg, float *lut) {
     if (int rc = check_cfg(cfg)) return rc;
     if (!lut) return fail(SGX_EINVAL, "lut is NULL%s");
@@ -250,6 +304,7 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
         }
     }
     memcpy(host_tab.obstacles, cfg->obstacles, rc_cells);
+    if (int rc = build_code_tables(cfg, &host_tab)) { delete h; return rc; }
     if (hipMalloc((void **)&h->boards, (size_t)n_envs * h->rec_bytes) != hipSuccess ||
         hipMalloc((void **)&h->tab, sizeof(DevTables)) != hipSuccess) {
         sgx_destroy(h);
