@@ -31,6 +31,7 @@ constexpr int FOBS_TAB_DWORDS = LUT_DWORDS + 2 * FOBS_CH * 4;
 // moves: 0.5 normalised, 0 raw; captured counts: -1 normalised, 0 raw) held in a per-variant template; the few entries that are
 // neither default nor 1.0 (captured counts >= 1, non-zero recent-move codes) are patched into the output afterwards.
 constexpr int NIB_ONE = 4, CODE_NONE = 0xFF, CODETAB_REC = 192, CODETAB_BYTES = 208;
+constexpr int CODE_ESC = 8;   // (-2.0, never a value of its own) marks an entry whose float has no code: see emit_codes / patch_uncoded
 constexpr int TMPL_MAX_BYTES = ((SGX_MAX_CELLS * FOBS_CH / 2) + 15) & ~15;   // 10,112
 __host__ __device__ constexpr int lut_row(int ch) { return ((ch >> 1) & 1) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH + (ch & 1) * 16; }
 
@@ -163,6 +164,8 @@ struct alignas(16) Lds {
     alignas(16) uint8_t occ[G::S];                     // gen_mask scratch: combined occupancy byte per cell
     alignas(16) uint8_t plist[G::CNT_PAD];             // gen_mask scratch: compacted list of movable cells
     alignas(16) uint8_t tail[G::TAIL_BYTES];           // record image from ST_OFF on: bitmaps, 32 B scalars, capture-event list
+    alignas(16) float unc_val[G::EVL_MAX + 4];         // entries of the observation being rendered whose value has no code:
+    alignas(16) uint16_t unc_entry[(G::EVL_MAX + 4 + 7) & ~7];   //   the float / the entry index
 };
 
 // ---------------------------------------------------------------------------------------------

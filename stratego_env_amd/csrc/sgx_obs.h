@@ -61,10 +61,11 @@ __device__ inline bool special_entry(const Lds<G, NB> &L, int i, int n_events, i
 }
 
 // Fills L.nib with the codes of Spec's observation from player index qi's perspective.  tmpl = the variant's default codes,
-// codetab = codes of captured counts / recent-move codes (both workgroup-shared LDS copies).  Returns (per game) whether some
-// entry's value has no code and must be patched into the output (emit_obs_patches).
+// codetab = codes of captured counts / recent-move codes (both workgroup-shared LDS copies), glut = this kind's LUT in global
+// memory.  Returns the number of entries whose value has no code (L.unc_entry / L.unc_val; the same for every lane of the game).
 template <class G, class Spec, int NB>
-__device__ inline bool build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uint8_t *codetab, int qi, int n_events, int rp0, int rp1, int lane) {
+__device__ inline int build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uint8_t *codetab, const float *__restrict__ glut, int qi, int n_events,
+                                  int rp0, int rp1, int lane) {
     constexpr int RC = G::RC, NCH = Spec::NCH, NBYTES = ((RC * NCH + 1) / 2 + 15) & ~15;
     static_assert(NBYTES <= Lds<G, NB>::NIB_BYTES, "code buffer too small for this observation kind");
     for (int i = lane; i < NBYTES / 16; i += G::LPG) reinterpret_cast<int4 *>(L.nib)[i] = reinterpret_cast<const int4 *>(tmpl)[i];
@@ -86,22 +87,37 @@ __device__ inline bool build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uin
             if (L.b[B_STILL + 1 - qi][i]) set_code_one(L, base + Spec::STILL0 + 1);
         }
     }
-    bool uncoded = false;
-    for (int i = lane; i < n_events + 4; i += G::LPG) {
-        int entry, ch, v, ti;
-        if (special_entry<G, Spec>(L, i, n_events, rp0, rp1, qi, entry, ch, v, ti)) {
-            const int now = codetab[ti], was = codetab[i < n_events ? (ti & ~15) : CODETAB_REC + 3];   // default: count 0 / code 0
-            if (now == CODE_NONE) uncoded = true;
-            else swap_code(L, entry, was, now);
+    // captured counts / recent-move codes: their code replaces the channel default; a value without a code gets CODE_ESC and
+    // goes on the game's list of uncoded entries (float from the LUT in global memory: a few lanes, once per step)
+    int n_unc = 0;
+    for (int i0 = 0; i0 < n_events + 4; i0 += G::LPG) {
+        const int i = i0 + lane;
+        int entry = 0, ch, v, ti;
+        bool unc = false;
+        float val = 0.f;
+        if (i < n_events + 4 && special_entry<G, Spec>(L, i, n_events, rp0, rp1, qi, entry, ch, v, ti)) {
+            int now = codetab[ti];
+            const int was = codetab[i < n_events ? (ti & ~15) : CODETAB_REC + 3];   // the default: count 0 / code 0
+            if (now == CODE_NONE) { unc = true; now = CODE_ESC; val = glut[lut_row(ch) + v]; }
+            swap_code(L, entry, was, now);
         }
+        const unsigned long long bal = gballot<G>(unc);
+        if (unc) {
+            const int pos = n_unc + __popcll(bal & ((1ull << lane) - 1ull));
+            L.unc_entry[pos] = (uint16_t)entry;
+            L.unc_val[pos] = val;
+        }
+        n_unc += __popcll(bal);
     }
     wave_sync<G>();
-    return gballot<G>(uncoded) != 0ull;
+    return n_unc;
 }
 
 // L.nib -> global.  The observation is written in 1 KiB chunks aligned to 1 KiB ADDRESS boundaries (whole 128-byte lines per
 // store instruction; chunking by cell group left two partial lines per store and ran 1.5x slower in the store-pattern probe).
-template <class G, class Spec, int NB>
+// CHECKED (games with uncoded entries, 4-aligned boards): a quad that holds a CODE_ESC entry is not stored here -- patch_uncoded
+// writes it whole, so no address is written twice and nothing has to be waited for.
+template <class G, class Spec, bool CHECKED, int NB>
 __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, int lane) {
     constexpr int RC = G::RC, NCH = Spec::NCH;
     const uint16_t *n16 = reinterpret_cast<const uint16_t *>(L.nib);
@@ -115,9 +131,15 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
             const bool in = (unsigned)q < (unsigned)NQ;
             const unsigned x = n16[in ? q : 0];
             f32x4 o = {code_to_float(x), code_to_float(x >> 4), code_to_float(x >> 8), code_to_float(x >> 12)};
-            if (in) stream_store(&base[q], o);
+            bool esc = false;
+            if constexpr (CHECKED) {
+                const unsigned y = x ^ (0x1111u * CODE_ESC);                           // a CODE_ESC nibble becomes 0
+                esc = ((y - 0x1111u) & ~y & 0x8888u) != 0;                            // some nibble of y is 0
+            }
+            if (in && !esc) stream_store(&base[q], o);
         }
     } else {
+        static_assert(!CHECKED, "odd boards patch single floats after a wait (patch_uncoded_floats)");
         // odd cell counts (5x5, 15x15): an env's observation is only 4-byte aligned.  Lanes own the 16-byte slots of the
         // ADDRESS range; slot k holds floats 4k-a .. 4k-a+3 (a = floats past a 16-byte boundary), i.e. 16 code bits that start
         // (4-a) nibbles into halfword k-1: two halfword reads and a shift.  Whole slots leave as one 16-byte store, the partial
@@ -150,18 +172,43 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
     }
 }
 
-// The entries of Spec's observation (perspective qi) whose value has no code (CODES kinds: codetab says CODE_NONE) or that the LUT
-// path leaves at the default ('original' kinds: every capture event): written as single floats.  `lut` = this kind's LUT in
-// GLOBAL memory (L2-resident; a handful of lanes read it once per step), codetab may be NULL for 'original' kinds.  The caller
-// has waited for the bulk stores of `dst` (s_waitcnt vmcnt(0)): these stores hit addresses other lanes have just written.
+// 4-aligned boards: every quad that holds an uncoded entry, written whole (codes of the other entries + the floats of ALL uncoded
+// entries in it; two lanes that own entries of the same quad store the same 16 bytes).
 template <class G, class Spec, int NB>
-__device__ inline void emit_obs_patches(const Lds<G, NB> &L, const float *__restrict__ lut, const uint8_t *codetab, int qi, float *__restrict__ dst,
-                                        int n_events, int rp0, int rp1, int lane) {
-    const int n = n_events + (Spec::CODES ? 4 : 0);     // ('original' kinds render the recent-move channels through the LUT)
-    for (int i = lane; i < n; i += G::LPG) {
+__device__ inline void patch_uncoded(const Lds<G, NB> &L, float *__restrict__ dst, int n_unc, int lane) {
+    static_assert(G::RC % 4 == 0, "");
+    const uint16_t *n16 = reinterpret_cast<const uint16_t *>(L.nib);
+    for (int k = lane; k < n_unc; k += G::LPG) {
+        const int q = L.unc_entry[k] >> 2;
+        const unsigned x = n16[q];
+        float o[4] = {code_to_float(x), code_to_float(x >> 4), code_to_float(x >> 8), code_to_float(x >> 12)};
+        for (int m = 0; m < n_unc; ++m) {
+            const int em = L.unc_entry[m];
+            if ((em >> 2) == q) {
+                const float vm = L.unc_val[m];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (em & 3) == j ? vm : o[j];
+            }
+        }
+        f32x4 qv = {o[0], o[1], o[2], o[3]};
+        stream_store(&reinterpret_cast<f32x4 *>(dst)[q], qv);
+    }
+}
+// odd boards: the uncoded entries as single floats; the caller has waited for the bulk stores (s_waitcnt vmcnt(0)): these
+// stores hit addresses other lanes have just written
+template <class G, int NB>
+__device__ inline void patch_uncoded_floats(const Lds<G, NB> &L, float *__restrict__ dst, int n_unc, int lane) {
+    for (int k = lane; k < n_unc; k += G::LPG) dst[L.unc_entry[k]] = L.unc_val[k];
+}
+
+// 'original' kinds: the LUT path leaves the captured-count channels at their default; every capture event is written as a single
+// float afterwards (`lut` = this kind's LUT in global memory).  The caller has waited for the bulk stores of `dst`.
+template <class G, class Spec, int NB>
+__device__ inline void emit_obs_patches(const Lds<G, NB> &L, const float *__restrict__ lut, int qi, float *__restrict__ dst, int n_events, int lane) {
+    static_assert(!Spec::CODES, "");
+    for (int i = lane; i < n_events; i += G::LPG) {
         int entry, ch, v, ti;
-        if (special_entry<G, Spec>(L, i, n_events, rp0, rp1, qi, entry, ch, v, ti))
-            if (!Spec::CODES || codetab[ti] == CODE_NONE) dst[entry] = lut[lut_row(ch) + v];
+        if (special_entry<G, Spec>(L, i, n_events, 0, 0, qi, entry, ch, v, ti)) dst[entry] = lut[lut_row(ch) + v];
     }
 }
 

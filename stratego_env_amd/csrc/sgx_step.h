@@ -336,43 +336,52 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
         if (fp) fp[env] = fv;
     }
 
-    // ---- observation rendering (sgx_obs.h).  render(): the bulk stores of one observation; returns whether single entries
-    //      remain to be written as floats (no code for the value / 'original' kinds' non-zero captured counts): patch() does that
-    //      once the wave has waited for its bulk stores -- the entries lie inside lines other lanes have just stored.
+    // ---- observation rendering (sgx_obs.h).  render() writes one observation.  'extended' kinds on 4-aligned boards need no
+    //      second pass over memory: quads with an uncoded entry are left out of the bulk stores and written whole right after.
+    //      Odd boards and 'original' kinds write single floats over lines other lanes have just stored, so they wait for the
+    //      bulk stores first; render() then returns what is still to do and finish() does it.
     const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
     const float *glut_p = P.tab->lut[(ORIG ? 4 : 0) + (raw ? 2 : 0)], *glut_f = P.tab->lut[(ORIG ? 4 : 0) + (raw ? 2 : 0) + 1];
     const uint8_t *codetab = ORIG ? nullptr : shared + tmpl_bytes<G, KIND>(false) + (FULL ? tmpl_bytes<G, KIND>(true) : 0);
-    auto render = [&](auto spec, bool full, int q, float *dst) -> bool {
+    auto render = [&](auto spec, bool full, int q, float *dst) -> int {
         using Spec = decltype(spec);
         if constexpr (Spec::CODES) {
-            const bool uncoded = build_codes<G, Spec>(L, full ? shared + tmpl_bytes<G, KIND>(false) : shared, codetab, q, n_events, rp0, rp1, lane);
-            emit_codes<G, Spec>(L, dst, lane);
-            return uncoded;
+            const int n_unc = build_codes<G, Spec>(L, full ? shared + tmpl_bytes<G, KIND>(false) : shared, codetab, full ? glut_f : glut_p, q,
+                                                   n_events, rp0, rp1, lane);
+            if constexpr (RC % 4 == 0) {
+                if (n_unc == 0) emit_codes<G, Spec, false>(L, dst, lane);
+                else { emit_codes<G, Spec, true>(L, dst, lane); patch_uncoded<G, Spec>(L, dst, n_unc, lane); }
+                return 0;
+            } else {
+                emit_codes<G, Spec, false>(L, dst, lane);
+                if (n_unc) {                                     // (rare board sizes: settle it here, L.unc_* is per rendering)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    patch_uncoded_floats(L, dst, n_unc, lane);
+                }
+                return 0;
+            }
         } else {
             emit_obs_lut<G, Spec>(L, reinterpret_cast<const float *>(shared) + (full ? OBS_TAB_DWORDS : 0), q, dst, lane);
-            return n_events > 0;
+            if (n_events > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                emit_obs_patches<G, Spec>(L, full ? glut_f : glut_p, q, dst, n_events, lane);
+            }
+            return 0;
         }
-    };
-    auto patch = [&](auto spec, bool full, int q, float *dst) {
-        using Spec = decltype(spec);
-        emit_obs_patches<G, Spec>(L, full ? glut_f : glut_p, codetab, q, dst, n_events, rp0, rp1, lane);
     };
 
-    // ---- terminal observations of both players (maenv:772-773); patched at once (rare step, and an auto-reset empties the events)
-    if (P.mode == 0 && ended_now && (P.io.final_obs_dev || (FULL && P.io.final_fobs_dev))) {
-        float *fo = P.io.final_obs_dev ? P.io.final_obs_dev + env * (int64_t)(2 * RC * PS::NCH) : nullptr;
-        float *ffo = (FULL && P.io.final_fobs_dev) ? P.io.final_fobs_dev + env * (int64_t)(2 * RC * FS::NCH) : nullptr;
-        bool todo = false;
-        if (fo) { todo |= render(PS{}, false, 0, fo); todo |= render(PS{}, false, 1, fo + RC * PS::NCH); }
-        if constexpr (FULL)
-            if (ffo) { todo |= render(FS{}, true, 0, ffo); todo |= render(FS{}, true, 1, ffo + RC * FS::NCH); }
-        if (todo) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (fo) { patch(PS{}, false, 0, fo); patch(PS{}, false, 1, fo + RC * PS::NCH); }
-            if constexpr (FULL)
-                if (ffo) { patch(FS{}, true, 0, ffo); patch(FS{}, true, 1, ffo + RC * FS::NCH); }
-        }
+    // ---- terminal observations of both players (maenv:772-773)
+    if (P.mode == 0 && ended_now && P.io.final_obs_dev) {
+        float *fo = P.io.final_obs_dev + env * (int64_t)(2 * RC * PS::NCH);
+        render(PS{}, false, 0, fo);
+        render(PS{}, false, 1, fo + RC * PS::NCH);
     }
+    if constexpr (FULL)
+        if (P.mode == 0 && ended_now && P.io.final_fobs_dev) {
+            float *fo = P.io.final_fobs_dev + env * (int64_t)(2 * RC * FS::NCH);
+            render(FS{}, true, 0, fo);
+            render(FS{}, true, 1, fo + RC * FS::NCH);
+        }
 
     // ---- auto-reset: the finished env starts its next game now
     bool wrote_reset = false;
@@ -397,10 +406,9 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     }
     STAMP(5);   // mask stores issued
     // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
-    bool patch_p = false, patch_f = false;
-    if (P.io.obs_dev) patch_p = render(PS{}, false, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH));
+    if (P.io.obs_dev) render(PS{}, false, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH));
     if constexpr (FULL)
-        if (P.io.fobs_dev) patch_f = render(FS{}, true, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH));
+        if (P.io.fobs_dev) render(FS{}, true, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH));
     STAMP(6);   // obs stores issued
     if (P.mode == 0 && P.io.next_actions_dev) {
         const int total = nvalid == 0 ? 1 : nvalid;
@@ -414,12 +422,6 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     //      of only the <= 9 touched bytes + 32 B of scalars are partial-line writes: measured 7 % slower.)
     if (applied || wrote_reset || (MAPPED && P.src_boards))
         write_record(L, rec_g, P.rec_bytes, make_int4(turn, flags, max_turns, game_no), make_int4(n_events, rp0, rp1, 0), n_events, lane);
-    if (patch_p || patch_f) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (patch_p) patch(PS{}, false, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH));
-        if constexpr (FULL)
-            if (patch_f) patch(FS{}, true, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH));
-    }
     STAMP(8);   // write-back issued
 #ifdef SGX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

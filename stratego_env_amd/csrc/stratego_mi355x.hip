@@ -192,7 +192,7 @@ static void build_lut(const sgx_config *cfg, bool full, float *lut, bool raw_val
 // defaults and the codes of captured counts / recent-move codes, derived from the LUTs themselves.
 static int float_code(float f) {
     for (int c = 0; c < 16; ++c)
-        if ((float)(c < 8 ? c : c - 16) / 4.0f == f) return c;
+        if (c != CODE_ESC && (float)(c < 8 ? c : c - 16) / 4.0f == f) return c;    // (CODE_ESC marks uncoded entries)
     return CODE_NONE;
 }
 static int build_code_tables(const sgx_config *cfg, DevTables *tab) {
