@@ -322,13 +322,15 @@ def time_workload(rk, env, steps, warmup, unfused=False):
     return elapsed, dev_ms, games, invalid
 
 
-def other_workload(rk, version, n, seconds=1.0):
-    """One of the other BASELINE configs on this GPU, about `seconds` of timed steps on an ordinary (untuned) allocation."""
+def other_workload(rk, version, n, seconds=1.0, extra_bytes=0):
+    """One of the other BASELINE configs on this GPU, about `seconds` of timed steps; output buffers from the same bounded
+    placement trial as the headline (extra_bytes = 0: plain first allocation)."""
     import torch
     from stratego_env_amd.config import VARIANTS
     v = VARIANTS[version]
     env = make_env(version, n, 0, rk.local_rank)
     try:
+        trial = env.tune_placement(max_extra_bytes=extra_bytes) if extra_bytes else None
         _, probe_ms, _, _ = time_workload(rk, env, 8, 8)
         steps = int(max(16, min(4096, seconds * 1e3 / max(probe_ms / 8, 1e-3))))
         elapsed, dev_ms, games, invalid = time_workload(rk, env, steps, 4)
@@ -339,7 +341,9 @@ def other_workload(rk, version, n, seconds=1.0):
                 "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
                 "frac": bpl / launch_s / 1e9 / HBM_PEAK_GBS, "b_alg_bytes_per_step": b_alg(v.rows, v.columns),
                 "kernel": "step_kernel<%d,%d>" % (v.rows, v.columns), "games_finished_in_timed_region": games,
-                "traffic": measured_traffic(version, n)}
+                "traffic": measured_traffic(version, n),
+                "placement_trial_us": ({"candidates": len(trial['obs']), "first": round(trial['obs'][0], 1), "min": round(min(trial['obs']), 1)}
+                                       if trial and trial['obs'] else None)}
     finally:
         env.close()
         del env
@@ -432,7 +436,9 @@ def run_rank(args):
     if rk.rank == 0:
         out["config"]["other_workloads"] = None
         if rk.world == 1 and not args.no_other_workloads and args.version == 'barrage':
-            out["config"]["other_workloads"] = [other_workload(rk, 'standard', 262144), other_workload(rk, 'micro', 65536)]
+            extra = int(args.placement_gb * (1 << 30)) if placement_us else 0
+            out["config"]["other_workloads"] = [other_workload(rk, 'standard', 262144, extra_bytes=extra),
+                                                other_workload(rk, 'micro', 65536, extra_bytes=extra)]
         if not args.no_cpu_baseline and rk.world == 1:         # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
         else:

@@ -84,6 +84,11 @@ struct Geo {
     // at the VALU issue limit with 80 % of the lanes idle).  Everything below that says `lane` means the lane inside the game.
     static constexpr int LPG = RC <= 16 ? 16 : (RC <= 32 ? 32 : 64);   // (6x6 with two games per wave measured 5 % slower)
     static constexpr int GPW = 64 / LPG;              // games per wave
+#ifdef SGX_NO_NT
+    static constexpr bool NT_STORES = false;
+#else
+    static constexpr bool NT_STORES = LPG == 64;
+#endif      // observation lines written whole leave as non-temporal stores (sgx_obs.h)
     static constexpr int CPL = (RC + LPG - 1) / LPG;  // cells per lane
     static constexpr int CNT_PAD = CPL * LPG;
 };

@@ -125,6 +125,13 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
         constexpr int NQ = (RC / 4) * NCH;                                           // quads (16 B) of one observation
         const int m0 = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & (G::LPG - 1));  // quads past a chunk boundary
         f32x4 *base = reinterpret_cast<f32x4 *>(dst);
+        // Lines written whole by this wave leave as non-temporal stores (they are never read back by this kernel and need no
+        // merging: 325.8 -> 281.1 us per launch of 65,536 Barrage games, 137 -> 117 us on 6x6, 244 -> 198 us on 8x8, in-process A/B).
+        // The first and the last 128-byte line of a game's observation are shared with the neighbouring games (other waves): those
+        // go through L2 so that the halves merge (everything non-temporal: 316 us; toy boards, whose games are a few lines long, are
+        // faster without: Geo::NT_STORES).
+        const int l0 = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7);               // quads past a 128-byte line
+        const int first_line = l0 ? 0 : -1, last_line = ((l0 + NQ) & 7) ? (NQ - 1 + l0) >> 3 : -1;   // lines counted from dst - 16 * l0
 #pragma unroll SGX_OBS_UNROLL
         for (int q0 = -m0; q0 < NQ; q0 += G::LPG) {
             const int q = q0 + lane;
@@ -136,7 +143,13 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
                 const unsigned y = x ^ (0x1111u * CODE_ESC);                           // a CODE_ESC nibble becomes 0
                 esc = ((y - 0x1111u) & ~y & 0x8888u) != 0;                            // some nibble of y is 0
             }
-            if (in && !esc) stream_store(&base[q], o);
+            if constexpr (G::NT_STORES) {
+                const bool edge = ((q + l0) >> 3) == first_line || ((q + l0) >> 3) == last_line;
+                if (in && !esc && edge) base[q] = o;
+                if (in && !esc && !edge) __builtin_nontemporal_store(o, &base[q]);
+            } else {
+                if (in && !esc) base[q] = o;
+            }
         }
     } else {
         static_assert(!CHECKED, "odd boards patch single floats after a wait (patch_uncoded_floats)");
@@ -150,6 +163,7 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
         const int nslots = (a + NF + 3) >> 2;
         const int m0 = (int)((reinterpret_cast<uintptr_t>(base) >> 4) & (G::LPG - 1));
         const int sh = a ? (4 - a) * 4 : 0, back = a ? 1 : 0;
+        const int l0 = (int)((reinterpret_cast<uintptr_t>(base) >> 4) & 7), last_line = (nslots - 1 + l0) >> 3;   // (both edge lines may be shared)
 #pragma unroll 2
         for (int k0 = -m0; k0 < nslots; k0 += G::LPG) {
             const int k = k0 + lane;
@@ -162,7 +176,9 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
             const int f0 = 4 * kk - a;
             if (slot_in && f0 >= 0 && f0 + 3 < NF) {
                 f32x4 qv = {o[0], o[1], o[2], o[3]};
-                stream_store(&reinterpret_cast<f32x4 *>(base)[k], qv);
+                const int line = (k + l0) >> 3;
+                if (G::NT_STORES && line != 0 && line != last_line) __builtin_nontemporal_store(qv, &reinterpret_cast<f32x4 *>(base)[k]);
+                else reinterpret_cast<f32x4 *>(base)[k] = qv;
             } else if (slot_in) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)

@@ -82,7 +82,11 @@ __device__ inline void write_record(Lds<G, NB> &L, int8_t *rec_g, int rec_bytes,
         } else if (i < G::ST_OFF / 16 + n_tail_q) {
             v = tsrc[i - G::ST_OFF / 16];
         }
+#ifdef SGX_NT_RECORD
+        { i32x4 nv = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(nv, reinterpret_cast<i32x4 *>(&dst[i])); }
+#else
         dst[i] = v;
+#endif
     }
 }
 

@@ -484,7 +484,8 @@ int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t 
     trial_us[0] = best_us;
     *n_trials = 1;
     const size_t room = (size_t)max_extra - bytes;                        // what the padding may take
-    size_t step = bytes / 8;
+    size_t step = bytes / 8;                                              // (a big buffer leaves little room: smaller steps then)
+    if (step * 12 > room) step = room / 12;
     step = (step + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
     for (int k = 1; k < max_trials && k < SGX_OUT_MAX_TRIALS; ++k) {
         const size_t pad_bytes = (size_t)k * step;
