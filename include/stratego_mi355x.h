@@ -107,6 +107,11 @@ typedef struct sgx_step_io {
 
 /* Library / geometry queries (penv:32-36: action_size, spatial_action_size). */
 int sgx_abi_version(void);
+/* 1 if kernels for this board size are compiled into the library.  Every reference variant is (10x10, 15x15, 8x8, 6x6, 5x5, 4x4, 3x4);
+ * the reference's StrategoProceduralEnv(rows, columns) takes ANY size >= 3 (penv:27-36): for other sizes (rows * cols <= SGX_MAX_CELLS)
+ * the same sources are compiled into a library of their own with -DSGX_EXTRA_R=<rows> -DSGX_EXTRA_C=<cols> -DSGX_ONLY_EXTRA
+ * (stratego_env_amd/build.py build_geometry does it on first use). */
+int sgx_supports_geometry(int32_t rows, int32_t cols);
 const char *sgx_last_error(void);
 int64_t sgx_num_envs(const sgx_env *h);
 int sgx_spatial_channels(const sgx_env *h);          /* K */

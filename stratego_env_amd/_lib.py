@@ -6,7 +6,7 @@ raises.  (The CPU oracle under oracle/ is test infrastructure and is never impor
 import ctypes as C
 import os
 
-from .build import LIB_PATH
+from .build import LIB_PATH, BUILTIN_GEOMETRIES, build_geometry
 
 SGX_MAX_CELLS = 256
 SGX_OBS_LUT_STRIDE = 16
@@ -21,7 +21,7 @@ OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
 
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (
-    'sgx_abi_version', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
+    'sgx_abi_version', 'sgx_supports_geometry', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
     'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
     'sgx_observe', 'sgx_time_observe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_step_n', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
 )
@@ -58,6 +58,8 @@ def _bind(L):
     vp, i64, u64 = C.c_void_p, C.c_int64, C.c_uint64
     L.sgx_abi_version.restype = C.c_int
     L.sgx_abi_version.argtypes = []
+    L.sgx_supports_geometry.restype = C.c_int
+    L.sgx_supports_geometry.argtypes = [C.c_int32, C.c_int32]
     L.sgx_last_error.restype = C.c_char_p
     L.sgx_last_error.argtypes = []
     L.sgx_num_envs.restype = i64
@@ -132,6 +134,14 @@ def load(path=None):
                        % (path, L.sgx_abi_version(), ABI_VERSION))
     _libs[path] = L
     return L
+
+
+def load_for_geometry(rows, columns, path=None):
+    """The library that holds the kernels of a rows x columns board: the main one for the sizes of the reference's variants, else
+    a library of its own built on first use (build.build_geometry).  An explicit `path` / $SGX_LIB_PATH wins."""
+    if path or os.environ.get('SGX_LIB_PATH') or (int(rows), int(columns)) in BUILTIN_GEOMETRIES:
+        return load(path)
+    return load(build_geometry(rows, columns))
 
 
 def check(rc, lib=None):

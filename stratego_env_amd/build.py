@@ -41,5 +41,41 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+BUILTIN_GEOMETRIES = ((10, 10), (15, 15), (8, 8), (6, 6), (5, 5), (4, 4), (3, 4))    # SGX_BUILTIN_GEOMETRIES in the .hip
+MAX_CELLS = 256
+
+
+def geometry_lib_path(rows, columns):
+    return os.path.join(OUT_DIR, 'libstratego_mi355x_%dx%d.so' % (rows, columns))
+
+
+def build_geometry(rows, columns, force=False, verbose=False):
+    """The library for a board size that is not compiled into libstratego_mi355x.so: the same sources with that one size
+    (-DSGX_EXTRA_R / -DSGX_EXTRA_C / -DSGX_ONLY_EXTRA, ~20 s of hipcc), cached in _build/.  This is how any (rows, columns) the
+    reference's StrategoProceduralEnv accepts (penv:27-36; here rows * columns <= 256) gets its own specialised kernels."""
+    rows, columns = int(rows), int(columns)
+    if rows < 3 or columns < 3:
+        raise ValueError("Both rows and columns have to be at least 3 (you passed rows: {} columns: {}).".format(rows, columns))
+    if rows * columns > MAX_CELLS:
+        raise ValueError("boards of more than %d cells are not supported (%d x %d)" % (MAX_CELLS, rows, columns))
+    path = geometry_lib_path(rows, columns)
+    csrc = os.path.dirname(SRC)
+    deps = [SRC, os.path.join(INCLUDE, 'stratego_mi355x.h')] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.h')]
+    if not force and os.path.exists(path) and os.path.getmtime(path) >= max(os.path.getmtime(f) for f in deps):
+        return path
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build the %dx%d kernels" % (rows, columns))
+    os.makedirs(OUT_DIR, exist_ok=True)
+    tmp = '%s.%d.tmp' % (path, os.getpid())
+    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-fvisibility=hidden', '-Wall',
+           '-DSGX_EXTRA_R=%d' % rows, '-DSGX_EXTRA_C=%d' % columns, '-DSGX_ONLY_EXTRA', '-I', INCLUDE, SRC, '-o', tmp]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, path)
+    return path
+
+
 if __name__ == '__main__':
     print(build(force=True, verbose=True))

@@ -106,8 +106,31 @@ VARIANTS: Dict[str, Variant] = {
 }
 
 
+def custom_variant(rows, columns, max_turns=2000, obstacle_locations=(), piece_counts=None, initial_state_usable_rows=None,
+                   name=None) -> Variant:
+    """A variant the reference has no name for: any board of rows, columns >= 3 (the reference's StrategoProceduralEnv takes any
+    size, penv:27-36).  Without piece_counts the side gets one of each movable rank that fits plus a flag -- the count only sizes
+    the capture-event list and the random setups; the functional API works on the caller's states."""
+    rows, columns = int(rows), int(columns)
+    if rows < 3 or columns < 3:
+        raise ValueError("Both rows and columns have to be at least 3 (you passed rows: {} columns: {}).".format(rows, columns))
+    usable = int(initial_state_usable_rows) if initial_state_usable_rows is not None else max(1, (rows - 1) // 2)
+    if piece_counts is None:
+        room = usable * columns
+        piece_counts = [0] * NUM_PIECE_TYPES
+        piece_counts[10] = 1                                   # flag
+        for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 0, 11):           # scout .. marshal, spy, bomb; then more scouts
+            if sum(piece_counts) < room:
+                piece_counts[t] = 1
+        piece_counts[1] += room - sum(piece_counts)
+    return Variant(name or 'custom_%dx%d' % (rows, columns), rows, columns, int(max_turns), tuple(tuple(x) for x in obstacle_locations),
+                   tuple(int(x) for x in piece_counts), usable, '')
+
+
 def get_variant(version) -> Variant:
-    """Accepts a GameVersions member or its string value."""
+    """Accepts a GameVersions member, its string value, or a Variant (custom_variant)."""
+    if isinstance(version, Variant):
+        return version
     if isinstance(version, GameVersions):
         version = version.value
     if version not in VARIANTS:

@@ -87,8 +87,8 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
         const int cell = lane + G::LPG * cc;
         int n = 0;
         if (cell < RC) {
-            n = __popc(mask_bits(L, cell * K, K < 32 ? K : 32));
-            if constexpr (K > 32) n += __popc(mask_bits(L, cell * K + 32, K - 32));
+#pragma unroll
+            for (int o = 0; o < K; o += 32) n += __popc(mask_bits(L, cell * K + o, K - o < 32 ? K - o : 32));
         }
         L.cnt[cell] = (uint8_t)n;
         mine += n;

@@ -21,7 +21,8 @@ constexpr int LUT_ROW_PITCH = 33, LUT_BLK = 673 /* >= 20*33 (79 channels), = 1 m
 #ifndef SGX_MIN_WAVES
 #define SGX_MIN_WAVES 6
 #endif
-constexpr int WPB = SGX_WPB;  // waves per workgroup (WPB * Geo::GPW games); they share the LUT
+// waves per workgroup (WPB * Geo::GPW games; they share the observation tables): SGX_WPB wherever the games' LDS regions fit the
+// 160 KiB of a CU, fewer on the longest thin boards (3 x 85: 21 KB per game) -- Geo::WPB
 // 'original' channel mode only -- per observation kind in LDS: the LUT followed by the quad table (2 perspectives x NCH quads x 4
 // packed entries, see emit_obs_lut)
 constexpr int QTAB_DWORDS = 2 * OBS_CH * 4, OBS_TAB_DWORDS = LUT_DWORDS + QTAB_DWORDS;   // partial kind; the full kind follows it
@@ -91,6 +92,11 @@ struct Geo {
 #endif      // observation lines written whole leave as non-temporal stores (sgx_obs.h)
     static constexpr int CPL = (RC + LPG - 1) / LPG;  // cells per lane
     static constexpr int CNT_PAD = CPL * LPG;
+    // upper estimate of one game's LDS region (struct Lds with the widest code buffer) + the workgroup's shared tables
+    static constexpr int LDS_GAME_EST = N_LDS_BOARDS * S + (RC * FOBS_CH / 2 + 64) + 4 * MB_WORDS + 2 * CNT_PAD + S + TAIL_BYTES + 6 * (EVL_MAX + 12) + 64;
+    static constexpr int LDS_SHARED_EST = 2 * (RC * FOBS_CH / 2 + 32) + 1024;
+    static constexpr int WPB = (SGX_WPB * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? SGX_WPB
+                             : (4 * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? 4 : 2;
 };
 
 struct DevTables {

@@ -248,11 +248,29 @@ __device__ int kth_valid(const Lds<G, NB> &L, int k, int lane) {
     }
     cell = uni<G>(cell);
     int kk = uni<G>(k - before);
-    const int p = cell * K + (lane < K ? lane : 0);
-    unsigned long long bits = gballot<G>(lane < K && ((L.mbits[p >> 5] >> (p & 31)) & 1u) != 0);
-    for (int i = 0; i < kk; ++i) bits &= bits - 1;
-    const int ch = __ffsll((long long)bits) - 1;
-    return cell * K + ch;
+    if constexpr (K <= G::LPG) {
+        const int p = cell * K + (lane < K ? lane : 0);
+        unsigned long long bits = gballot<G>(lane < K && ((L.mbits[p >> 5] >> (p & 31)) & 1u) != 0);
+        for (int i = 0; i < kk; ++i) bits &= bits - 1;
+        const int ch = __ffsll((long long)bits) - 1;
+        return cell * K + ch;
+    } else {
+        // long thin boards (R + C > 33): the cell's K channels in slices of LPG
+        int ch = 0;
+        for (int c0 = 0; c0 < K; c0 += G::LPG) {
+            const bool in = c0 + lane < K;
+            const int p = cell * K + (in ? c0 + lane : 0);
+            unsigned long long bits = gballot<G>(in && ((L.mbits[p >> 5] >> (p & 31)) & 1u) != 0);
+            const int n = __popcll(bits);
+            if (kk < n) {
+                for (int i = 0; i < kk; ++i) bits &= bits - 1;
+                ch = c0 + __ffsll((long long)bits) - 1;
+                break;
+            }
+            kk -= n;
+        }
+        return cell * K + ch;
+    }
 }
 
 }  // namespace

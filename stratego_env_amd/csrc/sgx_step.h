@@ -20,9 +20,9 @@ constexpr int shared_table_bytes() {
 // waves per SIMD this geometry can reach: LDS per workgroup = WPB game regions + the shared LUT, 160 KiB per CU
 template <class G, int KIND>
 constexpr int waves_per_simd() {
-    constexpr int per_wg = WPB * G::GPW * (int)sizeof(Lds<G, ObsKind<KIND>::NIB_CH>) + shared_table_bytes<G, KIND>() + SGX_MAX_CELLS;
+    constexpr int per_wg = G::WPB * G::GPW * (int)sizeof(Lds<G, ObsKind<KIND>::NIB_CH>) + shared_table_bytes<G, KIND>() + SGX_MAX_CELLS;
     constexpr int wgs = (160 * 1024) / per_wg;
-    constexpr int w = wgs * WPB / 4;
+    constexpr int w = wgs * G::WPB / 4;
     // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
     constexpr int want = G::RC <= 64 ? 8 : SGX_MIN_WAVES;
     return w > want ? want : (w < 1 ? 1 : w);
@@ -441,36 +441,36 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
     constexpr bool FULL = ObsKind<KIND>::FULL, ORIG = ObsKind<KIND>::ORIG;
-    __shared__ Lds<G, ObsKind<KIND>::NIB_CH> LW[WPB * G::GPW];
+    __shared__ Lds<G, ObsKind<KIND>::NIB_CH> LW[G::WPB * G::GPW];
     __shared__ alignas(16) uint8_t shared[shared_table_bytes<G, KIND>()];
     __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS];
     const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;     // lane inside the game, game inside the workgroup
-    const int64_t env = group_of_block() * (WPB * G::GPW) + slot;
+    const int64_t env = group_of_block() * (G::WPB * G::GPW) + slot;
 
     // ---- the workgroup's shared tables (L2-resident sources)
     const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
     if constexpr (ORIG) {
         float *lut_s = reinterpret_cast<float *>(shared);
         const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[4 + (raw ? 2 : 0)]);
-        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
-        build_quad_table<G, PS>(reinterpret_cast<uint32_t *>(lut_s + LUT_DWORDS), threadIdx.x, 64 * WPB);
+        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * G::WPB) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
+        build_quad_table<G, PS>(reinterpret_cast<uint32_t *>(lut_s + LUT_DWORDS), threadIdx.x, 64 * G::WPB);
         if constexpr (FULL) {
             const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[4 + (raw ? 2 : 0) + 1]);
-            for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * WPB) reinterpret_cast<f32x4 *>(lut_s + OBS_TAB_DWORDS)[i] = fsrc[i];
-            build_quad_table<G, FS>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * WPB);
+            for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * G::WPB) reinterpret_cast<f32x4 *>(lut_s + OBS_TAB_DWORDS)[i] = fsrc[i];
+            build_quad_table<G, FS>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * G::WPB);
         }
     } else {
         constexpr int NP = tmpl_bytes<G, KIND>(false), NF = FULL ? tmpl_bytes<G, KIND>(true) : 0;
         const int4 *tp = reinterpret_cast<const int4 *>(P.tab->tmpl[raw ? 2 : 0]);
-        for (int i = threadIdx.x; i < NP / 16; i += 64 * WPB) reinterpret_cast<int4 *>(shared)[i] = tp[i];
+        for (int i = threadIdx.x; i < NP / 16; i += 64 * G::WPB) reinterpret_cast<int4 *>(shared)[i] = tp[i];
         if constexpr (FULL) {
             const int4 *tf = reinterpret_cast<const int4 *>(P.tab->tmpl[(raw ? 2 : 0) + 1]);
-            for (int i = threadIdx.x; i < NF / 16; i += 64 * WPB) reinterpret_cast<int4 *>(shared + NP)[i] = tf[i];
+            for (int i = threadIdx.x; i < NF / 16; i += 64 * G::WPB) reinterpret_cast<int4 *>(shared + NP)[i] = tf[i];
         }
         const int4 *ct = reinterpret_cast<const int4 *>(P.tab->codetab[raw ? 1 : 0]);
-        for (int i = threadIdx.x; i < CODETAB_BYTES / 16; i += 64 * WPB) reinterpret_cast<int4 *>(shared + NP + NF)[i] = ct[i];
+        for (int i = threadIdx.x; i < CODETAB_BYTES / 16; i += 64 * G::WPB) reinterpret_cast<int4 *>(shared + NP + NF)[i] = ct[i];
     }
-    for (int i = threadIdx.x; i < G::S / 4; i += 64 * WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
+    for (int i = threadIdx.x; i < G::S / 4; i += 64 * G::WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
     __syncthreads();   // from here on every wave works on its own game
     if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], shared, obst_s, env, lane);
 }
@@ -479,11 +479,11 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
 // step kernel's schedule and cost 3.7 % on Barrage); two kernel symbols, so that a kernel trace keeps the env.step() launches
 // apart from the state-preserving observe launches (placement trials, reset())
 template <int R_, int C_, int KIND, bool MAPPED = false>
-__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) void step_kernel(const KParams P) {
+__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND>())) void step_kernel(const KParams P) {
     game_kernel_body<R_, C_, KIND, MAPPED>(P);
 }
 template <int R_, int C_, int KIND, bool MAPPED = false>
-__global__ __launch_bounds__(64 * WPB, (waves_per_simd<Geo<R_, C_>, KIND>())) void observe_kernel(const KParams P) {
+__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND>())) void observe_kernel(const KParams P) {
     game_kernel_body<R_, C_, KIND, MAPPED>(P);
 }
 

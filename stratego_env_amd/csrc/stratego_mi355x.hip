@@ -71,22 +71,37 @@ struct sgx_env {
 
 namespace {
 
+// Board sizes compiled into this library.  Every reference variant (game/config.py) is built in; any other size (rows, cols >= 3,
+// rows * cols <= SGX_MAX_CELLS) gets a library of its own, compiled from the same sources with -DSGX_EXTRA_R=<rows>
+// -DSGX_EXTRA_C=<cols> -DSGX_ONLY_EXTRA (stratego_env_amd/build.py: build_geometry), like the reference's
+// StrategoProceduralEnv(rows, columns) accepts any size (penv:27-36).
+#ifdef SGX_ONLY_EXTRA
+#define SGX_BUILTIN_GEOMETRIES(X, A)
+#else
+#define SGX_BUILTIN_GEOMETRIES(X, A) X(A, 10, 10) X(A, 15, 15) X(A, 8, 8) X(A, 6, 6) X(A, 5, 5) X(A, 4, 4) X(A, 3, 4)
+#endif
+#ifdef SGX_EXTRA_R
+#define SGX_EXTRA_GEOMETRY(X, A) X(A, SGX_EXTRA_R, SGX_EXTRA_C)
+static_assert(SGX_EXTRA_R >= 3 && SGX_EXTRA_C >= 3 && SGX_EXTRA_R * SGX_EXTRA_C <= SGX_MAX_CELLS, "SGX_EXTRA_R x SGX_EXTRA_C out of range");
+#else
+#define SGX_EXTRA_GEOMETRY(X, A)
+#endif
+#define SGX_ALL_GEOMETRIES(X, A) SGX_BUILTIN_GEOMETRIES(X, A) SGX_EXTRA_GEOMETRY(X, A)
+
 bool supported_geometry(int r, int c) {
-    return (r == 10 && c == 10) || (r == 15 && c == 15) || (r == 8 && c == 8) || (r == 6 && c == 6) || (r == 5 && c == 5) ||
-           (r == 4 && c == 4) || (r == 3 && c == 4);
+#define SGX_MATCH(A, R, C) if (r == (R) && c == (C)) return true;
+    SGX_ALL_GEOMETRIES(SGX_MATCH, _)
+#undef SGX_MATCH
+    return false;
 }
 
-#define DISPATCH_GEOMETRY(h, CALL)                                   \
-    do {                                                             \
-        const int r_ = (h)->cfg.rows, c_ = (h)->cfg.cols;            \
-        if (r_ == 10 && c_ == 10) { CALL(10, 10); }                  \
-        else if (r_ == 15 && c_ == 15) { CALL(15, 15); }             \
-        else if (r_ == 8 && c_ == 8) { CALL(8, 8); }                 \
-        else if (r_ == 6 && c_ == 6) { CALL(6, 6); }                 \
-        else if (r_ == 5 && c_ == 5) { CALL(5, 5); }                 \
-        else if (r_ == 4 && c_ == 4) { CALL(4, 4); }                 \
-        else if (r_ == 3 && c_ == 4) { CALL(3, 4); }                 \
-        else return fail(SGX_EINVAL, "unsupported board size%s");    \
+#define SGX_DISPATCH_ONE(CALL, R, C) if (!done_ && r_ == (R) && c_ == (C)) { CALL(R, C); done_ = true; }
+#define DISPATCH_GEOMETRY(h, CALL)                                                     \
+    do {                                                                               \
+        const int r_ = (h)->cfg.rows, c_ = (h)->cfg.cols;                              \
+        bool done_ = false;                                                            \
+        SGX_ALL_GEOMETRIES(SGX_DISPATCH_ONE, CALL)                                     \
+        if (!done_) return fail(SGX_EINVAL, "unsupported board size%s");               \
     } while (0)
 
 KParams make_params(const sgx_env *h) {
@@ -129,6 +144,7 @@ int check_cfg(const sgx_config *cfg) {
 }  // namespace
 
 SGX_API int sgx_abi_version(void) { return SGX_ABI_VERSION; }
+SGX_API int sgx_supports_geometry(int32_t rows, int32_t cols) { return supported_geometry(rows, cols) ? 1 : 0; }
 SGX_API const char *sgx_last_error(void) { return g_last_error.c_str(); }
 SGX_API int64_t sgx_num_envs(const sgx_env *h) { return h ? h->n_envs : 0; }
 SGX_API int sgx_spatial_channels(const sgx_env *h) { return h ? h->K : 0; }
@@ -267,7 +283,9 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     if (!out) return fail(SGX_EINVAL, "out is NULL%s");
     *out = nullptr;
     if (int rc = check_cfg(cfg)) return rc;
-    if (!supported_geometry(cfg->rows, cfg->cols)) return fail(SGX_EINVAL, "unsupported board size (built for 10x10, 15x15, 8x8, 6x6, 5x5, 4x4, 3x4)%s");
+    if (!supported_geometry(cfg->rows, cfg->cols))
+        return fail(SGX_EINVAL, "board size not compiled into this library (built in: 10x10, 15x15, 8x8, 6x6, 5x5, 4x4, 3x4; any other size: "
+                                "build the same sources with -DSGX_EXTRA_R=<rows> -DSGX_EXTRA_C=<cols>, stratego_env_amd/build.py build_geometry)%s");
     if (n_envs <= 0 || n_envs > (int64_t)1 << 30) return fail(SGX_EINVAL, "n_envs out of range%s");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -372,13 +390,13 @@ SGX_API int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p
 }
 
 static int launch_step(sgx_env *h, const KParams &p, void *stream) {
-    const int gpw = h->cfg.rows * h->cfg.cols <= 16 ? 4 : (h->cfg.rows * h->cfg.cols <= 32 ? 2 : 1);   // Geo::GPW
-    const unsigned grid = grid_for((h->n_envs + WPB * gpw - 1) / (WPB * gpw));
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
 #define CALL_STEP_KIND(R, C, KIND)                                                                 \
     do {                                                                                           \
-        if (p.mode) observe_kernel<R, C, KIND><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p);     \
-        else step_kernel<R, C, KIND><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p);               \
+        using G_ = Geo<R, C>;                                                                      \
+        const unsigned grid = grid_for((h->n_envs + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW)); \
+        if (p.mode) observe_kernel<R, C, KIND><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p); \
+        else step_kernel<R, C, KIND><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);           \
     } while (0)
 #define CALL_STEP0(R, C) CALL_STEP_KIND(R, C, 0)
 #define CALL_STEP1(R, C) CALL_STEP_KIND(R, C, 1)
@@ -388,8 +406,10 @@ static int launch_step(sgx_env *h, const KParams &p, void *stream) {
         if (full || original) return fail(SGX_EINVAL, "state-coordinate masks and sgx_expand come with the 67-channel partial observation only%s");
 #define CALL_STEP_MAPPED(R, C)                                                                     \
     do {                                                                                           \
-        if (p.mode) observe_kernel<R, C, 0, true><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p);  \
-        else step_kernel<R, C, 0, true><<<grid, 64 * WPB, 0, (hipStream_t)stream>>>(p);            \
+        using G_ = Geo<R, C>;                                                                      \
+        const unsigned grid = grid_for((h->n_envs + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW)); \
+        if (p.mode) observe_kernel<R, C, 0, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);  \
+        else step_kernel<R, C, 0, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);        \
     } while (0)
         DISPATCH_GEOMETRY(h, CALL_STEP_MAPPED);
 #undef CALL_STEP_MAPPED

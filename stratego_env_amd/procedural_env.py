@@ -44,7 +44,7 @@ class BatchedStrategoProceduralEnv:
         self.batch_size = int(batch_size)
         self.action_size = v.action_size                                                            # penv:34
         self.spatial_action_size = v.spatial_action_size                                            # penv:35
-        self._vec = VecStrategoEnv(v.name, batch_size, device=device, human_inits=False)
+        self._vec = VecStrategoEnv(v, batch_size, device=device, human_inits=False)
         self.device = self._vec.device
         self._held = None            # (states, players) objects held loaded by a `with env.loaded(...)` scope
         self._scratch_is_held = False
@@ -315,7 +315,7 @@ class BatchedStrategoProceduralEnv:
     # ---- packed states: search nodes kept in the library's records (no int64 import / export per call) ---------------
     def new_packed(self, n=None):
         """An empty pool of `n` packed states of this variant (default: batch_size)."""
-        return PackedStates(self.variant.name, self.batch_size if n is None else n, self.device)
+        return PackedStates(self.variant, self.batch_size if n is None else n, self.device)
 
     def pack(self, states, players, out=None):
         """int64 [n,34,R,C] + players -> PackedStates (`out` or a new pool); `sanitised` uint8 [n] reports altered states."""
@@ -388,14 +388,23 @@ class PackedStates:
         self._vec.close()
 
 
-def _default_version(rows, columns):
-    """The reference's StrategoProceduralEnv is built from (rows, columns) only; pick the variant of that size with the most
-    pieces (its capture-event capacity covers the others; obstacles are checked per call)."""
-    from .config import VARIANTS
+def _variant_obstacles(version):
+    return get_variant(version).obstacle_map() != 0
+
+
+def _default_variant(rows, columns, obstacle_map=None):
+    """The reference's StrategoProceduralEnv is built from (rows, columns) only.  For a board size one of the reference's variants
+    has, that variant with the most pieces (its capture-event capacity covers the others), else a custom variant of that size;
+    the obstacle cells are the caller's (they are a per-handle constant here, taken from the first state / obstacle map seen)."""
+    import dataclasses
+    from .config import VARIANTS, custom_variant
     cands = [v for v in VARIANTS.values() if v.rows == rows and v.columns == columns]
-    if not cands:
-        raise ValueError("no game variant with a %dx%d board" % (rows, columns))
-    return max(cands, key=lambda v: sum(v.piece_counts)).name
+    v = max(cands, key=lambda v: sum(v.piece_counts)) if cands else custom_variant(rows, columns)
+    if obstacle_map is not None:
+        obst = tuple((int(r), int(c)) for r, c in zip(*np.nonzero(np.asarray(obstacle_map))))
+        if obst != tuple(sorted(v.obstacle_locations)):
+            v = dataclasses.replace(v, name='%s_obstacles_%x' % (v.name, hash(obst) & 0xFFFFFFFF), obstacle_locations=obst, human_inits='')
+    return v
 
 
 class StrategoProceduralEnv:
@@ -412,21 +421,40 @@ class StrategoProceduralEnv:
         self.action_size = np.int64(ia.action_size(int(rows), int(columns)))                        # penv:34
         k = ia.spatial_channels(int(rows), int(columns))
         self.spatial_action_size = (np.int64(rows), np.int64(columns), np.int64(k))                 # penv:35
-        self._version = version if version is not None else _default_version(int(rows), int(columns))
+        if int(rows) * int(columns) > 256:
+            raise ValueError("boards of more than 256 cells are not supported ({} x {})".format(rows, columns))
+        self._version = version
         self._device = device
+        self._by_obstacles = {}      # obstacle map bytes -> one-state batched env (obstacles are a per-handle constant)
         self._batched = None
+
+    def _for_obstacles(self, obstacle_map):
+        """The one-state batched env whose handle carries these obstacle cells (the reference reads them from every state)."""
+        ob = np.ascontiguousarray(np.asarray(obstacle_map) != 0)
+        key = ob.tobytes()
+        b = self._by_obstacles.get(key)
+        if b is None:
+            v = self._version if self._version is not None else _default_variant(int(self.rows), int(self.columns), ob)
+            b = BatchedStrategoProceduralEnv(v, 1, device=self._device)
+            b.strict = True          # a state the packed record cannot carry is an error here, never silently altered
+            self._by_obstacles[key] = b
+        self._batched = b
+        return b
 
     @property
     def _b(self):
+        """The env of the most recent state (methods that take a state select it through _state())."""
         if self._batched is None:
-            self._batched = BatchedStrategoProceduralEnv(self._version, 1, device=self._device)
-            self._batched.strict = True      # a state the packed record cannot carry is an error here, never silently altered
+            self._for_obstacles(np.zeros((int(self.rows), int(self.columns)), dtype=bool) if self._version is None
+                                else _variant_obstacles(self._version))
         return self._batched
 
     def _state(self, state):
         st = np.asarray(state, dtype=np.int64)
         if st.shape != (NUM_STATE_LAYERS, int(self.rows), int(self.columns)):
             raise ValueError("state must have shape (34, rows, columns)")
+        if self._version is None:
+            self._for_obstacles(st[2])
         if not np.array_equal(st[2] != 0, self._b.variant.obstacle_map() != 0):
             raise ValueError("the state's obstacle layer differs from the %s variant's (a per-handle constant here)" % self._version)
         return st[None]
@@ -442,7 +470,9 @@ class StrategoProceduralEnv:
                         ("player_2_initial_piece_map map", player_2_initial_piece_map)):
             if tuple(np.shape(m)) != correct_shape:
                 raise ValueError("{} needs to be of shape {}, was {}".format(name, correct_shape, np.shape(m)))   # penv:44-55
-        if not np.array_equal(np.asarray(obstacle_map) != 0, self._b.variant.obstacle_map() != 0):
+        if self._version is None:
+            self._for_obstacles(obstacle_map)
+        elif not np.array_equal(np.asarray(obstacle_map) != 0, self._b.variant.obstacle_map() != 0):
             raise ValueError("obstacle_map differs from the %s variant's (a per-handle constant here)" % self._version)
         st = self._b.create_initial_state(np.asarray(player_1_initial_piece_map, dtype=np.int8)[None],
                                           np.asarray(player_2_initial_piece_map, dtype=np.int8)[None])[0].cpu().numpy()
@@ -538,6 +568,7 @@ class StrategoProceduralEnv:
         return tuple(np.int64(x) for x in self._b.get_action_spatial_index_from_1d_index(int(action_index)))
 
     def close(self):
-        if self._batched is not None:
-            self._batched.close()
-            self._batched = None
+        for b in self._by_obstacles.values():
+            b.close()
+        self._by_obstacles = {}
+        self._batched = None

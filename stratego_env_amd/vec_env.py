@@ -61,9 +61,9 @@ class VecStrategoEnv:
         self.f_channels = FO_OBS_CHANNELS_ORIGINAL if self._mode_flags else FO_OBS_CHANNELS
         if not torch.cuda.is_available():
             raise _lib.SgxError("VecStrategoEnv needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
-        self._L = _lib.load(lib_path)
         self.variant = get_variant(version)
         v = self.variant
+        self._L = _lib.load_for_geometry(v.rows, v.columns, lib_path)
         self.num_envs = int(num_envs)
         self.device = torch.device('cuda', device if isinstance(device, int) else torch.device(device).index or 0)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
