@@ -32,6 +32,8 @@ constexpr int FOBS_TAB_DWORDS = LUT_DWORDS + 2 * FOBS_CH * 4;
 // moves: 0.5 normalised, 0 raw; captured counts: -1 normalised, 0 raw) held in a per-variant template; the few entries that are
 // neither default nor 1.0 (captured counts >= 1, non-zero recent-move codes) are patched into the output afterwards.
 constexpr int NIB_ONE = 4, CODE_NONE = 0xFF, CODETAB_REC = 192, CODETAB_BYTES = 208;
+constexpr int COMBAT_BYTES = 16 * 16;
+enum { COMBAT_LOSE = 0, COMBAT_TIE = 1, COMBAT_WIN = 2, COMBAT_WIN_FLAG = 3 };
 constexpr int CODE_ESC = 8;   // (-2.0, never a value of its own) marks an entry whose float has no code: see emit_codes / patch_uncoded
 constexpr int TMPL_MAX_BYTES = ((SGX_MAX_CELLS * FOBS_CH / 2) + 15) & ~15;   // 10,112
 __host__ __device__ constexpr int lut_row(int ch) { return ((ch >> 1) & 1) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH + (ch & 1) * 16; }
@@ -113,6 +115,8 @@ struct DevTables {
     // the enemy block of a piece type share their normalisation), [CODETAB_REC + code + 3] for a recent-move code; CODE_NONE where
     // the float is not one of the 16 decodable values (such entries are patched into the output as floats)
     alignas(16) uint8_t codetab[2][CODETAB_BYTES];
+    // combat outcome of attacker type a on defender type d (impl:968-982): [16 * a + d] = COMBAT_*
+    alignas(16) uint8_t combat[COMBAT_BYTES];
 };
 
 struct KParams {

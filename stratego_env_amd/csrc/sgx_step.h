@@ -20,7 +20,7 @@ constexpr int shared_table_bytes() {
 // waves per SIMD this geometry can reach: LDS per workgroup = WPB game regions + the shared LUT, 160 KiB per CU
 template <class G, int KIND>
 constexpr int waves_per_simd() {
-    constexpr int per_wg = G::WPB * G::GPW * (int)sizeof(Lds<G, ObsKind<KIND>::NIB_CH>) + shared_table_bytes<G, KIND>() + SGX_MAX_CELLS;
+    constexpr int per_wg = G::WPB * G::GPW * (int)sizeof(Lds<G, ObsKind<KIND>::NIB_CH>) + shared_table_bytes<G, KIND>() + SGX_MAX_CELLS + COMBAT_BYTES;
     constexpr int wgs = (160 * 1024) / per_wg;
     constexpr int w = wgs * G::WPB / 4;
     // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
@@ -99,6 +99,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
     constexpr bool ORIG = ObsKind<KIND>::ORIG, FULL = ObsKind<KIND>::FULL;
+    const uint8_t *combat_s = obst_s + SGX_MAX_CELLS;           // the combat table follows the obstacle map in the shared LDS
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     STAMP(0);
 
@@ -265,10 +266,12 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
                 turn += 1;
                 bool wins = false, tied = false;
                 if (dest != 0) {
-                    if (moved == SP_MINER && dest == SP_BOMB) wins = true;
-                    else if (moved == SP_SPY && dest == SP_MARSHALL) wins = true;
-                    else if (dest == SP_FLAG) { wins = true; over = true; flags |= F_OVER | (player == 1 ? F_WIN_P1 : F_WIN_M1); }
-                    else if (dest != SP_BOMB) { if (moved == dest) tied = true; else if (moved > dest) wins = true; }
+                    // branch-free combat: one read of the 16 x 16 outcome table (the first-match chain of impl:968-982, tabulated
+                    // on the host: miner > bomb, spy > marshal when attacking, anything > flag, bomb > the rest, else by rank)
+                    const int outcome = uni<G>((int)combat_s[16 * moved + dest]);
+                    wins = outcome >= COMBAT_WIN;
+                    tied = outcome == COMBAT_TIE;
+                    if (outcome == COMBAT_WIN_FLAG) { over = true; flags |= F_OVER | (player == 1 ? F_WIN_P1 : F_WIN_M1); }
                 }
                 wave_sync<G>();
                 // clear the mover's recent-moves board (np.zeros_like, impl:1014)
@@ -443,7 +446,7 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     constexpr bool FULL = ObsKind<KIND>::FULL, ORIG = ObsKind<KIND>::ORIG;
     __shared__ Lds<G, ObsKind<KIND>::NIB_CH> LW[G::WPB * G::GPW];
     __shared__ alignas(16) uint8_t shared[shared_table_bytes<G, KIND>()];
-    __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS];
+    __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS + COMBAT_BYTES];    // obstacle map, then the combat outcome table
     const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;     // lane inside the game, game inside the workgroup
     const int64_t env = group_of_block() * (G::WPB * G::GPW) + slot;
 
@@ -471,6 +474,8 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
         for (int i = threadIdx.x; i < CODETAB_BYTES / 16; i += 64 * G::WPB) reinterpret_cast<int4 *>(shared + NP + NF)[i] = ct[i];
     }
     for (int i = threadIdx.x; i < G::S / 4; i += 64 * G::WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
+    for (int i = threadIdx.x; i < COMBAT_BYTES / 4; i += 64 * G::WPB)
+        reinterpret_cast<int *>(obst_s + SGX_MAX_CELLS)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
     __syncthreads();   // from here on every wave works on its own game
     if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], shared, obst_s, env, lane);
 }

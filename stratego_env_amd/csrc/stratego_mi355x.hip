@@ -204,6 +204,16 @@ static void build_lut(const sgx_config *cfg, bool full, float *lut, bool raw_val
     }
 }
 
+// Outcome of piece type `att` attacking piece type `def` (both 1..12): the reference's first-match chain, impl:968-982.
+static int combat_outcome(int att, int def) {
+    if (att == SP_MINER && def == SP_BOMB) return COMBAT_WIN;         // only the miner defuses
+    if (att == SP_SPY && def == SP_MARSHALL) return COMBAT_WIN;       // the spy wins only when it attacks
+    if (def == SP_FLAG) return COMBAT_WIN_FLAG;
+    if (def == SP_BOMB) return COMBAT_LOSE;
+    if (att == def) return COMBAT_TIE;
+    return att > def ? COMBAT_WIN : COMBAT_LOSE;
+}
+
 // 'extended' observations are rendered from 4-bit codes (sgx_obs.h): code c decodes to sext(c) / 4.  Templates of the channel
 // defaults and the codes of captured counts / recent-move codes, derived from the LUTs themselves.
 static int float_code(float f) {
@@ -323,6 +333,8 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     }
     memcpy(host_tab.obstacles, cfg->obstacles, rc_cells);
     if (int rc = build_code_tables(cfg, &host_tab)) { delete h; return rc; }
+    for (int a = 0; a < 16; ++a)
+        for (int d = 0; d < 16; ++d) host_tab.combat[16 * a + d] = (uint8_t)combat_outcome(a, d);
     if (hipMalloc((void **)&h->boards, (size_t)n_envs * h->rec_bytes) != hipSuccess ||
         hipMalloc((void **)&h->tab, sizeof(DevTables)) != hipSuccess) {
         sgx_destroy(h);

@@ -24,7 +24,16 @@ CUSTOM = {
                              piece_counts=(1, 8, 5, 4, 4, 4, 3, 2, 1, 1, 1, 6), initial_state_usable_rows=4, name='c12x12'),
     'c3x40': custom_variant(3, 40, max_turns=120, piece_counts=(1, 6, 2, 1, 1, 1, 1, 1, 1, 1, 1, 3), name='c3x40'),   # K = 83 > 64 lanes
 }
-config.VARIANTS.update(CUSTOM)          # (test-only names; the product takes the Variant objects themselves)
+
+
+@pytest.fixture(autouse=True)
+def _custom_names():
+    """The shared checkers look variants up by name: register the test-only names for the duration of a test (the product
+    takes the Variant objects themselves)."""
+    config.VARIANTS.update(CUSTOM)
+    yield
+    for k in CUSTOM:
+        config.VARIANTS.pop(k, None)
 
 
 @pytest.mark.parametrize('name,n_envs,n_steps', [('c3x3', 48, 80), ('c7x7', 32, 200), ('c9x5', 32, 200), ('c12x12', 12, 250), ('c3x40', 12, 120)])
