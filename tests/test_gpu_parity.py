@@ -660,9 +660,10 @@ def test_cabi_error_returns_on_device():
     assert L.sgx_create(C.byref(cfg), 0, 0, 1, 0, C.byref(h)) == -1 and not h.value and b'n_envs' in L.sgx_last_error()
     assert L.sgx_create(C.byref(cfg), 16, 99, 1, 0, C.byref(h)) == -1 and not h.value and b'device' in L.sgx_last_error()
     bad = _lib.make_config(VARIANTS['barrage'])
-    bad.rows, bad.cols = 7, 7                                   # a size no reference variant uses: not built
-    bad.usable_rows = 2
-    assert L.sgx_create(C.byref(bad), 16, 0, 1, 0, C.byref(h)) == -1 and not h.value and b'unsupported board size' in L.sgx_last_error()
+    bad.rows, bad.cols = 7, 7                                   # a size no reference variant uses: not in the MAIN library
+    bad.usable_rows = 2                                         # (build_geometry gives it a library of its own)
+    assert L.sgx_supports_geometry(7, 7) == 0 and L.sgx_supports_geometry(10, 10) == 1
+    assert L.sgx_create(C.byref(bad), 16, 0, 1, 0, C.byref(h)) == -1 and not h.value and b'not compiled into this library' in L.sgx_last_error()
     assert L.sgx_create(C.byref(cfg), 16, 0, 1, 0, None) == -1
     assert L.sgx_create(C.byref(cfg), 16, 0, 1, 0, C.byref(h)) == 0 and h.value
     assert L.sgx_step(h, None, None) == -1
