@@ -388,6 +388,18 @@ class PackedStates:
         self._vec.close()
 
 
+class _LateBound:
+    def __init__(self, owner):
+        self._owner = owner
+
+    def __getattr__(self, name):
+        owner = self._owner
+        attr = getattr(owner._current(), name)
+        if not callable(attr):
+            return attr
+        return lambda *a, **k: getattr(owner._current(), name)(*a, **k)
+
+
 def _variant_obstacles(version):
     return get_variant(version).obstacle_map() != 0
 
@@ -443,7 +455,12 @@ class StrategoProceduralEnv:
 
     @property
     def _b(self):
-        """The env of the most recent state (methods that take a state select it through _state())."""
+        """The one-state env the call goes to.  Methods are written `self._b.method(self._state(state), ...)`: Python evaluates
+        `self._b` BEFORE the arguments, and `_state()` is what selects the env (by the state's obstacle layer) -- so this returns
+        a proxy that picks the env when the method is finally called."""
+        return _LateBound(self)
+
+    def _current(self):
         if self._batched is None:
             self._for_obstacles(np.zeros((int(self.rows), int(self.columns)), dtype=bool) if self._version is None
                                 else _variant_obstacles(self._version))
