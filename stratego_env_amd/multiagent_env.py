@@ -7,9 +7,10 @@ behaviour (ValueError on an invalid action, AssertionError when the wrong player
 numpy's / Python's global RNGs at reset, so `np.random.seed(s); random.seed(s)` reproduces the reference's
 setups.  Every game-logic operation runs in the HIP kernels through a VecStrategoEnv of one game.
 
-All three observation modes are built (PARTIALLY_OBSERVABLE, FULLY_OBSERVABLE, BOTH_OBSERVATIONS = the reference default).
-Not built here (out of the hot-path scope): vs_human GUI, vs_bot sockets, HDF5 curriculum starts,
-the 'original' 32/33-layer channel mode.
+All three observation modes (PARTIALLY_OBSERVABLE, FULLY_OBSERVABLE, BOTH_OBSERVATIONS = the reference default), both channel
+modes ('extended' 67 / 79 channels, 'original' 32 / 33) and curriculum start states (`curriculum_start_states_path`: `.npz`, or the
+reference's HDF5 file where h5py is installed) are built.  Not built (out of the hot-path scope): the vs_human GUI and
+the vs_bot socket link.
 """
 import copy
 
