@@ -91,7 +91,9 @@ struct Geo {
     static constexpr bool NT_STORES = false;
 #else
     static constexpr bool NT_STORES = LPG == 64;
-#endif      // observation lines written whole leave as non-temporal stores (sgx_obs.h)
+#endif
+    // a wave may play several games in turn with the next game's reads in flight (13 more VGPRs: one-game-per-wave boards only)
+    static constexpr bool PIPELINED = LPG == 64;      // observation lines written whole leave as non-temporal stores (sgx_obs.h)
     static constexpr int CPL = (RC + LPG - 1) / LPG;  // cells per lane
     static constexpr int CNT_PAD = CPL * LPG;
     // upper estimate of one game's LDS region (struct Lds with the widest code buffer) + the workgroup's shared tables

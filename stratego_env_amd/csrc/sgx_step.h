@@ -90,11 +90,38 @@ __device__ inline void write_record(Lds<G, NB> &L, int8_t *rec_g, int rec_bytes,
     }
 }
 
+// Everything one game's step reads from global memory: the record (one or two int4 per lane) and the action.
+struct GameInput {
+    int4 rq0, rq1, pos_raw;
+    int a_raw;
+};
+template <class G, bool MAPPED>
+__device__ __forceinline__ GameInput load_game(const KParams &P, const int64_t env, const int lane) {
+    constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + G::LPG - 1) / G::LPG;
+    static_assert(G::TAIL_BYTES % 16 == 0 && NLOAD <= 2, "record image must fit two int4 per lane");
+    const int4 zero4 = make_int4(0, 0, 0, 0);
+    GameInput in{zero4, zero4, zero4, 0};
+    if (env >= P.n_envs) return in;
+    const int8_t *rec_src = P.boards + env * (int64_t)P.rec_bytes;
+    if constexpr (MAPPED)        // sgx_expand: the game comes from another handle's records (functional-API instantiation only)
+        if (P.src_boards) rec_src = P.src_boards + (int64_t)(P.src_index ? P.src_index[env] : env) * (int64_t)P.rec_bytes;
+    const int4 *src = reinterpret_cast<const int4 *>(rec_src);
+    const int nq = min(P.rec_bytes >> 4, Q_REC);
+    if (lane < nq) in.rq0 = src[lane];
+    if constexpr (NLOAD > 1)
+        if (lane + G::LPG < nq) in.rq1 = src[lane + G::LPG];
+    if (P.mode == 0) {
+        if (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) in.pos_raw = reinterpret_cast<const int4 *>(P.io.actions_dev)[env];
+        else in.a_raw = P.io.actions_dev[env];
+    }
+    return in;
+}
+
 // One game's env.step() by one wave (called with the wave's private LDS region).
 // `shared` = the workgroup's tables (shared_table_bytes): templates + code table, or LUTs + quad tables
 template <int R_, int C_, int KIND, bool MAPPED>
 __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsKind<KIND>::NIB_CH> &L, const uint8_t *shared, const uint8_t *obst_s,
-                                         const int64_t env, const int lane) {
+                                         const int64_t env, const int lane, const GameInput &in) {
     using G = Geo<R_, C_>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
@@ -104,31 +131,15 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     STAMP(0);
 
     int8_t *rec_g = P.boards + env * (int64_t)P.rec_bytes;
-    const int8_t *rec_src = rec_g;
-    if constexpr (MAPPED)        // sgx_expand: the game comes from another handle's records (functional-API instantiation only)
-        if (P.src_boards) rec_src = P.src_boards + (int64_t)(P.src_index ? P.src_index[env] : env) * (int64_t)P.rec_bytes;
-    // ---- stage.  Every global read of the step is issued up front -- the whole record (a few 128-byte lines) as one or
-    //      two int4 per lane, and the action -- so the wave pays ONE memory round trip.  The scalars, never-moved bitmaps
-    //      and capture events are then read from the LDS image of the record (L.tail has the record's layout from ST_OFF
-    //      on).  They used to be five dependent loads: a quarter of a toy game's lifetime.
+    // ---- stage.  Every global read of the step has been issued up front (load_game) -- the whole record (a few 128-byte lines)
+    //      as one or two int4 per lane, and the action -- so the wave pays ONE memory round trip, which overlaps the staging of
+    //      the workgroup's shared tables.  The scalars, never-moved bitmaps and
+    //      capture events are then read from the LDS image of the record (L.tail has the record's layout from ST_OFF on).
     constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + G::LPG - 1) / G::LPG;
-    static_assert(G::TAIL_BYTES % 16 == 0 && NLOAD <= 2, "record image must fit two int4 per lane");
-    const int4 zero4 = make_int4(0, 0, 0, 0);
-    int4 rq0 = zero4, rq1 = zero4;
-    {
-        const int4 *src = reinterpret_cast<const int4 *>(rec_src);
-        const int nq = min(P.rec_bytes >> 4, Q_REC);
-        if (lane < nq) rq0 = src[lane];
-        if constexpr (NLOAD > 1)
-            if (lane + G::LPG < nq) rq1 = src[lane + G::LPG];
-    }
-    int a_raw = 0;
-    int4 pos_raw = zero4;
-    if (P.mode == 0) {
-        if (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) pos_raw = reinterpret_cast<const int4 *>(P.io.actions_dev)[env];
-        else a_raw = P.io.actions_dev[env];
-    }
-    {   // while the loads are in flight: clear the recent-move boards and the zero board, copy the obstacle map (shared per
+    const int4 rq0 = in.rq0, rq1 = in.rq1;
+    const int a_raw = in.a_raw;
+    const int4 pos_raw = in.pos_raw;
+    {   // (the loads may still be in flight) clear the recent-move boards and the zero board, copy the obstacle map (shared per
         // workgroup).  (The never-moved boards are written cell by cell below; captured counts are never dense.)
         int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
         static_assert((B_RECENT * S) % 16 == 0 || true, "");
@@ -449,7 +460,9 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS + COMBAT_BYTES];    // obstacle map, then the combat outcome table
     const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;     // lane inside the game, game inside the workgroup
     const int64_t env = group_of_block() * (G::WPB * G::GPW) + slot;
-
+    // The game's record and action are requested FIRST: the reads fly while the workgroup stages its shared tables (another
+    // global round trip) and waits at the barrier -- the two round trips used to follow each other.
+    const GameInput in = load_game<G, MAPPED>(P, env, lane);
     // ---- the workgroup's shared tables (L2-resident sources)
     const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
     if constexpr (ORIG) {
@@ -477,7 +490,7 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     for (int i = threadIdx.x; i < COMBAT_BYTES / 4; i += 64 * G::WPB)
         reinterpret_cast<int *>(obst_s + SGX_MAX_CELLS)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
     __syncthreads();   // from here on every wave works on its own game
-    if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], shared, obst_s, env, lane);
+    if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], shared, obst_s, env, lane, in);
 }
 
 // sgx_step and sgx_observe run the same body (P.mode tells them apart at run time: specialising the body on the mode changed the
