@@ -106,15 +106,18 @@ int main(int argc, char **argv) {
     io.auto_reset = 1;
 
     if (argc > 5) {
-        /* the observation buffer's allocation decides 312 vs 400 us per step: try a few, keep the fastest */
-        float best_us = 0.f;
-        SGX_TRY(sgx_time_observe(h, obs, mask, 4, stream, &best_us));
-        for (int c = 0; c < 23; c++) {
-            float *cand, us;
-            if (hipMalloc((void **)&cand, N * obs_n * sizeof(float)) != hipSuccess) break;
-            SGX_TRY(sgx_time_observe(h, cand, mask, 4, stream, &us));
-            if (us < best_us) { best_us = us; io.obs_dev = cand; }         /* (rejected candidates are kept until exit, */
-        }                                                                  /*  so that every candidate is different memory) */
+        /* which physical memory backs the observation buffer decides up to 20 % of a step's time: let the
+         * library pick its output buffers with its bounded placement trial (never more than 8 GiB held beyond what it returns) */
+        sgx_outputs out;
+        SGX_TRY(sgx_alloc_outputs(h, 0, (int64_t)8 << 30, 32, stream, &out));
+        io.obs_dev = out.obs_dev;
+        io.mask_dev = out.mask_dev;
+        printf("placement trial: %d candidates, first %.1f us", out.n_trials, out.n_trials ? out.trial_us[0] : 0.f);
+        float best = out.n_trials ? out.trial_us[0] : 0.f;
+        for (int c = 1; c < out.n_trials; c++) best = out.trial_us[c] < best ? out.trial_us[c] : best;
+        printf(", kept %.1f us, peak extra %.2f GiB\n", best, (double)out.peak_extra_bytes / (1 << 30));
+        SGX_TRY(sgx_observe(h, io.obs_dev, NULL, io.mask_dev, player, 0, stream));
+        SGX_TRY(sgx_sample_valid(h, io.mask_dev, actions, stream));
         hipEvent_t e0, e1;
         HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
         SGX_TRY(sgx_step_n(h, &io, 32, stream));                           /* warm-up */
