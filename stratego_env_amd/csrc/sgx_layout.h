@@ -85,12 +85,14 @@ struct Geo {
     // Lanes per game.  A 64-lane wave is one game on boards of more than 32 cells; toy boards share a wave between 2 or 4
     // games (each VALU instruction costs 4 cycles whether 12 or 64 lanes do useful work: one 3x4 game per wave ran the chip
     // at the VALU issue limit with 80 % of the lanes idle).  Everything below that says `lane` means the lane inside the game.
-    static constexpr int LPG = RC <= 16 ? 16 : (RC <= 32 ? 32 : 64);   // (6x6 with two games per wave measured 5 % slower)
+    // (twice the games per wave -- 8 / 16 / 32 lanes per game, two cells per lane up to 8x8 -- is bit-exact too but 3-5 % slower on
+    // every board size: the cell loops double)
+    static constexpr int LPG = RC <= 16 ? 16 : (RC <= 32 ? 32 : 64);
     static constexpr int GPW = 64 / LPG;              // games per wave
 #ifdef SGX_NO_NT
     static constexpr bool NT_STORES = false;
 #else
-    static constexpr bool NT_STORES = LPG == 64;
+    static constexpr bool NT_STORES = LPG == 64;      // (no change on 5x5 with it, slower on the 16-lane boards)
 #endif
     // a wave may play several games in turn with the next game's reads in flight (13 more VGPRs: one-game-per-wave boards only)
     static constexpr bool PIPELINED = LPG == 64;      // observation lines written whole leave as non-temporal stores (sgx_obs.h)
