@@ -89,11 +89,7 @@ struct Geo {
     // every board size: the cell loops double)
     static constexpr int LPG = RC <= 16 ? 16 : (RC <= 32 ? 32 : 64);
     static constexpr int GPW = 64 / LPG;              // games per wave
-#ifdef SGX_NO_NT
-    static constexpr bool NT_STORES = false;
-#else
     static constexpr bool NT_STORES = LPG == 64;      // (no change on 5x5 with it, slower on the 16-lane boards)
-#endif
     // a wave may play several games in turn with the next game's reads in flight (13 more VGPRs: one-game-per-wave boards only)
     static constexpr bool PIPELINED = LPG == 64;      // observation lines written whole leave as non-temporal stores (sgx_obs.h)
     static constexpr int CPL = (RC + LPG - 1) / LPG;  // cells per lane
@@ -162,13 +158,6 @@ struct KParams {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-// streaming stores of the big outputs (written once per step, read by a later kernel)
-#ifdef SGX_NT_STORES
-template <class T> __device__ inline void stream_store(T *p, T v) { __builtin_nontemporal_store(v, p); }
-#else
-template <class T> __device__ inline void stream_store(T *p, T v) { *p = v; }
-#endif
 
 // per-wave LDS: one game.  NIB_CH = channels of the widest observation rendered from codes by this kernel instantiation
 // (0: 'original' channel mode, no code buffer).

@@ -127,7 +127,6 @@ __device__ void emit_mask(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int la
     const int nchunks = (A + G::NA + 15) >> 4;
     uint8_t *gbase = dst - A;                       // 16-byte aligned
     const int shift = (int)((reinterpret_cast<uintptr_t>(gbase) >> 4) & (G::LPG - 1));   // start the sweep on a 1 KiB boundary
-    const int l0 = (int)((reinterpret_cast<uintptr_t>(gbase) >> 4) & 7), last_line = (nchunks - 1 + l0) >> 3;
     for (int c0 = -shift; c0 < nchunks; c0 += G::LPG) {
         const int c = c0 + lane;
         if (c < 0 || c >= nchunks) continue;
@@ -135,15 +134,7 @@ __device__ void emit_mask(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int la
         if (lo >= 0 && lo + 16 <= G::NA) {
             const uint32_t b16 = mask_bits(L, lo, 16);
             i32x4 q4 = {(int)expand4(b16 & 15), (int)expand4((b16 >> 4) & 15), (int)expand4((b16 >> 8) & 15), (int)expand4(b16 >> 12)};
-#ifdef SGX_NT_MASK
-            // (like the observation: lines this wave writes whole are non-temporal, the two shared edge lines merge in L2)
-            const int line = (c + l0) >> 3;
-            if (G::NT_STORES && line != 0 && line != last_line) __builtin_nontemporal_store(q4, &reinterpret_cast<i32x4 *>(gbase)[c]);
-            else reinterpret_cast<i32x4 *>(gbase)[c] = q4;
-#else
-            (void)last_line;
-            stream_store(&reinterpret_cast<i32x4 *>(gbase)[c], q4);
-#endif
+            reinterpret_cast<i32x4 *>(gbase)[c] = q4;     // (non-temporal stores for the mask's interior lines: no change)
         } else if constexpr (G::NA % 4 == 0) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -178,7 +169,7 @@ __device__ void emit_mask_mapped(const Lds<G, NB> &L, uint8_t *__restrict__ dst,
         }
         if (lo >= 0 && lo + 16 <= n_bytes) {
             i32x4 q4 = {(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-            stream_store(&reinterpret_cast<i32x4 *>(gbase)[c], q4);
+            reinterpret_cast<i32x4 *>(gbase)[c] = q4;
         } else {
 #pragma unroll                                   // (a rolled loop would index w[] dynamically: scratch memory for the whole kernel)
             for (int j = 0; j < 16; ++j)

@@ -207,7 +207,7 @@ __device__ inline void patch_uncoded(const Lds<G, NB> &L, float *__restrict__ ds
             }
         }
         f32x4 qv = {o[0], o[1], o[2], o[3]};
-        stream_store(&reinterpret_cast<f32x4 *>(dst)[q], qv);
+        reinterpret_cast<f32x4 *>(dst)[q] = qv;
     }
 }
 // odd boards: the uncoded entries as single floats; the caller has waited for the bulk stores (s_waitcnt vmcnt(0)): these
@@ -279,7 +279,7 @@ __device__ void emit_obs_lut(const Lds<G, NB> &L, const float *tab, int qi, floa
             o.y = lut[(e.y >> 16) + bb[(e.y & 0xFFFF) + g4]];
             o.z = lut[(e.z >> 16) + bb[(e.z & 0xFFFF) + g4]];
             o.w = lut[(e.w >> 16) + bb[(e.w & 0xFFFF) + g4]];
-            if (in) stream_store(&base[q], o);
+            if (in) base[q] = o;
         }
     } else {
         constexpr int NF = RC * NCH;
@@ -305,7 +305,7 @@ __device__ void emit_obs_lut(const Lds<G, NB> &L, const float *tab, int qi, floa
             }
             if (in[0] && in[3]) {
                 f32x4 q = {o[0], o[1], o[2], o[3]};
-                stream_store(&reinterpret_cast<f32x4 *>(base)[k], q);
+                reinterpret_cast<f32x4 *>(base)[k] = q;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)

@@ -82,11 +82,7 @@ __device__ inline void write_record(Lds<G, NB> &L, int8_t *rec_g, int rec_bytes,
         } else if (i < G::ST_OFF / 16 + n_tail_q) {
             v = tsrc[i - G::ST_OFF / 16];
         }
-#ifdef SGX_NT_RECORD
-        { i32x4 nv = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(nv, reinterpret_cast<i32x4 *>(&dst[i])); }
-#else
-        dst[i] = v;
-#endif
+        dst[i] = v;        // (non-temporal: no change)
     }
 }
 
@@ -142,7 +138,6 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     {   // (the loads may still be in flight) clear the recent-move boards and the zero board, copy the obstacle map (shared per
         // workgroup).  (The never-moved boards are written cell by cell below; captured counts are never dense.)
         int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
-        static_assert((B_RECENT * S) % 16 == 0 || true, "");
         for (int i = lane; i < S / 4; i += G::LPG) {
             reinterpret_cast<int *>(L.b[B_RECENT])[i] = 0;
             reinterpret_cast<int *>(L.b[B_RECENT + 1])[i] = 0;
