@@ -215,6 +215,33 @@ __device__ inline unsigned long long gballot(bool pred) {
     else return (b >> (__lane_id() & ~(G::LPG - 1))) & ((1ull << G::LPG) - 1ull);
 }
 
+// Cross-lane sums on the DPP path of the VALU (one instruction per step, no LDS round trip; __shfl_* compiles to ds_bpermute).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ inline int dpp_or_zero(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xF, true); }
+// inclusive prefix sum over the LPG lanes of this lane's game (a game = one, two or four 16-lane DPP rows)
+template <class G>
+__device__ inline int gscan_incl(int x) {
+    x += dpp_or_zero<0x111>(x);            // row_shr:1
+    x += dpp_or_zero<0x112>(x);            // row_shr:2
+    x += dpp_or_zero<0x114>(x);            // row_shr:4
+    x += dpp_or_zero<0x118>(x);            // row_shr:8
+    if constexpr (G::LPG >= 32) x += dpp_or_zero<0x142, 0xA>(x);    // row_bcast:15 -> rows 1 and 3
+    if constexpr (G::LPG == 64) x += dpp_or_zero<0x143, 0xC>(x);    // row_bcast:31 -> rows 2 and 3
+    return x;
+}
+// the value of the game's lane `l` (the same l for every lane of the game)
+template <class G>
+__device__ inline int glane(int x, int l) {
+    if constexpr (G::LPG == 64) return __builtin_amdgcn_readlane(x, __builtin_amdgcn_readfirstlane(l));
+    else return __shfl(x, l, G::LPG);
+}
+// sum over the four lanes of a quad (lanes 4i .. 4i+3), in every lane of the quad
+__device__ inline int quad_sum(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);    // quad_perm:[1,0,3,2]
+    x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);    // quad_perm:[2,3,0,1]
+    return x;
+}
+
 // XCD-aware block -> env map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
 // range of envs so neighbouring envs' output lines meet in one L2.
 __device__ inline int64_t group_of_block() {

@@ -88,13 +88,10 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over
                     }
                 }
             }
-            n += __shfl_xor(n, 1);
-            n += __shfl_xor(n, 2);                                                // moves of the piece = its 4 rays
+            n = quad_sum(n);                                                      // moves of the piece = its 4 rays
             if (act && d == 0) { L.cnt[pcell] = (uint8_t)n; mine += n; }
         }
-#pragma unroll
-        for (int o = G::LPG / 2; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-        total = uni<G>(mine);
+        total = uni<G>(glane<G>(gscan_incl<G>(mine), G::LPG - 1));
     }
     if (total == 0 && lane == 0) {
         L.mbits[(K - 1) >> 5] = 1u << ((K - 1) & 31);  // valid_moves_mask[0, 0, -1] (impl:514-515); mbits was just zeroed
@@ -222,20 +219,15 @@ __device__ int kth_valid(const Lds<G, NB> &L, int k, int lane) {
 #pragma unroll
     for (int cc = 0; cc < G::CPL; ++cc) {
         const int c0 = L.cnt[lane + G::LPG * cc];
-        int incl = c0;
-#pragma unroll
-        for (int o = 1; o < G::LPG; o <<= 1) {
-            const int v = __shfl_up(incl, o, G::LPG);
-            if (lane >= o) incl += v;
-        }
+        const int incl = gscan_incl<G>(c0);
         const unsigned long long hit = gballot<G>(run + incl > k);
         if (!found && hit) {
             const int l = __ffsll((long long)hit) - 1;
             cell = G::LPG * cc + l;
-            before = run + __shfl(incl - c0, l, G::LPG);
+            before = run + glane<G>(incl - c0, l);
             found = true;
         }
-        run += __shfl(incl, G::LPG - 1, G::LPG);
+        run += glane<G>(incl, G::LPG - 1);
     }
     cell = uni<G>(cell);
     int kk = uni<G>(k - before);
