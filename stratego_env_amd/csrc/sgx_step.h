@@ -210,20 +210,27 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
             else if (ch < 2 * (R - 1)) { er = sr - (ch - (R - 1) + 1); ec = sc_; }
             else if (ch < 2 * (R - 1) + (C - 1)) { er = sr; ec = sc_ + (ch - 2 * (R - 1) + 1); }
             else { er = sr; ec = sc_ - (ch - (2 * (R - 1) + (C - 1)) + 1); }                   // also the no-op channel
-            int idx = (sr * C + sc_) * MPA + ((er != sr) ? er : R + ec);                     // impl:268-277
-            if (player == -1 && idx != AS - 1) {                                             // impl:698-720
-                const int q = fdiv_(idx, MPA), off = fmod_(idx, MPA);
-                int r0 = fdiv_(q, C), c0 = fmod_(q, C), r1, c1;
-                if (off >= R) { c1 = off - R; r1 = r0; } else { r1 = off; c1 = c0; }
-                r0 = R - 1 - r0; r1 = R - 1 - r1; c0 = C - 1 - c0; c1 = C - 1 - c1;
-                idx = (r0 * C + c0) * MPA + ((r1 != r0) ? r1 : R + c1);
-            }
-            if (idx == AS - 1) {
-                noop_path = true;                                                            // impl:809-814
-            } else {                                                                         // impl:369-383
-                const int q = fdiv_(idx, MPA), off = fmod_(idx, MPA);
-                sr = fdiv_(q, C); sc_ = fmod_(q, C);
-                if (off >= R) { ec = off - R; er = sr; } else { er = off; ec = sc_; }
+            if (ch < K - 1 && er >= 0 && er < R && ec >= 0 && ec < C) {
+                // A straight move that stays on the board: its 1-D index (impl:268-277) decodes back to the same four
+                // coordinates (impl:369-383) and the perspective flip through the 1-D index (impl:698-720) is the flip of the
+                // coordinates -- the reference's chain below, which exists for the garbage cases, is the identity here.
+                if (player == -1) { sr = R - 1 - sr; sc_ = C - 1 - sc_; er = R - 1 - er; ec = C - 1 - ec; }
+            } else {
+                int idx = (sr * C + sc_) * MPA + ((er != sr) ? er : R + ec);                 // impl:268-277
+                if (player == -1 && idx != AS - 1) {                                         // impl:698-720
+                    const int q = fdiv_(idx, MPA), off = fmod_(idx, MPA);
+                    int r0 = fdiv_(q, C), c0 = fmod_(q, C), r1, c1;
+                    if (off >= R) { c1 = off - R; r1 = r0; } else { r1 = off; c1 = c0; }
+                    r0 = R - 1 - r0; r1 = R - 1 - r1; c0 = C - 1 - c0; c1 = C - 1 - c1;
+                    idx = (r0 * C + c0) * MPA + ((r1 != r0) ? r1 : R + c1);
+                }
+                if (idx == AS - 1) {
+                    noop_path = true;                                                        // impl:809-814
+                } else {                                                                     // impl:369-383
+                    const int q = fdiv_(idx, MPA), off = fmod_(idx, MPA);
+                    sr = fdiv_(q, C); sc_ = fmod_(q, C);
+                    if (off >= R) { ec = off - R; er = sr; } else { er = off; ec = sc_; }
+                }
             }
         }
         const int pi = player == 1 ? 0 : 1;
