@@ -46,3 +46,14 @@ def test_c_rollout_matches_oracle():
                            setups=S.load_setup_table('barrage'))
     _, d, _ = orc.rollout(cv, seed, 0, 1, steps, threads=1)
     assert int(d[0]) == int(m.group(3), 16)
+
+
+@pytest.mark.gpu
+def test_c_rollout_bench_mode_uses_library_owned_outputs():
+    """`c_rollout <table> <envs> <steps> <seed> bench`: output buffers from sgx_alloc_outputs (bounded placement trial), K steps
+    through sgx_step_n -- plain C, no torch in the process."""
+    exe = compile_example()
+    out = subprocess.check_output([exe, TABLE, '8192', '64', '0x1', 'bench'], text=True)
+    m = re.search(r'placement trial: (\d+) candidates, first ([0-9.]+) us, kept ([0-9.]+) us, peak extra ([0-9.]+) GiB', out)
+    assert m and int(m.group(1)) >= 2 and float(m.group(3)) <= float(m.group(2)) and float(m.group(4)) <= 8.0, out
+    assert re.search(r'envs 8192 steps 64: [0-9.]+ us per batched step, [0-9.]+ M env steps/s', out), out
