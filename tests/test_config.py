@@ -38,3 +38,28 @@ def test_captured_count_highs_quirk():
     assert VARIANTS['barrage'].captured_count_highs() == (8, 2, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8)
     assert VARIANTS['standard'].captured_count_highs() == (8, 8, 5, 4, 4, 4, 3, 2, 8, 8, 8, 6)
     assert np.sum(VARIANTS['standard'].obstacle_map()) == 8
+
+
+def test_custom_variants_and_geometry_libraries():
+    """Boards the reference has no variant for: custom_variant() fills the usable rows, get_variant() takes the object, and the
+    loader maps a size to the main library or to a library of its own (built on first use on a box with hipcc)."""
+    import os
+    import pytest
+    from stratego_env_amd import build as hip_build
+    from stratego_env_amd import _lib
+    from stratego_env_amd.config import custom_variant, get_variant, VARIANTS
+    v = custom_variant(7, 9)
+    assert (v.rows, v.columns, v.initial_state_usable_rows) == (7, 9, 3) and sum(v.piece_counts) == 3 * 9 and v.piece_counts[10] == 1
+    assert v.spatial_channels == 2 * 6 + 2 * 8 + 1 and v.action_size == 63 * 16 + 1 and get_variant(v) is v
+    w = custom_variant(3, 3, max_turns=10, obstacle_locations=[(1, 1)], piece_counts=(0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0))
+    assert w.obstacle_map()[1, 1] == 1 and w.pieces_per_side == 2 and w.max_turns == 10
+    for bad in ((2, 5), (5, 2)):
+        with pytest.raises(ValueError):
+            custom_variant(*bad)
+    with pytest.raises(ValueError):
+        hip_build.build_geometry(17, 17)                      # more than 256 cells
+    assert {(x.rows, x.columns) for x in VARIANTS.values()} == set(hip_build.BUILTIN_GEOMETRIES)
+    assert os.path.basename(hip_build.geometry_lib_path(7, 9)) == 'libstratego_mi355x_7x9.so'
+    main = _lib.load()
+    assert main.sgx_supports_geometry(10, 10) == 1 and main.sgx_supports_geometry(7, 9) == 0
+    assert _lib.load_for_geometry(10, 10) is main and _lib.load_for_geometry(3, 4) is main
