@@ -89,7 +89,6 @@ struct Geo {
     // every board size: the cell loops double)
     static constexpr int LPG = RC <= 16 ? 16 : (RC <= 32 ? 32 : 64);
     static constexpr int GPW = 64 / LPG;              // games per wave
-    static constexpr bool NT_STORES = LPG == 64;      // (no change on 5x5 with it, slower on the 16-lane boards)
     // a wave may play several games in turn with the next game's reads in flight (13 more VGPRs: one-game-per-wave boards only)
     static constexpr bool PIPELINED = LPG == 64;      // observation lines written whole leave as non-temporal stores (sgx_obs.h)
     static constexpr int CPL = (RC + LPG - 1) / LPG;  // cells per lane
@@ -134,6 +133,7 @@ struct KParams {
     int64_t env_id_offset;
     sgx_step_io io;
     int32_t mode;  // 0 = step, 1 = observe
+    int32_t nt_stores;  // the launch's observations do not fit the Infinity Cache: whole lines leave as non-temporal stores (sgx_obs.h)
     // functional-API instantiation only (sgx_expand): game i is read from record src_index[i] (i when NULL) of ANOTHER handle's
     // records and written to record i of this one, whether or not the move was valid
     const int8_t *src_boards;

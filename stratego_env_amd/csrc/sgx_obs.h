@@ -117,7 +117,8 @@ __device__ inline int build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uint
 // store instruction; chunking by cell group left two partial lines per store and ran 1.5x slower in the store-pattern probe).
 // CHECKED (games with uncoded entries, 4-aligned boards): a quad that holds a CODE_ESC entry is not stored here -- patch_uncoded
 // writes it whole, so no address is written twice and nothing has to be waited for.
-template <class G, class Spec, bool CHECKED, int NB>
+// NT: lines this wave writes whole leave as non-temporal stores -- chosen per launch, see KParams::nt_stores.
+template <class G, class Spec, bool CHECKED, bool NT, int NB>
 __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, int lane) {
     constexpr int RC = G::RC, NCH = Spec::NCH;
     const uint16_t *n16 = reinterpret_cast<const uint16_t *>(L.nib);
@@ -125,11 +126,12 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
         constexpr int NQ = (RC / 4) * NCH;                                           // quads (16 B) of one observation
         const int m0 = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & (G::LPG - 1));  // quads past a chunk boundary
         f32x4 *base = reinterpret_cast<f32x4 *>(dst);
-        // Lines written whole by this wave leave as non-temporal stores (they are never read back by this kernel and need no
+        // NT: lines written whole by this wave leave as non-temporal stores (they are never read back by this kernel and need no
         // merging: 325.8 -> 281.1 us per launch of 65,536 Barrage games, 137 -> 117 us on 6x6, 244 -> 198 us on 8x8, in-process A/B).
         // The first and the last 128-byte line of a game's observation are shared with the neighbouring games (other waves): those
-        // go through L2 so that the halves merge (everything non-temporal: 316 us; toy boards, whose games are a few lines long, are
-        // faster without: Geo::NT_STORES).
+        // go through L2 so that the halves merge (everything non-temporal: 316 us).  It pays when the launch's observations do
+        // not fit the 256 MiB Infinity Cache and costs 5-20 % when they do (8,192 Barrage games 41 vs 50 us, 65,536 Micro games
+        // 42 vs 47 us; 16,384 Barrage games 102 vs 87 us, 131,072 Micro games 100 vs 82 us): the host decides per launch.
         const int l0 = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7);               // quads past a 128-byte line
         const int first_line = l0 ? 0 : -1, last_line = ((l0 + NQ) & 7) ? (NQ - 1 + l0) >> 3 : -1;   // lines counted from dst - 16 * l0
 #pragma unroll SGX_OBS_UNROLL
@@ -143,7 +145,7 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
                 const unsigned y = x ^ (0x1111u * CODE_ESC);                           // a CODE_ESC nibble becomes 0
                 esc = ((y - 0x1111u) & ~y & 0x8888u) != 0;                            // some nibble of y is 0
             }
-            if constexpr (G::NT_STORES) {
+            if constexpr (NT) {
                 const bool edge = ((q + l0) >> 3) == first_line || ((q + l0) >> 3) == last_line;
                 if (in && !esc && edge) base[q] = o;
                 if (in && !esc && !edge) __builtin_nontemporal_store(o, &base[q]);
@@ -177,7 +179,7 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
             if (slot_in && f0 >= 0 && f0 + 3 < NF) {
                 f32x4 qv = {o[0], o[1], o[2], o[3]};
                 const int line = (k + l0) >> 3;
-                if (G::NT_STORES && line != 0 && line != last_line) __builtin_nontemporal_store(qv, &reinterpret_cast<f32x4 *>(base)[k]);
+                if (NT && line != 0 && line != last_line) __builtin_nontemporal_store(qv, &reinterpret_cast<f32x4 *>(base)[k]);
                 else reinterpret_cast<f32x4 *>(base)[k] = qv;
             } else if (slot_in) {
 #pragma unroll

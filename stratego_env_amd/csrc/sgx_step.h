@@ -369,11 +369,18 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
             const int n_unc = build_codes<G, Spec>(L, full ? shared + tmpl_bytes<G, KIND>(false) : shared, codetab, full ? glut_f : glut_p, q,
                                                    n_events, rp0, rp1, lane);
             if constexpr (RC % 4 == 0) {
-                if (n_unc == 0) emit_codes<G, Spec, false>(L, dst, lane);
-                else { emit_codes<G, Spec, true>(L, dst, lane); patch_uncoded<G, Spec>(L, dst, n_unc, lane); }
+                if (n_unc == 0) {
+                    if (P.nt_stores) emit_codes<G, Spec, false, true>(L, dst, lane);
+                    else emit_codes<G, Spec, false, false>(L, dst, lane);
+                } else {
+                    if (P.nt_stores) emit_codes<G, Spec, true, true>(L, dst, lane);
+                    else emit_codes<G, Spec, true, false>(L, dst, lane);
+                    patch_uncoded<G, Spec>(L, dst, n_unc, lane);
+                }
                 return 0;
             } else {
-                emit_codes<G, Spec, false>(L, dst, lane);
+                if (P.nt_stores) emit_codes<G, Spec, false, true>(L, dst, lane);
+                else emit_codes<G, Spec, false, false>(L, dst, lane);
                 if (n_unc) {                                     // (rare board sizes: settle it here, L.unc_* is per rendering)
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     patch_uncoded_floats(L, dst, n_unc, lane);
