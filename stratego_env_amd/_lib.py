@@ -123,6 +123,11 @@ def load(path=None):
     if not os.path.exists(path):
         raise SgxError("libstratego_mi355x.so is not built (%s missing). Run `python -m stratego_env_amd.build` "
                        "or __graft_entry__.build(); there is no CPU fallback." % path)
+    if path == LIB_PATH:
+        from . import build as _build
+        if _build.needs_build():        # (a stale library of the same ABI version still loads; say so)
+            import warnings
+            warnings.warn("%s is older than its sources: rebuild with `python -m stratego_env_amd.build`" % path, RuntimeWarning)
     L = C.CDLL(path)
     missing = [sym for sym in EXPORTED_SYMBOLS if not hasattr(L, sym)]
     if missing:
