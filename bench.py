@@ -126,6 +126,9 @@ def parse_args(argv=None):
                     help='most extra device memory the placement trial may hold at any time')
     ap.add_argument('--wake-seconds', type=float, default=2.0,
                     help='untimed GPU wake-up before the warmup steps (a fresh box runs its first ~second at idle clocks)')
+    ap.add_argument('--chains', type=int, default=1,
+                    help='sgx_rollout: split the batch into this many ranges of games whose launches overlap on streams of their own '
+                         '(1 = sgx_step_n, one launch per step: what the headline uses, so that the per-launch figures are per step)')
     ap.add_argument('--dry-run', action='store_true',
                     help="launcher self-test on CPU: gloo, stub env, no measurement (value is null)")
     return ap.parse_args(argv)
@@ -291,7 +294,7 @@ def make_env(version, n, first, local_rank):
     return env
 
 
-def time_workload(rk, env, steps, warmup, unfused=False):
+def time_workload(rk, env, steps, warmup, unfused=False, chains=1):
     """(elapsed s, device ms, games finished, invalid actions) of `steps` batched steps on `env`, all MAX / SUM over ranks."""
     import torch
 
@@ -312,7 +315,7 @@ def time_workload(rk, env, steps, warmup, unfused=False):
             for _ in range(steps):
                 one_step()
         else:
-            env.rollout_steps(steps)    # the same K batched steps, enqueued by one C-ABI call (sgx_step_n)
+            env.rollout_steps(steps, chains=chains)    # the same K batched steps, enqueued by one C-ABI call (sgx_step_n / sgx_rollout)
 
     def counters():
         return [int(env.env_info()[:, 1].to(torch.int64).sum()), 0]
@@ -322,7 +325,7 @@ def time_workload(rk, env, steps, warmup, unfused=False):
     return elapsed, dev_ms, games, invalid
 
 
-def other_workload(rk, version, n, seconds=1.0, extra_bytes=0):
+def other_workload(rk, version, n, seconds=1.0, extra_bytes=0, chains=1):
     """One of the other BASELINE configs on this GPU, about `seconds` of timed steps; output buffers from the same bounded
     placement trial as the headline (extra_bytes = 0: plain first allocation)."""
     import torch
@@ -334,6 +337,12 @@ def other_workload(rk, version, n, seconds=1.0, extra_bytes=0):
         _, probe_ms, _, _ = time_workload(rk, env, 8, 8)
         steps = int(max(16, min(4096, seconds * 1e3 / max(probe_ms / 8, 1e-3))))
         elapsed, dev_ms, games, invalid = time_workload(rk, env, steps, 4)
+        two = None
+        if chains > 1:                     # the same steps with the batch split over concurrent chains of launches (sgx_rollout)
+            e2, d2, _, inv2 = time_workload(rk, env, steps, 4, chains=chains)
+            assert inv2 == 0
+            two = {"chains": chains, "value": n * steps / e2, "us_per_step": d2 / steps * 1e3,
+                   "frac": b_alg(v.rows, v.columns) * n / (d2 / 1e3 / steps) / 1e9 / HBM_PEAK_GBS}
         assert invalid == 0
         launch_s = dev_ms / 1e3 / steps
         bpl = b_alg(v.rows, v.columns) * n
@@ -341,7 +350,7 @@ def other_workload(rk, version, n, seconds=1.0, extra_bytes=0):
                 "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
                 "frac": bpl / launch_s / 1e9 / HBM_PEAK_GBS, "b_alg_bytes_per_step": b_alg(v.rows, v.columns),
                 "kernel": "step_kernel<%d,%d>" % (v.rows, v.columns), "games_finished_in_timed_region": games,
-                "traffic": measured_traffic(version, n),
+                "traffic": measured_traffic(version, n), "concurrent_chains": two,
                 "placement_trial_us": ({"candidates": len(trial['obs']), "first": round(trial['obs'][0], 1), "min": round(min(trial['obs']), 1)}
                                        if trial and trial['obs'] else None)}
     finally:
@@ -370,7 +379,8 @@ def run_rank(args):
             print(json.dumps({"metric": "env steps/sec", "value": None, "unit": "env steps/s", "n_gpus": rk.world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                               "dry_run": True, "data": "none (launcher self-test)",
-                              "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external'),
+                              "concurrent_chains": args.chains,
+                       "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external'),
                               "scaling": "strong" if args.total_envs else "weak",
                               "config": {"total_games": total, "games_covered_by_ranks": covered,
                                          "stub_steps_x_games": steps_x_games}}), flush=True)
@@ -392,7 +402,7 @@ def run_rank(args):
     placement_us = None
     if args.placement_trials is None or args.placement_trials > 1:
         placement_us = env.tune_placement(args.placement_trials, max_extra_bytes=int(args.placement_gb * (1 << 30)))
-    elapsed, dev_ms, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused)
+    elapsed, dev_ms, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains)
     assert invalid == 0, "rollout produced invalid actions"
 
     out = None
@@ -413,6 +423,7 @@ def run_rank(args):
                                                        "separate" if args.unfused else "fused"),
                        "games_per_gpu": n, "total_games": total, "version": args.version, "seed": BASE_SEED,
                        "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns),
+                       "concurrent_chains": args.chains,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),
                        # per-candidate sgx_observe times of the start-up placement trial: the fastest is kept;
                        # "first" is the allocation the env would have used without the trial
@@ -438,7 +449,7 @@ def run_rank(args):
         if rk.world == 1 and not args.no_other_workloads and args.version == 'barrage':
             extra = int(args.placement_gb * (1 << 30)) if placement_us else 0
             out["config"]["other_workloads"] = [other_workload(rk, 'standard', 262144, extra_bytes=extra),
-                                                other_workload(rk, 'micro', 65536, extra_bytes=extra)]
+                                                other_workload(rk, 'micro', 65536, extra_bytes=extra, chains=2)]
         if not args.no_cpu_baseline and rk.world == 1:         # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
         else:

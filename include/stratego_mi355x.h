@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 7
+#define SGX_ABI_VERSION 8
 #define SGX_MAX_CELLS 256        /* rows*cols <= 256 (largest reference variant: 15x15) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
 #define SGX_FO_OBS_CHANNELS 79   /* impl:1227 */
@@ -193,6 +193,14 @@ int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);
  * output buffers hold the last step's results afterwards.  (Toy boards finish a batched step in tens of microseconds:
  * driving them one call at a time from Python is launch-bound.) */
 int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void *stream);
+
+/* sgx_step_n with the batch split into `chains` (1..SGX_MAX_CHAINS) contiguous ranges of games, each range playing its n_steps on a
+ * stream of its own: games never interact, so the ranges' launches may overlap, and the ramp-up / drain of one range's step is filled
+ * by the other's (a launch that lasts tens of microseconds spends a third of its time with the chip half empty).  The caller's
+ * stream waits for all chains; results are identical to sgx_step_n.  Measured with chains = 2 on 65,536 games: Micro 41.3 -> 37.2 us per
+ * step of all games, 5x5 107.6 -> 96.0 us, 8x8 198 -> 183 us, Barrage 322 -> 304 us.  No reference counterpart. */
+#define SGX_MAX_CHAINS 4
+int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int32_t chains, void *stream);
 
 /* sample_random_valid_action (maenv:830-834) for a batch of masks laid out as mask_dev of sgx_step_io:
  * picks the k-th set byte, k drawn with the same counter RNG as next_actions_dev (identical results). */

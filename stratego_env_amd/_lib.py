@@ -14,7 +14,7 @@ PO_OBS_CHANNELS = 67
 FO_OBS_CHANNELS = 79
 PO_OBS_CHANNELS_ORIGINAL = 32
 FO_OBS_CHANNELS_ORIGINAL = 33
-ABI_VERSION = 7
+ABI_VERSION = 8
 STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, STEP_ORIGINAL_CHANNELS = 1, 2, 4, 8, 16
 STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
 OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
@@ -23,7 +23,7 @@ OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_supports_geometry', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
     'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
-    'sgx_observe', 'sgx_time_observe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_step_n', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
+    'sgx_observe', 'sgx_time_observe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_step_n', 'sgx_rollout', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
 )
 
 
@@ -96,6 +96,8 @@ def _bind(L):
     L.sgx_step.argtypes = [vp, C.POINTER(SgxStepIO), vp]
     L.sgx_step_n.restype = C.c_int
     L.sgx_step_n.argtypes = [vp, C.POINTER(SgxStepIO), C.c_int32, vp]
+    L.sgx_rollout.restype = C.c_int
+    L.sgx_rollout.argtypes = [vp, C.POINTER(SgxStepIO), C.c_int32, C.c_int32, vp]
     L.sgx_sample_valid.restype = C.c_int
     L.sgx_sample_valid.argtypes = [vp, vp, vp, vp]
     L.sgx_export_state.restype = C.c_int

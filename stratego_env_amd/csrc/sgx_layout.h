@@ -133,6 +133,7 @@ struct KParams {
     int64_t env_id_offset;
     sgx_step_io io;
     int32_t mode;  // 0 = step, 1 = observe
+    int64_t env_first;  // this launch plays envs [env_first, n_envs) of the handle (sgx_rollout splits a batch over concurrent chains)
     int32_t nt_stores;  // the launch's observations do not fit the Infinity Cache: whole lines leave as non-temporal stores (sgx_obs.h)
     // functional-API instantiation only (sgx_expand): game i is read from record src_index[i] (i when NULL) of ANOTHER handle's
     // records and written to record i of this one, whether or not the move was valid

@@ -67,6 +67,8 @@ struct sgx_env {
     int max_events;
     int K;
     unsigned long long *stamps;  // SGX_STAMPS builds only
+    hipStream_t chain_stream[SGX_MAX_CHAINS];   // sgx_rollout: created on first use
+    hipEvent_t chain_fork, chain_join[SGX_MAX_CHAINS];
 };
 
 namespace {
@@ -368,6 +370,11 @@ SGX_API int sgx_destroy(sgx_env *h) {
     if (h->tab) (void)hipFree(h->tab);
     if (h->setups) (void)hipFree(h->setups);
     if (h->stamps) (void)hipFree(h->stamps);
+    for (int c = 0; c < SGX_MAX_CHAINS; ++c) {
+        if (h->chain_stream[c]) (void)hipStreamDestroy(h->chain_stream[c]);
+        if (h->chain_join[c]) (void)hipEventDestroy(h->chain_join[c]);
+    }
+    if (h->chain_fork) (void)hipEventDestroy(h->chain_fork);
     delete h;
     return SGX_OK;
 }
@@ -419,7 +426,7 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream) {
 #define CALL_STEP_KIND(R, C, KIND)                                                                 \
     do {                                                                                           \
         using G_ = Geo<R, C>;                                                                      \
-        const unsigned grid = grid_for((h->n_envs + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW)); \
+        const unsigned grid = grid_for((p.n_envs - p.env_first + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW)); \
         if (p.mode) observe_kernel<R, C, KIND><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p); \
         else step_kernel<R, C, KIND><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);           \
     } while (0)
@@ -432,7 +439,7 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream) {
 #define CALL_STEP_MAPPED(R, C)                                                                     \
     do {                                                                                           \
         using G_ = Geo<R, C>;                                                                      \
-        const unsigned grid = grid_for((h->n_envs + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW)); \
+        const unsigned grid = grid_for((p.n_envs - p.env_first + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW)); \
         if (p.mode) observe_kernel<R, C, 0, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);  \
         else step_kernel<R, C, 0, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);        \
     } while (0)
@@ -619,6 +626,41 @@ SGX_API int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void 
     p.io = *io;
     for (int32_t i = 0; i < n_steps; ++i)
         if (int rc = launch_step(h, p, stream)) return rc;
+    return SGX_OK;
+}
+
+SGX_API int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int32_t chains, void *stream) {
+    if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
+    if (!io->actions_dev || io->next_actions_dev != io->actions_dev)
+        return fail(SGX_EINVAL, "sgx_rollout needs next_actions_dev == actions_dev (each step plays the action the previous one drew)%s");
+    if (n_steps < 0 || chains < 1 || chains > SGX_MAX_CHAINS) return fail(SGX_EINVAL, "n_steps or chains out of range%s");
+    // games per chain: a multiple of what eight workgroups play, so that every chain keeps the XCD-aware map
+    const int cells = h->cfg.rows * h->cfg.cols;
+    const int64_t unit = 8 * 8 * (cells <= 16 ? 4 : (cells <= 32 ? 2 : 1));     // 8 workgroups x SGX_WPB waves x Geo::GPW games
+    int64_t per = (h->n_envs / chains) / unit * unit;
+    if (chains == 1 || per == 0 || n_steps == 0) return sgx_step_n(h, io, n_steps, stream);
+    HIP_TRY(hipSetDevice(h->device));
+    if (!h->chain_fork) HIP_TRY(hipEventCreateWithFlags(&h->chain_fork, hipEventDisableTiming));
+    for (int c = 0; c < chains; ++c) {
+        if (!h->chain_stream[c]) HIP_TRY(hipStreamCreateWithFlags(&h->chain_stream[c], hipStreamNonBlocking));
+        if (!h->chain_join[c]) HIP_TRY(hipEventCreateWithFlags(&h->chain_join[c], hipEventDisableTiming));
+    }
+    KParams p = make_params(h);
+    p.mode = 0;
+    p.io = *io;
+    HIP_TRY(hipEventRecord(h->chain_fork, (hipStream_t)stream));
+    for (int c = 0; c < chains; ++c) HIP_TRY(hipStreamWaitEvent(h->chain_stream[c], h->chain_fork, 0));
+    for (int32_t i = 0; i < n_steps; ++i)                    // (interleaved enqueue: the chains' k-th steps are submitted together)
+        for (int c = 0; c < chains; ++c) {
+            KParams pc = p;
+            pc.env_first = c * per;
+            pc.n_envs = c == chains - 1 ? h->n_envs : (c + 1) * per;
+            if (int rc = launch_step(h, pc, (void *)h->chain_stream[c])) return rc;
+        }
+    for (int c = 0; c < chains; ++c) {
+        HIP_TRY(hipEventRecord(h->chain_join[c], h->chain_stream[c]));
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->chain_join[c], 0));
+    }
     return SGX_OK;
 }
 

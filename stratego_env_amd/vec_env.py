@@ -219,14 +219,18 @@ class VecStrategoEnv:
             self.sample_valid_actions()
         return self.step(self.next_actions, want_next_actions=True)
 
-    def rollout_steps(self, n_steps):
+    def rollout_steps(self, n_steps, chains=1):
         """`n_steps` rollout steps enqueued by one library call (sgx_step_n): same results as calling rollout_step()
-        n_steps times, without a Python round trip per step (toy boards are launch-bound otherwise)."""
+        n_steps times, without a Python round trip per step (toy boards are launch-bound otherwise).  chains > 1 (sgx_rollout):
+        the batch is split into that many contiguous ranges of games whose launches overlap on streams of their own."""
         if not self._next_actions_fresh:
             self.sample_valid_actions()
         io = self._fill_io(self.next_actions, True, True, True, 0)
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_step_n(self._h, C.byref(io), int(n_steps), self._stream()), self._L)
+            if chains > 1:
+                _lib.check(self._L.sgx_rollout(self._h, C.byref(io), int(n_steps), int(chains), self._stream()), self._L)
+            else:
+                _lib.check(self._L.sgx_step_n(self._h, C.byref(io), int(n_steps), self._stream()), self._L)
         return self.obs, self.mask, self.reward, self.done, self.player
 
     def sample_valid_actions(self, mask=None, out=None):

@@ -677,3 +677,29 @@ def test_cabi_error_returns_on_device():
     assert L.sgx_num_envs(h) == 16 and L.sgx_spatial_channels(h) == 37 and L.sgx_num_spatial_actions(h) == 3700
     assert L.sgx_action_size_1d(h) == 2001
     assert L.sgx_destroy(h) == 0 and L.sgx_destroy(None) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,n', [('micro', 4096), ('barrage', 1024), ('fives', 1500)])
+def test_rollout_chains_equal_a_single_chain(name, n):
+    """sgx_rollout: the batch split into 2 / 3 / 4 ranges of games playing on streams of their own leaves exactly the state and the
+    outputs of sgx_step_n (ragged batch sizes included: the last range takes the remainder)."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    ref = VecStrategoEnv(name, n, seed=77, auto_reset=True)
+    ref.reset()
+    ref.rollout_steps(41)
+    want_state, want_player = ref.export_state()
+    for chains in (2, 3, 4):
+        env = VecStrategoEnv(name, n, seed=77, auto_reset=True)
+        env.reset()
+        env.rollout_steps(20, chains=chains)
+        env.rollout_steps(21, chains=chains)
+        torch.cuda.synchronize()
+        st, pl = env.export_state()
+        assert torch.equal(st, want_state) and torch.equal(pl, want_player), (name, chains)
+        for a, b in ((env.obs, ref.obs), (env.mask, ref.mask), (env.reward, ref.reward), (env.done, ref.done), (env.next_actions, ref.next_actions)):
+            assert torch.equal(a, b), (name, chains)
+        assert int(env.invalid_action.sum()) == 0
+        env.close()
+    ref.close()
