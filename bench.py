@@ -307,6 +307,9 @@ def time_workload(rk, env, steps, warmup, unfused=False, chains=1):
 
     def run_warmup():
         env.sample_valid_actions()
+        if chains > 1 and not unfused:       # (the chains' streams are created on first use: not inside the timed region)
+            env.rollout_steps(warmup, chains=chains)
+            return
         for _ in range(warmup):
             one_step()
 
@@ -379,8 +382,7 @@ def run_rank(args):
             print(json.dumps({"metric": "env steps/sec", "value": None, "unit": "env steps/s", "n_gpus": rk.world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                               "dry_run": True, "data": "none (launcher self-test)",
-                              "concurrent_chains": args.chains,
-                       "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external'),
+                              "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external'),
                               "scaling": "strong" if args.total_envs else "weak",
                               "config": {"total_games": total, "games_covered_by_ranks": covered,
                                          "stub_steps_x_games": steps_x_games}}), flush=True)
@@ -404,6 +406,14 @@ def run_rank(args):
         placement_us = env.tune_placement(args.placement_trials, max_extra_bytes=int(args.placement_gb * (1 << 30)))
     elapsed, dev_ms, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains)
     assert invalid == 0, "rollout produced invalid actions"
+    two_chains = None
+    if rk.world == 1 and args.chains == 1 and not args.unfused:
+        # The same K steps with the batch split into two ranges of games whose launches overlap (sgx_rollout, chains = 2): reported
+        # next to the headline, which stays one launch per step so that its per-launch figures can be checked against a kernel trace.
+        e2, d2, _, inv2 = time_workload(rk, env, args.steps, args.warmup, False, 2)
+        assert inv2 == 0
+        two_chains = {"chains": 2, "value": total * args.steps / e2, "us_per_step": d2 / args.steps * 1e3,
+                      "frac": b_alg(v.rows, v.columns) * n / (d2 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
 
     out = None
     if rk.rank == 0:
@@ -423,7 +433,7 @@ def run_rank(args):
                                                        "separate" if args.unfused else "fused"),
                        "games_per_gpu": n, "total_games": total, "version": args.version, "seed": BASE_SEED,
                        "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns),
-                       "concurrent_chains": args.chains,
+                       "concurrent_chains": args.chains, "two_chains": two_chains,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),
                        # per-candidate sgx_observe times of the start-up placement trial: the fastest is kept;
                        # "first" is the allocation the env would have used without the trial
@@ -448,7 +458,7 @@ def run_rank(args):
         out["config"]["other_workloads"] = None
         if rk.world == 1 and not args.no_other_workloads and args.version == 'barrage':
             extra = int(args.placement_gb * (1 << 30)) if placement_us else 0
-            out["config"]["other_workloads"] = [other_workload(rk, 'standard', 262144, extra_bytes=extra),
+            out["config"]["other_workloads"] = [other_workload(rk, 'standard', 262144, extra_bytes=extra, chains=2),
                                                 other_workload(rk, 'micro', 65536, extra_bytes=extra, chains=2)]
         if not args.no_cpu_baseline and rk.world == 1:         # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
