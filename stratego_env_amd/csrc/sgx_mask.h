@@ -116,10 +116,6 @@ __device__ inline uint32_t mask_bits(const Lds<G, NB> &L, int p, int n) {
 // the base is not 4-byte aligned).
 template <class G, int NB>
 __device__ void emit_mask(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int lane) {
-    if constexpr (G::NA % 4 != 0 && G::NA < 2048) {      // small byte-aligned masks (5x5: 425 bytes): plain byte stores measured faster
-        for (int i = lane; i < G::NA; i += G::LPG) dst[i] = (uint8_t)((L.mbits[i >> 5] >> (i & 31)) & 1u);
-        return;
-    }
     const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
     const int nchunks = (A + G::NA + 15) >> 4;
     uint8_t *gbase = dst - A;                       // 16-byte aligned
