@@ -3,28 +3,36 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): 65,536 concurrent Barrage games PER GPU, synthetic
-random-valid-action rollout with auto-reset, setups from the Gravon table, everything keyed by the counter RNG on
-(seed, global env id, game, turn).  One "step" = one batched env.step() over all of the rank's games: action in,
-move/combat/capture applied, win/draw detection, next mover's valid-actions mask (uint8 [R,C,K]) and normalised
-partial observation (float32 [R,C,67]) written to HBM, plus the next random valid action.  Inputs are resident in
-HBM when the timed region starts.
+Workload.  N = 1 (BASELINE.json configs[1]): 65,536 concurrent Barrage games, synthetic random-valid-action
+rollout with auto-reset, setups from the Gravon table, everything keyed by the counter RNG on (seed, global env id, game, turn).
+N > 1 (configs[4]): 262,144 games PER GPU (2,097,152 on 8 GPUs; "scaling": "weak"), plus, in the same line,
+the strong-scaling leg (2,097,152 games in total split over the ranks: config.strong_scaling) and the N = 1 workload's
+65,536 games per GPU (config.weak_65536) so that the 1-GPU line has a like-for-like counterpart; --envs / --total-envs override.
+One "step" = one batched env.step() over all of the rank's games: action in, move/combat/capture applied, win/draw detection,
+next mover's valid-actions mask (uint8 [R,C,K]) and normalised partial observation (float32 [R,C,67]) written to HBM, plus the
+next random valid action.  Inputs are resident in HBM when the timed region starts.
 
 Multi-GPU: one process per GPU.  Under a launcher (RANK / WORLD_SIZE set) this process is one rank; run directly with
 --gpus N > 1 it starts the N ranks itself as fresh child processes BEFORE anything touches the GPU (a process that has
-initialised HIP is never re-executed) and relays rank 0's line.  Global env ids are sharded contiguously across the ranks
-(stratego_env_amd.sharding.shard_range), no collective on the data path: one barrier on each side of the timed region and
-one MAX / SUM all-reduce for reporting => "scaling": "weak" (fixed games per GPU) or "strong" (--total-envs).
+initialised HIP is never re-executed; the parent does not even import torch) and relays rank 0's line.  Global env ids are sharded
+contiguously across the ranks (stratego_env_amd.sharding.shard_range), no collective on the data path: one barrier on each side
+of the timed region and one MAX / SUM all-reduce for reporting.
 
-Prints ONE JSON line (rank 0) with `roofline` (HBM; algorithmic bytes = B_alg x games per launch / measured launch time via
-HIP events on the launch stream; also the fraction on an untuned output allocation and the fraction by measured HBM traffic),
-`config.other_workloads` (BASELINE configs 3 and 4 timed after the headline, 1-GPU run only) and `cpu_baseline` (the CPU
-oracle, a port of the reference's algorithm, timed on this box's host cores on a bounded sample of the same workload).
+Prints ONE JSON line (rank 0) with
+  `roofline`      HBM; `frac` = HBM bytes per launch by the rocprofv3 counters (profiles/traffic.json, committed next to the
+                  rocprof summaries they come from) / launch time measured live with HIP events on the launch stream / 8 TB/s;
+                  `frac_algorithmic` = SURVEY 8d's B_alg x games per launch over the same time (the kernel moves fewer bytes than
+                  B_alg assumes, so this one can exceed 1); `frac_untuned` = the same on the process's plain first allocation;
+  `verified_envs` sampled envs of the very env object that was timed, checked after the timed region against the CPU oracle
+                  replaying the same number of steps (outputs of the last step, turn and game counters);
+  `config.other_workloads`  BASELINE configs 3 and 4 and the reference's default BOTH_OBSERVATIONS mode (1-GPU run only);
+  `cpu_baseline`  the CPU oracle (a port of the reference's algorithm) timed on this box's host cores on a bounded sample.
 
 `--dry-run` is the launcher's self-test: same process / rendezvous / sharding / reduction code over gloo with a stub in
 place of the env, no GPU, no measurement (`value` is null) -- what tests/test_bench_launcher_cpu.py runs.
 """
 import argparse
+import glob
 import json
 import os
 import socket
@@ -38,14 +46,15 @@ if ROOT not in sys.path:
 
 BASE_SEED = 0x5712A7E60
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+GAMES_1GPU, GAMES_PER_GPU_MULTI, STRONG_TOTAL = 65536, 262144, 2097152
 
 
-def b_alg(rows, cols):
+def b_alg(rows, cols, full_obs=False):
     """Algorithmic bytes per env step (SURVEY 8d / BASELINE.md): state read + compulsory write-back + action +
-    float32 obs + uint8 mask + result record."""
+    float32 obs + uint8 mask + result record; BOTH_OBSERVATIONS adds the 79-channel observation."""
     rc = rows * cols
     k = 2 * (rows - 1) + 2 * (cols - 1) + 1
-    return (32 * rc + 16) + (rc + 16) + 4 + 4 * 67 * rc + rc * k + 12
+    return (32 * rc + 16) + (rc + 16) + 4 + 4 * 67 * rc + rc * k + 12 + (4 * 79 * rc if full_obs else 0)
 
 
 def usable_cores():
@@ -61,27 +70,36 @@ def usable_cores():
     return n
 
 
-def measured_traffic(version, n_envs):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
+def measured_traffic(key, n_envs):
+    """(HBM bytes per launch, source) from the committed rocprofv3 --pmc passes (profiles/traffic.json), or (None, None).
+    The kernel moves the same bytes for every game, so an entry measured at another batch size is scaled by the game count
+    (and labelled as such)."""
     try:
         t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
-        e = t.get(version)
-        if e and e['games_per_launch'] == n_envs:
-            return e['hbm_bytes_per_launch']
+        e = t.get(key)
+        if not e:
+            return None, None
+        src = "profiles/traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of %s" % (key, e.get('source', 'the committed pmc summary'))
+        if e['games_per_launch'] == n_envs:
+            return e['hbm_bytes_per_launch'], src
+        return e['hbm_bytes_per_launch'] * (n_envs / e['games_per_launch']), src + " (measured at %d games per launch, scaled per game)" % e['games_per_launch']
     except Exception:
-        pass
-    return None
+        return None, None
 
 
-def cpu_baseline(version, seed, target_seconds):
-    """Time the oracle's rollout harness (same workload rule) on the host cores; bounded to ~target_seconds."""
+def oracle_variant(version):
     from oracle import oracle as orc   # checker / baseline only
     from stratego_env_amd import setups as S
     from stratego_env_amd.config import VARIANTS
     v = VARIANTS[version]
     table = S.load_setup_table(v.human_inits) if v.human_inits else None
-    cv = orc.make_cvariant(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts,
-                           v.initial_state_usable_rows, setups=table)
+    return orc, orc.make_cvariant(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts,
+                                  v.initial_state_usable_rows, setups=table)
+
+
+def cpu_baseline(version, seed, target_seconds):
+    """Time the oracle's rollout harness (same workload rule) on the host cores; bounded to ~target_seconds."""
+    orc, cv = oracle_variant(version)
     cores = usable_cores()
     n_probe, t_probe = 16 * cores, 256
     orc.rollout(cv, seed, 0, n_probe, t_probe, threads=cores)    # untimed: starts the OpenMP team, pages everything in
@@ -109,19 +127,26 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=512)
     ap.add_argument('--warmup', type=int, default=64)
-    ap.add_argument('--envs', type=int, default=65536, help='games per GPU (weak scaling: fixed as --gpus grows)')
+    ap.add_argument('--envs', type=int, default=None,
+                    help='games per GPU (weak scaling: fixed as --gpus grows); default 65,536 on one GPU (BASELINE config 2), '
+                         '262,144 per GPU on several (config 5)')
     ap.add_argument('--total-envs', type=int, default=0,
                     help='strong scaling instead (SURVEY 8d config 5): this many games in total, split over the ranks')
+    ap.add_argument('--strong-total', type=int, default=None,
+                    help='games of the strong-scaling LEG reported next to the weak headline (default 2,097,152 when --gpus > 1, '
+                         '0 = skip; pass it explicitly to get the leg on one GPU)')
     ap.add_argument('--version', default='barrage')
     ap.add_argument('--unfused', action='store_true', help='sample actions with the standalone sampler kernel')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-workloads', action='store_true',
-                    help='skip the BASELINE config 3 / 4 legs (262,144 Standard games, 65,536 Micro games) after the headline')
+                    help='skip the legs after the headline (262,144 Standard games, 65,536 Micro games, BOTH_OBSERVATIONS; the '
+                         'other per-GPU sizes of a multi-GPU run)')
     ap.add_argument('--traffic-bytes', type=float, default=None, help='HBM bytes per launch from a rocprofv3 --pmc pass')
-    ap.add_argument('--placement-trials', type=int, default=None,
-                    help='candidate allocations of the output tensors tried by VecStrategoEnv.tune_placement (1 = off; '
-                         'default: as many as --placement-gb allows)')
+    ap.add_argument('--placement', default='trial', choices=('trial', 'plain'),
+                    help="output buffers: 'trial' = library-owned, picked by sgx_alloc_outputs' bounded placement trial; "
+                         "'plain' = the torch.empty tensors of VecStrategoEnv")
+    ap.add_argument('--placement-trials', type=int, default=None, help='most candidate allocations (default: what --placement-gb allows)')
     ap.add_argument('--placement-gb', type=float, default=8.0,
                     help='most extra device memory the placement trial may hold at any time')
     ap.add_argument('--wake-seconds', type=float, default=2.0,
@@ -129,9 +154,24 @@ def parse_args(argv=None):
     ap.add_argument('--chains', type=int, default=1,
                     help='sgx_rollout: split the batch into this many ranges of games whose launches overlap on streams of their own '
                          '(1 = sgx_step_n, one launch per step: what the headline uses, so that the per-launch figures are per step)')
+    ap.add_argument('--verify-envs', type=int, default=32,
+                    help='envs per rank checked against the CPU oracle after the timed region (0 = off)')
+    ap.add_argument('--devices', default=None,
+                    help='comma-separated device index per local rank (default: LOCAL_RANK); "0,0" runs two ranks on one GPU '
+                         '(tests/test_gpu_two_ranks.py)')
+    ap.add_argument('--backend', default=None, choices=('nccl', 'gloo'),
+                    help='process-group backend of the reporting reductions (default nccl = RCCL; gloo when ranks share a GPU)')
     ap.add_argument('--dry-run', action='store_true',
                     help="launcher self-test on CPU: gloo, stub env, no measurement (value is null)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.envs is None:
+        args.envs = GAMES_1GPU if args.gpus == 1 else GAMES_PER_GPU_MULTI
+        args.envs_defaulted = True
+    else:
+        args.envs_defaulted = False
+    if args.strong_total is None:
+        args.strong_total = STRONG_TOTAL if (args.gpus > 1 and not args.total_envs and args.envs_defaulted) else 0
+    return args
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -145,15 +185,33 @@ def _free_port():
     return p
 
 
+def visible_gpus():
+    """Number of AMD GPUs this process could open, WITHOUT loading torch or the HIP runtime (a launcher parent must never
+    initialise the GPU before it starts its ranks): KFD topology nodes with SIMDs, narrowed by *_VISIBLE_DEVICES."""
+    n = 0
+    for props in glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'):
+        try:
+            for line in open(props):
+                if line.startswith('simd_count') and int(line.split()[1]) > 0:
+                    n += 1
+        except Exception:
+            pass
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+    return n
+
+
 def launch_ranks(args, argv):
     """Start one fresh `python bench.py` process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's
-    stdout, return the first non-zero exit code (the other ranks are then terminated).  This process never initialises HIP:
-    torch.cuda.device_count() does not, and nothing else here touches torch.cuda."""
+    stdout, return the first non-zero exit code (the other ranks are then terminated).  This process never initialises HIP
+    and never imports torch: GPUs are counted from the KFD topology in sysfs."""
     n = args.gpus
     if not args.dry_run:
-        import torch
-        have = torch.cuda.device_count()
-        if have < n:
+        have = visible_gpus()
+        need = n if not args.devices else len(set(args.devices.split(',')))
+        if have < need:
             print("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
             return 2
     port = _free_port()
@@ -188,7 +246,7 @@ class Rank:
     """This process's place in the job, from the launcher's environment.  world must equal --gpus: a launcher that
     silently started fewer ranks is an error, not a smaller run."""
 
-    def __init__(self, gpus, backend, use_cuda):
+    def __init__(self, gpus, backend, use_cuda, devices=None):
         import torch
         self.rank = int(os.environ.get('RANK', '0'))
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -197,20 +255,27 @@ class Rank:
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (gpus, self.world))
         if not 0 <= self.rank < self.world:
             raise SystemExit("bench.py: RANK=%d outside WORLD_SIZE=%d" % (self.rank, self.world))
+        self.device_index = self.local_rank
+        if devices:
+            dmap = [int(x) for x in devices.split(',')]
+            if self.local_rank >= len(dmap):
+                raise SystemExit("bench.py: --devices lists %d devices, LOCAL_RANK=%d" % (len(dmap), self.local_rank))
+            self.device_index = dmap[self.local_rank]
         self.use_cuda = use_cuda
         self.dist = None
         if use_cuda:
-            torch.cuda.set_device(self.local_rank)
+            torch.cuda.set_device(self.device_index)
+        # reductions run on the GPU over RCCL, or on the host over gloo (dry run; ranks that share one GPU, which RCCL refuses)
+        self.reduce_device = 'cuda' if (use_cuda and backend == 'nccl') else 'cpu'
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
-            kw = {'device_id': torch.device('cuda', self.local_rank)} if use_cuda else {}
+            kw = {'device_id': torch.device('cuda', self.device_index)} if self.reduce_device == 'cuda' else {}
             dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
             if dist.get_world_size() != gpus:
                 raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), gpus))
             self.dist = dist
-        self.device = 'cuda' if use_cuda else 'cpu'
 
     def sync(self):
         if self.use_cuda:
@@ -229,9 +294,9 @@ class Rank:
         if not self.dist:
             return list(maxes), list(sums)
         import torch
-        t = torch.tensor(list(maxes), dtype=torch.float64, device=self.device)
+        t = torch.tensor(list(maxes), dtype=torch.float64, device=self.reduce_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        c = torch.tensor(list(sums), dtype=torch.int64, device=self.device)
+        c = torch.tensor(list(sums), dtype=torch.int64, device=self.reduce_device)
         self.dist.all_reduce(c, op=self.dist.ReduceOp.SUM)
         return [float(x) for x in t], [int(x) for x in c]
 
@@ -240,16 +305,16 @@ class Rank:
             self.dist.destroy_process_group()
 
 
-def shard_of(args, rk):
-    """(first global env id, games) of this rank: --envs games per GPU (weak) or --total-envs split over the ranks (strong)."""
+def shard_of(rk, per_gpu, total_envs):
+    """(first global env id, games, total) of this rank: per_gpu games per GPU (weak) or total_envs split over the ranks (strong)."""
     from stratego_env_amd.sharding import shard_range
-    total = args.total_envs if args.total_envs else args.envs * rk.world
+    total = total_envs if total_envs else per_gpu * rk.world
     return shard_range(total, rk.rank, rk.world) + (total,)
 
 
 def timed_steps(rk, run_warmup, run_timed, counters):
     """Warm up, then time run_timed() between barrier + synchronize brackets.  Returns (elapsed seconds MAX over ranks,
-    device ms MAX over ranks or None, summed counter deltas)."""
+    device ms MAX over ranks or None, elapsed seconds MIN over ranks, summed counter deltas)."""
     run_warmup()
     before = counters()
     ev = None
@@ -263,13 +328,15 @@ def timed_steps(rk, run_warmup, run_timed, counters):
     run_timed()
     if ev:
         ev[1].record()
+    rk.sync()
+    own = time.perf_counter() - t0            # this rank's own K steps (no waiting for the others)
     rk.barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = ev[0].elapsed_time(ev[1]) if ev else 0.0
     after = counters()
-    (elapsed, dev_ms), sums = rk.reduce([elapsed, dev_ms], [a - b for a, b in zip(after, before)] + [1])
+    (elapsed, dev_ms, neg_own, max_own), sums = rk.reduce([elapsed, dev_ms, -own, own], [a - b for a, b in zip(after, before)] + [1])
     assert sums[-1] == rk.world, "reduction covered %d ranks of %d" % (sums[-1], rk.world)
-    return elapsed, (dev_ms if ev else None), sums[:-1]
+    return elapsed, (dev_ms if ev else None), (-neg_own, max_own), sums[:-1]
 
 
 class _StubEnv:
@@ -287,15 +354,17 @@ class _StubEnv:
         return [self.steps_done * self.n, 0]
 
 
-def make_env(version, n, first, local_rank):
+def make_env(version, n, first, device_index, full_obs=False):
     from stratego_env_amd.vec_env import VecStrategoEnv
-    env = VecStrategoEnv(version, n, device=local_rank, seed=BASE_SEED, env_id_offset=first, auto_reset=True)
+    env = VecStrategoEnv(version, n, device=device_index, seed=BASE_SEED, env_id_offset=first, auto_reset=True, full_obs=full_obs)
     env.reset()
+    env.bench_steps_played = 0               # rollout steps since reset(): what the oracle replays in verify_against_oracle
     return env
 
 
 def time_workload(rk, env, steps, warmup, unfused=False, chains=1):
-    """(elapsed s, device ms, games finished, invalid actions) of `steps` batched steps on `env`, all MAX / SUM over ranks."""
+    """(elapsed s, device ms, (min, max) of the ranks' own seconds, games finished, invalid actions) of `steps` batched steps on
+    `env`, MAX / SUM over ranks."""
     import torch
 
     def one_step():
@@ -323,39 +392,144 @@ def time_workload(rk, env, steps, warmup, unfused=False, chains=1):
     def counters():
         return [int(env.env_info()[:, 1].to(torch.int64).sum()), 0]
 
-    elapsed, dev_ms, (games, _) = timed_steps(rk, run_warmup, run_timed, counters)
+    elapsed, dev_ms, own, (games, _) = timed_steps(rk, run_warmup, run_timed, counters)
+    env.bench_steps_played += warmup + steps
     _, (invalid,) = rk.reduce([], [int(env.invalid_action.sum())])
-    return elapsed, dev_ms, games, invalid
+    return elapsed, dev_ms, own, games, invalid
 
 
-def other_workload(rk, version, n, seconds=1.0, extra_bytes=0, chains=1):
-    """One of the other BASELINE configs on this GPU, about `seconds` of timed steps; output buffers from the same bounded
-    placement trial as the headline (extra_bytes = 0: plain first allocation)."""
+def verify_against_oracle(env, version, n_check, both=False):
+    """Ties the number to verified outputs: `n_check` sampled envs of the env object that has just been timed -- the first and the
+    last of the rank plus an even spread -- must hold, after env.bench_steps_played steps, exactly what the CPU oracle holds
+    after replaying that many steps of the same global env ids: the last step's mask / observation(s) / rewards / flags (one
+    FNV digest, so_rollout_ex's `last_digests`) and the turn / game / game-over / player counters.  Raises on any difference.
+    Returns the number of envs checked."""
+    import numpy as np
+    import torch
+    n_check = min(int(n_check), env.num_envs)
+    if n_check <= 0 or env.bench_steps_played <= 0:
+        return 0
+    orc, cv = oracle_variant(version)
+    ids = np.unique(np.concatenate([[0, env.num_envs - 1], np.linspace(0, env.num_envs - 1, n_check).astype(np.int64)]))[:max(n_check, 2)]
+    idx = torch.from_numpy(ids).to(env.device)
+    mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
+    fo = env.fobs[idx].cpu().numpy() if both else None
+    rw, dn, pl = env.reward[idx].cpu().numpy(), env.done[idx].cpu().numpy(), env.player[idx].cpu().numpy()
+    ei, info = env.ending_invalid[idx].cpu().numpy(), env.env_info()[idx].cpu().numpy()
+    cores = usable_cores()
+    for i, e in enumerate(ids):
+        r = orc.rollout_ex(cv, BASE_SEED, env.env_id_offset + int(e), 1, env.bench_steps_played, both=both, threads=1)
+        got = orc.step_digest(mk[i], ob[i], rw[i], dn[i], pl[i], ei[i], fobs=None if fo is None else fo[i])
+        if int(r['last_digests'][0]) != got or not np.array_equal(r['info'][0], info[i]):
+            raise SystemExit("bench.py: env %d (global id %d) differs from the CPU oracle after %d steps (oracle turn/game/over/player %s, "
+                             "GPU %s)" % (int(e), env.env_id_offset + int(e), env.bench_steps_played, r['info'][0].tolist(), info[i].tolist()))
+    del cores
+    return len(ids)
+
+
+def outputs_checksum(env):
+    """Checksum of checksums over ALL envs of this rank (size-independent property: the sum over ranks does not depend on the
+    sharding): per env a 40-bit mix of its observation words, mask bytes, rewards and flags, summed."""
+    import torch
+    n = env.num_envs
+    tot = torch.zeros((), dtype=torch.int64, device=env.device)
+    chunk = 8192
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        o = env.obs[a:b].reshape(b - a, -1).view(torch.int32).to(torch.int64)
+        w = (torch.arange(o.shape[1], device=env.device, dtype=torch.int64) * 2654435761 + 12345) & 0xFFFF
+        c = (o * (w + 1)).sum(dim=1)
+        m = env.mask[a:b].reshape(b - a, -1).to(torch.int64)
+        wm = (torch.arange(m.shape[1], device=env.device, dtype=torch.int64) * 40503 + 7) & 0xFFFF
+        c = c + (m * (wm + 1)).sum(dim=1) * 3
+        c = c + env.reward[a:b].view(torch.int32).to(torch.int64).sum(dim=1) * 5 + env.done[a:b].to(torch.int64) * 7
+        c = c + env.player[a:b].to(torch.int64) * 11 + env.next_actions[a:b].to(torch.int64) * 13
+        tot = tot + (c & ((1 << 40) - 1)).sum()
+    return int(tot)
+
+
+def place_outputs(env, args):
+    """Library-owned output buffers from sgx_alloc_outputs' bounded placement trial, unless --placement plain.
+    -> {'candidates', 'plain_us' (the allocation a caller would have got first), 'kept_us', 'median_us', 'max_us', 'peak_extra_gb'}."""
+    if args.placement != 'trial':
+        return None
+    rep = env.tune_placement(args.placement_trials, max_extra_bytes=int(args.placement_gb * (1 << 30)))
+    t = rep.get('obs') or []
+    out = {"candidates": len(t), "peak_extra_gb": round(getattr(env, 'placement_peak_extra_bytes', 0) / 2.0 ** 30, 2)}
+    if t:
+        out.update({"plain_us": round(t[0], 1), "kept_us": round(min(t), 1), "median_us": round(sorted(t)[len(t) // 2], 1),
+                    "max_us": round(max(t), 1)})
+    if rep.get('fobs'):
+        out["fobs_plain_us"], out["fobs_kept_us"] = round(rep['fobs'][0], 1), round(min(rep['fobs']), 1)
+    return out
+
+
+def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, first_us=None):
+    key = version + ('+full_obs' if full_obs else '')
+    alg_bytes = b_alg(v.rows, v.columns, full_obs) * n
+    traffic, source = (traffic_override, "--traffic-bytes") if traffic_override is not None else measured_traffic(key, n)
+    alg = alg_bytes / launch_s / 1e9
+    ach = (traffic / launch_s / 1e9) if traffic else alg
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "frac_basis": "rocprofv3 counter bytes per launch" if traffic else "algorithmic bytes (no counter entry for this workload)",
+            "traffic": traffic, "traffic_source": source,
+            "achieved_algorithmic": alg, "frac_algorithmic": alg / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel": "step_kernel<%d,%d,%d>" % (v.rows, v.columns, 1 if full_obs else 0), "launch_us": launch_s * 1e6,
+            # the same kernel writing the allocation the process got first (observe launch of the placement trial's first candidate):
+            # what an integrator who passes plain torch.empty tensors may get
+            "frac_untuned": ((traffic or alg_bytes) / (first_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if first_us else None}
+
+
+def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, verify=8):
+    """One of the other BASELINE configs on this GPU, about `seconds` of timed steps; output buffers built like the headline's."""
     import torch
     from stratego_env_amd.config import VARIANTS
     v = VARIANTS[version]
-    env = make_env(version, n, 0, rk.local_rank)
+    env = make_env(version, n, 0, rk.device_index, full_obs=full_obs)
     try:
-        trial = env.tune_placement(max_extra_bytes=extra_bytes) if extra_bytes else None
-        _, probe_ms, _, _ = time_workload(rk, env, 8, 8)
+        trial = place_outputs(env, args)
+        _, probe_ms, _, _, _ = time_workload(rk, env, 8, 8)
         steps = int(max(16, min(4096, seconds * 1e3 / max(probe_ms / 8, 1e-3))))
-        elapsed, dev_ms, games, invalid = time_workload(rk, env, steps, 4)
+        elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, 4)
         two = None
         if chains > 1:                     # the same steps with the batch split over concurrent chains of launches (sgx_rollout)
-            e2, d2, _, inv2 = time_workload(rk, env, steps, 4, chains=chains)
+            e2, d2, _, _, inv2 = time_workload(rk, env, steps, 4, chains=chains)
             assert inv2 == 0
             two = {"chains": chains, "value": n * steps / e2, "us_per_step": d2 / steps * 1e3,
-                   "frac": b_alg(v.rows, v.columns) * n / (d2 / 1e3 / steps) / 1e9 / HBM_PEAK_GBS}
+                   "frac_algorithmic": b_alg(v.rows, v.columns, full_obs) * n / (d2 / 1e3 / steps) / 1e9 / HBM_PEAK_GBS}
         assert invalid == 0
+        checked = verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
         launch_s = dev_ms / 1e3 / steps
-        bpl = b_alg(v.rows, v.columns) * n
-        return {"workload": "%d concurrent %s games (%dx%d), same rollout" % (n, version, v.rows, v.columns),
+        rf = roofline(version, v, n, launch_s, full_obs=full_obs, first_us=(trial or {}).get('plain_us'))
+        return {"workload": "%d concurrent %s games (%dx%d)%s, same rollout" % (n, version, v.rows, v.columns,
+                                                                                 ", BOTH_OBSERVATIONS (67 + 79 channels)" if full_obs else ""),
                 "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
-                "frac": bpl / launch_s / 1e9 / HBM_PEAK_GBS, "b_alg_bytes_per_step": b_alg(v.rows, v.columns),
-                "kernel": "step_kernel<%d,%d>" % (v.rows, v.columns), "games_finished_in_timed_region": games,
-                "traffic": measured_traffic(version, n), "concurrent_chains": two,
-                "placement_trial_us": ({"candidates": len(trial['obs']), "first": round(trial['obs'][0], 1), "min": round(min(trial['obs']), 1)}
-                                       if trial and trial['obs'] else None)}
+                "frac": rf["frac"], "frac_basis": rf["frac_basis"], "frac_algorithmic": rf["frac_algorithmic"],
+                "frac_untuned": rf["frac_untuned"], "traffic": rf["traffic"],
+                "b_alg_bytes_per_step": b_alg(v.rows, v.columns, full_obs), "kernel": rf["kernel"],
+                "games_finished_in_timed_region": games, "concurrent_chains": two, "verified_envs": checked,
+                "placement": trial}
+    finally:
+        env.close()
+        del env
+        torch.cuda.empty_cache()
+
+
+def scaling_leg(rk, args, per_gpu, total_envs, label):
+    """Another games-per-GPU size of the multi-GPU run, same K / W as the headline: {value, ms_per_step, ...}."""
+    import torch
+    first, n, total = shard_of(rk, per_gpu, total_envs)
+    env = make_env(args.version, n, first, rk.device_index)
+    try:
+        place_outputs(env, args)
+        elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup)
+        assert invalid == 0
+        checked = verify_against_oracle(env, args.version, min(args.verify_envs, 8)) if args.verify_envs else 0
+        _, (checked,) = rk.reduce([], [checked])
+        return {"workload": label, "scaling": "strong" if total_envs else "weak", "total_games": total, "games_per_gpu": n,
+                "value": total * args.steps / elapsed, "unit": "env steps/s", "ms_per_step": elapsed / args.steps * 1e3,
+                "per_gpu_value_min": n * args.steps / own[1], "per_gpu_value_max": n * args.steps / own[0],
+                "launch_us": dev_ms / args.steps * 1e3, "verified_envs": checked}
     finally:
         env.close()
         del env
@@ -368,15 +542,16 @@ def run_rank(args):
         import torch
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    rk = Rank(args.gpus, 'gloo' if dry else 'nccl', use_cuda=not dry)
-    first, n, total = shard_of(args, rk)
+    backend = 'gloo' if dry else (args.backend or 'nccl')
+    rk = Rank(args.gpus, backend, use_cuda=not dry, devices=args.devices)
+    first, n, total = shard_of(rk, args.envs, args.total_envs)
     if n <= 0:
         raise SystemExit("bench.py: rank %d got no games (%d games over %d ranks)" % (rk.rank, total, rk.world))
 
     if dry:
         env = _StubEnv(first, n)
-        elapsed, _, (steps_x_games, _) = timed_steps(rk, lambda: env.rollout_steps(args.warmup),
-                                                     lambda: env.rollout_steps(args.steps), env.counters)
+        elapsed, _, _, (steps_x_games, _) = timed_steps(rk, lambda: env.rollout_steps(args.warmup),
+                                                        lambda: env.rollout_steps(args.steps), env.counters)
         _, (covered, lo_gap) = rk.reduce([], [n, first if rk.rank == 0 else 0])
         if rk.rank == 0:
             print(json.dumps({"metric": "env steps/sec", "value": None, "unit": "env steps/s", "n_gpus": rk.world,
@@ -384,7 +559,8 @@ def run_rank(args):
                               "dry_run": True, "data": "none (launcher self-test)",
                               "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external'),
                               "scaling": "strong" if args.total_envs else "weak",
-                              "config": {"total_games": total, "games_covered_by_ranks": covered,
+                              "config": {"total_games": total, "games_covered_by_ranks": covered, "games_per_gpu": n,
+                                         "strong_leg_total_games": args.strong_total,
                                          "stub_steps_x_games": steps_x_games}}), flush=True)
         rk.close()
         return
@@ -400,34 +576,32 @@ def run_rank(args):
 
     from stratego_env_amd.config import VARIANTS
     v = VARIANTS[args.version]
-    env = make_env(args.version, n, first, rk.local_rank)
-    placement_us = None
-    if args.placement_trials is None or args.placement_trials > 1:
-        placement_us = env.tune_placement(args.placement_trials, max_extra_bytes=int(args.placement_gb * (1 << 30)))
-    elapsed, dev_ms, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains)
+    env = make_env(args.version, n, first, rk.device_index)
+    placement = place_outputs(env, args)
+    elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains)
     assert invalid == 0, "rollout produced invalid actions"
     two_chains = None
     if rk.world == 1 and args.chains == 1 and not args.unfused:
         # The same K steps with the batch split into two ranges of games whose launches overlap (sgx_rollout, chains = 2): reported
         # next to the headline, which stays one launch per step so that its per-launch figures can be checked against a kernel trace.
-        e2, d2, _, inv2 = time_workload(rk, env, args.steps, args.warmup, False, 2)
+        e2, d2, _, _, inv2 = time_workload(rk, env, args.steps, args.warmup, False, 2)
         assert inv2 == 0
         two_chains = {"chains": 2, "value": total * args.steps / e2, "us_per_step": d2 / args.steps * 1e3,
-                      "frac": b_alg(v.rows, v.columns) * n / (d2 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
+                      "frac_algorithmic": b_alg(v.rows, v.columns) * n / (d2 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
+    # outside the timed region: the envs that were just timed against the CPU oracle, and the sharding-independent checksum
+    checked = verify_against_oracle(env, args.version, args.verify_envs) if args.verify_envs else 0
+    _, (checked, checksum) = rk.reduce([], [checked, outputs_checksum(env)])
 
     out = None
     if rk.rank == 0:
         total_steps = total * args.steps
         launch_s = dev_ms / 1e3 / args.steps                 # average device time per batched step (HIP events)
-        bytes_per_launch = b_alg(v.rows, v.columns) * n
-        achieved = bytes_per_launch / launch_s / 1e9
-        traffic = args.traffic_bytes if args.traffic_bytes is not None else measured_traffic(args.version, n)
-        first_us = placement_us['obs'][0] if placement_us and placement_us['obs'] else None
         out = {
             "metric": "env steps/sec", "value": total_steps / elapsed, "unit": "env steps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_envs else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "verified_envs": checked, "verified_steps": env.bench_steps_played,
             "config": {"workload": "%d concurrent %s games per GPU (%dx%d), random-valid-action rollout with auto-reset, "
                                    "%s step+sample" % (n, args.version, v.rows, v.columns,
                                                        "separate" if args.unfused else "fused"),
@@ -435,31 +609,33 @@ def run_rank(args):
                        "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns),
                        "concurrent_chains": args.chains, "two_chains": two_chains,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),
-                       # per-candidate sgx_observe times of the start-up placement trial: the fastest is kept;
-                       # "first" is the allocation the env would have used without the trial
-                       "placement_trial_us": ({k: {"candidates": len(t), "first": round(t[0], 1), "min": round(min(t), 1),
-                                                   "median": round(sorted(t)[len(t) // 2], 1), "max": round(max(t), 1)}
-                                               for k, t in placement_us.items() if t} if placement_us else None),
-                       # most device memory the trial held beyond the buffers it kept (budget: --placement-gb)
-                       "placement_peak_extra_gb": round(getattr(env, 'placement_peak_extra_bytes', 0) / 2.0 ** 30, 2)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "step_kernel<%d,%d>" % (v.rows, v.columns),
-                         "launch_us": launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         # the same kernel on the allocation the process got first (observe-only launch of the placement trial,
-                         # algorithmic bytes over its time) and by measured HBM traffic instead of algorithmic bytes
-                         "frac_untuned": (bytes_per_launch / (first_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if first_us else None,
-                         "frac_traffic": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None},
+                       "reduction_backend": backend if rk.world > 1 else None, "devices": args.devices,
+                       # the slowest / fastest rank's own K steps (no waiting for the others): weak scaling without a data-path
+                       # collective loses nothing as long as these stay at the 1-GPU rate of the same games-per-GPU size
+                       "per_gpu_value_min": n * args.steps / own[1], "per_gpu_value_max": n * args.steps / own[0],
+                       "outputs_checksum": checksum,
+                       # sgx_alloc_outputs' report: observe-launch time on the plain first allocation and on the candidate it kept
+                       "placement": placement},
+            "roofline": roofline(args.version, v, n, launch_s, args.traffic_bytes, first_us=(placement or {}).get('plain_us')),
         }
     env.close()
     del env
     torch.cuda.empty_cache()
+    legs = None
+    if not args.no_other_workloads and rk.world > 1 and not args.total_envs and args.envs_defaulted:
+        # the other per-GPU sizes of the scaling study (every rank takes part)
+        legs = [scaling_leg(rk, args, GAMES_1GPU, 0, "%d games per GPU: the 1-GPU line's workload (BASELINE config 2) on every GPU" % GAMES_1GPU)]
+        if args.strong_total:
+            legs.append(scaling_leg(rk, args, 0, args.strong_total, "%d games in total split over the GPUs (BASELINE config 5, strong scaling)" % args.strong_total))
+    elif args.strong_total and not args.no_other_workloads:
+        legs = [scaling_leg(rk, args, 0, args.strong_total, "%d games in total split over the GPUs (BASELINE config 5, strong scaling)" % args.strong_total)]
     if rk.rank == 0:
+        out["config"]["scaling_legs"] = legs
         out["config"]["other_workloads"] = None
         if rk.world == 1 and not args.no_other_workloads and args.version == 'barrage':
-            extra = int(args.placement_gb * (1 << 30)) if placement_us else 0
-            out["config"]["other_workloads"] = [other_workload(rk, 'standard', 262144, extra_bytes=extra, chains=2),
-                                                other_workload(rk, 'micro', 65536, extra_bytes=extra, chains=2)]
+            out["config"]["other_workloads"] = [other_workload(rk, args, 'standard', 262144, chains=2),
+                                                other_workload(rk, args, 'micro', 65536, chains=2),
+                                                other_workload(rk, args, 'barrage', 65536, full_obs=True)]
         if not args.no_cpu_baseline and rk.world == 1:         # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
         else:
@@ -474,7 +650,7 @@ def main(argv=None):
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args, argv))     # nothing in this process has touched the GPU
+        sys.exit(launch_ranks(args, argv))     # nothing in this process has touched the GPU (torch is not even imported)
     run_rank(args)
 
 

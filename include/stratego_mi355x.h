@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 8
+#define SGX_ABI_VERSION 9
 #define SGX_MAX_CELLS 256        /* rows*cols <= 256 (largest reference variant: 15x15) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
 #define SGX_FO_OBS_CHANNELS 79   /* impl:1227 */
@@ -135,6 +135,13 @@ int sgx_build_original_obs_lut(const sgx_config *cfg, int32_t full, float *lut);
 int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64_t seed, int64_t env_id_offset, sgx_env **out);
 int sgx_destroy(sgx_env *h);
 
+/* Store policy of the observation writes of sgx_step / sgx_observe.  Lines a wave writes whole can leave as non-temporal stores:
+ * faster when a launch's observations do not fit the 256 MiB Infinity Cache, slower when they do.
+ * mode -1 (default): decided per launch from the observation bytes it writes (> 300 MB: non-temporal); 0: never; 1: always.
+ * The environment variable SGX_NT=0|1|auto sets the default of handles created afterwards.  Results are identical in every
+ * mode (tests/test_gpu_nt_stores.py runs the parity suites with the mode forced).  No reference counterpart. */
+int sgx_set_nt_stores(sgx_env *h, int32_t mode);
+
 /* Upload a human-setup table (game/inits/{barrage,standard}_human_inits.py decoded to piece codes, util.py:154-180):
  * table_host is uint8 [n_setups][usable_rows*cols] in Gravon string order.  Replaces get_random_human_init_fn
  * (util.py:301-319).  Without a table, sampled resets place pieces uniformly at random in the usable rows
@@ -159,6 +166,14 @@ int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, 
  * No reference counterpart. */
 int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int32_t launches, void *stream, float *microseconds);
 
+/* Write-stream rate (GB/s) of the device memory range [ptr_dev, ptr_dev + bytes) under the step kernel's store pattern: one wave
+ * per 26 KiB segment, 1 KiB non-temporal store instructions, eight concurrent fronts -- the observation stream without the game.
+ * OVERWRITES the range.  On MI355X device memory comes in large regions of two kinds that differ by ~25 % under this pattern (and
+ * not under a sequential fill); a host that allocates its own output tensors can tell with this call which kind
+ * an allocation is.  ptr_dev 1 KiB aligned; `launches` timed launches after one untimed; synchronises `stream`.  No reference
+ * counterpart. */
+int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t launches, void *stream, float *gb_per_s);
+
 /* Library-owned output buffers with a bounded placement trial.  On MI355X the same launch takes
  * 313-400 us depending on which physical memory backs the big observation buffer: device memory comes in regions of two
  * kinds, a buffer lying inside one region runs at that region's rate (~350 or ~380-395 us for 65,536 Barrage games), and
@@ -166,9 +181,9 @@ int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int32_t laun
  * on what was allocated before it.  sgx_alloc_outputs allocates the mask buffer, then tries up to `max_trials` candidate
  * allocations of the observation buffer (and of the fully-observable one with SGX_OUT_FULL_OBS): before each candidate a
  * padding allocation of growing size is made and released again afterwards, which moves the candidate to other buddy blocks;
- * each candidate is timed with a few sgx_observe launches (no state change) and only the fastest so far is kept.  At no
- * time does the trial hold more than `max_extra_bytes` beyond the buffers it returns (0 or max_trials <= 1: no trial, first
- * allocation).  Channel counts follow `flags` (SGX_STEP_ORIGINAL_CHANNELS).  Waits for the device.  No reference counterpart. */
+ * each candidate is timed with a few sgx_observe launches (no state change) and only the fastest so far is kept.  The trial
+ * stops early once the kept candidate is >= 9 % faster than the slowest one seen (the classes lie further apart than that).  At no time does the trial hold more than `max_extra_bytes`
+ * beyond the buffers it returns (0 or max_trials <= 1: no trial, first allocation).  Channel counts follow `flags` (SGX_STEP_ORIGINAL_CHANNELS).  Waits for the device.  No reference counterpart. */
 #define SGX_OUT_FULL_OBS 1024         /* also allocate fobs_dev [N,R,C,79] (or 33) */
 #define SGX_OUT_MAX_TRIALS 64
 typedef struct sgx_outputs {
@@ -180,8 +195,12 @@ typedef struct sgx_outputs {
     int32_t n_trials, n_ftrials;   /* candidates timed for obs_dev / fobs_dev */
     float trial_us[SGX_OUT_MAX_TRIALS];    /* sgx_observe launch time with each obs candidate; [0] = the plain first allocation */
     float ftrial_us[SGX_OUT_MAX_TRIALS];   /* the same for fobs_dev */
+    int32_t device;                /* the device the buffers live on (sgx_free_outputs works without the handle) */
+    int32_t reserved_;
 } sgx_outputs;
 int sgx_alloc_outputs(sgx_env *h, int32_t flags, int64_t max_extra_bytes, int32_t max_trials, void *stream, sgx_outputs *out);
+/* Frees the buffers of `out` (h may be NULL, also after sgx_destroy of the handle that allocated them: the buffers belong to
+ * whoever holds the sgx_outputs -- the Python binding ties them to the tensors that view them). */
 int sgx_free_outputs(sgx_env *h, sgx_outputs *out);
 
 /* One batched env.step(): see sgx_step_io. */
@@ -224,8 +243,10 @@ int sgx_import_state_checked(sgx_env *h, const int64_t *state_dev, const int8_t 
  * sgx_expand: one env.step() per env i of `dst`, reading the game from record src_index[i] of `src` (i when NULL) and writing
  * the successor to record i of `dst`; where the action is invalid (invalid_action[i] = 1) record i becomes a copy of the
  * parent.  `io` as in sgx_step (flags SGX_STEP_ACTIONS_1D / _POSITIONS / _ALLOW_OSCILLATION / _RAW_OBS / _MASK_*; no auto_reset,
- * no fully-observable / original-channel outputs); src == dst with a NULL index is sgx_step.  No reference counterpart beyond
- * get_next_state itself. */
+ * no fully-observable / original-channel outputs); src == dst with a NULL index is sgx_step.  Inside ONE handle an indexed
+ * copy / expansion would race (a wave reads a record another wave of the same launch rewrites): sgx_expand with src == dst and
+ * a non-NULL index, and sgx_copy_envs with src == dst and any index, return SGX_EINVAL -- use a second handle as the target.
+ * No reference counterpart beyond get_next_state itself. */
 int sgx_copy_envs(sgx_env *dst, const int32_t *dst_index_dev, sgx_env *src, const int32_t *src_index_dev, int64_t n, void *stream);
 int sgx_expand(sgx_env *dst, sgx_env *src, const int32_t *src_index_dev, const sgx_step_io *io, void *stream);
 

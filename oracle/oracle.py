@@ -118,6 +118,9 @@ def lib():
         L.so_fnv1a.argtypes = [C.c_uint64, C.c_void_p, I64]
         L.so_rollout.restype = I64
         L.so_rollout.argtypes = [C.POINTER(CVariant), C.c_uint64, I64, I64, I64, C.c_int, P_U64, P_I64]
+        L.so_rollout_ex.restype = I64
+        L.so_rollout_ex.argtypes = [C.POINTER(CVariant), C.c_uint64, I64, I64, I64, I64, C.c_int, C.c_int, P_U64, P_I64, P_U64, P_I64,
+                                    C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -432,6 +435,29 @@ def rollout(cv, seed, g0, n_envs, n_steps, threads=1):
     fin = np.zeros(n_envs, dtype=np.int64)
     total = lib().so_rollout(C.byref(cv), seed, g0, n_envs, n_steps, threads, _p(dig, P_U64), _p(fin, P_I64))
     return int(total), dig, fin
+
+
+def rollout_ex(cv, seed, g0, n_envs, n_steps, skip=0, both=False, threads=1, want_states=False):
+    """so_rollout_ex: rolling digests over steps skip.., digests of the last step alone, games finished, final info
+    int32 [n,4] = (turn, game number, game_over, player) and (optionally) the final int64 states."""
+    dig = np.zeros(n_envs, dtype=np.uint64)
+    last = np.zeros(n_envs, dtype=np.uint64)
+    fin = np.zeros(n_envs, dtype=np.int64)
+    info = np.zeros((n_envs, 4), dtype=np.int32)
+    states = np.zeros((n_envs, 34, int(cv.rows), int(cv.cols)), dtype=np.int64) if want_states else None
+    lib().so_rollout_ex(C.byref(cv), seed, g0, n_envs, n_steps, skip, 1 if both else 0, threads, _p(dig, P_U64), _p(fin, P_I64),
+                        _p(last, P_U64), _p(states, P_I64) if want_states else None, info.ctypes.data_as(C.POINTER(C.c_int32)))
+    return {'digests': dig, 'last_digests': last, 'games_finished': fin, 'info': info, 'states': states}
+
+
+def step_digest(mask, obs, reward, done, player, ending_invalid, fobs=None, h=None):
+    """One step's contribution to so_rollout's digest (continuing from h, default: the FNV offset basis)."""
+    tail = np.asarray([int(done), int(player), int(ending_invalid), 0], dtype=np.int32)
+    data = np.ascontiguousarray(mask, dtype=np.uint8).tobytes() + np.ascontiguousarray(obs, dtype=np.float32).tobytes()
+    if fobs is not None:
+        data += np.ascontiguousarray(fobs, dtype=np.float32).tobytes()
+    data += np.ascontiguousarray(reward, dtype=np.float32).tobytes() + tail.tobytes()
+    return fnv1a(FNV_OFFSET if h is None else h, data)
 
 
 FNV_OFFSET = 0xCBF29CE484222325

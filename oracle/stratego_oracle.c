@@ -808,3 +808,72 @@ SO_EXPORT i64 so_rollout(const so_variant *v, uint64_t seed, i64 g0, i64 n_envs,
     }
     return total;
 }
+
+/* so_rollout for the checks that cannot read back every step (bench.py's verification of the envs it has just timed, the
+ * full-size GPU tests that play hundreds of untested warm-up steps first):
+ *   skip            the rolling digest covers steps skip .. n_steps-1 only (skip = 0: so_rollout's digest);
+ *   flags bit 0     BOTH_OBSERVATIONS: the fully-observable observation is digested right after the partial one;
+ *   last_digests    digest of the LAST step's outputs alone (FNV offset basis -> mask, obs, [fobs,] rewards, tail);
+ *   final_states    int64 [n_envs][34][R][C] after the last step (post-auto-reset);
+ *   final_info      int32 [n_envs][4] = {turn count, game number, game_over, current player} (sgx_get_env_info's record).
+ * Every output pointer may be NULL.  Harness code, not reference code. */
+SO_EXPORT i64 so_rollout_ex(const so_variant *v, uint64_t seed, i64 g0, i64 n_envs, i64 n_steps, i64 skip, int flags, int threads,
+                            uint64_t *digests, i64 *games_finished, uint64_t *last_digests, i64 *final_states, int32_t *final_info) {
+    i64 R = v->rows, C = v->cols, K = so_spatial_channels(R, C), NA = R * C * K, NO = R * C * PO_OBS_LAYERS, NF = R * C * FO_OBS_LAYERS;
+    const int both = flags & 1;
+    float mids[PO_OBS_LAYERS], ranges[PO_OBS_LAYERS], f_mids[FO_OBS_LAYERS], f_ranges[FO_OBS_LAYERS];
+    so_p_obs_norm_constants(v->piece_amounts, mids, ranges);
+    so_f_obs_norm_constants(v->piece_amounts, f_mids, f_ranges);
+    i64 total = 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads > 0 ? threads : 1) reduction(+ : total) schedule(dynamic, 16)
+#endif
+    for (i64 e = 0; e < n_envs; e++) {
+        uint64_t g = (uint64_t)(g0 + e), j = 0, dig = 0xCBF29CE484222325ull, last = 0xCBF29CE484222325ull;
+        i64 *state = (i64 *)malloc(sizeof(i64) * NUM_STATE_LAYERS * R * C);
+        uint8_t *mask = (uint8_t *)malloc(2 * NA);
+        float *obs = (float *)malloc(sizeof(float) * 2 * NO);
+        float *fobs = both ? (float *)malloc(sizeof(float) * 2 * NF) : 0;
+        i64 player = 1, fin = 0;
+        so_reset_env(v, seed, g, j, state);
+        so_env_current_obs3(R, C, state, player, 0, mids, ranges, f_mids, f_ranges, mask, obs, fobs);
+        for (i64 s = 0; s < n_steps; s++) {
+            i64 a = so_sample_action(mask, NA, seed, g, j, (uint32_t)TURN_COUNT(state));
+            so_step_result res;
+            so_env_step3(R, C, state, &player, a, 0, 0, mids, ranges, f_mids, f_ranges, mask, obs, fobs, &res);
+            total++;
+            if (res.done) {
+                fin++; j++;
+                so_reset_env(v, seed, g, j, state);
+                player = 1;
+                so_env_current_obs3(R, C, state, player, 0, mids, ranges, f_mids, f_ranges, mask, obs, fobs);
+            }
+            int32_t tail[4] = {res.done, (int32_t)player, res.ending_invalid, res.error};
+            uint64_t one = 0xCBF29CE484222325ull;
+            for (int pass = 0; pass < 2; pass++) {
+                if (pass == 0 && s < skip) continue;
+                uint64_t d = pass == 0 ? dig : one;
+                d = fnv1a(d, mask, NA);
+                d = fnv1a(d, obs, sizeof(float) * NO);
+                if (both) d = fnv1a(d, fobs, sizeof(float) * NF);
+                d = fnv1a(d, &res.reward_p1, 4);
+                d = fnv1a(d, &res.reward_m1, 4);
+                d = fnv1a(d, tail, sizeof(tail));
+                if (pass == 0) dig = d; else one = d;
+            }
+            last = one;
+        }
+        if (digests) digests[e] = dig;
+        if (games_finished) games_finished[e] = fin;
+        if (last_digests) last_digests[e] = last;
+        if (final_states) memcpy(final_states + e * NUM_STATE_LAYERS * R * C, state, sizeof(i64) * NUM_STATE_LAYERS * R * C);
+        if (final_info) {
+            final_info[4 * e + 0] = (int32_t)TURN_COUNT(state);
+            final_info[4 * e + 1] = (int32_t)j;
+            final_info[4 * e + 2] = (int32_t)state[5 * R * C + 1];
+            final_info[4 * e + 3] = (int32_t)player;
+        }
+        free(state); free(mask); free(obs); free(fobs);
+    }
+    return total;
+}

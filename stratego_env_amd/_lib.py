@@ -14,7 +14,7 @@ PO_OBS_CHANNELS = 67
 FO_OBS_CHANNELS = 79
 PO_OBS_CHANNELS_ORIGINAL = 32
 FO_OBS_CHANNELS_ORIGINAL = 33
-ABI_VERSION = 8
+ABI_VERSION = 9
 STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, STEP_ORIGINAL_CHANNELS = 1, 2, 4, 8, 16
 STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
 OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
@@ -22,8 +22,8 @@ OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_supports_geometry', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
-    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_setup_table', 'sgx_reset',
-    'sgx_observe', 'sgx_time_observe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_step_n', 'sgx_rollout', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
+    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_nt_stores', 'sgx_set_setup_table', 'sgx_reset',
+    'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_step_n', 'sgx_rollout', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
 )
 
 
@@ -44,7 +44,8 @@ class SgxOutputs(C.Structure):
     _fields_ = [('obs_dev', C.c_void_p), ('fobs_dev', C.c_void_p), ('mask_dev', C.c_void_p),
                 ('obs_bytes', C.c_int64), ('fobs_bytes', C.c_int64), ('mask_bytes', C.c_int64), ('peak_extra_bytes', C.c_int64),
                 ('n_trials', C.c_int32), ('n_ftrials', C.c_int32),
-                ('trial_us', C.c_float * OUT_MAX_TRIALS), ('ftrial_us', C.c_float * OUT_MAX_TRIALS)]
+                ('trial_us', C.c_float * OUT_MAX_TRIALS), ('ftrial_us', C.c_float * OUT_MAX_TRIALS),
+                ('device', C.c_int32), ('reserved_', C.c_int32)]
 
 
 class SgxError(RuntimeError):
@@ -80,6 +81,8 @@ def _bind(L):
     L.sgx_create.argtypes = [C.POINTER(SgxConfig), i64, C.c_int, u64, i64, C.POINTER(vp)]
     L.sgx_destroy.restype = C.c_int
     L.sgx_destroy.argtypes = [vp]
+    L.sgx_set_nt_stores.restype = C.c_int
+    L.sgx_set_nt_stores.argtypes = [vp, C.c_int32]
     L.sgx_set_setup_table.restype = C.c_int
     L.sgx_set_setup_table.argtypes = [vp, vp, i64]
     L.sgx_reset.restype = C.c_int
@@ -88,6 +91,8 @@ def _bind(L):
     L.sgx_observe.argtypes = [vp, vp, vp, vp, vp, C.c_int32, vp]
     L.sgx_time_observe.restype = C.c_int
     L.sgx_time_observe.argtypes = [vp, vp, vp, C.c_int32, vp, C.POINTER(C.c_float)]
+    L.sgx_mem_probe.restype = C.c_int
+    L.sgx_mem_probe.argtypes = [C.c_int, vp, i64, C.c_int32, vp, C.POINTER(C.c_float)]
     L.sgx_alloc_outputs.restype = C.c_int
     L.sgx_alloc_outputs.argtypes = [vp, C.c_int32, i64, C.c_int32, vp, C.POINTER(SgxOutputs)]
     L.sgx_free_outputs.restype = C.c_int

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
     const int tid = threadIdx.x;
     const int64_t env = blockIdx.x;
     if (env >= P.n_envs) return;
-    if (tid == 0) altered = 0;
+    if (tid == 0) altered = 0;     // (ordered before every `altered = 1` below by the __syncthreads() that follows the img clear)
     int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
     const int64_t *s = in + env * (int64_t)(SGX_STATE_LAYERS * RC);
     // all of the thread's loads first (the scatter below is branchy, the compiler would otherwise wait for each load in turn:

@@ -134,6 +134,7 @@ struct KParams {
     sgx_step_io io;
     int32_t mode;  // 0 = step, 1 = observe
     int64_t env_first;  // this launch plays envs [env_first, n_envs) of the handle (sgx_rollout splits a batch over concurrent chains)
+    int32_t map_mode, map_arg;   // experiment only: see group_of_block
     int32_t nt_stores;  // the launch's observations do not fit the Infinity Cache: whole lines leave as non-temporal stores (sgx_obs.h)
     // functional-API instantiation only (sgx_expand): game i is read from record src_index[i] (i when NULL) of ANOTHER handle's
     // records and written to record i of this one, whether or not the move was valid
@@ -245,9 +246,19 @@ __device__ inline int quad_sum(int x) {
 
 // XCD-aware block -> env map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
 // range of envs so neighbouring envs' output lines meet in one L2.
-__device__ inline int64_t group_of_block() {
+__device__ inline int64_t group_of_block(int map_mode = 0, int map_arg = 0) {
     const int64_t nb = gridDim.x, b = blockIdx.x;
-    return (b & 7) * (nb >> 3) + (b >> 3);   // grid is a multiple of 8
+    if (map_mode == 0) return (b & 7) * (nb >> 3) + (b >> 3);   // grid is a multiple of 8
+    // experiment modes (SGX_MAP, tools/microbench/map_probe.cpp): how the launch time depends on where the eight XCDs' write fronts
+    // are relative to each other
+    const int64_t per = nb >> 3, x = b & 7, i = b >> 3;
+    if (map_mode == 1) return b;                                                        // linear: one front
+    if (map_mode == 2) { const int64_t s = map_arg; return (i / s) * (8 * s) + x * s + (i % s); }   // stripes of s workgroups per XCD (s divides nb / 8)
+    if (map_mode == 3) return x * per + (i + x * (int64_t)map_arg) % per;             // XCD ranges, every front started at another phase
+    if (map_mode == 4) return x * per + (per - 1 - i);                                  // XCD ranges walked downwards
+    if (map_mode == 5) return x * per + ((x & 1) ? per - 1 - i : i);                   // neighbouring XCDs walk towards each other
+    if (map_mode == 6) { const int64_t f = map_arg, sub = per / f; return x * per + (i % f) * sub + (i / f); }   // f sub-fronts per XCD (f divides nb / 8)
+    return (b & 7) * (nb >> 3) + (b >> 3);
 }
 
 // Orders the LDS phases of ONE wave (each wave owns its game's LDS region; waves of a workgroup never exchange

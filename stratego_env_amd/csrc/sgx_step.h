@@ -267,9 +267,8 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
                 const int dist = (er != sr) ? abs(er - sr) : abs(ec - sc_);
                 if (t == SP_SCOUT) {
                     const int stepc = (er != sr) ? ((er > sr) ? C : -C) : ((ec > sc_) ? 1 : -1);
-                    const int k = lane + 1;  // lanes 0.. check the intermediate cells
-                    bool blk = false;
-                    if (k < dist) { const int m = s + k * stepc; blk = own[m] != 0 || enemy[m] != 0 || obst[m] != 0; }
+                    bool blk = false;        // lanes check the intermediate cells (a board side can exceed LPG + 1 cells: loop)
+                    for (int k = lane + 1; k < dist; k += G::LPG) { const int m = s + k * stepc; blk = blk || own[m] != 0 || enemy[m] != 0 || obst[m] != 0; }
                     if (gballot<G>(blk) != 0ull) valid = false;
                 } else if (dist > 1) valid = false;
             }
@@ -468,7 +467,7 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     __shared__ alignas(16) uint8_t shared[shared_table_bytes<G, KIND>()];
     __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS + COMBAT_BYTES];    // obstacle map, then the combat outcome table
     const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;     // lane inside the game, game inside the workgroup
-    const int64_t env = P.env_first + group_of_block() * (G::WPB * G::GPW) + slot;
+    const int64_t env = P.env_first + group_of_block(P.map_mode, P.map_arg) * (G::WPB * G::GPW) + slot;
     // The game's record and action are requested FIRST: the reads fly while the workgroup stages its shared tables (another
     // global round trip) and waits at the barrier -- the two round trips used to follow each other.
     const GameInput in = load_game<G, MAPPED>(P, env, lane);

@@ -47,6 +47,7 @@ int fail(int code, const char *fmt, const char *detail = "") {
 #include "sgx_setup.h"
 #include "sgx_step.h"
 #include "sgx_aux_kernels.h"
+#include "sgx_mem.h"
 
 
 // =============================================================================================
@@ -67,6 +68,8 @@ struct sgx_env {
     int max_events;
     int K;
     unsigned long long *stamps;  // SGX_STAMPS builds only
+    int map_mode, map_arg;       // SGX_MAP experiment (group_of_block)
+    int nt_mode;                 // sgx_set_nt_stores: -1 = by the launch's output size, 0 = never, 1 = always
     hipStream_t chain_stream[SGX_MAX_CHAINS];   // sgx_rollout: created on first use
     hipEvent_t chain_fork, chain_join[SGX_MAX_CHAINS];
 };
@@ -137,6 +140,8 @@ int check_cfg(const sgx_config *cfg) {
     int total = 0;
     for (int i = 0; i < 12; ++i) {
         if (cfg->piece_counts[i] < 0) return fail(SGX_EINVAL, "negative piece count%s");
+        // a capture event counts the pieces of one type captured on one cell in 3 bits (sgx_layout.h): 8 = the scouts of Standard
+        if (cfg->piece_counts[i] > EV_COUNT_MAX) return fail(SGX_EINVAL, "more than 8 pieces of one type per side%s");
         total += cfg->piece_counts[i];
     }
     if (total > cfg->usable_rows * cfg->cols) return fail(SGX_EINVAL, "more pieces than usable cells%s");
@@ -311,6 +316,12 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     h->device = device;
     h->seed = seed;
     h->env_id_offset = env_id_offset;
+    h->nt_mode = -1;
+    if (const char *e = getenv("SGX_NT")) {           // SGX_NT=0|1|auto: the default of sgx_set_nt_stores for new handles
+        if (!strcmp(e, "0")) h->nt_mode = 0;
+        else if (!strcmp(e, "1")) h->nt_mode = 1;
+    }
+    if (const char *e = getenv("SGX_MAP")) { h->map_mode = atoi(e); if (const char *c = strchr(e, ',')) h->map_arg = atoi(c + 1); }
     const int rc_cells = cfg->rows * cfg->cols;
     {
         int pieces = 0;
@@ -379,6 +390,12 @@ SGX_API int sgx_destroy(sgx_env *h) {
     return SGX_OK;
 }
 
+SGX_API int sgx_set_nt_stores(sgx_env *h, int32_t mode) {
+    if (!h || mode < -1 || mode > 1) return fail(SGX_EINVAL, "sgx_set_nt_stores: mode must be -1 (auto), 0 or 1%s");
+    h->nt_mode = mode;
+    return SGX_OK;
+}
+
 SGX_API int sgx_set_setup_table(sgx_env *h, const uint8_t *table_host, int64_t n_setups) {
     if (!h || !table_host || n_setups <= 0 || n_setups > 0x7fffffff) return fail(SGX_EINVAL, "bad setup table%s");
     HIP_TRY(hipSetDevice(h->device));
@@ -421,7 +438,8 @@ static bool launch_streams_past_cache(const sgx_env *h, const KParams &p) {
 
 static int launch_step(sgx_env *h, const KParams &p_in, void *stream) {
     KParams p = p_in;
-    p.nt_stores = launch_streams_past_cache(h, p) ? 1 : 0;
+    p.map_mode = h->map_mode; p.map_arg = h->map_arg;
+    p.nt_stores = h->nt_mode < 0 ? (launch_streams_past_cache(h, p) ? 1 : 0) : h->nt_mode;
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
 #define CALL_STEP_KIND(R, C, KIND)                                                                 \
     do {                                                                                           \
@@ -493,6 +511,41 @@ SGX_API int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int3
     return rc;
 }
 
+// ---- device-memory probe
+namespace {
+// GB/s of `launches` probe launches over [ptr, ptr + bytes) (one untimed first touch); e0 / e1: scratch events
+int probe_range(void *ptr, int64_t bytes, int32_t launches, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, float *gbps) {
+    const int64_t n_seg = bytes / PROBE_SEG;
+    if (n_seg < 1) return fail(SGX_EINVAL, "sgx_mem_probe: range shorter than one 26 KiB segment%s");
+    const int64_t want = ((int64_t)1 << 30) / PROBE_SEG;                      // at least ~1 GiB of stores per launch
+    const int64_t passes = n_seg >= want ? 1 : (want + n_seg - 1) / n_seg, n_waves = n_seg * passes;
+    const unsigned grid = (unsigned)((((n_waves + 7) / 8) + 7) & ~(int64_t)7);
+    mem_probe_kernel<<<grid, 512, 0, stream>>>((char *)ptr, n_seg, n_waves);
+    HIP_TRY(hipEventRecord(e0, stream));
+    for (int i = 0; i < launches; ++i) mem_probe_kernel<<<grid, 512, 0, stream>>>((char *)ptr, n_seg, n_waves);
+    HIP_TRY(hipEventRecord(e1, stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *gbps = (float)((double)n_waves * PROBE_SEG * launches / (ms * 1e-3) / 1e9);
+    return SGX_OK;
+}
+}  // namespace
+
+SGX_API int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t launches, void *stream, float *gb_per_s) {
+    if (!ptr_dev || !gb_per_s || launches <= 0 || bytes <= 0) return fail(SGX_EINVAL, "sgx_mem_probe: bad argument%s");
+    if ((reinterpret_cast<uintptr_t>(ptr_dev) & 1023) != 0) return fail(SGX_EINVAL, "sgx_mem_probe: the range must start on a 1 KiB boundary%s");
+    HIP_TRY(hipSetDevice(device));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const int rc = probe_range(ptr_dev, bytes, launches, (hipStream_t)stream, e0, e1, gb_per_s);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 // ---- library-owned output buffers with a bounded placement trial
 namespace {
 
@@ -555,6 +608,12 @@ int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t 
         *n_trials = k + 1;
         if (us < best_us) { (void)hipFree(best); best = cand; best_us = us; *best_out = best; }
         else (void)hipFree(cand);
+        // Early stop: the classes lie >= 10 % apart; once the kept candidate beats the slowest one seen by
+        // that much the fast class has been found and more candidates would only cost start-up time.  (A run of equally slow
+        // candidates is no reason to stop: fast memory was found behind six and more slow candidates on several boxes.)
+        float worst = 0.f;
+        for (int j = 0; j <= k; ++j) worst = trial_us[j] > worst ? trial_us[j] : worst;
+        if (best_us < 0.91f * worst && k >= 2) break;
     }
     return SGX_OK;
 }
@@ -562,8 +621,9 @@ int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t 
 }  // namespace
 
 SGX_API int sgx_free_outputs(sgx_env *h, sgx_outputs *out) {
-    if (!h || !out) return fail(SGX_EINVAL, "NULL argument%s");
-    HIP_TRY(hipSetDevice(h->device));
+    if (!out) return fail(SGX_EINVAL, "NULL argument%s");
+    if (!out->obs_dev && !out->fobs_dev && !out->mask_dev) return SGX_OK;
+    HIP_TRY(hipSetDevice(h ? h->device : out->device));
     HIP_TRY(hipDeviceSynchronize());
     if (out->obs_dev) (void)hipFree(out->obs_dev);
     if (out->fobs_dev) (void)hipFree(out->fobs_dev);
@@ -577,6 +637,7 @@ SGX_API int sgx_alloc_outputs(sgx_env *h, int32_t flags, int64_t max_extra_bytes
     if (!h || !out) return fail(SGX_EINVAL, "NULL argument%s");
     if (flags & ~(SGX_OUT_FULL_OBS | SGX_STEP_ORIGINAL_CHANNELS)) return fail(SGX_EINVAL, "sgx_alloc_outputs: unknown flag%s");
     memset(out, 0, sizeof(*out));
+    out->device = h->device;
     HIP_TRY(hipSetDevice(h->device));
     const bool original = (flags & SGX_STEP_ORIGINAL_CHANNELS) != 0, full = (flags & SGX_OUT_FULL_OBS) != 0;
     const int64_t cells = (int64_t)h->cfg.rows * h->cfg.cols;
@@ -719,7 +780,10 @@ SGX_API int sgx_copy_envs(sgx_env *dst, const int32_t *dst_index_dev, sgx_env *s
     if (!dst || !src) return fail(SGX_EINVAL, "handle is NULL%s");
     if (int rc = same_variant(dst, src)) return rc;
     if (n < 0 || (!dst_index_dev && n > dst->n_envs) || (!src_index_dev && n > src->n_envs)) return fail(SGX_EINVAL, "n out of range%s");
-    if (n == 0) return SGX_OK;
+    // inside one pool a wave may read a record another wave of the same launch rewrites: only the identity copy is race-free
+    if (dst == src && (dst_index_dev || src_index_dev))
+        return fail(SGX_EINVAL, "sgx_copy_envs: an indexed copy inside one handle would race; stage through a second handle%s");
+    if (n == 0 || dst == src) return SGX_OK;
     HIP_TRY(hipSetDevice(dst->device));
     copy_records_kernel<<<(unsigned)((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(dst->boards, dst_index_dev, src->boards, src_index_dev, dst->rec_bytes, n);
     HIP_TRY(hipGetLastError());
@@ -731,6 +795,10 @@ SGX_API int sgx_expand(sgx_env *dst, sgx_env *src, const int32_t *src_index_dev,
     if (!io->actions_dev) return fail(SGX_EINVAL, "actions_dev is NULL%s");
     if (int rc = same_variant(dst, src)) return rc;
     if (!src_index_dev && src->n_envs < dst->n_envs) return fail(SGX_EINVAL, "without src_index_dev the source handle needs at least as many envs%s");
+    // wave i reads record src_index[i] while another wave of the same launch rewrites that record: in-place expansion through an
+    // index (a gather or a permutation) would silently mix parents and children
+    if (src == dst && src_index_dev)
+        return fail(SGX_EINVAL, "sgx_expand: src == dst with an index array would race; expand into a second handle%s");
     if (io->auto_reset) return fail(SGX_EINVAL, "sgx_expand does not auto-reset%s");
     if (io->fobs_dev || io->final_fobs_dev || (io->flags & SGX_STEP_ORIGINAL_CHANNELS))
         return fail(SGX_EINVAL, "sgx_expand renders the 67-channel partial observation only%s");

@@ -348,6 +348,8 @@ class PackedStates:
     def copy_from(self, src, src_index=None, dst_index=None, n=None):
         """records src[src_index[i]] -> self[dst_index[i]] (index tensors int32 on the device, None = identity)."""
         vec = self._vec
+        if src is self and (src_index is not None or dst_index is not None):
+            raise ValueError("an indexed copy inside one pool would race (records read and rewritten by one launch): copy into another pool")
         si = None if src_index is None else torch.as_tensor(src_index).to(device=self.device, dtype=torch.int32).contiguous()
         di = None if dst_index is None else torch.as_tensor(dst_index).to(device=self.device, dtype=torch.int32).contiguous()
         if n is None:
@@ -363,6 +365,9 @@ class PackedStates:
         the slot holds a copy of the parent.  mask_1d_out: optional uint8 [n, action_size] receiving the successors'
         get_valid_moves_as_1d_mask in the same launch."""
         vec = self._vec
+        if parents is self and parent_index is not None:
+            raise ValueError("in-place expansion through parent_index would race (a parent may be overwritten before it is read): "
+                             "expand into another pool")
         a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.n).contiguous()
         pi = None if parent_index is None else torch.as_tensor(parent_index).to(device=self.device, dtype=torch.int32).reshape(self.n).contiguous()
         flags = _lib.STEP_ACTIONS_1D | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)

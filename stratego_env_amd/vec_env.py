@@ -31,17 +31,34 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _OutputsOwner:
+    """One sgx_alloc_outputs allocation.  It is freed when the LAST reference goes: the env holds one, and so does every tensor
+    that views the buffers (torch keeps the object behind __cuda_array_interface__ alive as long as the tensor's storage), so a
+    tensor handed out by step() / rollout_steps() / observe() stays valid after env.close(), `del env` or another
+    tune_placement() -- like the torch-owned buffers it replaces."""
+
+    def __init__(self, lib, out):
+        self._L, self.out = lib, out
+
+    def __del__(self):
+        try:
+            self._L.sgx_free_outputs(None, C.byref(self.out))      # (works without the handle: the record names its device)
+        except Exception:
+            pass
+
+
 class _DeviceBuffer:
     """A library-owned device allocation seen through __cuda_array_interface__ (zero-copy into a torch tensor)."""
 
-    def __init__(self, ptr, shape, typestr):
+    def __init__(self, ptr, shape, typestr, owner):
+        self._owner = owner
         self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2,
                                          'strides': None}
 
 
-def _wrap_device(ptr, shape, dtype, device):
+def _wrap_device(ptr, shape, dtype, device, owner):
     typestr = {torch.float32: '<f4', torch.uint8: '|u1'}[dtype]
-    t = torch.as_tensor(_DeviceBuffer(ptr, shape, typestr), device=device)
+    t = torch.as_tensor(_DeviceBuffer(ptr, shape, typestr, owner), device=device)
     assert t.data_ptr() == int(ptr) and t.dtype == dtype
     return t
 
@@ -103,6 +120,10 @@ class VecStrategoEnv:
     # ---- lifecycle -----------------------------------------------------------------------------------
     def close(self):
         if getattr(self, '_h', None):
+            if getattr(self, '_outputs_owner', None) is not None:
+                # library-owned buffers: the env lets go of its views too, so that the memory is freed now unless the caller still
+                # holds a tensor of it (which then stays valid)
+                self.obs = self.mask = self.fobs = None
             self._release_outputs()
             self._L.sgx_destroy(self._h)
             self._h = None
@@ -115,6 +136,17 @@ class VecStrategoEnv:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_nt_stores(self, mode='auto'):
+        """Store policy of the observation writes (sgx_set_nt_stores): 'auto' (by the launch's output size), False or True.
+        Results are identical in every mode; it only moves the launch time."""
+        if mode is None or mode == 'auto' or (mode == -1 and mode is not True):
+            m = -1
+        elif mode is True or mode is False or mode in (0, 1):
+            m = int(mode)
+        else:
+            raise ValueError("set_nt_stores: 'auto', True or False")
+        _lib.check(self._L.sgx_set_nt_stores(self._h, m), self._L)
 
     # ---- API -----------------------------------------------------------------------------------------
     def reset(self, p1_maps=None, p2_maps=None, env_select=None):
@@ -162,24 +194,23 @@ class VecStrategoEnv:
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_alloc_outputs(self._h, flags, int(max_extra_bytes), int(trials or _lib.OUT_MAX_TRIALS),
                                                  self._stream(), C.byref(out)), self._L)
-        self._release_outputs()
+        owner = _OutputsOwner(self._L, out)
+        self._outputs_owner = owner          # replaces the env's reference to an earlier allocation (its tensors keep theirs)
         self._outputs = out
         N, R, Cc, K = self.num_envs, self.R, self.Cc, self.K
-        self.obs = _wrap_device(out.obs_dev, (N, R, Cc, self.p_channels), torch.float32, self.device)
-        self.mask = _wrap_device(out.mask_dev, (N, R, Cc, K), torch.uint8, self.device)
+        self.obs = _wrap_device(out.obs_dev, (N, R, Cc, self.p_channels), torch.float32, self.device, owner)
+        self.mask = _wrap_device(out.mask_dev, (N, R, Cc, K), torch.uint8, self.device, owner)
         report = {'obs': [float(x) for x in out.trial_us[:out.n_trials]]}
         if out.fobs_dev:
-            self.fobs = _wrap_device(out.fobs_dev, (N, R, Cc, self.f_channels), torch.float32, self.device)
+            self.fobs = _wrap_device(out.fobs_dev, (N, R, Cc, self.f_channels), torch.float32, self.device, owner)
             report['fobs'] = [float(x) for x in out.ftrial_us[:out.n_ftrials]]
         self.placement_peak_extra_bytes = int(out.peak_extra_bytes)
         self.observe()
         return report
 
     def _release_outputs(self):
-        """Frees library-owned output buffers (tensors wrapping them must not be used afterwards)."""
-        out = getattr(self, '_outputs', None)
-        if out is not None and getattr(self, '_h', None):
-            self._L.sgx_free_outputs(self._h, C.byref(out))
+        """Drops the env's own reference to library-owned output buffers; they are freed when the last tensor viewing them goes."""
+        self._outputs_owner = None
         self._outputs = None
 
     def step(self, actions, want_next_actions=False, emit_obs=True, emit_mask=True, flags=0):

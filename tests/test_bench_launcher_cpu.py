@@ -92,3 +92,21 @@ def test_measured_run_refuses_to_run_without_a_gpu():
     assert p.returncode != 0 and 'no CPU fallback' in (p.stderr + p.stdout)
     p = _run(['--gpus', '2', '--steps', '2', '--warmup', '1'])          # the launcher counts devices before starting ranks
     assert p.returncode != 0 and 'GPU(s) are visible' in (p.stderr + p.stdout)
+
+
+def test_defaults_follow_the_baseline_configs_and_the_parent_never_loads_torch():
+    """--gpus 1: 65,536 games (BASELINE config 2); --gpus N > 1: 262,144 games per GPU (config 5: 2,097,152 on 8 GPUs) plus the
+    strong-scaling leg of 2,097,152 games in total; the launcher parent counts GPUs from sysfs without importing torch."""
+    p = _run(['--gpus', '1', '--dry-run', '--steps', '2', '--warmup', '1'])
+    assert p.returncode == 0, p.stderr
+    d = _json_lines(p.stdout)[0]
+    assert d['config']['games_per_gpu'] == 65536 and d['config']['strong_leg_total_games'] == 0
+    p = _run(['--gpus', '2', '--dry-run', '--steps', '2', '--warmup', '1'])
+    assert p.returncode == 0, p.stderr
+    d = _json_lines(p.stdout)[0]
+    assert d['config']['games_per_gpu'] == 262144 and d['config']['total_games'] == 524288
+    assert d['config']['strong_leg_total_games'] == 2097152
+    code = ("import sys; sys.path.insert(0, %r); import bench; n = bench.visible_gpus(); "
+            "assert isinstance(n, int) and n >= 0; assert 'torch' not in sys.modules; print('ok', n)" % ROOT)
+    q = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
+    assert q.returncode == 0 and q.stdout.startswith('ok'), q.stderr
