@@ -137,6 +137,9 @@ def parse_args(argv=None):
                          '0 = skip; pass it explicitly to get the leg on one GPU)')
     ap.add_argument('--version', default='barrage')
     ap.add_argument('--unfused', action='store_true', help='sample actions with the standalone sampler kernel')
+    ap.add_argument('--full-obs', action='store_true',
+                    help="BOTH_OBSERVATIONS (the reference's default observation mode): the 79-channel fully-observable observation is "
+                         "written next to the partial one (profiling runs of that workload; the headline is PARTIALLY_OBSERVABLE)")
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-workloads', action='store_true',
@@ -154,6 +157,8 @@ def parse_args(argv=None):
     ap.add_argument('--chains', type=int, default=1,
                     help='sgx_rollout: split the batch into this many ranges of games whose launches overlap on streams of their own '
                          '(1 = sgx_step_n, one launch per step: what the headline uses, so that the per-launch figures are per step)')
+    ap.add_argument('--no-two-chains', action='store_true', help='skip the two-concurrent-chains leg after the headline (profiling runs: '
+                    'keeps the kernel statistics to one launch shape)')
     ap.add_argument('--verify-envs', type=int, default=32,
                     help='envs per rank checked against the CPU oracle after the timed region (0 = off)')
     ap.add_argument('--devices', default=None,
@@ -576,21 +581,24 @@ def run_rank(args):
 
     from stratego_env_amd.config import VARIANTS
     v = VARIANTS[args.version]
-    env = make_env(args.version, n, first, rk.device_index)
+    env = make_env(args.version, n, first, rk.device_index, full_obs=args.full_obs)
     placement = place_outputs(env, args)
     elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains)
     assert invalid == 0, "rollout produced invalid actions"
+    # outside the timed region: the envs that were just timed against the CPU oracle, and the sharding-independent checksum
+    checked = verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if args.verify_envs else 0
+    verified_steps = env.bench_steps_played
+    _, (checked, checksum) = rk.reduce([], [checked, outputs_checksum(env)])
     two_chains = None
-    if rk.world == 1 and args.chains == 1 and not args.unfused:
+    if rk.world == 1 and args.chains == 1 and not args.unfused and not args.no_two_chains:
         # The same K steps with the batch split into two ranges of games whose launches overlap (sgx_rollout, chains = 2): reported
         # next to the headline, which stays one launch per step so that its per-launch figures can be checked against a kernel trace.
         e2, d2, _, _, inv2 = time_workload(rk, env, args.steps, args.warmup, False, 2)
         assert inv2 == 0
         two_chains = {"chains": 2, "value": total * args.steps / e2, "us_per_step": d2 / args.steps * 1e3,
-                      "frac_algorithmic": b_alg(v.rows, v.columns) * n / (d2 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
-    # outside the timed region: the envs that were just timed against the CPU oracle, and the sharding-independent checksum
-    checked = verify_against_oracle(env, args.version, args.verify_envs) if args.verify_envs else 0
-    _, (checked, checksum) = rk.reduce([], [checked, outputs_checksum(env)])
+                      "frac_algorithmic": b_alg(v.rows, v.columns, args.full_obs) * n / (d2 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS,
+                      "verified_envs": verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if args.verify_envs else 0,
+                      "verified_steps": env.bench_steps_played}
 
     out = None
     if rk.rank == 0:
@@ -601,12 +609,13 @@ def run_rank(args):
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_envs else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "verified_envs": checked, "verified_steps": env.bench_steps_played,
-            "config": {"workload": "%d concurrent %s games per GPU (%dx%d), random-valid-action rollout with auto-reset, "
+            "verified_envs": checked, "verified_steps": verified_steps,
+            "config": {"workload": "%d concurrent %s games per GPU (%dx%d)%s, random-valid-action rollout with auto-reset, "
                                    "%s step+sample" % (n, args.version, v.rows, v.columns,
+                                                       ", BOTH_OBSERVATIONS (67 + 79 channels)" if args.full_obs else "",
                                                        "separate" if args.unfused else "fused"),
                        "games_per_gpu": n, "total_games": total, "version": args.version, "seed": BASE_SEED,
-                       "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns),
+                       "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns, args.full_obs),
                        "concurrent_chains": args.chains, "two_chains": two_chains,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),
                        "reduction_backend": backend if rk.world > 1 else None, "devices": args.devices,
@@ -616,7 +625,8 @@ def run_rank(args):
                        "outputs_checksum": checksum,
                        # sgx_alloc_outputs' report: observe-launch time on the plain first allocation and on the candidate it kept
                        "placement": placement},
-            "roofline": roofline(args.version, v, n, launch_s, args.traffic_bytes, first_us=(placement or {}).get('plain_us')),
+            "roofline": roofline(args.version, v, n, launch_s, args.traffic_bytes, full_obs=args.full_obs,
+                                 first_us=(placement or {}).get('fobs_plain_us' if args.full_obs else 'plain_us')),
         }
     env.close()
     del env

@@ -55,7 +55,10 @@ typedef struct sgx_config {
     int32_t rows, cols;               /* >= 3 each (penv:28-30), rows*cols <= SGX_MAX_CELLS */
     int32_t max_turns;                /* config 'max_turns' -> StateData.MAX_TURNS (impl:247) */
     int32_t usable_rows;              /* config 'initial_state_usable_rows' */
-    int32_t piece_counts[12];         /* config 'piece_amounts' for piece codes 1..12 (SPY..BOMB) */
+    int32_t piece_counts[12];         /* config 'piece_amounts' for piece codes 1..12 (SPY..BOMB), <= 8 each */
+    int32_t capture_capacity;         /* most pieces ONE side can have on the board, 0 = sum of piece_counts.  An env_config that
+                                         overrides 'piece_amounts' changes the normalisation constants only (maenv:323-326, 370-382)
+                                         while the setups keep the version's pieces: sizes the capture-event list */
     uint8_t obstacles[SGX_MAX_CELLS]; /* config 'obstacle_locations' as a row-major rows*cols 0/1 map */
 } sgx_config;
 

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
 
 class SgxConfig(C.Structure):
     _fields_ = [('rows', C.c_int32), ('cols', C.c_int32), ('max_turns', C.c_int32), ('usable_rows', C.c_int32),
-                ('piece_counts', C.c_int32 * 12), ('obstacles', C.c_uint8 * SGX_MAX_CELLS)]
+                ('piece_counts', C.c_int32 * 12), ('capture_capacity', C.c_int32), ('obstacles', C.c_uint8 * SGX_MAX_CELLS)]
 
 
 class SgxStepIO(C.Structure):
@@ -169,6 +169,7 @@ def make_config(variant) -> SgxConfig:
     cfg.usable_rows = variant.initial_state_usable_rows
     for i, n in enumerate(variant.piece_counts):
         cfg.piece_counts[i] = n
+    cfg.capture_capacity = int(getattr(variant, 'capture_capacity', 0))
     for r, c in variant.obstacle_locations:
         cfg.obstacles[r * variant.columns + c] = 1
     return cfg

@@ -36,6 +36,9 @@ class Variant:
     piece_counts: Tuple[int, ...]          # index t-1 holds the count of piece code t (1..12)
     initial_state_usable_rows: int
     human_inits: str = ''                  # name of the packed Gravon table, '' if unsupported (util.py:305-310)
+    capture_capacity: int = 0              # most pieces one side may have on the board when that exceeds sum(piece_counts): an
+    #                                        env_config that overrides `piece_amounts` changes the normalisation only (maenv:323-326,
+    #                                        370-382), the setups keep the version's pieces; sizes the capture-event list
 
     @property
     def cells(self) -> int:
@@ -62,6 +65,10 @@ class Variant:
     @property
     def pieces_per_side(self) -> int:
         return int(sum(self.piece_counts))
+
+    @property
+    def max_pieces_on_board(self) -> int:
+        return max(self.pieces_per_side, int(self.capture_capacity))
 
     def piece_amounts(self) -> Dict[int, int]:
         """{piece code: count}, the reference's `piece_amounts` keyed by code instead of the SP enum."""
@@ -110,7 +117,7 @@ MAX_PIECES_PER_TYPE = 8       # EV_COUNT_MAX of the packed record (csrc/sgx_layo
 
 
 def custom_variant(rows, columns, max_turns=2000, obstacle_locations=(), piece_counts=None, initial_state_usable_rows=None,
-                   name=None) -> Variant:
+                   name=None, human_inits='', capture_capacity=0) -> Variant:
     """A variant the reference has no name for: any board of rows, columns >= 3 (the reference's StrategoProceduralEnv takes any
     size, penv:27-36).  Without piece_counts the side gets one of each movable rank that fits plus a flag -- the count only sizes
     the capture-event list and the random setups; the functional API works on the caller's states."""
@@ -131,7 +138,19 @@ def custom_variant(rows, columns, max_turns=2000, obstacle_locations=(), piece_c
     if max(piece_counts) > MAX_PIECES_PER_TYPE:
         raise ValueError("at most %d pieces of one type per side (got %s)" % (MAX_PIECES_PER_TYPE, list(piece_counts)))
     return Variant(name or 'custom_%dx%d' % (rows, columns), rows, columns, int(max_turns), tuple(tuple(x) for x in obstacle_locations),
-                   tuple(int(x) for x in piece_counts), usable, '')
+                   tuple(int(x) for x in piece_counts), usable, human_inits, int(capture_capacity))
+
+
+def piece_counts_from_amounts(piece_amounts) -> Tuple[int, ...]:
+    """The reference's `piece_amounts` dict (keys: SP members, piece codes or SP names) -> counts of piece codes 1..12."""
+    from .enums import SP
+    counts = [0] * NUM_PIECE_TYPES
+    for k, n in dict(piece_amounts).items():
+        code = k.value if isinstance(k, SP) else (SP[k].value if isinstance(k, str) else int(getattr(k, 'value', k)))
+        if not 1 <= code <= NUM_PIECE_TYPES:
+            raise ValueError("piece_amounts key %r is not a piece" % (k,))
+        counts[code - 1] = int(n)
+    return tuple(counts)
 
 
 def get_variant(version) -> Variant:

@@ -144,11 +144,22 @@ int check_cfg(const sgx_config *cfg) {
         if (cfg->piece_counts[i] > EV_COUNT_MAX) return fail(SGX_EINVAL, "more than 8 pieces of one type per side%s");
         total += cfg->piece_counts[i];
     }
-    if (total > cfg->usable_rows * cfg->cols) return fail(SGX_EINVAL, "more pieces than usable cells%s");
+    // (more pieces than usable cells is legal for a handle that never samples random setups: an env_config that overrides
+    //  'piece_amounts' changes the normalisation only; sgx_reset checks it where it matters)
+    if (cfg->capture_capacity < 0 || 2 * cfg->capture_capacity > cfg->rows * cfg->cols) return fail(SGX_EINVAL, "capture_capacity out of range%s");
     return SGX_OK;
 }
 
 }  // namespace
+
+// sampled setups without a table place piece_counts pieces on the usable back rows: they have to fit
+static int check_random_setups(const sgx_env *h) {
+    if (h->setups) return SGX_OK;
+    int total = 0;
+    for (int i = 0; i < 12; ++i) total += h->cfg.piece_counts[i];
+    if (total > h->cfg.usable_rows * h->cfg.cols) return fail(SGX_EINVAL, "random setups: more pieces than usable cells%s");
+    return SGX_OK;
+}
 
 SGX_API int sgx_abi_version(void) { return SGX_ABI_VERSION; }
 SGX_API int sgx_supports_geometry(int32_t rows, int32_t cols) { return supported_geometry(rows, cols) ? 1 : 0; }
@@ -326,6 +337,7 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     {
         int pieces = 0;
         for (int i = 0; i < 12; ++i) pieces += cfg->piece_counts[i];
+        if (cfg->capture_capacity > pieces) pieces = cfg->capture_capacity;
         h->max_events = 2 * pieces;                                   // every piece can be captured once
         const int st_off = (STORED_BOARDS * ((rc_cells + 3) & ~3) + 15) & ~15, sb = (((rc_cells + 7) / 8) + 15) & ~15;
         const int sc_off = st_off + 2 * sb;
@@ -412,6 +424,8 @@ SGX_API int sgx_set_setup_table(sgx_env *h, const uint8_t *table_host, int64_t n
 SGX_API int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p1_maps_dev, const int8_t *p2_maps_dev, void *stream) {
     if (!h) return fail(SGX_EINVAL, "handle is NULL%s");
     if ((p1_maps_dev == nullptr) != (p2_maps_dev == nullptr)) return fail(SGX_EINVAL, "pass both piece maps or neither%s");
+    if (!p1_maps_dev)
+        if (int rc = check_random_setups(h)) return rc;
     HIP_TRY(hipSetDevice(h->device));
     ResetParams rp;
     rp.k = make_params(h);
@@ -438,6 +452,8 @@ static bool launch_streams_past_cache(const sgx_env *h, const KParams &p) {
 
 static int launch_step(sgx_env *h, const KParams &p_in, void *stream) {
     KParams p = p_in;
+    if (p.mode == 0 && p.io.auto_reset)
+        if (int rc = check_random_setups(h)) return rc;
     p.map_mode = h->map_mode; p.map_arg = h->map_arg;
     p.nt_stores = h->nt_mode < 0 ? (launch_streams_past_cache(h, p) ? 1 : 0) : h->nt_mode;
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;

@@ -87,19 +87,47 @@ def load_curriculum_start_states(path):
         return np.asarray(f['state']), np.asarray(f['winner'])
 
 
+def resolve_variant(env_config, human_inits=None):
+    """(variant of the games, variant of the SETUPS) for an env_config.
+
+    The reference merges env_config OVER the version's config dict (maenv:320-323, with_base_config maenv:72-77), so a caller may
+    override single variant fields -- and only some code paths honour them (reproduced; tests/golden/facade_overrides.json):
+      rows / columns / piece_amounts   the merged values: board of the operator object and observation normalisation (maenv:325-329,
+                                       370-382); the SETUPS keep the version's pieces (random: VERSION_CONFIGS, maenv:347-349;
+                                       human: the Gravon strings), so piece_amounts changes the normalisation only;
+      max_turns / obstacle_locations   honoured with human_inits (get_random_human_init_fn gets the merged dict, maenv:336-338);
+                                       the random and the curriculum paths read VERSION_CONFIGS[version] (maenv:340-349);
+      initial_state_usable_rows        read by nothing but the random path, i.e. from VERSION_CONFIGS: no effect."""
+    user = env_config if env_config else {}
+    base = get_variant(user.get('version', DEFAULT_CONFIG['version']))
+    if human_inits is None:
+        human_inits = user.get('human_inits', DEFAULT_CONFIG['human_inits'])
+    ref_cfg = base.as_reference_config()
+    overridden = [k for k in ('rows', 'columns', 'max_turns', 'obstacle_locations', 'piece_amounts', 'initial_state_usable_rows')
+                  if k in user and user[k] != ref_cfg[k]]
+    if not overridden:
+        return base, base
+    from .config import custom_variant, piece_counts_from_amounts
+    merged = {k: (user[k] if k in user else ref_cfg[k]) for k in ref_cfg}
+    init_src = merged if human_inits else ref_cfg
+    counts = piece_counts_from_amounts(merged['piece_amounts'])
+    rows, columns = int(merged['rows']), int(merged['columns'])
+    obstacles = [tuple(x) for x in init_src['obstacle_locations'] if x[0] < rows and x[1] < columns]
+    variant = custom_variant(rows, columns, max_turns=init_src['max_turns'], obstacle_locations=obstacles, piece_counts=counts,
+                             initial_state_usable_rows=min(base.initial_state_usable_rows, max(1, rows // 2)),
+                             name='%s_overridden_%s' % (base.name, '_'.join(overridden)), human_inits=base.human_inits,
+                             capture_capacity=min(max(sum(counts), base.pieces_per_side), rows * columns // 2))
+    return variant, base
+
+
 class StrategoMultiAgentEnv:
 
     def __init__(self, env_config=None, device=0):
         cfg = copy.deepcopy(DEFAULT_CONFIG)
         cfg.update(env_config if env_config else {})
-        self.variant = get_variant(cfg['version'])
+        # (variant the kernels run, variant the setup functions see): differ when env_config overrides fields of the version's config
+        self.variant, self._setup_variant = resolve_variant(env_config, cfg['human_inits'])
         v = self.variant
-        # the reference merges env_config over the version's config dict (maenv:323), so a caller could override single variant
-        # fields (and only some code paths would honour them); variants are compiled-in constants here: refuse instead of diverging
-        overridden = [k for k in ('rows', 'columns', 'max_turns', 'obstacle_locations', 'piece_amounts', 'initial_state_usable_rows')
-                      if env_config and k in env_config and env_config[k] != self.variant.as_reference_config()[k]]
-        if overridden:
-            raise NotImplementedError("env_config overrides variant fields %s; pick one of the built game versions" % overridden)
         for key in ('vs_human', 'vs_bot'):
             if cfg[key]:
                 raise NotImplementedError("%s is outside the MI355X hot-path build (SURVEY.md section 8)" % key)
@@ -131,7 +159,7 @@ class StrategoMultiAgentEnv:
             raise ValueError("Human inits not supported with {} game version".format(v.name))   # util.py:310
         self._table = load_setup_table(v.human_inits) if self.human_inits else None
 
-        self._vec = VecStrategoEnv(v.name, 1, device=device, seed=0, human_inits=False, auto_reset=False, final_obs=True,
+        self._vec = VecStrategoEnv(v, 1, device=device, seed=0, human_inits=False, auto_reset=False, final_obs=True,
                                    full_obs=self._want_f, obs_channel_mode=cfg['obs_channel_mode'])
         self._p_obs_num_layers, self._f_obs_num_layers = self._vec.p_channels, self._vec.f_channels   # maenv:370-382
         original = not self._extended_channels
@@ -141,7 +169,7 @@ class StrategoMultiAgentEnv:
         self._f_obs_ranges, self._f_obs_mids = obs_norm.ranges_mids(self._f_obs_highs, self._f_obs_lows)   # maenv:393-396
         self._build_host_mirror()
         # the operator-level object the reference exposes (maenv:329); its one-game handle is created on first use
-        self.base_env = StrategoProceduralEnv(v.rows, v.columns, version=v.name, device=device)
+        self.base_env = StrategoProceduralEnv(v.rows, v.columns, version=v, device=device)
         self.rows, self.columns = v.rows, v.columns
         self.spatial_action_size = v.spatial_action_size
         self.action_size = v.action_size
@@ -185,9 +213,13 @@ class StrategoMultiAgentEnv:
 
     # ---- setup sampling with the reference's RNG consumption -------------------------------------------
     def _random_initial_maps(self):
-        v = self.variant
-        if self._fixed_maps is not None:
+        v = self._setup_variant          # the VERSION's config: the reference's setup functions never see overridden piece_amounts /
+        if self._fixed_maps is not None:  # usable rows (maenv:347-349, util.py:241-275)
             return self._fixed_maps
+        if (v.rows, v.columns) != (self.variant.rows, self.variant.columns):
+            # the reference builds the version's rows x columns piece maps and create_initial_state refuses them (penv:44-55)
+            raise ValueError("player_1_initial_piece_map (shape {}) is not the correct shape. (Should be {})".format(
+                (v.rows, v.columns), (self.variant.rows, self.variant.columns)))
         return sample_initial_maps_like_reference(v, self._table)
 
     # ---- state access -------------------------------------------------------------------------------------

@@ -162,7 +162,7 @@ class VecStrategoEnv:
             m1 = torch.as_tensor(p1_maps).to(device=self.device, dtype=torch.int8).contiguous().reshape(self.num_envs, -1)
             m2 = torch.as_tensor(p2_maps).to(device=self.device, dtype=torch.int8).contiguous().reshape(self.num_envs, -1)
             assert m1.shape[1] == self.R * self.Cc and m2.shape == m1.shape
-            pieces = sum(self.variant.piece_counts)      # the record's capture-event list holds 2 x pieces entries
+            pieces = self.variant.max_pieces_on_board    # the record's capture-event list holds 2 x pieces entries
             if int(torch.maximum((m1 != 0).sum(1).max(), (m2 != 0).sum(1).max())) > pieces:
                 raise ValueError("a piece map holds more pieces than the %s variant has (%d per side)" % (self.variant.name, pieces))
         with torch.cuda.device(self.device):

@@ -66,8 +66,28 @@ def test_curriculum_init_fn_draws_like_the_reference():
         assert winner in (1, -1) and state[5, 0, 0] == 0 and state[5, 1, 0] == VARIANTS['barrage'].max_turns
 
 
-def test_facade_refuses_per_env_variant_overrides():
+def test_env_config_overrides_follow_the_reference_merge():
+    """env_config merged over the version's config (maenv:320-323): which fields reach the games (resolve_variant; the replay of
+    reference-recorded episodes is tests/test_gpu_facade.py::test_facade_env_config_overrides_replay_reference_goldens)."""
     from stratego_env_amd import GameVersions
-    from stratego_env_amd.multiagent_env import StrategoMultiAgentEnv
-    with pytest.raises(NotImplementedError):
-        StrategoMultiAgentEnv({'version': GameVersions.BARRAGE, 'max_turns': 50})
+    from stratego_env_amd.enums import SP
+    from stratego_env_amd.config import VARIANTS
+    from stratego_env_amd.multiagent_env import resolve_variant
+    base = VARIANTS['barrage']
+    v, setup = resolve_variant({'version': GameVersions.BARRAGE})
+    assert v is base and setup is base
+    v, setup = resolve_variant({'version': GameVersions.BARRAGE, 'max_turns': 1000})            # equal to the version's: no override
+    assert v is base
+    # max_turns / obstacles count only with human_inits (the random path reads VERSION_CONFIGS, maenv:347-349)
+    v, setup = resolve_variant({'version': GameVersions.BARRAGE, 'max_turns': 50, 'obstacle_locations': [(4, 4)]})
+    assert (v.max_turns, v.obstacle_locations) == (base.max_turns, base.obstacle_locations) and setup is base
+    v, setup = resolve_variant({'version': GameVersions.BARRAGE, 'max_turns': 50, 'obstacle_locations': [(4, 4)], 'human_inits': True})
+    assert v.max_turns == 50 and v.obstacle_locations == ((4, 4),) and v.human_inits == 'barrage' and setup is base
+    # piece_amounts: normalisation only; the setups keep the version's 8 pieces, which the capture-event list must hold
+    v, setup = resolve_variant({'version': GameVersions.BARRAGE, 'piece_amounts': {SP.FLAG: 1, SP.SCOUT: 3}})
+    assert v.piece_counts == (0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0) and v.max_pieces_on_board == 8 and setup.piece_counts == base.piece_counts
+    assert v.captured_count_highs()[1] == 3 and v.captured_count_highs()[0] == 8
+    v, setup = resolve_variant({'version': GameVersions.TINY, 'rows': 5, 'columns': 4})
+    assert (v.rows, v.columns) == (5, 4) and (setup.rows, setup.columns) == (4, 4)
+    with pytest.raises(ValueError):
+        resolve_variant({'version': GameVersions.STANDARD, 'piece_amounts': {SP.SCOUT: 9, SP.FLAG: 1}})

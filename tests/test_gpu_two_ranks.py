@@ -37,7 +37,8 @@ def test_two_ranks_on_one_gpu_equal_one_rank_and_the_oracle(version, per_rank):
     assert two['config']['total_games'] == one['config']['total_games'] == 2 * per_rank
     assert two['config']['games_per_gpu'] == per_rank and two['scaling'] == 'weak'
     assert two['verified_envs'] >= 32 and one['verified_envs'] >= 16          # both ranks checked their sample against the oracle
-    assert two['verified_steps'] == 30 and one['verified_steps'] == 60     # (the 1-GPU line also plays the two-chains leg)
+    assert two['verified_steps'] == one['verified_steps'] == 30
+    assert one['config']['two_chains']['verified_steps'] == 60 and one['config']['two_chains']['verified_envs'] >= 16
     assert two['config']['outputs_checksum'] == one['config']['outputs_checksum']
     assert two['value'] > 0 and two['config']['per_gpu_value_min'] <= two['config']['per_gpu_value_max']
 

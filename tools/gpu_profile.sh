@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel stats + PMC passes of bench.py, results under gpurun_out/prof_<tag>/.
-# (bench.py runs with --placement-trials 1 here to keep the profiled runs short; sgx_observe launches -- placement trials, reset() --
+# (bench.py runs with --placement plain here to keep the profiled runs short; sgx_observe launches -- placement trials, reset() --
 # have their own kernel symbol, observe_kernel, and do not mix into step_kernel's statistics.)
 # usage: tools/gpu_profile.sh <tag> [extra bench args]
 TAG=$1; shift
@@ -11,14 +11,14 @@ mkdir -p $OUT
 cd /tmp
 python3 -c "import torch,time; x=torch.empty(1<<28,device='cuda'); t=time.time()
 while time.time()-t<3: x.fill_(1.0); torch.cuda.synchronize()"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-other-workloads --placement-trials 1 "$@" > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-other-workloads --no-two-chains --placement plain "$@" > $OUT/stats.log 2>&1
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" \
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
   "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
   "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-workloads --placement-trials 1 "$@" > $OUT/pmc$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-other-workloads --no-two-chains --placement plain "$@" > $OUT/pmc$i.log 2>&1
 done
 cd $R
 python3 tools/pmc_summary.py "gpurun_out/prof_$TAG" > $OUT/summary.txt 2>&1
