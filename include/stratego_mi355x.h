@@ -240,6 +240,17 @@ int sgx_import_state(sgx_env *h, const int64_t *state_dev, const int8_t *player_
  * variant's is used), a player that is not +1 / -1; 0 otherwise -- results for flagged states may differ from the reference's. */
 int sgx_import_state_checked(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, uint8_t *sanitised_dev, void *stream);
 
+/* The functional operator API on caller-provided int64 states in one call: sgx_import_state_checked -> sgx_step -> sgx_export_state
+ * (state_out_dev NULL: no export -- is_move_valid_*, masks and observations of the given states), i.e. get_next_state (penv:148-155)
+ * for a batch.  The batch is split into `chains` (1..SGX_MAX_CHAINS) ranges of states on streams of their own, so that one range's
+ * 27 KB-per-state reads overlap another's writes; the caller's stream waits for all of them.  io as in sgx_step with the SGX_STEP_*
+ * flags of the functional API; no auto_reset, no next_actions_dev; io->actions_dev NULL = sgx_observe of the given states (their
+ * movers' masks / observations, nothing is played).  The handle's own states are overwritten.  On boards of more than 32 cells with
+ * the 67-channel observation kind the three steps are ONE launch (a 128-thread block per state, the packed record never leaves
+ * LDS): 65,536 Barrage states 745 -> ~640 us; `chains` only matters on the other paths. */
+int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_t *player_in_dev, uint8_t *sanitised_dev,
+                    const sgx_step_io *io, int64_t *state_out_dev, int8_t *player_out_dev, int32_t chains, void *stream);
+
 /* Search callers (MCTS on get_next_state, penv:148-155) keep their nodes in the packed records instead of paying the 27 KB
  * int64 import / export per state: handles of the same variant on the same device act as node pools.
  * sgx_copy_envs: records src[src_index[i]] -> dst[dst_index[i]] for i < n (an index array may be NULL = identity).

@@ -107,130 +107,185 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
 }
 
 // ---------------------------------------------------------------------------------------------
-// export / import in the reference's int64 [N,34,R,C] layout (impl:16-60)
+// export / import in the reference's int64 [N,34,R,C] layout (impl:16-60); 256 threads per state
 // ---------------------------------------------------------------------------------------------
-template <int R_, int C_>
-__global__ void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t *__restrict__ player_out) {
-    using G = Geo<R_, C_>;
-    constexpr int RC = G::RC, C = G::C, S = G::S;
-    const int64_t env = blockIdx.x;
-    if (env >= P.n_envs) return;
-    const int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
-    const int4 sc = rec_scal<G>(P.boards, P.rec_bytes, env)[0], sc2 = rec_scal<G>(P.boards, P.rec_bytes, env)[1];
-    int64_t *o = out + env * (int64_t)(SGX_STATE_LAYERS * RC);
-    for (int x = threadIdx.x; x < SGX_STATE_LAYERS * RC; x += blockDim.x) {
-        const int l = x / RC, cell = x - l * RC;
-        int64_t v = 0;
-        if (l == 0 || l == 1) v = rec[(B_PIECES + l) * S + cell];
-        else if (l == 2) v = P.tab->obstacles[cell];
-        else if (l == 3 || l == 4) v = rec[(B_PO + l - 3) * S + cell];
-        else if (l == 32 || l == 33)
-            v = (reinterpret_cast<const uint32_t *>(rec + G::ST_OFF)[(l - 32) * (G::SB / 4) + (cell >> 5)] >> (cell & 31)) & 1u;
-        else if (l == 5) {
-            const int w = (sc.y & F_WIN_P1) ? 1 : (sc.y & F_WIN_M1) ? -1 : 0;
-            if (cell == 0) v = sc.x;                               // TURN_COUNT  [5,0,0]
-            else if (cell == 1) v = (sc.y & F_OVER) ? 1 : 0;       // GAME_OVER   [5,0,1]
-            else if (cell == 2) v = w;                             // WINNER      [5,0,2]
-            else if (cell == C) v = sc.z;                          // MAX_TURNS   [5,1,0]
-            else if (cell == C + 1) v = (sc.y & F_END_INVALID) ? 1 : 0;  // ENDING_INVALID [5,1,1]
+template <class G, int NT_ = 256>
+struct StateIO {
+    static constexpr int RC = G::RC, NT = NT_, NX = SGX_STATE_LAYERS * RC, NQ = NX / 2;
+    static constexpr int IMG = (G::EVL_OFF + 2 * G::EVL_MAX + 127) & ~127;      // >= rec_bytes of any piece set on this board
+    static constexpr int DENSE = (NX + 15) & ~15;
+    static constexpr int NE = 24 * RC, PER = (NE + NT - 1) / NT, NEP = (NE + 3) & ~3;
+    static constexpr int ITER = (NQ + NT - 1) / NT;
+};
+// LDS of one state: the record image, and scratch of the import (count table, recent-move codes, ...) that the export reuses as
+// its byte-per-(layer, cell) table
+template <class G, int NT_ = 256>
+struct alignas(16) StateLds {
+    using IO = StateIO<G, NT_>;
+    alignas(16) uint8_t img[IO::IMG];
+    alignas(16) int8_t dense[IO::DENSE];               // export: [layer][cell] as bytes; import: cap[] at 8 * RC, recent[] at 6 * RC
+    int scan[IO::NT / 64];
+    int scal[5];       // layer 5: turn count, game over, winner, max turns, ending invalid
+    int pairs[2];
+    int altered;       // the state held something the packed record cannot carry: reported through sanitised[]
+};
+
+// Record image (W.img) -> the 34 int64 layers of `env`.  The image is expanded in LDS to one BYTE per (layer, cell) -- the boards,
+// the obstacle map, never-moved bits, recent-move pairs and capture events scattered by many lanes at once -- and the layers then
+// stream out as 16-byte stores (two int64 per lane, every wave's store instruction one aligned KiB; non-temporal when the batch
+// does not fit the Infinity Cache).  (Round 2 computed every element from the record in global memory and patched the
+// recent-move and captured layers with one thread's read-modify-writes to global memory: 4.0 TB/s.)
+template <class G, int NT_>
+__device__ __forceinline__ void export_from_image(const KParams &P, StateLds<G, NT_> &W, int64_t *__restrict__ out, int8_t *__restrict__ player_out,
+                                                  const int64_t env, const int tid, const int nt) {
+    using IO = StateIO<G, NT_>;
+    constexpr int RC = G::RC, C = G::C, S = G::S, NT = IO::NT, NX = IO::NX, NQ = IO::NQ;
+    const uint8_t *img = W.img;
+    int8_t *dense = W.dense;
+    for (int i = tid; i < IO::DENSE / 4; i += NT) reinterpret_cast<int *>(dense)[i] = 0;
+    __syncthreads();
+    const int4 sc = reinterpret_cast<const int4 *>(img + G::SC_OFF)[0], sc2 = reinterpret_cast<const int4 *>(img + G::SC_OFF)[1];
+    for (int i = tid; i < RC; i += NT) {
+        dense[0 * RC + i] = (int8_t)img[(B_PIECES + 0) * S + i];
+        dense[1 * RC + i] = (int8_t)img[(B_PIECES + 1) * S + i];
+        dense[2 * RC + i] = (int8_t)P.tab->obstacles[i];
+        dense[3 * RC + i] = (int8_t)img[(B_PO + 0) * S + i];
+        dense[4 * RC + i] = (int8_t)img[(B_PO + 1) * S + i];
+        const uint32_t *stb = reinterpret_cast<const uint32_t *>(img + G::ST_OFF);
+        dense[32 * RC + i] = (int8_t)((stb[i >> 5] >> (i & 31)) & 1u);
+        dense[33 * RC + i] = (int8_t)((stb[G::SB / 4 + (i >> 5)] >> (i & 31)) & 1u);
+    }
+    if (tid < 4) {
+        const int pr = (((tid >> 1) ? sc2.z : sc2.y) >> (16 * (tid & 1))) & 0xFFFF;
+        if (pr >> 8) dense[(6 + (tid >> 1)) * RC + (pr & 0xFF)] = (int8_t)(pr >> 8);
+    }
+    {   // one event per (layer, cell) with captured pieces: no two lanes write the same byte
+        const uint16_t *ev = reinterpret_cast<const uint16_t *>(img + G::EVL_OFF);
+        const int n_events = min(sc2.x, (int)G::EVL_MAX);
+        for (int i = tid; i < n_events; i += NT) {
+            const int e = ev[i], at = (8 + ((e >> 8) & 31)) * RC + (e & 0xFF);
+            if (((e >> 8) & 31) < 24 && (e & 0xFF) < RC) dense[at] = (int8_t)((e >> EV_COUNT_SHIFT) + 1);
         }
-        o[x] = v;   // recent-moves and captured layers start at 0 and are filled below
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int pl = 0; pl < 2; ++pl)
-            for (int h = 0; h < 2; ++h) {
-                const int pr = ((pl ? sc2.z : sc2.y) >> (16 * h)) & 0xFFFF;
-                if (pr >> 8) o[(6 + pl) * RC + (pr & 0xFF)] = (int8_t)(pr >> 8);
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    i64x2 *o = reinterpret_cast<i64x2 *>(out + env * (int64_t)NX);                 // NX * 8 is a multiple of 16
+    const int w = (sc.y & F_WIN_P1) ? 1 : (sc.y & F_WIN_M1) ? -1 : 0;
+    // like the observation stream (sgx_obs.h): every wave's store instruction covers one 1 KiB-aligned KiB (a state is 272 * RC bytes:
+    // only 16-byte aligned), and the first / last 128-byte line, shared with the neighbouring states, goes through L2
+    const int m0 = (int)((reinterpret_cast<uintptr_t>(o) >> 4) & 63), l0 = (int)((reinterpret_cast<uintptr_t>(o) >> 4) & 7);
+    const int first_line = l0 ? 0 : -1, last_line = ((l0 + NQ) & 7) ? (NQ - 1 + l0) >> 3 : -1;
+    for (int q = tid - m0; q < NQ; q += NT) {
+        if (q < 0) continue;
+        i64x2 v = {(long long)dense[2 * q], (long long)dense[2 * q + 1]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int x = 2 * q + j - 5 * RC;                                          // index inside layer 5
+            if (x >= 0 && x < RC) {
+                long long d = 0;
+                if (x == 0) d = sc.x;                                    // TURN_COUNT  [5,0,0]
+                else if (x == 1) d = (sc.y & F_OVER) ? 1 : 0;            // GAME_OVER   [5,0,1]
+                else if (x == 2) d = w;                                  // WINNER      [5,0,2]
+                else if (x == C) d = sc.z;                               // MAX_TURNS   [5,1,0]
+                else if (x == C + 1) d = (sc.y & F_END_INVALID) ? 1 : 0; // ENDING_INVALID [5,1,1]
+                if (j == 0) v.x = d; else v.y = d;
             }
-        const uint16_t *ev = reinterpret_cast<const uint16_t *>(rec + G::EVL_OFF);
-        for (int i = 0; i < sc2.x; ++i) o[(8 + ((ev[i] >> 8) & 31)) * RC + (ev[i] & 0xFF)] += (ev[i] >> EV_COUNT_SHIFT) + 1;
-        if (player_out) player_out[env] = (sc.y & F_PLAYER_M1) ? -1 : 1;
+        }
+        const bool edge = ((q + l0) >> 3) == first_line || ((q + l0) >> 3) == last_line;
+        if (nt && !edge) __builtin_nontemporal_store(v, &o[q]);
+        else o[q] = v;
     }
+    if (tid == 0 && player_out) player_out[env] = (sc.y & F_PLAYER_M1) ? -1 : 1;
 }
 
-// Reachable states only: at most two non-zero recent-move cells per player (impl:1013-1028), at most max_events (layer, cell)
-// pairs with captured pieces and at most 8 of them on one pair; anything beyond that cannot come from play and is dropped.
-// One 256-thread block per state: a single coalesced pass over the 34 int64 layers scatters them into LDS (dense boards
-// straight into the record image, never-moved flags, recent-move codes and captured counts as bytes), the capture-event list
-// is laid out with a block-wide prefix sum, and the finished record leaves as whole 128-byte lines.  (The first version
-// walked the 24 captured layers with one thread: 4.6 ms per 65,536 states against 0.44 ms for the export.)
-template <int R_, int C_>
-__global__ __launch_bounds__(256) void import_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in,
-                                                     uint8_t *__restrict__ sanitised) {
-    using G = Geo<R_, C_>;
-    constexpr int RC = G::RC, C = G::C, S = G::S, NT = 256;
-    constexpr int IMG = (G::EVL_OFF + 2 * G::EVL_MAX + 127) & ~127;      // >= rec_bytes of any piece set on this board
-    constexpr int NE = 24 * RC, PER = (NE + NT - 1) / NT;
-    __shared__ alignas(16) uint8_t img[IMG];
-    __shared__ uint8_t cap[NE];
-    __shared__ int8_t recent[2 * RC];
-    __shared__ uint8_t still[2 * RC];
-    __shared__ int scan[NT / 64];
-    __shared__ int altered;       // the state held something the packed record cannot carry: reported through sanitised[]
-    const int tid = threadIdx.x;
-    const int64_t env = blockIdx.x;
-    if (env >= P.n_envs) return;
-    if (tid == 0) altered = 0;     // (ordered before every `altered = 1` below by the __syncthreads() that follows the img clear)
-    int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
-    const int64_t *s = in + env * (int64_t)(SGX_STATE_LAYERS * RC);
-    // all of the thread's loads first (the scatter below is branchy, the compiler would otherwise wait for each load in turn:
-    // 13 dependent round trips per block made the kernel latency-bound at 2.4 TB/s)
-    constexpr int NX = SGX_STATE_LAYERS * RC, ITER = (NX + NT - 1) / NT;
-    int64_t rawv[ITER];
+// The 34 int64 layers of `env` -> record image (W.img).  Reachable states only: at most two non-zero recent-move cells per player
+// (impl:1013-1028), at most max_events (layer, cell) pairs with captured pieces and at most 8 of them on one pair; anything beyond
+// that cannot come from play and is dropped (and reported through sanitised[]).  All of the state's 16-byte loads are issued first
+// (two int64 per lane per load, fully coalesced, non-temporal), the values are scattered into the LDS image of the record (dense
+// boards, never-moved BITS by atomicOr, recent-move codes and captured counts as bytes), the capture-event list is laid out with a
+// block-wide prefix sum and the recent-move pairs by one wave per player with ballots.  Ends with a __syncthreads(): the image is
+// complete for every thread.  (Round 2 read 8 bytes per lane and finished with one thread walking both recent-move layers and
+// five dependent global loads: 3.0-3.3 TB/s.)
+template <class G, int NT_>
+__device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT_> &W, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in,
+                                                uint8_t *__restrict__ sanitised, const int64_t env, const int tid) {
+    using IO = StateIO<G, NT_>;
+    constexpr int RC = G::RC, C = G::C, S = G::S, NT = IO::NT, NX = IO::NX, NQ = IO::NQ, NE = IO::NE, PER = IO::PER, ITER = IO::ITER;
+    uint8_t *img = W.img;
+    uint8_t *cap = reinterpret_cast<uint8_t *>(W.dense) + 8 * RC;             // [24][RC] captured counts
+    int8_t *recent = W.dense + 6 * RC;                                        // [2][RC] recent-move codes
+    const int lane = tid & 63, wave = tid >> 6;
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    const i64x2 *s = reinterpret_cast<const i64x2 *>(in + env * (int64_t)NX);
+    i64x2 rawv[ITER];
 #pragma unroll
     for (int k = 0; k < ITER; ++k) {
-        const int x = tid + k * NT;
-        rawv[k] = x < NX ? s[x] : 0;
+        const int q = tid + k * NT;
+        rawv[k] = q < NQ ? __builtin_nontemporal_load(&s[q]) : i64x2{0, 0};
     }
-    for (int i = tid; i < IMG / 4; i += NT) reinterpret_cast<uint32_t *>(img)[i] = 0;
+    if (tid == 0) W.altered = 0;     // (ordered before every `altered = 1` below by the __syncthreads() that follows the clears)
+    for (int i = tid; i < IO::IMG / 4; i += NT) reinterpret_cast<uint32_t *>(img)[i] = 0;
     __syncthreads();
+    bool bad = false;
 #pragma unroll
     for (int k = 0; k < ITER; ++k) {
-        const int x = tid + k * NT;
-        if (x >= NX) continue;
-        const int l = x / RC, cell = x - l * RC;
-        if (l == 5) continue;                                         // scalars below
-        const int64_t raw = rawv[k];
-        bool ok = true;
-        if (l == 2) ok = raw == (int64_t)P.tab->obstacles[cell];      // obstacles are the variant's (a per-handle constant)
-        else if (l < 2 || l == 3 || l == 4) {                         // legal range of the layer; anything else -> 0
-            const int b = l < 2 ? B_PIECES + l : B_PO + (l - 3), hi = l < 2 ? SP_BOMB : SP_UNKNOWN;
-            ok = raw >= 0 && raw <= hi;
-            img[b * S + cell] = (uint8_t)(ok ? (int)raw : 0);
-        } else if (l == 6 || l == 7) { ok = raw >= -3 && raw <= 1; recent[(l - 6) * RC + cell] = (int8_t)(ok ? (int)raw : 0); }
-        else if (l < 32) { ok = raw >= 0 && raw <= EV_COUNT_MAX; cap[(l - 8) * RC + cell] = (uint8_t)(raw <= 0 ? 0 : (raw > EV_COUNT_MAX ? EV_COUNT_MAX : (int)raw)); }
-        else { ok = raw == 0 || raw == 1; still[(l - 32) * RC + cell] = raw == 1 ? 1 : 0; }
-        if (!ok) altered = 1;
-    }
-    __syncthreads();
-    for (int w = tid; w < 2 * (G::SB / 4); w += NT) {                  // never-moved bitmaps from layers 32/33
-        const int pl = w / (G::SB / 4), w0 = w - pl * (G::SB / 4);
-        uint32_t bits = 0;
-        for (int k = 0; k < 32; ++k) {
-            const int cell = 32 * w0 + k;
-            if (cell < RC && still[pl * RC + cell]) bits |= 1u << k;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int x = 2 * (tid + k * NT) + j;
+            if (x >= NX) continue;
+            const int l = x / RC, cell = x - l * RC;
+            const int64_t raw = j ? rawv[k].y : rawv[k].x;
+            bool ok = true;
+            if (l == 5) {                                                     // the scalars (other cells of the layer are not looked at)
+                const int which = cell == 0 ? 0 : cell == 1 ? 1 : cell == 2 ? 2 : cell == C ? 3 : cell == C + 1 ? 4 : -1;
+                if (which >= 0) W.scal[which] = which == 2 ? (raw > 0 ? 1 : raw < 0 ? -1 : 0) : (which == 0 || which == 3) ? (int)raw : (raw != 0);
+            } else if (l == 2) ok = raw == (int64_t)P.tab->obstacles[cell];   // obstacles are the variant's (a per-handle constant)
+            else if (l < 2 || l == 3 || l == 4) {                             // legal range of the layer; anything else -> 0
+                const int b = l < 2 ? B_PIECES + l : B_PO + (l - 3), hi = l < 2 ? SP_BOMB : SP_UNKNOWN;
+                ok = raw >= 0 && raw <= hi;
+                img[b * S + cell] = (uint8_t)(ok ? (int)raw : 0);
+            } else if (l == 6 || l == 7) { ok = raw >= -3 && raw <= 1; recent[(l - 6) * RC + cell] = (int8_t)(ok ? (int)raw : 0); }
+            else if (l < 32) { ok = raw >= 0 && raw <= EV_COUNT_MAX; cap[(l - 8) * RC + cell] = (uint8_t)(raw <= 0 ? 0 : (raw > EV_COUNT_MAX ? EV_COUNT_MAX : (int)raw)); }
+            else {
+                ok = raw == 0 || raw == 1;
+                if (raw == 1) atomicOr(reinterpret_cast<uint32_t *>(img + G::ST_OFF) + (l - 32) * (G::SB / 4) + (cell >> 5), 1u << (cell & 31));
+            }
+            bad = bad || !ok;
         }
-        reinterpret_cast<uint32_t *>(img + G::ST_OFF)[w] = bits;
     }
+    if (bad) W.altered = 1;
+    __syncthreads();
     // capture events (one per non-zero count) in (layer, cell) order: thread t owns entries [t*PER, (t+1)*PER) of the count table
     int cnt = 0;
     for (int k = 0; k < PER; ++k) {
         const int e = tid * PER + k;
         if (e < NE) cnt += cap[e] != 0;
     }
-    // block-wide inclusive scan: shuffle scan inside each wave, then the four wave totals through LDS
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if ((tid & 63) >= o) incl += v;
+    // block-wide inclusive scan: DPP scan inside each wave, then the four wave totals through LDS
+    const int incl = gscan_incl<Geo<10, 10>>(cnt);                            // (any one-game-per-wave geometry: a 64-lane scan)
+    if (lane == 63) W.scan[wave] = incl;
+    // the recent-move pairs of player `wave` (waves 0 and 1): the first two non-zero codes in cell order; more cannot come from play
+    if (wave < 2) {
+        int found = 0, total = 0, pair = 0;
+        for (int c0 = 0; c0 < RC; c0 += 64) {
+            const int cell = c0 + lane;
+            unsigned long long bal = __ballot(cell < RC && recent[wave * RC + (cell < RC ? cell : 0)] != 0);
+            total += __popcll(bal);
+            while (bal && found < 2) {
+                const int cb = c0 + __ffsll((long long)bal) - 1;
+                pair |= (cb | (((int)recent[wave * RC + cb] & 0xFF) << 8)) << (16 * found);
+                ++found;
+                bal &= bal - 1;
+            }
+        }
+        if (lane == 0) { W.pairs[wave] = pair; if (total > 2) W.altered = 1; }
     }
-    if ((tid & 63) == 63) scan[tid >> 6] = incl;
     __syncthreads();
     int wave_base = 0;
-    for (int w = 0; w < (tid >> 6); ++w) wave_base += scan[w];
-    const int total_events = scan[0] + scan[1] + scan[2] + scan[3];
+    for (int w = 0; w < wave; ++w) wave_base += W.scan[w];
+    int total_events = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) total_events += W.scan[w];
     {
         int at = wave_base + incl - cnt;
         uint16_t *ev = reinterpret_cast<uint16_t *>(img + G::EVL_OFF);
@@ -243,33 +298,88 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
         }
     }
     if (tid == 0) {
-        const int64_t *d = s + 5 * RC;
         int flags = 0;
-        if (d[1] != 0) flags |= F_OVER;
-        if (d[2] > 0) flags |= F_WIN_P1; else if (d[2] < 0) flags |= F_WIN_M1;
-        if (d[C + 1] != 0) flags |= F_END_INVALID;
+        if (W.scal[1] != 0) flags |= F_OVER;
+        if (W.scal[2] > 0) flags |= F_WIN_P1; else if (W.scal[2] < 0) flags |= F_WIN_M1;
+        if (W.scal[4] != 0) flags |= F_END_INVALID;
         if (player_in && player_in[env] < 0) flags |= F_PLAYER_M1;
-        int pairs[2] = {0, 0};
         bool dropped = total_events > P.max_events;
-        for (int pl = 0; pl < 2; ++pl) {
-            int k = 0;
-            for (int cell = 0; cell < RC; ++cell) {
-                const int code = recent[pl * RC + cell];
-                if (code == 0) continue;
-                if (k < 2) pairs[pl] |= (cell | ((code & 0xFF) << 8)) << (16 * k);
-                else dropped = true;                                  // more than two recent-move cells cannot come from play
-                ++k;
-            }
-        }
         if (player_in && player_in[env] != 1 && player_in[env] != -1) dropped = true;
-        if (sanitised) sanitised[env] = (altered || dropped) ? 1 : 0;
+        if (sanitised) sanitised[env] = (W.altered || dropped) ? 1 : 0;
         const int old_game = rec_scal<G>(P.boards, P.rec_bytes, env)[0].w;
         int4 *scg = reinterpret_cast<int4 *>(img + G::SC_OFF);
-        scg[0] = make_int4((int)d[0], flags, (int)d[C], old_game < 0 ? 0 : old_game);
-        scg[1] = make_int4(min(total_events, P.max_events), pairs[0], pairs[1], 0);
+        scg[0] = make_int4(W.scal[0], flags, W.scal[3], old_game < 0 ? 0 : old_game);
+        scg[1] = make_int4(min(total_events, P.max_events), W.pairs[0], W.pairs[1], 0);
     }
     __syncthreads();
-    for (int i = tid; i < P.rec_bytes / 16; i += NT) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(img)[i];
+}
+
+template <int R_, int C_>
+__global__ __launch_bounds__(256) void export_kernel(const KParams P, int64_t *__restrict__ out, int8_t *__restrict__ player_out, const int nt) {
+    using G = Geo<R_, C_>;
+    __shared__ StateLds<G> W;
+    const int tid = threadIdx.x;
+    const int64_t env = P.env_first + blockIdx.x;
+    if (env >= P.n_envs) return;
+    const int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
+    for (int i = tid; i < P.rec_bytes / 16; i += 256) reinterpret_cast<int4 *>(W.img)[i] = reinterpret_cast<const int4 *>(rec)[i];
+    export_from_image(P, W, out, player_out, env, tid, nt);                  // (its first barrier orders the staging above)
+}
+
+template <int R_, int C_>
+__global__ __launch_bounds__(256) void import_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in,
+                                                     uint8_t *__restrict__ sanitised) {
+    using G = Geo<R_, C_>;
+    __shared__ StateLds<G> W;
+    const int tid = threadIdx.x;
+    const int64_t env = P.env_first + blockIdx.x;
+    if (env >= P.n_envs) return;
+    import_to_image(P, W, in, player_in, sanitised, env, tid);
+    int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
+    for (int i = tid; i < P.rec_bytes / 16; i += 256) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(W.img)[i];
+}
+
+// sgx_step_states: import -> env.step() -> export of one state by one 128-thread block, the record never leaving LDS in between.
+// The step is one wave's work (sgx_step.h: env_step, ~10 us of dependent LDS round trips); the other wave waits at the barrier while
+// the CU's other blocks keep the memory pipes busy with their loads and stores, so the step costs no launch of its own (88 us per
+// 65,536 states as a separate launch between a 300 us import and a 330 us export).  Small blocks = many of them per CU = many
+// steps in flight beside the streaming.  OBS = false: no observation is rendered (get_next_state, is_move_valid_*, masks): no code
+// buffer and no templates in LDS (the step runs as the value-channel kind, whose Lds has no code buffer -- the game logic does
+// not depend on the observation kind), 16 blocks per CU instead of 11.  Partial-observation 'extended' kind only.
+template <int R_, int C_, bool MAPPED, bool OBS>
+__global__ __launch_bounds__(128) void states_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in,
+                                                     uint8_t *__restrict__ sanitised, int64_t *__restrict__ out, int8_t *__restrict__ player_out, const int nt) {
+    using G = Geo<R_, C_>;
+    static_assert(G::LPG == 64, "one game per wave");
+    constexpr int NT = 128, KIND = OBS ? 0 : 2;
+    __shared__ StateLds<G, NT> W;
+    __shared__ Lds<G, ObsKind<KIND>::NIB_CH> L;
+    __shared__ alignas(16) uint8_t shared[OBS ? shared_table_bytes<G, 0>() : 16];
+    __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS + COMBAT_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t env = P.env_first + blockIdx.x;
+    if (env >= P.n_envs) return;
+    {   // the step's workgroup-shared tables (game_kernel_body): default-code templates, code table, obstacle map, combat outcomes
+        if constexpr (OBS) {
+            const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
+            constexpr int NP = tmpl_bytes<G, 0>(false);
+            const int4 *tp = reinterpret_cast<const int4 *>(P.tab->tmpl[raw ? 2 : 0]);
+            for (int i = tid; i < NP / 16; i += NT) reinterpret_cast<int4 *>(shared)[i] = tp[i];
+            const int4 *ct = reinterpret_cast<const int4 *>(P.tab->codetab[raw ? 1 : 0]);
+            for (int i = tid; i < CODETAB_BYTES / 16; i += NT) reinterpret_cast<int4 *>(shared + NP)[i] = ct[i];
+        }
+        for (int i = tid; i < G::S / 4; i += NT) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
+        for (int i = tid; i < COMBAT_BYTES / 4; i += NT) reinterpret_cast<int *>(obst_s + SGX_MAX_CELLS)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
+    }
+    import_to_image(P, W, in, player_in, sanitised, env, tid);              // (ends with a barrier: image and tables are in place)
+    if (tid < 64) {
+        const GameInput gin = load_game_from<G>(P, reinterpret_cast<const int4 *>(W.img), env, lane);
+        env_step<R_, C_, KIND, MAPPED>(P, L, shared, obst_s, env, lane, gin, reinterpret_cast<int8_t *>(W.img));
+    }
+    __syncthreads();
+    int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;                       // the handle keeps the successor, like after sgx_step
+    for (int i = tid; i < P.rec_bytes / 16; i += NT) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(W.img)[i];
+    if (out) export_from_image(P, W, out, player_out, env, tid, nt);
 }
 
 // sgx_copy_envs: packed records between two handles of the same variant, one wave per record

@@ -91,17 +91,13 @@ struct GameInput {
     int4 rq0, rq1, pos_raw;
     int a_raw;
 };
-template <class G, bool MAPPED>
-__device__ __forceinline__ GameInput load_game(const KParams &P, const int64_t env, const int lane) {
+// (src: the game's record -- global memory, or the LDS image of sgx_step_states' fused kernel)
+template <class G>
+__device__ __forceinline__ GameInput load_game_from(const KParams &P, const int4 *src, const int64_t env, const int lane) {
     constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + G::LPG - 1) / G::LPG;
     static_assert(G::TAIL_BYTES % 16 == 0 && NLOAD <= 2, "record image must fit two int4 per lane");
     const int4 zero4 = make_int4(0, 0, 0, 0);
     GameInput in{zero4, zero4, zero4, 0};
-    if (env >= P.n_envs) return in;
-    const int8_t *rec_src = P.boards + env * (int64_t)P.rec_bytes;
-    if constexpr (MAPPED)        // sgx_expand: the game comes from another handle's records (functional-API instantiation only)
-        if (P.src_boards) rec_src = P.src_boards + (int64_t)(P.src_index ? P.src_index[env] : env) * (int64_t)P.rec_bytes;
-    const int4 *src = reinterpret_cast<const int4 *>(rec_src);
     const int nq = min(P.rec_bytes >> 4, Q_REC);
     if (lane < nq) in.rq0 = src[lane];
     if constexpr (NLOAD > 1)
@@ -112,12 +108,20 @@ __device__ __forceinline__ GameInput load_game(const KParams &P, const int64_t e
     }
     return in;
 }
+template <class G, bool MAPPED>
+__device__ __forceinline__ GameInput load_game(const KParams &P, const int64_t env, const int lane) {
+    if (env >= P.n_envs) { const int4 zero4 = make_int4(0, 0, 0, 0); return GameInput{zero4, zero4, zero4, 0}; }
+    const int8_t *rec_src = P.boards + env * (int64_t)P.rec_bytes;
+    if constexpr (MAPPED)        // sgx_expand: the game comes from another handle's records (functional-API instantiation only)
+        if (P.src_boards) rec_src = P.src_boards + (int64_t)(P.src_index ? P.src_index[env] : env) * (int64_t)P.rec_bytes;
+    return load_game_from<G>(P, reinterpret_cast<const int4 *>(rec_src), env, lane);
+}
 
 // One game's env.step() by one wave (called with the wave's private LDS region).
 // `shared` = the workgroup's tables (shared_table_bytes): templates + code table, or LUTs + quad tables
 template <int R_, int C_, int KIND, bool MAPPED>
 __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsKind<KIND>::NIB_CH> &L, const uint8_t *shared, const uint8_t *obst_s,
-                                         const int64_t env, const int lane, const GameInput &in) {
+                                         const int64_t env, const int lane, const GameInput &in, int8_t *rec_out = nullptr) {
     using G = Geo<R_, C_>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
@@ -126,7 +130,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     STAMP(0);
 
-    int8_t *rec_g = P.boards + env * (int64_t)P.rec_bytes;
+    int8_t *rec_g = rec_out ? rec_out : P.boards + env * (int64_t)P.rec_bytes;   // (rec_out: the LDS record image of sgx_step_states)
     // ---- stage.  Every global read of the step has been issued up front (load_game) -- the whole record (a few 128-byte lines)
     //      as one or two int4 per lane, and the action -- so the wave pays ONE memory round trip, which overlaps the staging of
     //      the workgroup's shared tables.  The scalars, never-moved bitmaps and

@@ -137,12 +137,10 @@ int check_cfg(const sgx_config *cfg) {
     if (cfg->rows < 3 || cfg->cols < 3) return fail(SGX_EINVAL, "Both rows and columns have to be at least 3%s");
     if (cfg->rows * cfg->cols > SGX_MAX_CELLS) return fail(SGX_EINVAL, "rows*cols exceeds SGX_MAX_CELLS%s");
     if (cfg->usable_rows < 1 || cfg->usable_rows * 2 > cfg->rows) return fail(SGX_EINVAL, "usable_rows out of range%s");
-    int total = 0;
     for (int i = 0; i < 12; ++i) {
         if (cfg->piece_counts[i] < 0) return fail(SGX_EINVAL, "negative piece count%s");
         // a capture event counts the pieces of one type captured on one cell in 3 bits (sgx_layout.h): 8 = the scouts of Standard
         if (cfg->piece_counts[i] > EV_COUNT_MAX) return fail(SGX_EINVAL, "more than 8 pieces of one type per side%s");
-        total += cfg->piece_counts[i];
     }
     // (more pieces than usable cells is legal for a handle that never samples random setups: an env_config that overrides
     //  'piece_amounts' changes the normalisation only; sgx_reset checks it where it matters)
@@ -448,6 +446,11 @@ static bool launch_streams_past_cache(const sgx_env *h, const KParams &p) {
     if (p.io.obs_dev) bytes += h->n_envs * cells * lut_channels(false, original) * 4;
     if (p.io.fobs_dev) bytes += h->n_envs * cells * lut_channels(true, original) * 4;
     return bytes > (int64_t)300 * 1000 * 1000;
+}
+
+static int check_step_io(sgx_env *h, const KParams &p) {
+    if (p.mode == 0 && p.io.auto_reset) return check_random_setups(h);
+    return SGX_OK;
 }
 
 static int launch_step(sgx_env *h, const KParams &p_in, void *stream) {
@@ -757,25 +760,103 @@ SGX_API int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actio
     return SGX_OK;
 }
 
-SGX_API int sgx_export_state(sgx_env *h, int64_t *state_dev, int8_t *player_dev, void *stream) {
-    if (!h || !state_dev) return fail(SGX_EINVAL, "NULL argument%s");
-    HIP_TRY(hipSetDevice(h->device));
-    KParams p = make_params(h);
-#define CALL_EXPORT(R, C) export_kernel<R, C><<<(unsigned)h->n_envs, 256, 0, (hipStream_t)stream>>>(p, state_dev, player_dev)
+namespace {
+// export / import of the envs [p.env_first, p.n_envs) of the handle
+int launch_export(sgx_env *h, const KParams &p, int64_t *state_dev, int8_t *player_dev, hipStream_t stream) {
+    // (the int64 layout is 27 KB per 10x10 state: past the Infinity Cache the layers leave as non-temporal stores, like the observations)
+    const int nt = h->nt_mode < 0 ? (h->n_envs * (int64_t)SGX_STATE_LAYERS * h->cfg.rows * h->cfg.cols * 8 > (int64_t)300 * 1000 * 1000) : h->nt_mode;
+    const unsigned grid = (unsigned)(p.n_envs - p.env_first);
+#define CALL_EXPORT(R, C) export_kernel<R, C><<<grid, 256, 0, stream>>>(p, state_dev, player_dev, nt)
     DISPATCH_GEOMETRY(h, CALL_EXPORT);
 #undef CALL_EXPORT
     HIP_TRY(hipGetLastError());
     return SGX_OK;
 }
+int launch_import(sgx_env *h, const KParams &p, const int64_t *state_dev, const int8_t *player_dev, uint8_t *sanitised_dev, hipStream_t stream) {
+    const unsigned grid = (unsigned)(p.n_envs - p.env_first);
+#define CALL_IMPORT(R, C) import_kernel<R, C><<<grid, 256, 0, stream>>>(p, state_dev, player_dev, sanitised_dev)
+    DISPATCH_GEOMETRY(h, CALL_IMPORT);
+#undef CALL_IMPORT
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}
+}  // namespace
+
+SGX_API int sgx_export_state(sgx_env *h, int64_t *state_dev, int8_t *player_dev, void *stream) {
+    if (!h || !state_dev) return fail(SGX_EINVAL, "NULL argument%s");
+    HIP_TRY(hipSetDevice(h->device));
+    return launch_export(h, make_params(h), state_dev, player_dev, (hipStream_t)stream);
+}
 
 SGX_API int sgx_import_state_checked(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, uint8_t *sanitised_dev, void *stream) {
     if (!h || !state_dev) return fail(SGX_EINVAL, "NULL argument%s");
     HIP_TRY(hipSetDevice(h->device));
+    return launch_import(h, make_params(h), state_dev, player_dev, sanitised_dev, (hipStream_t)stream);
+}
+
+// get_next_state (penv:148-155) and friends on caller-provided int64 states in ONE call: import -> step -> export, the batch split
+// into `chains` ranges of states that run on streams of their own, so that one range's reads overlap another's writes.
+SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_t *player_in_dev, uint8_t *sanitised_dev,
+                            const sgx_step_io *io, int64_t *state_out_dev, int8_t *player_out_dev, int32_t chains, void *stream) {
+    if (!h || !state_in_dev || !io) return fail(SGX_EINVAL, "NULL argument%s");
+    if (io->auto_reset || io->next_actions_dev) return fail(SGX_EINVAL, "sgx_step_states: no auto_reset, no sampled next actions%s");
+    if (chains < 1 || chains > SGX_MAX_CHAINS) return fail(SGX_EINVAL, "chains out of range%s");
+    HIP_TRY(hipSetDevice(h->device));
+    const int64_t unit = 64;
+    int64_t per = (h->n_envs / chains) / unit * unit;
+    if (per == 0) chains = 1;
     KParams p = make_params(h);
-#define CALL_IMPORT(R, C) import_kernel<R, C><<<(unsigned)h->n_envs, 256, 0, (hipStream_t)stream>>>(p, state_dev, player_dev, sanitised_dev)
-    DISPATCH_GEOMETRY(h, CALL_IMPORT);
-#undef CALL_IMPORT
-    HIP_TRY(hipGetLastError());
+    p.mode = io->actions_dev ? 0 : 1;        // no actions: observe -- masks / observations of the given states, nothing is played
+    p.io = *io;
+    const bool kind0 = !io->fobs_dev && !io->final_fobs_dev && !(io->flags & SGX_STEP_ORIGINAL_CHANNELS);
+    if (kind0 && h->cfg.rows * h->cfg.cols > 32) {
+        // one-game-per-wave boards, partial-observation kinds: ONE fused launch, the record never leaves LDS between the three steps
+        if (int rc = check_step_io(h, p)) return rc;
+        const int nt = h->nt_mode < 0 ? (h->n_envs * (int64_t)SGX_STATE_LAYERS * h->cfg.rows * h->cfg.cols * 8 > (int64_t)300 * 1000 * 1000) : h->nt_mode;
+        p.nt_stores = h->nt_mode < 0 ? (launch_streams_past_cache(h, p) ? 1 : 0) : h->nt_mode;
+        const bool mapped = (io->flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) != 0;
+        const bool obs = io->obs_dev || io->final_obs_dev;
+#define CALL_STATES_K(R, C, M, O) states_kernel<R, C, M, O><<<(unsigned)h->n_envs, 128, 0, (hipStream_t)stream>>>(p, state_in_dev, player_in_dev, sanitised_dev, state_out_dev, player_out_dev, nt)
+#define CALL_STATES(R, C)                                                                                                   \
+    do {                                                                                                                    \
+        if constexpr (Geo<R, C>::LPG == 64) {                                                                               \
+            if (mapped && obs) CALL_STATES_K(R, C, true, true);                                                             \
+            else if (mapped) CALL_STATES_K(R, C, true, false);                                                              \
+            else if (obs) CALL_STATES_K(R, C, false, true);                                                                 \
+            else CALL_STATES_K(R, C, false, false);                                                                         \
+        }                                                                                                                   \
+    } while (0)
+        DISPATCH_GEOMETRY(h, CALL_STATES);
+#undef CALL_STATES
+#undef CALL_STATES_K
+        HIP_TRY(hipGetLastError());
+        return SGX_OK;
+    }
+    if (chains == 1) {
+        if (int rc = launch_import(h, p, state_in_dev, player_in_dev, sanitised_dev, (hipStream_t)stream)) return rc;
+        if (int rc = launch_step(h, p, stream)) return rc;
+        return state_out_dev ? launch_export(h, p, state_out_dev, player_out_dev, (hipStream_t)stream) : SGX_OK;
+    }
+    if (!h->chain_fork) HIP_TRY(hipEventCreateWithFlags(&h->chain_fork, hipEventDisableTiming));
+    for (int c = 0; c < chains; ++c) {
+        if (!h->chain_stream[c]) HIP_TRY(hipStreamCreateWithFlags(&h->chain_stream[c], hipStreamNonBlocking));
+        if (!h->chain_join[c]) HIP_TRY(hipEventCreateWithFlags(&h->chain_join[c], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(h->chain_fork, (hipStream_t)stream));
+    for (int c = 0; c < chains; ++c) HIP_TRY(hipStreamWaitEvent(h->chain_stream[c], h->chain_fork, 0));
+    for (int c = 0; c < chains; ++c) {
+        KParams pc = p;
+        pc.env_first = c * per;
+        pc.n_envs = c == chains - 1 ? h->n_envs : (c + 1) * per;
+        if (int rc = launch_import(h, pc, state_in_dev, player_in_dev, sanitised_dev, h->chain_stream[c])) return rc;
+        if (int rc = launch_step(h, pc, (void *)h->chain_stream[c])) return rc;
+        if (state_out_dev)
+            if (int rc = launch_export(h, pc, state_out_dev, player_out_dev, h->chain_stream[c])) return rc;
+    }
+    for (int c = 0; c < chains; ++c) {
+        HIP_TRY(hipEventRecord(h->chain_join[c], h->chain_stream[c]));
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->chain_join[c], 0));
+    }
     return SGX_OK;
 }
 

@@ -34,6 +34,10 @@ _SWAP_A = [0, 3, 6, 32] + list(range(8, 20))
 _SWAP_B = [1, 4, 7, 33] + list(range(20, 32))
 
 
+def _ptr_or_none(t):
+    return t.data_ptr() if t is not None else None
+
+
 class BatchedStrategoProceduralEnv:
     def __init__(self, version, batch_size, device=0):
         self.variant = get_variant(version)
@@ -92,6 +96,33 @@ class BatchedStrategoProceduralEnv:
             self._held = prev
             self._scratch_is_held = False
 
+    def _in_loaded_scope(self, states, players):
+        return self._held is not None and self._scratch_is_held and states is self._held[0] and players is self._held[1]
+
+    def _step_states(self, states, players, actions, flags, export=False, mask_out=None, positions=False):
+        """sgx_step_states: import -> step (actions given) or observe (actions None) -> optional export, one library call (one
+        launch on boards of more than 32 cells).  -> (new_states, new_players) or None."""
+        st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64).contiguous()
+        if tuple(st.shape) != (self.batch_size, NUM_STATE_LAYERS, self.rows, self.columns):
+            raise ValueError("states must have shape (batch, 34, rows, columns)")
+        pl = self._players(players)
+        vec = self._vec
+        new_states = torch.empty_like(st) if export else None
+        new_players = torch.empty((self.batch_size,), dtype=torch.int8, device=self.device) if export else None
+        io = vec._fill_io(actions if actions is not None else vec.next_actions, False, False, False, flags)
+        io.auto_reset = 0
+        if actions is None:
+            io.actions_dev = None
+        io.mask_dev = mask_out.data_ptr() if mask_out is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(vec._L.sgx_step_states(vec._h, st.data_ptr(), pl.data_ptr(), self.last_sanitised.data_ptr(), io,
+                                              _ptr_or_none(new_states), _ptr_or_none(new_players), 2, vec._stream()), vec._L)
+        vec._next_actions_fresh = False
+        self._scratch_is_held = (actions is None and self._held is not None and states is self._held[0] and players is self._held[1])
+        if self.strict and bool(self.last_sanitised.any()):
+            raise ValueError("state is not one the packed record can carry (unreachable by play): see sgx_import_state_checked")
+        return (new_states, new_players) if export else None
+
     def _mask_in_state_coordinates(self, one_dim):
         """Mask of the loaded states' movers, indexed in the states' own coordinates (no perspective flip), rendered by the
         kernel: SGX_STEP_MASK_1D -> uint8 [N, action_size], SGX_STEP_MASK_STATE_COORDS -> uint8 [N, R, C, K]."""
@@ -113,20 +144,24 @@ class BatchedStrategoProceduralEnv:
 
     def get_next_state(self, states, players, action_indices, allow_piece_oscillation=False):      # penv:148-155
         """-> (new_states, new_players int8, valid bool).  action_indices: absolute 1-D indices (impl:262-277)."""
-        st, pl = self._load(states, players)
         flags = _lib.STEP_ACTIONS_1D | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
-        a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.batch_size)
-        self._vec.step(a, emit_obs=False, emit_mask=False, flags=flags)
-        self._scratch_changed()
-        new_states, new_players = self._vec.export_state()
+        a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.batch_size).contiguous()
+        if self._held is not None and self._scratch_is_held and states is self._held[0] and players is self._held[1]:
+            self._vec.step(a, emit_obs=False, emit_mask=False, flags=flags)          # inside `loaded`: the states are in the handle
+            self._scratch_changed()
+            new_states, new_players = self._vec.export_state()
+            return new_states, new_players, self._vec.invalid_action == 0
+        new_states, new_players = self._step_states(states, players, a, flags, export=True)
         return new_states, new_players, self._vec.invalid_action == 0
 
     def is_move_valid_by_1d_index(self, states, players, action_indices, allow_piece_oscillation=False):   # penv:94-99
-        self._load(states, players)
         flags = _lib.STEP_ACTIONS_1D | (_lib.STEP_ALLOW_OSCILLATION if allow_piece_oscillation else 0)
-        a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.batch_size)
-        self._vec.step(a, emit_obs=False, emit_mask=False, flags=flags)
-        self._scratch_changed()
+        a = torch.as_tensor(action_indices).to(device=self.device, dtype=torch.int32).reshape(self.batch_size).contiguous()
+        if self._in_loaded_scope(states, players):
+            self._vec.step(a, emit_obs=False, emit_mask=False, flags=flags)
+            self._scratch_changed()
+        else:
+            self._step_states(states, players, a, flags)
         return self._vec.invalid_action == 0
 
     def is_move_valid_by_position(self, states, players, start_r, start_c, end_r, end_c, allow_piece_oscillation=False):  # penv:87-92
@@ -141,7 +176,10 @@ class BatchedStrategoProceduralEnv:
     # ---- masks ---------------------------------------------------------------------------------------------------
     def get_valid_moves_as_spatial_mask(self, states, players):                                     # penv:127-128
         """uint8 [N,R,C,K] in the coordinates of the given states (no perspective flip), like impl:399-517."""
-        self._load(states, players)
+        if not self._in_loaded_scope(states, players):
+            out = torch.empty((self.batch_size,) + tuple(self.spatial_action_size), dtype=torch.uint8, device=self.device)
+            self._step_states(states, players, None, _lib.STEP_MASK_STATE_COORDS, mask_out=out)
+            return out
         return self._mask_in_state_coordinates(one_dim=False)
 
     def get_valid_moves_as_1d_mask(self, states, players, player_perspective=False):                # penv:74-80
@@ -150,7 +188,10 @@ class BatchedStrategoProceduralEnv:
         asks for player -1's moves on the flipped state."""
         if player_perspective:
             states = self.get_state_from_player_perspective(states, players)
-        self._load(states, players)
+        if not self._in_loaded_scope(states, players):
+            out = torch.empty((self.batch_size, self.action_size), dtype=torch.uint8, device=self.device)
+            self._step_states(states, players, None, _lib.STEP_MASK_1D, mask_out=out)
+            return out
         return self._mask_in_state_coordinates(one_dim=True)
 
     def get_dict_of_valid_moves_by_position(self, states, players):                                 # penv:82-85 / impl:1400-1429

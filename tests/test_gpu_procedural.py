@@ -206,11 +206,10 @@ def test_every_call_imports_and_the_loaded_scope_is_opt_in():
     assert torch.equal(m3, fresh.get_valid_moves_as_1d_mask(s2, p2)) and not torch.equal(m3, m1)
     # opt-in scope: one import for several questions about the same objects; a transition inside the scope re-imports
     calls = []
-    real = penv._vec._L.sgx_import_state_checked
-
-    class Counting:
+    class Counting:                                                       # (both entry points that import int64 states)
         def __getattr__(self, k):
-            if k == 'sgx_import_state_checked':
+            if k in ('sgx_import_state_checked', 'sgx_step_states'):
+                real = getattr(penv_L, k)
                 return lambda *a: (calls.append(1), real(*a))[1]
             return getattr(penv_L, k)
     penv_L = penv._vec._L
