@@ -209,6 +209,15 @@ int sgx_free_outputs(sgx_env *h, sgx_outputs *out);
 /* One batched env.step(): see sgx_step_io. */
 int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);
 
+/* Single-game latency (config 1: one game behind the reference's dict API).  sgx_host_alloc returns pinned host memory the device
+ * can address (*dev_ptr is its device alias): with sgx_step_io's output pointers -- and actions_dev -- pointing into it the step
+ * kernel writes a game's ~30 KB of outputs straight to host memory, and sgx_step_sync (= sgx_step + wait for `stream`) makes
+ * env.step() ONE library call: no upload, no download, no second launch.  Meant for a handful of games; batches belong in HBM.
+ * No reference counterpart (the reference is one game per object on the host, maenv:659-828). */
+int sgx_host_alloc(sgx_env *h, int64_t bytes, void **host_ptr, void **dev_ptr);
+int sgx_host_free(sgx_env *h, void *host_ptr);
+int sgx_step_sync(sgx_env *h, const sgx_step_io *io, void *stream);
+
 /* n_steps consecutive sgx_step calls with the same buffers, enqueued back to back without returning to the host language:
  * the random-action game loop of examples/basic_game_loop.py:34-63 (sample a valid action, step, repeat) for N games.
  * Requires io->next_actions_dev == io->actions_dev, so that every step plays the action the previous one drew; the

@@ -23,7 +23,7 @@ OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_supports_geometry', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
     'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_nt_stores', 'sgx_set_setup_table', 'sgx_reset',
-    'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_step_n', 'sgx_rollout', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_step_states', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
+    'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_host_alloc', 'sgx_host_free', 'sgx_step_sync', 'sgx_step_n', 'sgx_rollout', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_step_states', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
 )
 
 
@@ -99,6 +99,12 @@ def _bind(L):
     L.sgx_free_outputs.argtypes = [vp, C.POINTER(SgxOutputs)]
     L.sgx_step.restype = C.c_int
     L.sgx_step.argtypes = [vp, C.POINTER(SgxStepIO), vp]
+    L.sgx_host_alloc.restype = C.c_int
+    L.sgx_host_alloc.argtypes = [vp, i64, C.POINTER(vp), C.POINTER(vp)]
+    L.sgx_host_free.restype = C.c_int
+    L.sgx_host_free.argtypes = [vp, vp]
+    L.sgx_step_sync.restype = C.c_int
+    L.sgx_step_sync.argtypes = [vp, C.POINTER(SgxStepIO), vp]
     L.sgx_step_n.restype = C.c_int
     L.sgx_step_n.argtypes = [vp, C.POINTER(SgxStepIO), C.c_int32, vp]
     L.sgx_rollout.restype = C.c_int

@@ -695,6 +695,33 @@ SGX_API int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream) {
     return launch_step(h, p, stream);
 }
 
+// ---- single-game latency (the N = 1 facade): outputs in device-addressable pinned host memory, one call per env.step()
+SGX_API int sgx_host_alloc(sgx_env *h, int64_t bytes, void **host_ptr, void **dev_ptr) {
+    if (!h || !host_ptr || !dev_ptr || bytes <= 0) return fail(SGX_EINVAL, "sgx_host_alloc: bad argument%s");
+    HIP_TRY(hipSetDevice(h->device));
+    void *p = nullptr, *d = nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return fail(SGX_ENOMEM, "pinned host allocation failed%s"); }
+    if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return fail(SGX_EDEVICE, "hipHostGetDevicePointer failed%s"); }
+    memset(p, 0, (size_t)bytes);
+    *host_ptr = p;
+    *dev_ptr = d;
+    return SGX_OK;
+}
+
+SGX_API int sgx_host_free(sgx_env *h, void *host_ptr) {
+    if (!host_ptr) return SGX_OK;
+    if (h) HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipHostFree(host_ptr));
+    return SGX_OK;
+}
+
+SGX_API int sgx_step_sync(sgx_env *h, const sgx_step_io *io, void *stream) {
+    if (int rc = sgx_step(h, io, stream)) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return SGX_OK;
+}
+
 SGX_API int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void *stream) {
     if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
     if (!io->actions_dev || io->next_actions_dev != io->actions_dev)

@@ -252,8 +252,25 @@ class StrategoMultiAgentEnv:
         for n, o, nbytes, dtype, shape in layout:
             setattr(vec, n, self._slab[o:o + nbytes].view(dtype).view(shape))
             self._view[n] = self._host_np[o:o + nbytes].view(_NP_DTYPES[dtype]).reshape(shape)
-        self._act_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self._act_dev = torch.zeros(1, dtype=torch.int32, device=vec.device)
+        # step(): the same layout once more in pinned host memory that the device addresses (sgx_host_alloc), plus the action word:
+        # the kernel reads the action from there and writes the game's outputs there, and env.step() is ONE library call
+        # (sgx_step_sync) -- no upload, no download, no torch call on the path (19 k -> ~40 k steps/s, tools/facade_latency.py)
+        import ctypes as C
+        hp, dp = C.c_void_p(), C.c_void_p()
+        _lib.check(vec._L.sgx_host_alloc(vec._h, off + 256, C.byref(hp), C.byref(dp)), vec._L)
+        self._hslab_host, self._hslab_dev = hp.value, dp.value
+        raw = np.ctypeslib.as_array((C.c_uint8 * (off + 256)).from_address(hp.value))
+        self._hview = {n: raw[o:o + nbytes].view(_NP_DTYPES[dtype]).reshape(shape) for n, o, nbytes, dtype, shape in layout}
+        self._act_word = raw[off:off + 4].view(np.int32)
+        io = _lib.SgxStepIO()
+        dev = {n: dp.value + o for n, o, nbytes, dtype, shape in layout}
+        io.actions_dev = dp.value + off
+        io.obs_dev, io.fobs_dev, io.mask_dev = dev.get('obs'), dev.get('fobs'), dev['mask']
+        io.reward_dev, io.done_dev, io.player_dev = dev['reward'], dev['done'], dev['player']
+        io.invalid_action_dev, io.ending_invalid_dev = dev['invalid_action'], dev['ending_invalid']
+        io.final_obs_dev, io.final_fobs_dev = dev.get('final_obs'), dev.get('final_fobs')
+        io.next_actions_dev, io.auto_reset = None, 0
+        self._step_io = io
 
     def _fetch(self, nbytes):
         self._host[:nbytes].copy_(self._slab[:nbytes], non_blocking=True)
@@ -344,11 +361,12 @@ class StrategoMultiAgentEnv:
             flags |= _lib.STEP_ACTIONS_1D
         if not (-2 ** 31 <= action < 2 ** 31):                                         # np.unravel_index raises (maenv:685)
             raise ValueError("Couldn't get the next state because the move wasn't valid.")
-        self._act_host[0] = action
-        self._act_dev.copy_(self._act_host, non_blocking=True)
-        vec.step(self._act_dev, flags=flags)
-        self._fetch(self._step_bytes)
-        hv = self._view
+        self._act_word[0] = action
+        io = self._step_io
+        io.flags = flags | vec._mode_flags
+        _lib.check(vec._L.sgx_step_sync(vec._h, io, vec._stream()), vec._L)
+        vec._next_actions_fresh = False
+        hv = self._hview
         flags = (int(hv['invalid_action'][0]), int(hv['done'][0]), int(hv['player'][0]), int(hv['ending_invalid'][0]))
         if flags[0]:
             raise ValueError("Couldn't get the next state because the move wasn't valid.")   # impl:902
@@ -360,7 +378,6 @@ class StrategoMultiAgentEnv:
             infos = {}
         else:                                                                           # maenv:772-805
             dones = {1: True, -1: True, "__all__": True}
-            self._fetch(self._host.numel())                                             # + the terminal observations
             ff = hv.get('final_fobs')
             obs = {1: self._obs_dict(hv['final_obs'][0, 0], ff[0, 0] if ff is not None else None, hv['mask'][0], 1),
                    -1: self._obs_dict(hv['final_obs'][0, 1], ff[0, 1] if ff is not None else None, hv['mask'][0], -1)}
@@ -398,6 +415,9 @@ class StrategoMultiAgentEnv:
         return np.random.choice(range(len(flat)), p=p)
 
     def close(self):
+        if getattr(self, '_hslab_host', None) and getattr(self._vec, '_h', None):
+            self._vec._L.sgx_host_free(self._vec._h, self._hslab_host)
+            self._hslab_host = None
         self._vec.close()
         self.base_env.close()
 
