@@ -33,8 +33,9 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 9
-#define SGX_MAX_CELLS 256        /* rows*cols <= 256 (largest reference variant: 15x15) */
+#define SGX_ABI_VERSION 10
+#define SGX_MAX_CELLS 1024       /* rows*cols <= 1024 (largest reference variant: 15x15 = 225; the reference's StrategoProceduralEnv
+                                    takes any size, penv:27-36: boards of more than 256 cells use 10-bit cell indices in the record) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
 #define SGX_FO_OBS_CHANNELS 79   /* impl:1227 */
 #define SGX_PO_OBS_CHANNELS_ORIGINAL 32   /* impl:1148, obs_channel_mode='original' (maenv:67, 368-375) */

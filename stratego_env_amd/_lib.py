@@ -8,13 +8,13 @@ import os
 
 from .build import LIB_PATH, BUILTIN_GEOMETRIES, build_geometry
 
-SGX_MAX_CELLS = 256
+SGX_MAX_CELLS = 1024
 SGX_OBS_LUT_STRIDE = 16
 PO_OBS_CHANNELS = 67
 FO_OBS_CHANNELS = 79
 PO_OBS_CHANNELS_ORIGINAL = 32
 FO_OBS_CHANNELS_ORIGINAL = 33
-ABI_VERSION = 9
+ABI_VERSION = 10
 STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, STEP_ORIGINAL_CHANNELS = 1, 2, 4, 8, 16
 STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
 OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64

@@ -42,7 +42,7 @@ def build(force=False, verbose=False):
 
 
 BUILTIN_GEOMETRIES = ((10, 10), (15, 15), (8, 8), (6, 6), (5, 5), (4, 4), (3, 4))    # SGX_BUILTIN_GEOMETRIES in the .hip
-MAX_CELLS = 256
+MAX_CELLS = 1024
 
 
 def geometry_lib_path(rows, columns):
@@ -52,7 +52,7 @@ def geometry_lib_path(rows, columns):
 def build_geometry(rows, columns, force=False, verbose=False):
     """The library for a board size that is not compiled into libstratego_mi355x.so: the same sources with that one size
     (-DSGX_EXTRA_R / -DSGX_EXTRA_C / -DSGX_ONLY_EXTRA, ~20 s of hipcc), cached in _build/.  This is how any (rows, columns) the
-    reference's StrategoProceduralEnv accepts (penv:27-36; here rows * columns <= 256) gets its own specialised kernels."""
+    reference's StrategoProceduralEnv accepts (penv:27-36; here rows * columns <= 1024) gets its own specialised kernels."""
     rows, columns = int(rows), int(columns)
     if rows < 3 or columns < 3:
         raise ValueError("Both rows and columns have to be at least 3 (you passed rows: {} columns: {}).".format(rows, columns))

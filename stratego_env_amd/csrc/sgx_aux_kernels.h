@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
 template <class G, int NT_ = 256>
 struct StateIO {
     static constexpr int RC = G::RC, NT = NT_, NX = SGX_STATE_LAYERS * RC, NQ = NX / 2;
-    static constexpr int IMG = (G::EVL_OFF + 2 * G::EVL_MAX + 127) & ~127;      // >= rec_bytes of any piece set on this board
+    static constexpr int IMG = (G::EVL_OFF + G::EV_BYTES * G::EVL_MAX + 127) & ~127;   // >= rec_bytes of any piece set on this board
     static constexpr int DENSE = (NX + 15) & ~15;
     static constexpr int NE = 24 * RC, PER = (NE + NT - 1) / NT, NEP = (NE + 3) & ~3;
     static constexpr int ITER = (NQ + NT - 1) / NT;
@@ -157,14 +157,14 @@ __device__ __forceinline__ void export_from_image(const KParams &P, StateLds<G, 
     }
     if (tid < 4) {
         const int pr = (((tid >> 1) ? sc2.z : sc2.y) >> (16 * (tid & 1))) & 0xFFFF;
-        if (pr >> 8) dense[(6 + (tid >> 1)) * RC + (pr & 0xFF)] = (int8_t)(pr >> 8);
+        if (pr >> G::CELL_BITS) dense[(6 + (tid >> 1)) * RC + G::pair_cell(pr)] = (int8_t)G::pair_code(pr);
     }
     {   // one event per (layer, cell) with captured pieces: no two lanes write the same byte
-        const uint16_t *ev = reinterpret_cast<const uint16_t *>(img + G::EVL_OFF);
+        const typename G::ev_t *ev = reinterpret_cast<const typename G::ev_t *>(img + G::EVL_OFF);
         const int n_events = min(sc2.x, (int)G::EVL_MAX);
         for (int i = tid; i < n_events; i += NT) {
-            const int e = ev[i], at = (8 + ((e >> 8) & 31)) * RC + (e & 0xFF);
-            if (((e >> 8) & 31) < 24 && (e & 0xFF) < RC) dense[at] = (int8_t)((e >> EV_COUNT_SHIFT) + 1);
+            const int e = (int)ev[i], key = (e >> G::CELL_BITS) & 31, cell = e & G::CELL_MASK;
+            if (key < 24 && cell < RC) dense[(8 + key) * RC + cell] = (int8_t)((e >> G::EV_COUNT_SHIFT) + 1);
         }
     }
     __syncthreads();
@@ -217,9 +217,12 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
     const int lane = tid & 63, wave = tid >> 6;
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
     const i64x2 *s = reinterpret_cast<const i64x2 *>(in + env * (int64_t)NX);
-    i64x2 rawv[ITER];
+    // all of the state's loads in flight at once -- up to 16 per lane; bigger boards (15 x 15 needs 15, 32 x 32 would need 68
+    // = 272 VGPRs) go through them in batches of 8
+    constexpr int BATCH = ITER <= 16 ? ITER : 8;
+    i64x2 rawv[BATCH];
 #pragma unroll
-    for (int k = 0; k < ITER; ++k) {
+    for (int k = 0; k < BATCH; ++k) {
         const int q = tid + k * NT;
         rawv[k] = q < NQ ? __builtin_nontemporal_load(&s[q]) : i64x2{0, 0};
     }
@@ -227,14 +230,23 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
     for (int i = tid; i < IO::IMG / 4; i += NT) reinterpret_cast<uint32_t *>(img)[i] = 0;
     __syncthreads();
     bool bad = false;
+    for (int k0 = 0; k0 < ITER; k0 += BATCH) {
+    if (k0 > 0) {
 #pragma unroll
-    for (int k = 0; k < ITER; ++k) {
+        for (int k = 0; k < BATCH; ++k) {
+            const int q = tid + (k0 + k) * NT;
+            rawv[k] = q < NQ ? __builtin_nontemporal_load(&s[q]) : i64x2{0, 0};
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < BATCH; ++kk) {
+        const int k = k0 + kk;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int x = 2 * (tid + k * NT) + j;
             if (x >= NX) continue;
             const int l = x / RC, cell = x - l * RC;
-            const int64_t raw = j ? rawv[k].y : rawv[k].x;
+            const int64_t raw = j ? rawv[kk].y : rawv[kk].x;
             bool ok = true;
             if (l == 5) {                                                     // the scalars (other cells of the layer are not looked at)
                 const int which = cell == 0 ? 0 : cell == 1 ? 1 : cell == 2 ? 2 : cell == C ? 3 : cell == C + 1 ? 4 : -1;
@@ -252,6 +264,7 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
             }
             bad = bad || !ok;
         }
+    }
     }
     if (bad) W.altered = 1;
     __syncthreads();
@@ -273,7 +286,7 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
             total += __popcll(bal);
             while (bal && found < 2) {
                 const int cb = c0 + __ffsll((long long)bal) - 1;
-                pair |= (cb | (((int)recent[wave * RC + cb] & 0xFF) << 8)) << (16 * found);
+                pair |= G::make_pair(cb, (int)recent[wave * RC + cb]) << (16 * found);
                 ++found;
                 bal &= bal - 1;
             }
@@ -288,11 +301,11 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
     for (int w = 0; w < NT / 64; ++w) total_events += W.scan[w];
     {
         int at = wave_base + incl - cnt;
-        uint16_t *ev = reinterpret_cast<uint16_t *>(img + G::EVL_OFF);
+        typename G::ev_t *ev = reinterpret_cast<typename G::ev_t *>(img + G::EVL_OFF);
         for (int k = 0; k < PER; ++k) {
             const int e = tid * PER + k;
             if (e < NE && cap[e] != 0) {
-                if (at < P.max_events) ev[at] = (uint16_t)(((cap[e] - 1) << EV_COUNT_SHIFT) | ((e / RC) << 8) | (e % RC));
+                if (at < P.max_events) ev[at] = (typename G::ev_t)(((cap[e] - 1) << G::EV_COUNT_SHIFT) | ((e / RC) << G::CELL_BITS) | (e % RC));
                 ++at;
             }
         }
@@ -355,21 +368,21 @@ __global__ __launch_bounds__(128) void states_kernel(const KParams P, const int6
     __shared__ StateLds<G, NT> W;
     __shared__ Lds<G, ObsKind<KIND>::NIB_CH> L;
     __shared__ alignas(16) uint8_t shared[OBS ? shared_table_bytes<G, 0>() : 16];
-    __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS + COMBAT_BYTES];
+    __shared__ alignas(16) uint8_t obst_s[G::OBST_BYTES + COMBAT_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t env = P.env_first + blockIdx.x;
     if (env >= P.n_envs) return;
     {   // the step's workgroup-shared tables (game_kernel_body): default-code templates, code table, obstacle map, combat outcomes
         if constexpr (OBS) {
             const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
-            constexpr int NP = tmpl_bytes<G, 0>(false);
+            constexpr int NP = tmpl_lds_bytes<G, 0>(false);
             const int4 *tp = reinterpret_cast<const int4 *>(P.tab->tmpl[raw ? 2 : 0]);
             for (int i = tid; i < NP / 16; i += NT) reinterpret_cast<int4 *>(shared)[i] = tp[i];
             const int4 *ct = reinterpret_cast<const int4 *>(P.tab->codetab[raw ? 1 : 0]);
             for (int i = tid; i < CODETAB_BYTES / 16; i += NT) reinterpret_cast<int4 *>(shared + NP)[i] = ct[i];
         }
         for (int i = tid; i < G::S / 4; i += NT) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
-        for (int i = tid; i < COMBAT_BYTES / 4; i += NT) reinterpret_cast<int *>(obst_s + SGX_MAX_CELLS)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
+        for (int i = tid; i < COMBAT_BYTES / 4; i += NT) reinterpret_cast<int *>(obst_s + G::OBST_BYTES)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
     }
     import_to_image(P, W, in, player_in, sanitised, env, tid);              // (ends with a barrier: image and tables are in place)
     if (tid < 64) {

@@ -35,7 +35,7 @@ constexpr int NIB_ONE = 4, CODE_NONE = 0xFF, CODETAB_REC = 192, CODETAB_BYTES = 
 constexpr int COMBAT_BYTES = 16 * 16;
 enum { COMBAT_LOSE = 0, COMBAT_TIE = 1, COMBAT_WIN = 2, COMBAT_WIN_FLAG = 3 };
 constexpr int CODE_ESC = 8;   // (-2.0, never a value of its own) marks an entry whose float has no code: see emit_codes / patch_uncoded
-constexpr int TMPL_MAX_BYTES = ((SGX_MAX_CELLS * FOBS_CH / 2) + 15) & ~15;   // 10,112
+constexpr int TMPL_MAX_BYTES = ((SGX_MAX_CELLS * FOBS_CH / 2) + 15) & ~15;   // 40,448
 __host__ __device__ constexpr int lut_row(int ch) { return ((ch >> 1) & 1) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH + (ch & 1) * 16; }
 
 // internal board indices inside an env record (each board is S bytes, absolute coordinates)
@@ -48,14 +48,17 @@ constexpr int STORED_BOARDS = 4;  // boards 0..3 live in HBM as bytes; never-mov
 //   recent moves: at most two non-zero cells per player (impl:1013-1028)  -> two (cell, code) pairs per player in scal
 //   captured counts (impl layers 8-19 / 20-31): never dense, not even in LDS -- one EVENT per (layer, cell) with a non-zero
 //   count: uint16 = (count - 1) << 13 | (12 * pi + type - 1) << 8 | cell, <= 2 * pieces per side entries; a count cannot
-//   exceed the 8 pieces of the most numerous type
+//   exceed the 8 pieces of the most numerous type.  Boards of more than 256 cells (Geo::WIDE; the reference's
+//   StrategoProceduralEnv takes any size, penv:27-36) have 10-bit cell indices: events are uint32 = (count - 1) << 15 | key << 10 | cell
+//   and a recent pair keeps 6 instead of 8 bits for its code
 constexpr int B_OBST = 8;     // LDS only: per-variant obstacle map (impl layer 2)
 constexpr int B_ZERO = 9;     // LDS only: all zero ('original' channel mode reads the captured-count channels' defaults from it)
 constexpr int N_LDS_BOARDS = 10;
-constexpr int EV_KEY_MASK = 0x1FFF, EV_COUNT_SHIFT = 13, EV_COUNT_MAX = 8;
+constexpr int EV_COUNT_MAX = 8;          // (Geo::EV_COUNT_SHIFT / EV_KEY_MASK: the field positions depend on the cell-index width)
 
 // record scalars (32 B at SC_OFF): {turn, flags, max_turns, game_no} {n_events, recent pairs of +1, recent pairs of -1, 0}
-// a recent pair is cell | (code & 0xFF) << 8, two pairs per int (low / high half); code 0 = empty
+// a recent pair is 16 bits: cell | code << Geo::CELL_BITS (two's complement code in the remaining bits), two pairs per int (low / high
+// half); code 0 = empty
 constexpr int F_OVER = 1, F_WIN_P1 = 2, F_WIN_M1 = 4, F_END_INVALID = 8, F_PLAYER_M1 = 16;
 
 enum { SP_SPY = 1, SP_SCOUT = 2, SP_MINER = 3, SP_MARSHALL = 10, SP_FLAG = 11, SP_BOMB = 12, SP_UNKNOWN = 13 };
@@ -64,7 +67,18 @@ template <int R_, int C_>
 struct Geo {
     static constexpr int R = R_, C = C_;
     static constexpr int RC = R * C;
+    // cell-index width of the packed record: 8 bits up to 256 cells, 10 bits beyond (up to SGX_MAX_CELLS = 1024)
+    static constexpr bool WIDE = RC > 256;
+    static constexpr int CELL_BITS = WIDE ? 10 : 8, CELL_MASK = (1 << CELL_BITS) - 1, CODE_BITS = 16 - CELL_BITS;
+    using ev_t = std::conditional_t<WIDE, uint32_t, uint16_t>;        // capture event: (count - 1) << EV_COUNT_SHIFT | key << CELL_BITS | cell
+    using cell_t = std::conditional_t<WIDE, uint16_t, uint8_t>;       // a cell index in LDS scratch lists
+    using entry_t = std::conditional_t<WIDE, uint32_t, uint16_t>;     // an observation entry index (cell * channels + channel)
+    static constexpr int EV_COUNT_SHIFT = CELL_BITS + 5, EV_KEY_MASK = (1 << EV_COUNT_SHIFT) - 1;
+    __host__ __device__ static constexpr int pair_cell(int pr) { return pr & CELL_MASK; }
+    __host__ __device__ static constexpr int pair_code(int pr) { return (int)((unsigned)(pr & 0xFFFF) << 16) >> (16 + CELL_BITS); }   // sign-extended
+    __host__ __device__ static constexpr int make_pair(int cell, int code) { return cell | ((code & ((1 << CODE_BITS) - 1)) << CELL_BITS); }
     static constexpr int S = (RC + 3) & ~3;           // board stride (bytes)
+    static constexpr int OBST_BYTES = WIDE ? ((RC + 15) & ~15) : 256;   // the workgroup's LDS copy of the obstacle map (the combat table follows it)
     static constexpr int LDS_BOARDS_BYTES = N_BOARDS * S;            // bytes of the 8 boards of a game in LDS (multiple of 16)
     // HBM record (a multiple of 128 B, so every record is read and written as whole cache lines):
     //   [0, 4S) four dense boards (true pieces, PO pieces) | zero padding to 16 | ST_OFF: never-moved bitmaps 2 x SB |
@@ -74,7 +88,8 @@ struct Geo {
     static constexpr int SB = (((RC + 7) / 8) + 15) & ~15;           // bytes of one never-moved bitmap (bit i = cell i)
     static constexpr int SC_OFF = ST_OFF + 2 * SB, EVL_OFF = SC_OFF + 32;
     static constexpr int EVL_MAX = RC;                               // 2 * pieces per side <= cells
-    static constexpr int TAIL_BYTES = 2 * SB + 32 + ((2 * EVL_MAX + 15) & ~15);   // LDS image of the record from ST_OFF on
+    static constexpr int EV_BYTES = (int)sizeof(ev_t);
+    static constexpr int TAIL_BYTES = 2 * SB + 32 + ((EV_BYTES * EVL_MAX + 15) & ~15);   // LDS image of the record from ST_OFF on
     static constexpr int K = 2 * (R - 1) + 2 * (C - 1) + 1;
     static constexpr int NA = RC * K;                 // spatial actions
     static constexpr int NA_PAD = (NA + 15) & ~15;
@@ -94,10 +109,13 @@ struct Geo {
     static constexpr int CPL = (RC + LPG - 1) / LPG;  // cells per lane
     static constexpr int CNT_PAD = CPL * LPG;
     // upper estimate of one game's LDS region (struct Lds with the widest code buffer) + the workgroup's shared tables
-    static constexpr int LDS_GAME_EST = N_LDS_BOARDS * S + (RC * FOBS_CH / 2 + 64) + 4 * MB_WORDS + 2 * CNT_PAD + S + TAIL_BYTES + 6 * (EVL_MAX + 12) + 64;
-    static constexpr int LDS_SHARED_EST = 2 * (RC * FOBS_CH / 2 + 32) + 1024;
+    static constexpr int LDS_GAME_EST = N_LDS_BOARDS * S + (RC * FOBS_CH / 2 + 64) + 4 * MB_WORDS + (1 + (int)sizeof(cell_t)) * CNT_PAD + S + TAIL_BYTES +
+                                        (4 + (int)sizeof(entry_t)) * (EVL_MAX + 12) + 64;
+    // the workgroup's shared tables; WIDE boards read the default-code templates from global memory (L2) instead of an LDS copy
+    static constexpr int LDS_SHARED_EST = (WIDE ? 0 : 2 * (RC * FOBS_CH / 2 + 32)) + 1024 + S;
     static constexpr int WPB = (SGX_WPB * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? SGX_WPB
-                             : (4 * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? 4 : 2;
+                             : (4 * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? 4
+                             : (2 * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? 2 : 1;
 };
 
 struct DevTables {
@@ -172,10 +190,10 @@ struct alignas(16) Lds {
     alignas(16) uint32_t mbits[G::MB_WORDS];           // valid-actions mask of the next mover, one BIT per action
     alignas(16) uint8_t cnt[G::CNT_PAD];               // valid moves per perspective cell (also setup-shuffle scratch)
     alignas(16) uint8_t occ[G::S];                     // gen_mask scratch: combined occupancy byte per cell
-    alignas(16) uint8_t plist[G::CNT_PAD];             // gen_mask scratch: compacted list of movable cells
+    alignas(16) typename G::cell_t plist[G::CNT_PAD];  // gen_mask scratch: compacted list of movable cells (also setup-shuffle scratch)
     alignas(16) uint8_t tail[G::TAIL_BYTES];           // record image from ST_OFF on: bitmaps, 32 B scalars, capture-event list
     alignas(16) float unc_val[G::EVL_MAX + 4];         // entries of the observation being rendered whose value has no code:
-    alignas(16) uint16_t unc_entry[(G::EVL_MAX + 4 + 7) & ~7];   //   the float / the entry index
+    alignas(16) typename G::entry_t unc_entry[(G::EVL_MAX + 4 + 7) & ~7];   //   the float / the entry index
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -49,7 +49,7 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over
                                      (rec[i] == 1 ? OCC_CAME_FROM : 0));
             }
             const unsigned long long bm = gballot<G>(movable);
-            if (movable) L.plist[npieces + __popcll(bm & ((1ull << lane) - 1ull))] = (uint8_t)i;
+            if (movable) L.plist[npieces + __popcll(bm & ((1ull << lane) - 1ull))] = (typename G::cell_t)i;
             npieces += __popcll(bm);
         }
         wave_sync<G>();

@@ -39,19 +39,19 @@ __device__ inline void swap_code(Lds<G, NB> &L, int entry, int was, int now) {
 // Spec's observation from perspective qi; false for an empty pair
 template <class G, class Spec, int NB>
 __device__ inline bool special_entry(const Lds<G, NB> &L, int i, int n_events, int rp0, int rp1, int qi, int &entry, int &ch, int &v, int &tab_idx) {
-    const uint16_t *evl = reinterpret_cast<const uint16_t *>(L.tail + 2 * G::SB + 32);
+    const typename G::ev_t *evl = reinterpret_cast<const typename G::ev_t *>(L.tail + 2 * G::SB + 32);
     int cell;
     if (i < n_events) {
-        const int ev = evl[i], b = (ev >> 8) & 31, pi = b >= 12 ? 1 : 0, t = b - 12 * pi;
-        cell = ev & 0xFF;
+        const int ev = (int)evl[i], b = (ev >> G::CELL_BITS) & 31, pi = b >= 12 ? 1 : 0, t = b - 12 * pi;
+        cell = ev & G::CELL_MASK;
         ch = Spec::CAP0 + (pi == qi ? 0 : 12) + t;
-        v = (ev >> EV_COUNT_SHIFT) + 1;
+        v = (ev >> G::EV_COUNT_SHIFT) + 1;
         tab_idx = 16 * t + v;
     } else {
         const int k = i - n_events, pl = k >> 1, pr = (((pl ? rp1 : rp0) >> (16 * (k & 1))) & 0xFFFF);
-        const int code = (int)(int8_t)(pr >> 8);
+        const int code = G::pair_code(pr);
         if (code == 0) return false;
-        cell = pr & 0xFF;
+        cell = G::pair_cell(pr);
         ch = Spec::REC0 + (pl == qi ? 0 : 1);
         v = code + 3;
         tab_idx = CODETAB_REC + v;
@@ -104,7 +104,7 @@ __device__ inline int build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uint
         const unsigned long long bal = gballot<G>(unc);
         if (unc) {
             const int pos = n_unc + __popcll(bal & ((1ull << lane) - 1ull));
-            L.unc_entry[pos] = (uint16_t)entry;
+            L.unc_entry[pos] = (typename G::entry_t)entry;
             L.unc_val[pos] = val;
         }
         n_unc += __popcll(bal);

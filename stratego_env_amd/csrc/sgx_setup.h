@@ -39,13 +39,13 @@ __device__ void sample_boards(Lds<G, NB> &L, const KParams &P, uint64_t g, uint6
         }
     } else if (lane < 2) {
         // the two players' Fisher-Yates shuffles are independent (own RNG stream, own boards): lane 0 places player +1,
-        // lane 1 player -1, each in its own half of the scratch (2n <= cells <= CNT_PAD)
+        // lane 1 player -1, each in its own half of the scratch (L.plist: 2n <= cells <= CNT_PAD)
         const int pl = lane;
-        uint8_t *loc = L.cnt + pl * n;
-        for (int i = 0; i < n; ++i) loc[i] = (uint8_t)i;
+        typename G::cell_t *loc = L.plist + pl * n;
+        for (int i = 0; i < n; ++i) loc[i] = (typename G::cell_t)i;
         for (int i = n - 1; i > 0; --i) {
             const uint32_t k = rng_below(sgx_rng(P.seed, g, j, pl ? STREAM_SHUFFLE_P2 : STREAM_SHUFFLE_P1, (uint32_t)i), (uint32_t)(i + 1));
-            const uint8_t t = loc[i]; loc[i] = loc[k]; loc[k] = t;
+            const typename G::cell_t t = loc[i]; loc[i] = loc[k]; loc[k] = t;
         }
         int at = 0;
         for (int t = 1; t <= 12; ++t)

@@ -10,17 +10,21 @@ namespace {
 // workgroup-shared tables: 'extended' kinds -- default-code templates (+ the small code table); 'original' kinds -- LUT + quad table
 template <class G, int KIND>
 constexpr int tmpl_bytes(bool full) { return ((G::RC * (full ? FOBS_CH : OBS_CH) + 1) / 2 + 15) & ~15; }
+// bytes of the template(s) the workgroup holds in LDS: none on WIDE boards, which read the templates from global memory (a 32 x 32
+// board's two templates would take 74 KB of the CU's 160 KB)
+template <class G, int KIND>
+constexpr int tmpl_lds_bytes(bool full) { return G::WIDE ? 0 : tmpl_bytes<G, KIND>(full); }
 template <class G, int KIND>
 constexpr int shared_table_bytes() {
     constexpr bool FULL = (KIND & 1) != 0, ORIG = (KIND & 2) != 0;
     if (ORIG) return 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0));
-    return tmpl_bytes<G, KIND>(false) + (FULL ? tmpl_bytes<G, KIND>(true) : 0) + CODETAB_BYTES;
+    return tmpl_lds_bytes<G, KIND>(false) + (FULL ? tmpl_lds_bytes<G, KIND>(true) : 0) + CODETAB_BYTES;
 }
 
 // waves per SIMD this geometry can reach: LDS per workgroup = WPB game regions + the shared LUT, 160 KiB per CU
 template <class G, int KIND>
 constexpr int waves_per_simd() {
-    constexpr int per_wg = G::WPB * G::GPW * (int)sizeof(Lds<G, ObsKind<KIND>::NIB_CH>) + shared_table_bytes<G, KIND>() + SGX_MAX_CELLS + COMBAT_BYTES;
+    constexpr int per_wg = G::WPB * G::GPW * (int)sizeof(Lds<G, ObsKind<KIND>::NIB_CH>) + shared_table_bytes<G, KIND>() + G::OBST_BYTES + COMBAT_BYTES;
     constexpr int wgs = (160 * 1024) / per_wg;
     constexpr int w = wgs * G::WPB / 4;
     // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
@@ -28,20 +32,21 @@ constexpr int waves_per_simd() {
     return w > want ? want : (w < 1 ? 1 : w);
 }
 
-// One more captured piece on layer / cell `key` ((12 * pi + type - 1) << 8 | cell): the count of its event goes up, or a new event
+// One more captured piece on layer / cell `key` ((12 * pi + type - 1) << CELL_BITS | cell): the count of its event goes up, or a new event
 // is appended.  Returns the new number of events.
 template <class G, int NB>
 __device__ inline int add_capture(Lds<G, NB> &L, int n_events, int max_events, int key, int lane) {
-    uint16_t *evl = reinterpret_cast<uint16_t *>(L.tail + 2 * G::SB + 32);
+    using ev_t = typename G::ev_t;
+    ev_t *evl = reinterpret_cast<ev_t *>(L.tail + 2 * G::SB + 32);
     bool found = false;
     for (int i0 = 0; i0 < n_events; i0 += G::LPG) {                    // (wave-uniform bound for a 64-lane game)
         const int i = i0 + lane;
-        const bool hit = i < n_events && (evl[i] & EV_KEY_MASK) == key;
-        if (hit && (evl[i] >> EV_COUNT_SHIFT) < EV_COUNT_MAX - 1) evl[i] = (uint16_t)(evl[i] + (1 << EV_COUNT_SHIFT));
+        const bool hit = i < n_events && (int)(evl[i] & G::EV_KEY_MASK) == key;
+        if (hit && (int)(evl[i] >> G::EV_COUNT_SHIFT) < EV_COUNT_MAX - 1) evl[i] = (ev_t)(evl[i] + (1 << G::EV_COUNT_SHIFT));
         found = found || gballot<G>(hit) != 0ull;
     }
     if (!found && n_events < max_events) {
-        if (lane == 0) evl[n_events] = (uint16_t)key;
+        if (lane == 0) evl[n_events] = (ev_t)key;
         n_events += 1;
     }
     wave_sync<G>();
@@ -72,7 +77,7 @@ __device__ inline void write_record(Lds<G, NB> &L, int8_t *rec_g, int rec_bytes,
     wave_sync<G>();
     const int4 *bsrc = reinterpret_cast<const int4 *>(&L.b[0][0]), *tsrc = reinterpret_cast<const int4 *>(L.tail);
     int4 *dst = reinterpret_cast<int4 *>(rec_g);
-    const int n_tail_q = (2 * G::SB + 32 + 2 * n_events + 15) >> 4;            // tail int4s that carry data
+    const int n_tail_q = (2 * G::SB + 32 + G::EV_BYTES * n_events + 15) >> 4;  // tail int4s that carry data
     for (int i = lane; i < rec_bytes / 16; i += G::LPG) {
         int4 v = make_int4(0, 0, 0, 0);
         if (i < G::ST_OFF / 16) {
@@ -90,18 +95,21 @@ __device__ inline void write_record(Lds<G, NB> &L, int8_t *rec_g, int rec_bytes,
 struct GameInput {
     int4 rq0, rq1, pos_raw;
     int a_raw;
+    const int4 *src;      // WIDE boards (a record of more than two int4 per lane): staged straight from here in env_step
 };
 // (src: the game's record -- global memory, or the LDS image of sgx_step_states' fused kernel)
 template <class G>
 __device__ __forceinline__ GameInput load_game_from(const KParams &P, const int4 *src, const int64_t env, const int lane) {
     constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + G::LPG - 1) / G::LPG;
-    static_assert(G::TAIL_BYTES % 16 == 0 && NLOAD <= 2, "record image must fit two int4 per lane");
+    static_assert(G::TAIL_BYTES % 16 == 0 && (NLOAD <= 2 || G::WIDE), "record image must fit two int4 per lane");
     const int4 zero4 = make_int4(0, 0, 0, 0);
-    GameInput in{zero4, zero4, zero4, 0};
+    GameInput in{zero4, zero4, zero4, 0, src};
     const int nq = min(P.rec_bytes >> 4, Q_REC);
-    if (lane < nq) in.rq0 = src[lane];
-    if constexpr (NLOAD > 1)
-        if (lane + G::LPG < nq) in.rq1 = src[lane + G::LPG];
+    if constexpr (NLOAD <= 2) {
+        if (lane < nq) in.rq0 = src[lane];
+        if constexpr (NLOAD > 1)
+            if (lane + G::LPG < nq) in.rq1 = src[lane + G::LPG];
+    }
     if (P.mode == 0) {
         if (P.io.flags & SGX_STEP_ACTIONS_POSITIONS) in.pos_raw = reinterpret_cast<const int4 *>(P.io.actions_dev)[env];
         else in.a_raw = P.io.actions_dev[env];
@@ -110,7 +118,7 @@ __device__ __forceinline__ GameInput load_game_from(const KParams &P, const int4
 }
 template <class G, bool MAPPED>
 __device__ __forceinline__ GameInput load_game(const KParams &P, const int64_t env, const int lane) {
-    if (env >= P.n_envs) { const int4 zero4 = make_int4(0, 0, 0, 0); return GameInput{zero4, zero4, zero4, 0}; }
+    if (env >= P.n_envs) { const int4 zero4 = make_int4(0, 0, 0, 0); return GameInput{zero4, zero4, zero4, 0, nullptr}; }
     const int8_t *rec_src = P.boards + env * (int64_t)P.rec_bytes;
     if constexpr (MAPPED)        // sgx_expand: the game comes from another handle's records (functional-API instantiation only)
         if (P.src_boards) rec_src = P.src_boards + (int64_t)(P.src_index ? P.src_index[env] : env) * (int64_t)P.rec_bytes;
@@ -126,7 +134,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
     constexpr bool ORIG = ObsKind<KIND>::ORIG, FULL = ObsKind<KIND>::FULL;
-    const uint8_t *combat_s = obst_s + SGX_MAX_CELLS;           // the combat table follows the obstacle map in the shared LDS
+    const uint8_t *combat_s = obst_s + G::OBST_BYTES;           // the combat table follows the obstacle map in the shared LDS
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     STAMP(0);
 
@@ -149,11 +157,20 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
             reinterpret_cast<int *>(L.b[B_OBST])[i] = reinterpret_cast<const int *>(obst_s)[i];
         }
         int4 *tl = reinterpret_cast<int4 *>(L.tail);
-        if (lane < Q_BOARDS) dst[lane] = rq0;
-        else if (lane < Q_REC) tl[lane - Q_BOARDS] = rq0;
-        if constexpr (NLOAD > 1) {
-            if (lane + G::LPG < Q_BOARDS) dst[lane + G::LPG] = rq1;
-            else if (lane + G::LPG < Q_REC) tl[lane + G::LPG - Q_BOARDS] = rq1;
+        if constexpr (NLOAD <= 2) {
+            if (lane < Q_BOARDS) dst[lane] = rq0;
+            else if (lane < Q_REC) tl[lane - Q_BOARDS] = rq0;
+            if constexpr (NLOAD > 1) {
+                if (lane + G::LPG < Q_BOARDS) dst[lane + G::LPG] = rq1;
+                else if (lane + G::LPG < Q_REC) tl[lane + G::LPG - Q_BOARDS] = rq1;
+            }
+        } else {                                              // WIDE boards: the record is several KiB, staged in a loop
+            const int nq = min(P.rec_bytes >> 4, Q_REC);
+            for (int i = lane; i < Q_REC; i += G::LPG) {
+                const int4 v = i < nq ? in.src[i] : make_int4(0, 0, 0, 0);
+                if (i < Q_BOARDS) dst[i] = v;
+                else tl[i - Q_BOARDS] = v;
+            }
         }
     }
     wave_sync<G>();
@@ -175,7 +192,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
         }
         if (lane < 4) {
             const int pr = (((lane >> 1) ? rp1 : rp0) >> (16 * (lane & 1))) & 0xFFFF;
-            if (pr >> 8) L.b[B_RECENT + (lane >> 1)][pr & 0xFF] = (int8_t)(pr >> 8);
+            if (pr >> G::CELL_BITS) L.b[B_RECENT + (lane >> 1)][G::pair_cell(pr)] = (int8_t)G::pair_code(pr);
         }
     }
     wave_sync<G>();
@@ -310,12 +327,12 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
                 }
                 if (dest != 0) {
                     // captured counts (impl:999-1009): the attacker's own layer unless it won, the defender's if it lost or tied
-                    if (!wins) n_events = add_capture(L, n_events, P.max_events, ((12 * pi + moved - 1) << 8) | e, lane);
-                    if (wins || tied) n_events = add_capture(L, n_events, P.max_events, ((12 * (1 - pi) + dest - 1) << 8) | e, lane);
+                    if (!wins) n_events = add_capture(L, n_events, P.max_events, ((12 * pi + moved - 1) << G::CELL_BITS) | e, lane);
+                    if (wins || tied) n_events = add_capture(L, n_events, P.max_events, ((12 * (1 - pi) + dest - 1) << G::CELL_BITS) | e, lane);
                     if (pi) rp1 = 0; else rp0 = 0;                                       // an attack wipes the mover's layer
                 } else {
                     const int code = old_end == 1 ? (old_start == -2 ? -3 : -2) : -1;
-                    const int pr = (s | (1 << 8)) | ((e | ((code & 0xFF) << 8)) << 16);
+                    const int pr = G::make_pair(s, 1) | (G::make_pair(e, code) << 16);
                     if (pi) rp1 = pr; else rp0 = pr;
                 }
                 wave_sync<G>();
@@ -365,11 +382,13 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     //      bulk stores first; render() then returns what is still to do and finish() does it.
     const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
     const float *glut_p = P.tab->lut[(ORIG ? 4 : 0) + (raw ? 2 : 0)], *glut_f = P.tab->lut[(ORIG ? 4 : 0) + (raw ? 2 : 0) + 1];
-    const uint8_t *codetab = ORIG ? nullptr : shared + tmpl_bytes<G, KIND>(false) + (FULL ? tmpl_bytes<G, KIND>(true) : 0);
+    const uint8_t *codetab = ORIG ? nullptr : shared + tmpl_lds_bytes<G, KIND>(false) + (FULL ? tmpl_lds_bytes<G, KIND>(true) : 0);
     auto render = [&](auto spec, bool full, int q, float *dst) -> int {
         using Spec = decltype(spec);
         if constexpr (Spec::CODES) {
-            const int n_unc = build_codes<G, Spec>(L, full ? shared + tmpl_bytes<G, KIND>(false) : shared, codetab, full ? glut_f : glut_p, q,
+            const uint8_t *tmpl = full ? shared + tmpl_lds_bytes<G, KIND>(false) : shared;
+            if constexpr (G::WIDE) tmpl = P.tab->tmpl[(raw ? 2 : 0) + (full ? 1 : 0)];           // (global memory, L2-resident)
+            const int n_unc = build_codes<G, Spec>(L, tmpl, codetab, full ? glut_f : glut_p, q,
                                                    n_events, rp0, rp1, lane);
             if constexpr (RC % 4 == 0) {
                 if (n_unc == 0) {
@@ -469,7 +488,7 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     constexpr bool FULL = ObsKind<KIND>::FULL, ORIG = ObsKind<KIND>::ORIG;
     __shared__ Lds<G, ObsKind<KIND>::NIB_CH> LW[G::WPB * G::GPW];
     __shared__ alignas(16) uint8_t shared[shared_table_bytes<G, KIND>()];
-    __shared__ alignas(16) uint8_t obst_s[SGX_MAX_CELLS + COMBAT_BYTES];    // obstacle map, then the combat outcome table
+    __shared__ alignas(16) uint8_t obst_s[G::OBST_BYTES + COMBAT_BYTES];    // obstacle map, then the combat outcome table
     const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;     // lane inside the game, game inside the workgroup
     const int64_t env = P.env_first + group_of_block(P.map_mode, P.map_arg) * (G::WPB * G::GPW) + slot;
     // The game's record and action are requested FIRST: the reads fly while the workgroup stages its shared tables (another
@@ -488,7 +507,7 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
             build_quad_table<G, FS>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * G::WPB);
         }
     } else {
-        constexpr int NP = tmpl_bytes<G, KIND>(false), NF = FULL ? tmpl_bytes<G, KIND>(true) : 0;
+        constexpr int NP = tmpl_lds_bytes<G, KIND>(false), NF = FULL ? tmpl_lds_bytes<G, KIND>(true) : 0;
         const int4 *tp = reinterpret_cast<const int4 *>(P.tab->tmpl[raw ? 2 : 0]);
         for (int i = threadIdx.x; i < NP / 16; i += 64 * G::WPB) reinterpret_cast<int4 *>(shared)[i] = tp[i];
         if constexpr (FULL) {
@@ -500,7 +519,7 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     }
     for (int i = threadIdx.x; i < G::S / 4; i += 64 * G::WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
     for (int i = threadIdx.x; i < COMBAT_BYTES / 4; i += 64 * G::WPB)
-        reinterpret_cast<int *>(obst_s + SGX_MAX_CELLS)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
+        reinterpret_cast<int *>(obst_s + G::OBST_BYTES)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
     __syncthreads();   // from here on every wave works on its own game
     if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], shared, obst_s, env, lane, in);
 }

@@ -340,7 +340,7 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
         const int st_off = (STORED_BOARDS * ((rc_cells + 3) & ~3) + 15) & ~15, sb = (((rc_cells + 7) / 8) + 15) & ~15;
         const int sc_off = st_off + 2 * sb;
         h->sc_off = sc_off;
-        h->rec_bytes = (sc_off + 32 + 2 * h->max_events + 127) & ~127;   // whole 128-byte lines per game
+        h->rec_bytes = (sc_off + 32 + (rc_cells > 256 ? 4 : 2) * h->max_events + 127) & ~127;   // whole 128-byte lines per game (Geo::ev_t events)
     }
     h->K = 2 * (cfg->rows - 1) + 2 * (cfg->cols - 1) + 1;
     DevTables host_tab;
@@ -836,7 +836,7 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
     p.mode = io->actions_dev ? 0 : 1;        // no actions: observe -- masks / observations of the given states, nothing is played
     p.io = *io;
     const bool kind0 = !io->fobs_dev && !io->final_fobs_dev && !(io->flags & SGX_STEP_ORIGINAL_CHANNELS);
-    if (kind0 && h->cfg.rows * h->cfg.cols > 32) {
+    if (kind0 && h->cfg.rows * h->cfg.cols > 32 && h->cfg.rows * h->cfg.cols <= 256) {
         // one-game-per-wave boards, partial-observation kinds: ONE fused launch, the record never leaves LDS between the three steps
         if (int rc = check_step_io(h, p)) return rc;
         const int nt = h->nt_mode < 0 ? (h->n_envs * (int64_t)SGX_STATE_LAYERS * h->cfg.rows * h->cfg.cols * 8 > (int64_t)300 * 1000 * 1000) : h->nt_mode;
@@ -846,7 +846,7 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
 #define CALL_STATES_K(R, C, M, O) states_kernel<R, C, M, O><<<(unsigned)h->n_envs, 128, 0, (hipStream_t)stream>>>(p, state_in_dev, player_in_dev, sanitised_dev, state_out_dev, player_out_dev, nt)
 #define CALL_STATES(R, C)                                                                                                   \
     do {                                                                                                                    \
-        if constexpr (Geo<R, C>::LPG == 64) {                                                                               \
+        if constexpr (Geo<R, C>::LPG == 64 && !Geo<R, C>::WIDE) {                                                           \
             if (mapped && obs) CALL_STATES_K(R, C, true, true);                                                             \
             else if (mapped) CALL_STATES_K(R, C, true, false);                                                              \
             else if (obs) CALL_STATES_K(R, C, false, true);                                                                 \

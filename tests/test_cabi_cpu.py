@@ -27,12 +27,12 @@ def test_header_symbols_all_exported(lib):
     assert declared == sorted(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.sgx_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.sgx_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_struct_sizes_match_header():
-    # sgx_config: 4 + 12 + 1 int32 + 256 bytes; sgx_step_io: 12 pointers + 2 int32
-    assert C.sizeof(_lib.SgxConfig) == 17 * 4 + 256
+    # sgx_config: 4 + 12 + 1 int32 + SGX_MAX_CELLS bytes; sgx_step_io: 12 pointers + 2 int32
+    assert C.sizeof(_lib.SgxConfig) == 17 * 4 + 1024
     assert C.sizeof(_lib.SgxStepIO) == 12 * 8 + 8
     assert C.sizeof(_lib.SgxOutputs) == 3 * 8 + 4 * 8 + 2 * 4 + 2 * 64 * 4 + 2 * 4  # sgx_outputs of the header, field by field
 

@@ -62,7 +62,7 @@ def test_custom_variants_and_geometry_libraries():
         with pytest.raises(ValueError):
             custom_variant(*bad)
     with pytest.raises(ValueError):
-        hip_build.build_geometry(17, 17)                      # more than 256 cells
+        hip_build.build_geometry(33, 32)                      # more than 1024 cells
     assert {(x.rows, x.columns) for x in VARIANTS.values()} == set(hip_build.BUILTIN_GEOMETRIES)
     assert os.path.basename(hip_build.geometry_lib_path(7, 9)) == 'libstratego_mi355x_7x9.so'
     main = _lib.load()

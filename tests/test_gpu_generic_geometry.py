@@ -23,6 +23,14 @@ CUSTOM = {
     'c12x12': custom_variant(12, 12, max_turns=300, obstacle_locations=((5, 2), (6, 2), (5, 3), (6, 3), (5, 8), (6, 8), (5, 9), (6, 9)),
                              piece_counts=(1, 8, 5, 4, 4, 4, 3, 2, 1, 1, 1, 6), initial_state_usable_rows=4, name='c12x12'),
     'c3x40': custom_variant(3, 40, max_turns=120, piece_counts=(1, 6, 2, 1, 1, 1, 1, 1, 1, 1, 1, 3), name='c3x40'),   # K = 83 > 64 lanes
+    # more than 256 cells: 10-bit cell indices in the packed record (uint32 capture events, 6-bit recent-move codes), templates read from
+    # global memory, records staged in a loop
+    'c20x20': custom_variant(20, 20, max_turns=400, obstacle_locations=((9, 4), (10, 4), (9, 5), (10, 5), (9, 14), (10, 14), (9, 15), (10, 15)),
+                             piece_counts=(1, 8, 5, 4, 4, 4, 3, 2, 1, 1, 1, 6), initial_state_usable_rows=3, name='c20x20'),
+    'c32x32': custom_variant(32, 32, max_turns=250, obstacle_locations=((15, 7), (16, 7), (15, 24), (16, 24)),      # SGX_MAX_CELLS
+                             piece_counts=(1, 8, 5, 4, 4, 4, 3, 2, 1, 1, 1, 6), initial_state_usable_rows=2, name='c32x32'),
+    'c17x16': custom_variant(17, 16, max_turns=300, obstacle_locations=((8, 3), (8, 12)),
+                             piece_counts=(1, 6, 3, 2, 2, 2, 2, 1, 1, 1, 1, 4), initial_state_usable_rows=2, name='c17x16'),
 }
 
 
@@ -36,7 +44,8 @@ def _custom_names():
         config.VARIANTS.pop(k, None)
 
 
-@pytest.mark.parametrize('name,n_envs,n_steps', [('c3x3', 48, 80), ('c7x7', 32, 200), ('c9x5', 32, 200), ('c12x12', 12, 250), ('c3x40', 12, 120)])
+@pytest.mark.parametrize('name,n_envs,n_steps', [('c3x3', 48, 80), ('c7x7', 32, 200), ('c9x5', 32, 200), ('c12x12', 12, 250), ('c3x40', 12, 120),
+                                                 ('c20x20', 6, 300), ('c17x16', 8, 250), ('c32x32', 3, 160)])
 def test_step_mode_bit_exact_vs_oracle(name, n_envs, n_steps):
     from tests.test_gpu_parity import test_step_bit_exact_vs_oracle
     test_step_bit_exact_vs_oracle(name, n_envs, n_steps, 0.1)
@@ -65,12 +74,12 @@ def _sampled_states(name, n, seed):
     return np.stack(states[:n]), np.asarray(players[:n], dtype=np.int8)
 
 
-@pytest.mark.parametrize('name', ['c3x3', 'c7x7', 'c9x5', 'c12x12', 'c3x40'])
+@pytest.mark.parametrize('name', ['c3x3', 'c7x7', 'c9x5', 'c12x12', 'c3x40', 'c20x20', 'c17x16', 'c32x32'])
 def test_functional_mode_matches_oracle(name):
     import torch
     from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
     v = CUSTOM[name]
-    n = 64
+    n = 64 if v.cells <= 400 else 12
     states, players = _sampled_states(name, n, 5)
     ru = orc.OracleRules(v.rows, v.columns)
     pe = BatchedStrategoProceduralEnv(v, n)

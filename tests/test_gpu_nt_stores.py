@@ -50,7 +50,8 @@ def test_step_parity_with_nt_forced(nt_forced, name, n_envs, n_steps, garbage):
     test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=3)
 
 
-@pytest.mark.parametrize('name,n_envs,n_steps', [('c3x3', 48, 80), ('c7x7', 32, 200), ('c9x5', 32, 200), ('c12x12', 12, 250), ('c3x40', 12, 120)])
+@pytest.mark.parametrize('name,n_envs,n_steps', [('c3x3', 48, 80), ('c7x7', 32, 200), ('c9x5', 32, 200), ('c12x12', 12, 250), ('c3x40', 12, 120),
+                                                 ('c20x20', 4, 200)])
 def test_custom_geometries_with_nt_forced(nt_forced, custom_names, name, n_envs, n_steps):
     from tests.test_gpu_parity import test_step_bit_exact_vs_oracle
     test_step_bit_exact_vs_oracle(name, n_envs, n_steps, 0.1, seed_salt=4)

@@ -101,7 +101,7 @@ def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0):
             st, pl = env.export_state()
             assert np.array_equal(st.cpu().numpy(), np.stack([oe.state for oe in oenvs])), (name, t, 'state export')
             assert np.array_equal(pl.cpu().numpy(), np.asarray([oe.player for oe in oenvs], dtype=np.int8))
-    assert games_done > 0 or name in ('standard', 'standard2', 'medium_standard', 'short_standard', 'c12x12')
+    assert games_done > 0 or name in ('standard', 'standard2', 'medium_standard', 'short_standard', 'c12x12', 'c20x20', 'c17x16', 'c32x32')
     env.close()
 
 
