@@ -152,3 +152,49 @@ def test_reference_shaped_class_takes_any_size_and_any_obstacles():
             assert np.array_equal(st2, want) and p2 == -player
             st, player = st2, p2
         env.close()
+
+
+def test_long_scout_moves_on_a_3x85_board_check_every_intermediate_cell():
+    """A board side of more than 66 cells: the scout path check walks the intermediate cells in slices of 64 lanes (it used to look
+    at the first 64 only).  Directed positions on 3 x 85: a scout at (1, 2) moving along the row with a blocker 3 .. 80 cells away,
+    in front of and behind the target -- is_move_valid / get_next_state / masks vs the oracle."""
+    import torch
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    R, C = 3, 85
+    v = custom_variant(R, C, max_turns=500, piece_counts=(0, 2, 0, 0, 1, 0, 0, 0, 0, 0, 1, 1), name='c3x85')
+    ru = orc.OracleRules(R, C)
+    states, players, actions = [], [], []
+    for mover in (1, -1):
+        for blocker_c in (5, 40, 66, 67, 68, 70, 75, 82, None):
+            for target_c in (60, 69, 71, 83, 84):
+                for blocker_owner in (1, -1):
+                    st = np.zeros((34, R, C), dtype=np.int64)
+                    st[5, 0, 0], st[5, 1, 0] = 7, 500
+                    pi, oi = (0, 1) if mover == 1 else (1, 0)
+                    st[pi, 1, 2] = 2; st[3 + pi, 1, 2] = 13; st[32 + pi, 1, 2] = 1           # the scout
+                    st[pi, 0, 0] = 11; st[3 + pi, 0, 0] = 13; st[32 + pi, 0, 0] = 1          # flags out of the way
+                    st[oi, 2, 84] = 11; st[3 + oi, 2, 84] = 13; st[32 + oi, 2, 84] = 1
+                    st[oi, 2, 0] = 5; st[3 + oi, 2, 0] = 13                                  # a spare mover for the opponent
+                    if blocker_c is not None:
+                        bi = pi if blocker_owner == mover else oi
+                        st[bi, 1, blocker_c] = 12; st[3 + bi, 1, blocker_c] = 13; st[32 + bi, 1, blocker_c] = 1
+                    states.append(st); players.append(mover)
+                    actions.append(ru.get_action_1d_index_from_positions(1, 2, 1, target_c))
+    n = len(states)
+    states, players, actions = np.stack(states), np.asarray(players, dtype=np.int8), np.asarray(actions, dtype=np.int64)
+    pe = BatchedStrategoProceduralEnv(v, n)
+    valid = pe.is_move_valid_by_1d_index(states, players, actions).cpu().numpy()
+    ns, npl, ok = pe.get_next_state(states, players, actions)
+    m1 = pe.get_valid_moves_as_1d_mask(states, players).cpu().numpy()
+    ns, ok = ns.cpu().numpy(), ok.cpu().numpy()
+    n_valid = 0
+    for e in range(n):
+        p = int(players[e])
+        good = ru.is_move_valid_by_1d_index(states[e], p, int(actions[e]))
+        assert bool(valid[e]) == bool(ok[e]) == bool(good), e
+        assert np.array_equal(m1[e], ru.get_valid_moves_as_1d_mask(states[e], p)), e
+        if good:
+            n_valid += 1
+            assert np.array_equal(ns[e], ru.get_next_state(states[e], p, int(actions[e]))[0]), e
+    assert 0 < n_valid < n
+    pe.close()
