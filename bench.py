@@ -277,7 +277,18 @@ class Rank:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             kw = {'device_id': torch.device('cuda', self.device_index)} if self.reduce_device == 'cuda' else {}
-            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+            # (gloo announces its connections on stdout, which has to stay ONE JSON line: send that to stderr)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+                if backend == 'gloo':
+                    dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             if dist.get_world_size() != gpus:
                 raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), gpus))
             self.dist = dist

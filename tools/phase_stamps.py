@@ -40,8 +40,9 @@ def main():
     L.sgx_debug_stamps.argtypes = [C.c_void_p]
     env.reset()
     env.sample_valid_actions()
-    for _ in range(40):
-        env.rollout_step()
+    warm = int(sys.argv[3]) if len(sys.argv) > 3 else 40        # steps played before the stamped one (how deep into the games)
+    env.rollout_steps(warm - 1)
+    env.rollout_step()
     torch.cuda.synchronize()
     ptr = L.sgx_debug_stamps(env._h)
     buf = torch.empty((n, 16), dtype=torch.int64, device=env.device)
