@@ -146,6 +146,15 @@ int sgx_destroy(sgx_env *h);
  * mode (tests/test_gpu_nt_stores.py runs the parity suites with the mode forced).  No reference counterpart. */
 int sgx_set_nt_stores(sgx_env *h, int32_t mode);
 
+/* Shares of the eight XCDs in a launch of sgx_step / sgx_observe.  Under a saturating write stream the odd XCDs of MI355X drain their
+ * eighth of the games ~20 % slower than the even ones, so with equal eighths the even XCDs idle at the end of every launch; the
+ * library gives the even XCD of each pair `per_mille` more than the mean share and the odd one as much less (DESIGN.md section 3.1:
+ * -3 ... -5 % launch time where the write stream bounds the kernel: 8x8 and 10x10 boards; +3 ... +7 % where the game logic shares the
+ * critical path: 6x6, 15x15, Micro).  -1 (default): 100 per mille on boards of 64 .. 100 cells when a launch's observations do not fit
+ * the Infinity Cache, equal shares otherwise; 0: always equal; 1 .. 900: always that.  SGX_XCD_SKEW=<per mille>|auto sets the default of
+ * handles created afterwards.  Which workgroup plays which game cannot change any result.  No reference counterpart. */
+int sgx_set_xcd_skew(sgx_env *h, int32_t per_mille);
+
 /* Upload a human-setup table (game/inits/{barrage,standard}_human_inits.py decoded to piece codes, util.py:154-180):
  * table_host is uint8 [n_setups][usable_rows*cols] in Gravon string order.  Replaces get_random_human_init_fn
  * (util.py:301-319).  Without a table, sampled resets place pieces uniformly at random in the usable rows

@@ -69,6 +69,7 @@ struct sgx_env {
     int K;
     unsigned long long *stamps;  // SGX_STAMPS builds only
     int map_mode, map_arg;       // SGX_MAP experiment (group_of_block)
+    int xcd_skew;                // sgx_set_xcd_skew: per mille more work for the even XCDs; -1 = by the launch's output size
     int nt_mode;                 // sgx_set_nt_stores: -1 = by the launch's output size, 0 = never, 1 = always
     hipStream_t chain_stream[SGX_MAX_CHAINS];   // sgx_rollout: created on first use
     hipEvent_t chain_fork, chain_join[SGX_MAX_CHAINS];
@@ -129,8 +130,6 @@ KParams make_params(const sgx_env *h) {
 #endif
     return p;
 }
-
-unsigned grid_for(int64_t n) { return (unsigned)((n + 7) & ~(int64_t)7); }
 
 int check_cfg(const sgx_config *cfg) {
     if (!cfg) return fail(SGX_EINVAL, "cfg is NULL%s");
@@ -330,6 +329,9 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
         if (!strcmp(e, "0")) h->nt_mode = 0;
         else if (!strcmp(e, "1")) h->nt_mode = 1;
     }
+    h->xcd_skew = -1;
+    if (const char *e = getenv("SGX_XCD_SKEW")) { if (strcmp(e, "auto")) h->xcd_skew = atoi(e); }   // SGX_XCD_SKEW=<per mille>|auto
+    if (h->xcd_skew > 900) h->xcd_skew = 900;
     if (const char *e = getenv("SGX_MAP")) { h->map_mode = atoi(e); if (const char *c = strchr(e, ',')) h->map_arg = atoi(c + 1); }
     const int rc_cells = cfg->rows * cfg->cols;
     {
@@ -406,6 +408,12 @@ SGX_API int sgx_set_nt_stores(sgx_env *h, int32_t mode) {
     return SGX_OK;
 }
 
+SGX_API int sgx_set_xcd_skew(sgx_env *h, int32_t per_mille) {
+    if (!h || per_mille < -1 || per_mille > 900) return fail(SGX_EINVAL, "sgx_set_xcd_skew: -1 (auto) or 0 .. 900 per mille%s");
+    h->xcd_skew = per_mille;
+    return SGX_OK;
+}
+
 SGX_API int sgx_set_setup_table(sgx_env *h, const uint8_t *table_host, int64_t n_setups) {
     if (!h || !table_host || n_setups <= 0 || n_setups > 0x7fffffff) return fail(SGX_EINVAL, "bad setup table%s");
     HIP_TRY(hipSetDevice(h->device));
@@ -448,6 +456,17 @@ static bool launch_streams_past_cache(const sgx_env *h, const KParams &p) {
     return bytes > (int64_t)300 * 1000 * 1000;
 }
 
+// Workgroup-groups per even / odd XCD for `groups` groups of games (KParams::xcd_big / xcd_small); returns the grid size (8 x big).
+#define SGX_XCD_SKEW_DEFAULT 100
+static unsigned shares_for(KParams &p, int64_t groups, int skew_per_mille) {
+    const int64_t per = (groups + 7) / 8;                                  // mean share of an XCD
+    int64_t big = per + (per * skew_per_mille + 999) / 1000;
+    if (big > 2 * per) big = 2 * per;
+    p.xcd_big = (int32_t)big;
+    p.xcd_small = (int32_t)(2 * per - big);
+    return (unsigned)(8 * big);
+}
+
 static int check_step_io(sgx_env *h, const KParams &p) {
     if (p.mode == 0 && p.io.auto_reset) return check_random_setups(h);
     return SGX_OK;
@@ -458,12 +477,18 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream) {
     if (p.mode == 0 && p.io.auto_reset)
         if (int rc = check_random_setups(h)) return rc;
     p.map_mode = h->map_mode; p.map_arg = h->map_arg;
-    p.nt_stores = h->nt_mode < 0 ? (launch_streams_past_cache(h, p) ? 1 : 0) : h->nt_mode;
+    const bool streaming = launch_streams_past_cache(h, p);
+    p.nt_stores = h->nt_mode < 0 ? (streaming ? 1 : 0) : h->nt_mode;
+    // unequal XCD shares (sgx_layout.h: group_of_block): only where the launch is a saturating write stream
+    // and only where that stream is what bounds the kernel -- measured in one process on one set of buffers (tools/skew_ab.py,
+    // profiles/r03_skew_ab.log): 10x10 -3 ... -5 %, 8x8 -5 %; 6x6, 15x15 and Micro, where the game logic shares the critical path, +3 ... +7 %
+    const int cells = h->cfg.rows * h->cfg.cols;
+    const int skew = h->xcd_skew < 0 ? ((streaming && cells >= 64 && cells <= 100) ? SGX_XCD_SKEW_DEFAULT : 0) : h->xcd_skew;
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
 #define CALL_STEP_KIND(R, C, KIND)                                                                 \
     do {                                                                                           \
         using G_ = Geo<R, C>;                                                                      \
-        const unsigned grid = grid_for((p.n_envs - p.env_first + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW)); \
+        const unsigned grid = shares_for(p, (p.n_envs - p.env_first + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW), skew); \
         if (p.mode) observe_kernel<R, C, KIND><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p); \
         else step_kernel<R, C, KIND><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);           \
     } while (0)
@@ -476,7 +501,7 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream) {
 #define CALL_STEP_MAPPED(R, C)                                                                     \
     do {                                                                                           \
         using G_ = Geo<R, C>;                                                                      \
-        const unsigned grid = grid_for((p.n_envs - p.env_first + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW)); \
+        const unsigned grid = shares_for(p, (p.n_envs - p.env_first + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW), skew); \
         if (p.mode) observe_kernel<R, C, 0, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);  \
         else step_kernel<R, C, 0, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);        \
     } while (0)

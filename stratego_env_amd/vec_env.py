@@ -148,6 +148,11 @@ class VecStrategoEnv:
             raise ValueError("set_nt_stores: 'auto', True or False")
         _lib.check(self._L.sgx_set_nt_stores(self._h, m), self._L)
 
+    def set_xcd_skew(self, per_mille='auto'):
+        """Shares of the eight XCDs in a launch (sgx_set_xcd_skew): 'auto' (100 per mille more for the even XCDs when the launch streams
+        past the Infinity Cache, equal shares otherwise) or 0 .. 900.  Results are identical for every value."""
+        _lib.check(self._L.sgx_set_xcd_skew(self._h, -1 if per_mille in ('auto', None) else int(per_mille)), self._L)
+
     # ---- API -----------------------------------------------------------------------------------------
     def reset(self, p1_maps=None, p2_maps=None, env_select=None):
         """Start new games (all envs, or those with env_select[i] != 0) and return (obs, mask, player).

@@ -42,7 +42,7 @@ static sgx_env *make_env(int64_t N, const char *map) {
 int main(int argc, char **argv) {
     const int64_t N = argc > 1 ? atoll(argv[1]) : 65536;
     const int NB = argc > 2 ? atoi(argv[2]) : 12;
-    const char *maps[] = {"0", "1", "2,256", "4", "6,2", "6,4", "6,8", "6,16", "6,64"};
+    const char *maps[] = {"0", "7,40", "7,60", "7,80", "7,100", "7,120", "7,150", "7,200", "0"};
     const int NM = sizeof(maps) / sizeof(maps[0]);
     std::vector<sgx_env *> hs;
     for (auto m : maps) hs.push_back(make_env(N, m));
