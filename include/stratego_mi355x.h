@@ -154,6 +154,10 @@ int sgx_set_nt_stores(sgx_env *h, int32_t mode);
  * the Infinity Cache, equal shares otherwise; 0: always equal; 1 .. 900: always that.  SGX_XCD_SKEW=<per mille>|auto sets the default of
  * handles created afterwards.  Which workgroup plays which game cannot change any result.  No reference counterpart. */
 int sgx_set_xcd_skew(sgx_env *h, int32_t per_mille);
+/* The general form: a share per XCD, per mille of the mean share (NULL: back to the sgx_set_xcd_skew rule); sgx_get_xcd_shares returns
+ * what a streaming launch of the handle uses (*explicit_out, nullable: 1 if set by sgx_set_xcd_shares). */
+int sgx_set_xcd_shares(sgx_env *h, const int32_t *per_mille /* [8] or NULL */);
+int sgx_get_xcd_shares(sgx_env *h, int32_t *per_mille /* [8] */, int32_t *explicit_out);
 
 /* Upload a human-setup table (game/inits/{barrage,standard}_human_inits.py decoded to piece codes, util.py:154-180):
  * table_host is uint8 [n_setups][usable_rows*cols] in Gravon string order.  Replaces get_random_human_init_fn

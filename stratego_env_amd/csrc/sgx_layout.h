@@ -153,7 +153,7 @@ struct KParams {
     int32_t mode;  // 0 = step, 1 = observe
     int64_t env_first;  // this launch plays envs [env_first, n_envs) of the handle (sgx_rollout splits a batch over concurrent chains)
     int32_t map_mode, map_arg;   // experiment only: see group_of_block
-    int32_t xcd_big, xcd_small;  // workgroup-groups per even / odd XCD of this launch (group_of_block); equal = the plain eighths
+    int32_t xcd_first[8], xcd_count[8];   // workgroup-groups of this launch played by XCD x: [xcd_first[x], + xcd_count[x]) (group_of_block)
     int32_t nt_stores;  // the launch's observations do not fit the Infinity Cache: whole lines leave as non-temporal stores (sgx_obs.h)
     // functional-API instantiation only (sgx_expand): game i is read from record src_index[i] (i when NULL) of ANOTHER handle's
     // records and written to record i of this one, whether or not the move was valid
@@ -265,31 +265,34 @@ __device__ inline int quad_sum(int x) {
 
 // XCD-aware block -> env map: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
 // range of envs so neighbouring envs' output lines meet in one L2.
-// Unequal shares (round 3): under a saturating write stream the odd XCDs of MI355X drain their ranges ~20 % slower than the even
-// ones (per-XCD TCC_BUSY 660-700 k against 560-590 k cycles for equal eighths, profiles/r03_placement/class_pmc; the cause -- probably
-// the two XCDs of an IOD sharing its fabric port -- is not visible from user space), so with equal eighths the even XCDs idle at the
-// end of every launch.  The host gives the even XCD of each pair `big` workgroup-groups and the odd one `small` (big + small = 2 x
-// the mean share; KParams::xcd_big / xcd_small; the grid is 8 x big, surplus workgroups of the odd XCDs leave at once): -3 ... -5 % launch
-// time where the write stream bounds the kernel (8x8 and 10x10 boards; tools/skew_ab.py, tools/microbench/map_probe.cpp,
-// profiles/r03_skew_ab.log, r03_placement/map_probe_{e,f,g}.log); the host leaves the shares equal elsewhere.  Any share is a
-// bijection of games onto workgroups, so results cannot depend on it.
-__device__ inline int64_t group_of_block(int big, int small, int map_mode = 0, int map_arg = 0) {
+// Unequal shares (round 3).  Under a saturating write stream the odd XCD of every pair (the two XCDs of an IOD) drains its range
+// ~20 % slower than the even one (per-XCD TCC_BUSY of one launch with equal eighths: 602 716 | 600 724 | 602 674 | 609 674 k cycles,
+// profiles/r03_placement/class_pmc_per_xcd.txt), so with equal eighths the even XCDs idle at the end of every launch.  The host
+// gives every XCD its own share of the launch's workgroup-groups: xcd_first / xcd_count (stratego_mi355x.hip: launch_shares -- the even
+// XCDs 10 % more, the odd ones 10 % less where the write stream is what bounds the kernel: -3 ... -5 % launch time on 8x8 and 10x10
+// boards; equal shares elsewhere, where the same skew costs 3 ... 7 %: tools/skew_ab.py, profiles/r03_skew_ab.log).  The grid is 8 x the
+// largest share and surplus workgroups leave at once.  Any shares are a bijection of games onto workgroups, so results cannot depend
+// on them.  (Measuring the shares per output buffer from the workgroups' own end times -- an sgx_calibrate_xcd_shares -- was built and
+// dropped: it reproduces the odd / even skew (1090 / 900 per mille on every buffer, fast or slow) and nothing more, and on boards bound
+// by their game logic the observe launch it measures is balanced differently from the step: Micro +8 ... +12 %, profiles/r03_calib_ab.log.)
+__device__ inline int64_t group_of_block(const KParams &P) {
     const int64_t nb = gridDim.x, b = blockIdx.x;
-    const int64_t x = b & 7, i = b >> 3;                             // grid is a multiple of 8
-    if (map_mode == 0) {
-        if (big == small) return x * (nb >> 3) + i;
-        if (i >= ((x & 1) ? small : big)) return (int64_t)1 << 40;    // no work for this workgroup (beyond every env)
-        return (x >> 1) * (int64_t)(big + small) + ((x & 1) ? big : 0) + i;
+    const int x = (int)(b & 7);                                      // grid is a multiple of 8
+    const int64_t i = b >> 3;
+    if (P.map_mode == 0) {
+        if (i >= P.xcd_count[x]) return (int64_t)1 << 40;             // no work for this workgroup (beyond every env)
+        return P.xcd_first[x] + i;
     }
     // experiment modes (SGX_MAP, tools/microbench/map_probe.cpp): how the launch time depends on where the eight XCDs' write fronts
     // are relative to each other
     const int64_t per = nb >> 3;
-    if (map_mode == 1) return b;                                                        // linear: one front
-    if (map_mode == 2) { const int64_t s = map_arg; return (i / s) * (8 * s) + x * s + (i % s); }   // stripes of s workgroups per XCD (s divides nb / 8)
-    if (map_mode == 3) return x * per + (i + x * (int64_t)map_arg) % per;             // XCD ranges, every front started at another phase
-    if (map_mode == 4) return x * per + (per - 1 - i);                                  // XCD ranges walked downwards
-    if (map_mode == 5) return x * per + ((x & 1) ? per - 1 - i : i);                   // neighbouring XCDs walk towards each other
-    if (map_mode == 6) { const int64_t f = map_arg, sub = per / f; return x * per + (i % f) * sub + (i / f); }   // f sub-fronts per XCD (f divides nb / 8)
+    const int map_arg = P.map_arg;
+    if (P.map_mode == 1) return b;                                                        // linear: one front
+    if (P.map_mode == 2) { const int64_t s = map_arg; return (i / s) * (8 * s) + x * s + (i % s); }   // stripes of s workgroups per XCD (s divides nb / 8)
+    if (P.map_mode == 3) return x * per + (i + x * (int64_t)map_arg) % per;             // XCD ranges, every front started at another phase
+    if (P.map_mode == 4) return x * per + (per - 1 - i);                                  // XCD ranges walked downwards
+    if (P.map_mode == 5) return x * per + ((x & 1) ? per - 1 - i : i);                   // neighbouring XCDs walk towards each other
+    if (P.map_mode == 6) { const int64_t f = map_arg, sub = per / f; return x * per + (i % f) * sub + (i / f); }   // f sub-fronts per XCD (f divides nb / 8)
     return x * per + i;
 }
 

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <vector>
 
 #include "stratego_mi355x.h"
 
@@ -70,6 +71,8 @@ struct sgx_env {
     unsigned long long *stamps;  // SGX_STAMPS builds only
     int map_mode, map_arg;       // SGX_MAP experiment (group_of_block)
     int xcd_skew;                // sgx_set_xcd_skew: per mille more work for the even XCDs; -1 = by the launch's output size
+    int xcd_explicit;            // xcd_w was set by sgx_set_xcd_shares: it overrides the skew rule
+    int32_t xcd_w[8];            // shares of the eight XCDs, per mille of the mean share (sum 8000)
     int nt_mode;                 // sgx_set_nt_stores: -1 = by the launch's output size, 0 = never, 1 = always
     hipStream_t chain_stream[SGX_MAX_CHAINS];   // sgx_rollout: created on first use
     hipEvent_t chain_fork, chain_join[SGX_MAX_CHAINS];
@@ -408,9 +411,29 @@ SGX_API int sgx_set_nt_stores(sgx_env *h, int32_t mode) {
     return SGX_OK;
 }
 
+static void launch_shares(const sgx_env *h, bool streaming, int32_t *w);
+
 SGX_API int sgx_set_xcd_skew(sgx_env *h, int32_t per_mille) {
     if (!h || per_mille < -1 || per_mille > 900) return fail(SGX_EINVAL, "sgx_set_xcd_skew: -1 (auto) or 0 .. 900 per mille%s");
     h->xcd_skew = per_mille;
+    h->xcd_explicit = 0;
+    return SGX_OK;
+}
+
+SGX_API int sgx_set_xcd_shares(sgx_env *h, const int32_t *per_mille) {
+    if (!h) return fail(SGX_EINVAL, "handle is NULL%s");
+    if (!per_mille) { h->xcd_explicit = 0; return SGX_OK; }
+    for (int x = 0; x < 8; ++x)
+        if (per_mille[x] < 1 || per_mille[x] > 8000) return fail(SGX_EINVAL, "sgx_set_xcd_shares: every share must be 1 .. 8000 per mille%s");
+    for (int x = 0; x < 8; ++x) h->xcd_w[x] = per_mille[x];
+    h->xcd_explicit = 1;
+    return SGX_OK;
+}
+
+SGX_API int sgx_get_xcd_shares(sgx_env *h, int32_t *per_mille, int32_t *calibrated) {
+    if (!h || !per_mille) return fail(SGX_EINVAL, "NULL argument%s");
+    launch_shares(h, true, per_mille);
+    if (calibrated) *calibrated = h->xcd_explicit;
     return SGX_OK;
 }
 
@@ -456,15 +479,31 @@ static bool launch_streams_past_cache(const sgx_env *h, const KParams &p) {
     return bytes > (int64_t)300 * 1000 * 1000;
 }
 
-// Workgroup-groups per even / odd XCD for `groups` groups of games (KParams::xcd_big / xcd_small); returns the grid size (8 x big).
+// Workgroup-groups per XCD for `groups` groups of games from the shares w[8] (per mille of the mean share): KParams::xcd_first /
+// xcd_count; returns the grid size (8 x the largest share).
 #define SGX_XCD_SKEW_DEFAULT 100
-static unsigned shares_for(KParams &p, int64_t groups, int skew_per_mille) {
-    const int64_t per = (groups + 7) / 8;                                  // mean share of an XCD
-    int64_t big = per + (per * skew_per_mille + 999) / 1000;
-    if (big > 2 * per) big = 2 * per;
-    p.xcd_big = (int32_t)big;
-    p.xcd_small = (int32_t)(2 * per - big);
-    return (unsigned)(8 * big);
+static unsigned shares_for(KParams &p, int64_t groups, const int32_t *w) {
+    int64_t sum = 0, cnt[8], given = 0;
+    for (int x = 0; x < 8; ++x) sum += w[x];
+    for (int x = 0; x < 8; ++x) { cnt[x] = groups * w[x] / sum; given += cnt[x]; }
+    for (int x = 0; given < groups; x = (x + 1) & 7) { cnt[x] += 1; given += 1; }          // the remainder, one group each
+    int64_t at = 0, mx = 1;
+    for (int x = 0; x < 8; ++x) {
+        p.xcd_first[x] = (int32_t)at;
+        p.xcd_count[x] = (int32_t)cnt[x];
+        at += cnt[x];
+        if (cnt[x] > mx) mx = cnt[x];
+    }
+    return (unsigned)(8 * mx);
+}
+// the shares of a launch: explicit ones, else the odd-even skew where the launch is a saturating write stream
+static void launch_shares(const sgx_env *h, bool streaming, int32_t *w) {
+    if (h->xcd_explicit) { for (int x = 0; x < 8; ++x) w[x] = h->xcd_w[x]; return; }
+    // measured in one process on one set of buffers (tools/skew_ab.py, profiles/r03_skew_ab.log): 10x10 -3 ... -5 %, 8x8 -5 %; 6x6,
+    // 15x15 and Micro, where the game logic shares the critical path, +3 ... +7 %
+    const int cells = h->cfg.rows * h->cfg.cols;
+    const int skew = h->xcd_skew < 0 ? ((streaming && cells >= 64 && cells <= 100) ? SGX_XCD_SKEW_DEFAULT : 0) : h->xcd_skew;
+    for (int x = 0; x < 8; ++x) w[x] = (x & 1) ? 1000 - skew : 1000 + skew;
 }
 
 static int check_step_io(sgx_env *h, const KParams &p) {
@@ -479,11 +518,8 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream) {
     p.map_mode = h->map_mode; p.map_arg = h->map_arg;
     const bool streaming = launch_streams_past_cache(h, p);
     p.nt_stores = h->nt_mode < 0 ? (streaming ? 1 : 0) : h->nt_mode;
-    // unequal XCD shares (sgx_layout.h: group_of_block): only where the launch is a saturating write stream
-    // and only where that stream is what bounds the kernel -- measured in one process on one set of buffers (tools/skew_ab.py,
-    // profiles/r03_skew_ab.log): 10x10 -3 ... -5 %, 8x8 -5 %; 6x6, 15x15 and Micro, where the game logic shares the critical path, +3 ... +7 %
-    const int cells = h->cfg.rows * h->cfg.cols;
-    const int skew = h->xcd_skew < 0 ? ((streaming && cells >= 64 && cells <= 100) ? SGX_XCD_SKEW_DEFAULT : 0) : h->xcd_skew;
+    int32_t skew[8];                     // unequal XCD shares (sgx_layout.h: group_of_block)
+    launch_shares(h, streaming, skew);
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
 #define CALL_STEP_KIND(R, C, KIND)                                                                 \
     do {                                                                                           \

@@ -153,6 +153,11 @@ class VecStrategoEnv:
         past the Infinity Cache, equal shares otherwise) or 0 .. 900.  Results are identical for every value."""
         _lib.check(self._L.sgx_set_xcd_skew(self._h, -1 if per_mille in ('auto', None) else int(per_mille)), self._L)
 
+    def set_xcd_shares(self, per_mille=None):
+        """Explicit shares of the eight XCDs (per mille of the mean share), None = back to the set_xcd_skew rule."""
+        arr = None if per_mille is None else (C.c_int32 * 8)(*[int(x) for x in per_mille])
+        _lib.check(self._L.sgx_set_xcd_shares(self._h, arr), self._L)
+
     # ---- API -----------------------------------------------------------------------------------------
     def reset(self, p1_maps=None, p2_maps=None, env_select=None):
         """Start new games (all envs, or those with env_select[i] != 0) and return (obs, mask, player).
