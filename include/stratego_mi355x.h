@@ -225,8 +225,13 @@ int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);
 
 /* Single-game latency (config 1: one game behind the reference's dict API).  sgx_host_alloc returns pinned host memory the device
  * can address (*dev_ptr is its device alias): with sgx_step_io's output pointers -- and actions_dev -- pointing into it the step
- * kernel writes a game's ~30 KB of outputs straight to host memory, and sgx_step_sync (= sgx_step + wait for `stream`) makes
- * env.step() ONE library call: no upload, no download, no second launch.  Meant for a handful of games; batches belong in HBM.
+ * kernel writes a game's ~30 KB of outputs straight to host memory, and sgx_step_sync (= sgx_step + wait until the outputs are
+ * complete) makes env.step() ONE library call: no upload, no download, no second launch.  Meant for a handful of games; batches
+ * belong in HBM.  Up to 8 games on a board of more than 32 cells with a multiple of 4 cells, 'extended' channel modes, are played by a
+ * kernel of their own -- one workgroup per game: one wave plays the move, all eight emit the mask and the observations -- which
+ * publishes its completion in a host-mapped word that sgx_step_sync polls: the call returns when the outputs are visible to the host,
+ * typically before `stream` has retired the kernel (later work on `stream` is ordered behind it as usual).  Every other case is
+ * sgx_step + hipStreamSynchronize.  Same results either way (tests/test_gpu_step_sync.py).
  * No reference counterpart (the reference is one game per object on the host, maenv:659-828). */
 int sgx_host_alloc(sgx_env *h, int64_t bytes, void **host_ptr, void **dev_ptr);
 int sgx_host_free(sgx_env *h, void *host_ptr);

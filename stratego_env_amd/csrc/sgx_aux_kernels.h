@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void export_kernel(const KParams P, int64_t *_
     using G = Geo<R_, C_>;
     __shared__ StateLds<G> W;
     const int tid = threadIdx.x;
-    const int64_t env = P.env_first + blockIdx.x;
+    const int64_t env = P.env_first + group_of_block(P);
     if (env >= P.n_envs) return;
     const int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
     for (int i = tid; i < P.rec_bytes / 16; i += 256) reinterpret_cast<int4 *>(W.img)[i] = reinterpret_cast<const int4 *>(rec)[i];
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
     using G = Geo<R_, C_>;
     __shared__ StateLds<G> W;
     const int tid = threadIdx.x;
-    const int64_t env = P.env_first + blockIdx.x;
+    const int64_t env = P.env_first + group_of_block(P);
     if (env >= P.n_envs) return;
     import_to_image(P, W, in, player_in, sanitised, env, tid);
     int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(128) void states_kernel(const KParams P, const int6
     __shared__ alignas(16) uint8_t shared[OBS ? shared_table_bytes<G, 0>() : 16];
     __shared__ alignas(16) uint8_t obst_s[G::OBST_BYTES + COMBAT_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t env = P.env_first + blockIdx.x;
+    const int64_t env = P.env_first + group_of_block(P);
     if (env >= P.n_envs) return;
     {   // the step's workgroup-shared tables (game_kernel_body): default-code templates, code table, obstacle map, combat outcomes
         if constexpr (OBS) {

@@ -114,13 +114,13 @@ __device__ inline uint32_t mask_bits(const Lds<G, NB> &L, int p, int n) {
 // (3700 = 4 mod 16), byte aligned when NA is odd (5x5, 15x15); lanes own 16-byte-aligned chunks of the global range, so
 // whole chunks leave as one 16-byte store per lane and only the partial first / last chunks go out as dwords (bytes when
 // the base is not 4-byte aligned).
-template <class G, int NB>
+template <class G, int STRIDE = G::LPG, int NB>
 __device__ void emit_mask(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int lane) {
     const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
     const int nchunks = (A + G::NA + 15) >> 4;
     uint8_t *gbase = dst - A;                       // 16-byte aligned
     const int shift = (int)((reinterpret_cast<uintptr_t>(gbase) >> 4) & (G::LPG - 1));   // start the sweep on a 1 KiB boundary
-    for (int c0 = -shift; c0 < nchunks; c0 += G::LPG) {
+    for (int c0 = -shift; c0 < nchunks; c0 += STRIDE) {
         const int c = c0 + lane;
         if (c < 0 || c >= nchunks) continue;
         const int lo = 16 * c - A;                  // first mask byte of this chunk

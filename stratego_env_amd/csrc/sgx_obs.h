@@ -118,7 +118,9 @@ __device__ inline int build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uint
 // CHECKED (games with uncoded entries, 4-aligned boards): a quad that holds a CODE_ESC entry is not stored here -- patch_uncoded
 // writes it whole, so no address is written twice and nothing has to be waited for.
 // NT: lines this wave writes whole leave as non-temporal stores -- chosen per launch, see KParams::nt_stores.
-template <class G, class Spec, bool CHECKED, bool NT, int NB>
+// STRIDE: lanes that share the sweep -- the game's LPG lanes, or every thread of the workgroup (`lane` = thread index) when a whole
+// workgroup emits one game (single_kernel).
+template <class G, class Spec, bool CHECKED, bool NT, int STRIDE = G::LPG, int NB>
 __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, int lane) {
     constexpr int RC = G::RC, NCH = Spec::NCH;
     const uint16_t *n16 = reinterpret_cast<const uint16_t *>(L.nib);
@@ -135,7 +137,7 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
         const int l0 = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7);               // quads past a 128-byte line
         const int first_line = l0 ? 0 : -1, last_line = ((l0 + NQ) & 7) ? (NQ - 1 + l0) >> 3 : -1;   // lines counted from dst - 16 * l0
 #pragma unroll SGX_OBS_UNROLL
-        for (int q0 = -m0; q0 < NQ; q0 += G::LPG) {
+        for (int q0 = -m0; q0 < NQ; q0 += STRIDE) {
             const int q = q0 + lane;
             const bool in = (unsigned)q < (unsigned)NQ;
             const unsigned x = n16[in ? q : 0];
@@ -155,6 +157,7 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
         }
     } else {
         static_assert(!CHECKED, "odd boards patch single floats after a wait (patch_uncoded_floats)");
+        static_assert(STRIDE == G::LPG, "odd boards are emitted by the game's own lanes");
         // odd cell counts (5x5, 15x15): an env's observation is only 4-byte aligned.  Lanes own the 16-byte slots of the
         // ADDRESS range; slot k holds floats 4k-a .. 4k-a+3 (a = floats past a 16-byte boundary), i.e. 16 code bits that start
         // (4-a) nibbles into halfword k-1: two halfword reads and a shift.  Whole slots leave as one 16-byte store, the partial

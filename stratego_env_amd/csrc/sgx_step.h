@@ -125,11 +125,18 @@ __device__ __forceinline__ GameInput load_game(const KParams &P, const int64_t e
     return load_game_from<G>(P, reinterpret_cast<const int4 *>(rec_src), env, lane);
 }
 
+// What the emission of the next mover's mask and observations needs from the step (SPLIT instantiation: single_kernel)
+struct StepOut {
+    int qi, n_events, rp0, rp1, n_unc;
+};
+
 // One game's env.step() by one wave (called with the wave's private LDS region).
 // `shared` = the workgroup's tables (shared_table_bytes): templates + code table, or LUTs + quad tables
-template <int R_, int C_, int KIND, bool MAPPED>
+// SPLIT: the next mover's mask and observations are NOT emitted here -- the caller does it with the whole workgroup from the LDS
+// state this function leaves behind and the scalars in *so.
+template <int R_, int C_, int KIND, bool MAPPED, bool SPLIT = false>
 __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsKind<KIND>::NIB_CH> &L, const uint8_t *shared, const uint8_t *obst_s,
-                                         const int64_t env, const int lane, const GameInput &in, int8_t *rec_out = nullptr) {
+                                         const int64_t env, const int lane, const GameInput &in, int8_t *rec_out = nullptr, StepOut *so = nullptr) {
     using G = Geo<R_, C_>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
@@ -446,6 +453,9 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     STAMP(4);   // results / terminal handling done
     // ---- outputs for the next mover
     if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
+    if constexpr (SPLIT) {
+        if (lane == 0) { so->qi = qi; so->n_events = n_events; so->rp0 = rp0; so->rp1 = rp1; }
+    } else {
     if (P.io.mask_dev) {
         // MAPPED: the separate instantiation behind SGX_STEP_MASK_1D / SGX_STEP_MASK_STATE_COORDS (kept out of the hot kernel: its
         // 16 index computations per lane cost 30 VGPRs)
@@ -458,6 +468,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     if (P.io.obs_dev) render(PS{}, false, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH));
     if constexpr (FULL)
         if (P.io.fobs_dev) render(FS{}, true, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH));
+    }
     STAMP(6);   // obs stores issued
     if (P.mode == 0 && P.io.next_actions_dev) {
         const int total = nvalid == 0 ? 1 : nvalid;
@@ -534,6 +545,80 @@ __global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_
 template <int R_, int C_, int KIND, bool MAPPED = false>
 __global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND>())) void observe_kernel(const KParams P) {
     game_kernel_body<R_, C_, KIND, MAPPED>(P);
+}
+
+// sgx_step_sync on a handful of games (the N = 1 facade, config 1): latency, not throughput.  ONE game per 512-thread workgroup: wave 0
+// plays the step (env_step<SPLIT>), then all eight waves emit the mask and the observations -- 30 KiB by one wave is 4.3 of the step's
+// 9.2 us (tools/phase_stamps.py barrage 1) -- and the last workgroup to finish publishes `seq` in a host-mapped word the host polls:
+// the caller does not wait for the end-of-kernel processing of the queue (signal, cache write-back, wake-up: ~5 us).
+// 'extended' kinds on 4-aligned one-game-per-wave boards.
+constexpr int SINGLE_WAVES = 8;
+template <int R_, int C_, int KIND>
+__global__ __launch_bounds__(64 * SINGLE_WAVES) void single_kernel(const KParams P, uint32_t *__restrict__ done_count, uint32_t *__restrict__ flag_host,
+                                                                 const uint32_t seq) {
+    using G = Geo<R_, C_>;
+    using PS = typename ObsKind<KIND>::P;
+    using FS = typename ObsKind<KIND>::F;
+    constexpr bool FULL = ObsKind<KIND>::FULL;
+    static_assert(!ObsKind<KIND>::ORIG && G::LPG == 64 && !G::WIDE && G::RC % 4 == 0, "single_kernel: 'extended' kinds, 4-aligned one-game-per-wave boards");
+    constexpr int NT = 64 * SINGLE_WAVES, RC = G::RC;
+    __shared__ Lds<G, ObsKind<KIND>::NIB_CH> L;
+    __shared__ alignas(16) uint8_t shared[shared_table_bytes<G, KIND>()];
+    __shared__ alignas(16) uint8_t obst_s[G::OBST_BYTES + COMBAT_BYTES];
+    __shared__ StepOut so;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t env = P.env_first + blockIdx.x;
+    GameInput in{};
+    if (wave == 0) in = load_game<G, false>(P, env, lane);
+    const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
+    constexpr int NP = tmpl_lds_bytes<G, KIND>(false), NF = FULL ? tmpl_lds_bytes<G, KIND>(true) : 0;
+    {
+        const int4 *tp = reinterpret_cast<const int4 *>(P.tab->tmpl[raw ? 2 : 0]);
+        for (int i = tid; i < NP / 16; i += NT) reinterpret_cast<int4 *>(shared)[i] = tp[i];
+        if constexpr (FULL) {
+            const int4 *tf = reinterpret_cast<const int4 *>(P.tab->tmpl[(raw ? 2 : 0) + 1]);
+            for (int i = tid; i < NF / 16; i += NT) reinterpret_cast<int4 *>(shared + NP)[i] = tf[i];
+        }
+        const int4 *ct = reinterpret_cast<const int4 *>(P.tab->codetab[raw ? 1 : 0]);
+        for (int i = tid; i < CODETAB_BYTES / 16; i += NT) reinterpret_cast<int4 *>(shared + NP + NF)[i] = ct[i];
+        for (int i = tid; i < G::S / 4; i += NT) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
+        for (int i = tid; i < COMBAT_BYTES / 4; i += NT) reinterpret_cast<int *>(obst_s + G::OBST_BYTES)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
+    }
+    __syncthreads();
+    if (wave == 0) env_step<R_, C_, KIND, false, true>(P, L, shared, obst_s, env, lane, in, nullptr, &so);
+    __syncthreads();
+    if (P.io.mask_dev) emit_mask<G, NT>(L, P.io.mask_dev + env * (int64_t)G::NA, tid);
+    const uint8_t *codetab = shared + NP + NF;
+    auto render_all = [&](auto spec, bool full, float *dst) {
+        using Spec = decltype(spec);
+        if (wave == 0) {
+            const int n_unc = build_codes<G, Spec>(L, full ? shared + NP : shared, codetab, P.tab->lut[(raw ? 2 : 0) + (full ? 1 : 0)], so.qi,
+                                                   so.n_events, so.rp0, so.rp1, lane);
+            if (lane == 0) so.n_unc = n_unc;
+        }
+        __syncthreads();
+        const int n_unc = so.n_unc;
+        if (n_unc == 0) emit_codes<G, Spec, false, false, NT>(L, dst, tid);
+        else {
+            emit_codes<G, Spec, true, false, NT>(L, dst, tid);
+            if (wave == 0) patch_uncoded<G, Spec>(L, dst, n_unc, lane);
+        }
+        __syncthreads();                    // (the code buffer is free again)
+    };
+    if (P.io.obs_dev) render_all(PS{}, false, P.io.obs_dev + env * (int64_t)(RC * PS::NCH));
+    if constexpr (FULL)
+        if (P.io.fobs_dev) render_all(FS{}, true, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH));
+    // every thread's stores are visible to the host before its workgroup counts as done
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        bool last = true;
+        if (gridDim.x > 1) {
+            last = __hip_atomic_fetch_add(done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+            if (last) __hip_atomic_store(done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (last) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace

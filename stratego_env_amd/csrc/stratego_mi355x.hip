@@ -76,6 +76,11 @@ struct sgx_env {
     int nt_mode;                 // sgx_set_nt_stores: -1 = by the launch's output size, 0 = never, 1 = always
     hipStream_t chain_stream[SGX_MAX_CHAINS];   // sgx_rollout: created on first use
     hipEvent_t chain_fork, chain_join[SGX_MAX_CHAINS];
+    // sgx_step_sync on a handful of games (single_kernel): a host-mapped word the kernel publishes its sequence number in, and the
+    // device counter of finished workgroups; created on first use
+    uint32_t *sync_flag_host, *sync_flag_dev, *sync_count;
+    uint32_t sync_seq;
+    int no_single;               // SGX_NO_SINGLE=1: sgx_step_sync never takes the single_kernel path (A/B measurements)
 };
 
 namespace {
@@ -335,6 +340,7 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     h->xcd_skew = -1;
     if (const char *e = getenv("SGX_XCD_SKEW")) { if (strcmp(e, "auto")) h->xcd_skew = atoi(e); }   // SGX_XCD_SKEW=<per mille>|auto
     if (h->xcd_skew > 900) h->xcd_skew = 900;
+    if (const char *e = getenv("SGX_NO_SINGLE")) h->no_single = atoi(e);
     if (const char *e = getenv("SGX_MAP")) { h->map_mode = atoi(e); if (const char *c = strchr(e, ',')) h->map_arg = atoi(c + 1); }
     const int rc_cells = cfg->rows * cfg->cols;
     {
@@ -401,6 +407,8 @@ SGX_API int sgx_destroy(sgx_env *h) {
         if (h->chain_join[c]) (void)hipEventDestroy(h->chain_join[c]);
     }
     if (h->chain_fork) (void)hipEventDestroy(h->chain_fork);
+    if (h->sync_flag_host) (void)hipHostFree(h->sync_flag_host);
+    if (h->sync_count) (void)hipFree(h->sync_count);
     delete h;
     return SGX_OK;
 }
@@ -777,7 +785,69 @@ SGX_API int sgx_host_free(sgx_env *h, void *host_ptr) {
     return SGX_OK;
 }
 
+// env.step() and wait for its outputs.  A handful of games on a 4-aligned one-game-per-wave board in an 'extended' channel mode (the
+// N = 1 facade) run as single_kernel -- one workgroup per game, completion published in a host-mapped word this call polls; anything
+// else is sgx_step + hipStreamSynchronize.
+#define SGX_SINGLE_MAX_ENVS 8
+namespace {
+int step_single(sgx_env *h, const KParams &p, bool full, hipStream_t stream, bool *launched) {
+    *launched = false;
+    if (!h->sync_flag_host) {
+        void *hp = nullptr, *dp = nullptr;
+        HIP_TRY(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(hp); return fail(SGX_EDEVICE, "hipHostGetDevicePointer failed%s"); }
+        memset(hp, 0, 64);
+        h->sync_flag_host = (uint32_t *)hp;
+        h->sync_flag_dev = (uint32_t *)dp;
+        HIP_TRY(hipMalloc((void **)&h->sync_count, 64));
+        HIP_TRY(hipMemset(h->sync_count, 0, 64));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    const uint32_t seq = ++h->sync_seq;
+#define CALL_SINGLE(R, C)                                                                                              \
+    do {                                                                                                               \
+        if constexpr (Geo<R, C>::LPG == 64 && !Geo<R, C>::WIDE && (R * C) % 4 == 0) {                                  \
+            if (full) single_kernel<R, C, 1><<<(unsigned)h->n_envs, 64 * SINGLE_WAVES, 0, stream>>>(p, h->sync_count, h->sync_flag_dev, seq); \
+            else single_kernel<R, C, 0><<<(unsigned)h->n_envs, 64 * SINGLE_WAVES, 0, stream>>>(p, h->sync_count, h->sync_flag_dev, seq);      \
+            *launched = true;                                                                                          \
+        }                                                                                                              \
+    } while (0)
+    DISPATCH_GEOMETRY(h, CALL_SINGLE);
+#undef CALL_SINGLE
+    if (!*launched) return SGX_OK;
+    HIP_TRY(hipGetLastError());
+    // poll the word the last workgroup writes after a system-scope fence; look at the stream now and then, so that a launch that
+    // failed on the device ends the wait with its error instead of hanging
+    volatile uint32_t *flag = h->sync_flag_host;
+    for (uint32_t spins = 0; *flag != seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFFF) == 0xFFFFF) {
+            const hipError_t q = hipStreamQuery(stream);
+            if (q == hipSuccess) break;                          // the kernel has retired: its stores are visible
+            if (q != hipErrorNotReady) return fail(SGX_EDEVICE, "sgx_step_sync: %s", hipGetErrorString(q));
+            (void)hipGetLastError();
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return SGX_OK;
+}
+}  // namespace
+
 SGX_API int sgx_step_sync(sgx_env *h, const sgx_step_io *io, void *stream) {
+    if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
+    if (!io->actions_dev) return fail(SGX_EINVAL, "actions_dev is NULL%s");
+    const bool original = (io->flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
+    if (h->n_envs <= SGX_SINGLE_MAX_ENVS && !original && !(io->flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) && h->map_mode == 0 &&
+        !h->no_single) {
+        HIP_TRY(hipSetDevice(h->device));
+        KParams p = make_params(h);
+        p.mode = 0;
+        p.io = *io;
+        if (int rc = check_step_io(h, p)) return rc;
+        bool launched = false;
+        if (int rc = step_single(h, p, io->fobs_dev || io->final_fobs_dev, (hipStream_t)stream, &launched)) return rc;
+        if (launched) return SGX_OK;
+    }
     if (int rc = sgx_step(h, io, stream)) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return SGX_OK;
@@ -850,18 +920,32 @@ SGX_API int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actio
 
 namespace {
 // export / import of the envs [p.env_first, p.n_envs) of the handle
-int launch_export(sgx_env *h, const KParams &p, int64_t *state_dev, int8_t *player_dev, hipStream_t stream) {
+// one state per workgroup, mapped onto the XCDs like the step's workgroups (group_of_block): contiguous ranges of states per XCD
+// (tools/states_ab.py, 65,536 Barrage states through sgx_step_states: 689 us against 736 us with the linear map; these kernels read as
+// much as they write and the odd / even skew of the write-only step does not pay here: 697 us at 100 per mille, 702 at 150)
+unsigned state_grid(const sgx_env *h, KParams &p) {
+    int32_t w[8];
+    launch_shares(h, false, w);
+    p.map_mode = h->map_mode; p.map_arg = h->map_arg;
+    return shares_for(p, p.n_envs - p.env_first, w);
+}
+bool states_stream_past_cache(const sgx_env *h) {
+    return h->n_envs * (int64_t)SGX_STATE_LAYERS * h->cfg.rows * h->cfg.cols * 8 > (int64_t)300 * 1000 * 1000;
+}
+int launch_export(sgx_env *h, const KParams &p_in, int64_t *state_dev, int8_t *player_dev, hipStream_t stream) {
     // (the int64 layout is 27 KB per 10x10 state: past the Infinity Cache the layers leave as non-temporal stores, like the observations)
-    const int nt = h->nt_mode < 0 ? (h->n_envs * (int64_t)SGX_STATE_LAYERS * h->cfg.rows * h->cfg.cols * 8 > (int64_t)300 * 1000 * 1000) : h->nt_mode;
-    const unsigned grid = (unsigned)(p.n_envs - p.env_first);
+    const int nt = h->nt_mode < 0 ? states_stream_past_cache(h) : h->nt_mode;
+    KParams p = p_in;
+    const unsigned grid = state_grid(h, p);
 #define CALL_EXPORT(R, C) export_kernel<R, C><<<grid, 256, 0, stream>>>(p, state_dev, player_dev, nt)
     DISPATCH_GEOMETRY(h, CALL_EXPORT);
 #undef CALL_EXPORT
     HIP_TRY(hipGetLastError());
     return SGX_OK;
 }
-int launch_import(sgx_env *h, const KParams &p, const int64_t *state_dev, const int8_t *player_dev, uint8_t *sanitised_dev, hipStream_t stream) {
-    const unsigned grid = (unsigned)(p.n_envs - p.env_first);
+int launch_import(sgx_env *h, const KParams &p_in, const int64_t *state_dev, const int8_t *player_dev, uint8_t *sanitised_dev, hipStream_t stream) {
+    KParams p = p_in;
+    const unsigned grid = state_grid(h, p);
 #define CALL_IMPORT(R, C) import_kernel<R, C><<<grid, 256, 0, stream>>>(p, state_dev, player_dev, sanitised_dev)
     DISPATCH_GEOMETRY(h, CALL_IMPORT);
 #undef CALL_IMPORT
@@ -900,11 +984,12 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
     if (kind0 && h->cfg.rows * h->cfg.cols > 32 && h->cfg.rows * h->cfg.cols <= 256) {
         // one-game-per-wave boards, partial-observation kinds: ONE fused launch, the record never leaves LDS between the three steps
         if (int rc = check_step_io(h, p)) return rc;
-        const int nt = h->nt_mode < 0 ? (h->n_envs * (int64_t)SGX_STATE_LAYERS * h->cfg.rows * h->cfg.cols * 8 > (int64_t)300 * 1000 * 1000) : h->nt_mode;
+        const int nt = h->nt_mode < 0 ? states_stream_past_cache(h) : h->nt_mode;
+        const unsigned grid = state_grid(h, p);
         p.nt_stores = h->nt_mode < 0 ? (launch_streams_past_cache(h, p) ? 1 : 0) : h->nt_mode;
         const bool mapped = (io->flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) != 0;
         const bool obs = io->obs_dev || io->final_obs_dev;
-#define CALL_STATES_K(R, C, M, O) states_kernel<R, C, M, O><<<(unsigned)h->n_envs, 128, 0, (hipStream_t)stream>>>(p, state_in_dev, player_in_dev, sanitised_dev, state_out_dev, player_out_dev, nt)
+#define CALL_STATES_K(R, C, M, O) states_kernel<R, C, M, O><<<grid, 128, 0, (hipStream_t)stream>>>(p, state_in_dev, player_in_dev, sanitised_dev, state_out_dev, player_out_dev, nt)
 #define CALL_STATES(R, C)                                                                                                   \
     do {                                                                                                                    \
         if constexpr (Geo<R, C>::LPG == 64 && !Geo<R, C>::WIDE) {                                                           \

@@ -262,6 +262,11 @@ class StrategoMultiAgentEnv:
         raw = np.ctypeslib.as_array((C.c_uint8 * (off + 256)).from_address(hp.value))
         self._hview = {n: raw[o:o + nbytes].view(_NP_DTYPES[dtype]).reshape(shape) for n, o, nbytes, dtype, shape in layout}
         self._act_word = raw[off:off + 4].view(np.int32)
+        # the four byte flags of a step, read as Python ints straight from the slab (a numpy scalar per flag costs 4 x 0.15 us)
+        self._hbytes = memoryview(raw)
+        offs = {n: o for n, o, nbytes, dtype, shape in layout}
+        self._flag_offs = (offs['invalid_action'], offs['done'], offs['player'], offs['ending_invalid'])
+        self._step_stream = vec._stream()                 # (refreshed by reset(): the caller's current stream at that time)
         io = _lib.SgxStepIO()
         dev = {n: dp.value + o for n, o, nbytes, dtype, shape in layout}
         io.actions_dev = dp.value + off
@@ -338,6 +343,7 @@ class StrategoMultiAgentEnv:
             self.player = int(first_player_override)
             self._vec.import_state(self.state[None], np.asarray([self.player], dtype=np.int8))
         self.episodes_completed += 1
+        self._step_stream = self._vec._stream()
         self._vec.observe()
         self._fetch(self._step_bytes)
         hv = self._view
@@ -364,13 +370,15 @@ class StrategoMultiAgentEnv:
         self._act_word[0] = action
         io = self._step_io
         io.flags = flags | vec._mode_flags
-        _lib.check(vec._L.sgx_step_sync(vec._h, io, vec._stream()), vec._L)
+        rc = vec._L.sgx_step_sync(vec._h, io, self._step_stream)
+        if rc:
+            _lib.check(rc, vec._L)
         vec._next_actions_fresh = False
-        hv = self._hview
-        flags = (int(hv['invalid_action'][0]), int(hv['done'][0]), int(hv['player'][0]), int(hv['ending_invalid'][0]))
+        hv, hb, fo = self._hview, self._hbytes, self._flag_offs
+        flags = (hb[fo[0]], hb[fo[1]], 1 if hb[fo[2]] == 1 else -1, hb[fo[3]])
         if flags[0]:
             raise ValueError("Couldn't get the next state because the move wasn't valid.")   # impl:902
-        self.player = int(flags[2])
+        self.player = flags[2]
         if not flags[1]:                                                                # maenv:767-770
             dones = {self.player: False, "__all__": False}
             obs = {self.player: self._obs_dict(hv['obs'][0], hv['fobs'][0] if self._want_f else None, hv['mask'][0], self.player)}

@@ -99,7 +99,7 @@ class BatchedStrategoProceduralEnv:
     def _in_loaded_scope(self, states, players):
         return self._held is not None and self._scratch_is_held and states is self._held[0] and players is self._held[1]
 
-    def _step_states(self, states, players, actions, flags, export=False, mask_out=None, positions=False):
+    def _step_states(self, states, players, actions, flags, export=False, mask_out=None, positions=False, out=None):
         """sgx_step_states: import -> step (actions given) or observe (actions None) -> optional export, one library call (one
         launch on boards of more than 32 cells).  -> (new_states, new_players) or None."""
         st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64).contiguous()
@@ -107,8 +107,11 @@ class BatchedStrategoProceduralEnv:
             raise ValueError("states must have shape (batch, 34, rows, columns)")
         pl = self._players(players)
         vec = self._vec
-        new_states = torch.empty_like(st) if export else None
-        new_players = torch.empty((self.batch_size,), dtype=torch.int8, device=self.device) if export else None
+        if out is not None:                                  # caller-provided successor tensors (benchmarks: same memory every call)
+            new_states, new_players = out
+        else:
+            new_states = torch.empty_like(st) if export else None
+            new_players = torch.empty((self.batch_size,), dtype=torch.int8, device=self.device) if export else None
         io = vec._fill_io(actions if actions is not None else vec.next_actions, False, False, False, flags)
         io.auto_reset = 0
         if actions is None:

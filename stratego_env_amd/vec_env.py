@@ -235,6 +235,20 @@ class VecStrategoEnv:
         self._next_actions_fresh = bool(want_next_actions)
         return self.obs, self.mask, self.reward, self.done, self.player
 
+    def step_sync(self, actions, emit_obs=True, emit_mask=True, flags=0):
+        """step() and wait until the outputs are complete (sgx_step_sync): the latency path of a handful of games -- up to 8 games on
+        a 4-aligned board of more than 32 cells run one workgroup per game and the call returns as soon as the kernel has published
+        its outputs, without a stream synchronisation."""
+        a = actions
+        if a.dtype != torch.int32 or a.device != self.device or not a.is_contiguous():
+            a = a.to(device=self.device, dtype=torch.int32).contiguous()
+        assert a.numel() == self.num_envs * (4 if (flags & _lib.STEP_ACTIONS_POSITIONS) else 1)
+        io = self._fill_io(a, False, emit_obs, emit_mask, flags)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_step_sync(self._h, C.byref(io), self._stream()), self._L)
+        self._next_actions_fresh = False
+        return self.obs, self.mask, self.reward, self.done, self.player
+
     def _fill_io(self, a, want_next_actions, emit_obs, emit_mask, flags):
         io = self._io
         io.actions_dev = a.data_ptr()
