@@ -219,6 +219,8 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
     const i64x2 *s = reinterpret_cast<const i64x2 *>(in + env * (int64_t)NX);
     // all of the state's loads in flight at once -- up to 16 per lane; bigger boards (15 x 15 needs 15, 32 x 32 would need 68
     // = 272 VGPRs) go through them in batches of 8
+    // (fewer loads per batch = fewer VGPRs = 8 instead of 7 waves per SIMD in the fused kernel: 14 / 7 / 5 loads per lane measured
+    // 653 / 650 / 647 us per 65,536 Barrage states in one process -- nothing)
     constexpr int BATCH = ITER <= 16 ? ITER : 8;
     i64x2 rawv[BATCH];
 #pragma unroll

@@ -20,13 +20,15 @@ def main():
     env.rollout_steps(60)
     states, players = env.export_state()
     variants = []
-    for name, envs in (('xcd ranges, skew auto', {}), ('xcd ranges, equal', {'SGX_XCD_SKEW': '0'}), ('linear', {'SGX_MAP': '1'}),
+    ab_libs = [x for x in os.environ.get('AB_LIBS', '').split(',') if x]          # alternative builds of the library, same process
+    specs = [(os.path.basename(x), {'SGX_LIB_PATH': os.path.abspath(x)}) for x in ab_libs] if ab_libs else None
+    for name, envs in specs or (('xcd ranges, skew auto', {}), ('xcd ranges, equal', {'SGX_XCD_SKEW': '0'}), ('linear', {'SGX_MAP': '1'}),
                        ('xcd ranges, skew 50', {'SGX_XCD_SKEW': '50'}), ('xcd ranges, skew 150', {'SGX_XCD_SKEW': '150'})):
-        for k in ('SGX_XCD_SKEW', 'SGX_MAP'):
+        for k in ('SGX_XCD_SKEW', 'SGX_MAP', 'SGX_LIB_PATH'):
             os.environ.pop(k, None)
         os.environ.update(envs)
         variants.append((name, BatchedStrategoProceduralEnv(version, n)))
-    for k in ('SGX_XCD_SKEW', 'SGX_MAP'):
+    for k in ('SGX_XCD_SKEW', 'SGX_MAP', 'SGX_LIB_PATH'):
         os.environ.pop(k, None)
     m1 = variants[0][1].get_valid_moves_as_1d_mask(states, players)
     acts = torch.argmax((m1 != 0).to(torch.int8), dim=1).to(torch.int32)
