@@ -516,7 +516,12 @@ def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, 
         assert invalid == 0
         checked = verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
         launch_s = dev_ms / 1e3 / steps
-        rf = roofline(version, v, n, launch_s, full_obs=full_obs, first_us=(trial or {}).get('plain_us'))
+        rf = roofline(version, v, n, launch_s, full_obs=full_obs)
+        # on the plain first allocation: this leg's step time scaled by the trial's observe launches, first candidate / kept one (the
+        # observe launch itself is not this leg's step: cheaper on the toy boards, and in BOTH mode the candidates were timed per buffer)
+        tr = trial or {}
+        first, kept = tr.get('fobs_plain_us' if full_obs else 'plain_us'), tr.get('fobs_kept_us' if full_obs else 'kept_us')
+        rf["frac_untuned"] = rf["frac"] * kept / first if (first and kept) else None
         return {"workload": "%d concurrent %s games (%dx%d)%s, same rollout" % (n, version, v.rows, v.columns,
                                                                                  ", BOTH_OBSERVATIONS (67 + 79 channels)" if full_obs else ""),
                 "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
