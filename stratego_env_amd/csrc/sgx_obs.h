@@ -148,7 +148,15 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
                 esc = ((y - 0x1111u) & ~y & 0x8888u) != 0;                            // some nibble of y is 0
             }
             if constexpr (NT) {
-                const bool edge = ((q + l0) >> 3) == first_line || ((q + l0) >> 3) == last_line;
+                bool edge = ((q + l0) >> 3) == first_line || ((q + l0) >> 3) == last_line;
+                if constexpr (CHECKED) {
+                    // a line with a left-out quad is completed by patch_uncoded's 16-byte store: both parts go through L2, which merges them
+                    // into one whole-line write-back; non-temporal, the line reached memory as two partial writes (Standard 300 steps into
+                    // the games, most envs with captured miners / majors / bombs, same buffers: 262,144 games 1,387 us against 1,328 us with
+                    // plain stores everywhere, tools/nt_ab.py).  A line = 8 consecutive lanes of the sweep.
+                    const unsigned line_esc = (unsigned)(__ballot(in && esc) >> (__lane_id() & ~7)) & 0xFFu;
+                    edge = edge || line_esc != 0;
+                }
                 if (in && !esc && edge) base[q] = o;
                 if (in && !esc && !edge) __builtin_nontemporal_store(o, &base[q]);
             } else {
@@ -182,6 +190,8 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
             if (slot_in && f0 >= 0 && f0 + 3 < NF) {
                 f32x4 qv = {o[0], o[1], o[2], o[3]};
                 const int line = (k + l0) >> 3;
+                // (sending the lines that hold an uncoded entry through L2, like the 4-aligned boards do, measured 11 % SLOWER here:
+                // 15x15, 32,768 games 250 steps in, 447 -> 497 us)
                 if (NT && line != 0 && line != last_line) __builtin_nontemporal_store(qv, &reinterpret_cast<f32x4 *>(base)[k]);
                 else reinterpret_cast<f32x4 *>(base)[k] = qv;
             } else if (slot_in) {

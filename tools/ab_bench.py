@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--envs', type=int, default=65536)
     ap.add_argument('--version', default='barrage')
+    ap.add_argument('--warm', type=int, default=32, help='steps played before the timed rounds (how deep into the games)')
     args = ap.parse_args()
     x = torch.empty(1 << 28, device='cuda')
     t0 = time.time()
@@ -37,8 +38,7 @@ def main():
             e.obs, e.mask = envs[0].obs, envs[0].mask
         e.reset()
         e.sample_valid_actions()
-        for _ in range(32):
-            e.rollout_step()
+        e.rollout_steps(args.warm)
         envs.append(e)
     times = [[] for _ in envs]
     for r in range(args.rounds):
