@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--envs', type=int, default=65536)
     ap.add_argument('--version', default='barrage')
+    ap.add_argument('--tune', action='store_true', help='the shared output tensors come from the placement trial (tune_placement) instead of a plain allocation')
     ap.add_argument('--warm', type=int, default=32, help='steps played before the timed rounds (how deep into the games)')
     args = ap.parse_args()
     x = torch.empty(1 << 28, device='cuda')
@@ -37,6 +38,9 @@ def main():
         if envs:   # share the big output tensors
             e.obs, e.mask = envs[0].obs, envs[0].mask
         e.reset()
+        if args.tune and not envs:
+            rep = e.tune_placement()
+            print("placement trial: first %.1f us, kept %.1f us, %d candidates" % (rep['obs'][0], min(rep['obs']), len(rep['obs'])))
         e.sample_valid_actions()
         e.rollout_steps(args.warm)
         envs.append(e)
