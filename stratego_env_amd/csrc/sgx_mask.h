@@ -69,39 +69,8 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over
             const int delta = d == 0 ? sgn * C : d == 1 ? -sgn * C : d == 2 ? sgn : -sgn;
             const int bit0 = pcell * K + (d == 0 ? 0 : d == 1 ? R - 1 : d == 2 ? 2 * (R - 1) : 2 * (R - 1) + (C - 1)) - 1;
             int lim = act ? (t == SP_SCOUT ? avail : min(avail, 1)) : 0;
-            int n = 0;
-            constexpr int MAXK = (R > C ? R : C) - 1;
-            if constexpr (MAXK <= 15) {
-                // Every cell of the ray is read up front -- ONE LDS round trip instead of one per step (a scout's open file was up to
-                // nine dependent read -> test -> atomic rounds, and the whole wave waits for its longest ray) -- the walk is then
-                // register work, and the ray's valid steps (consecutive bit positions) go out as at most two atomics.
-                int v[MAXK];
-#pragma unroll
-                for (int k = 1; k <= MAXK; ++k) {
-                    v[k - 1] = OCC_OBST;
-                    if (__any(k <= lim)) { if (k <= lim) v[k - 1] = L.occ[i + k * delta]; }
-                }
-                unsigned steps = 0;                                               // bit k: step k of this ray is a valid move
-                bool open = true;
-#pragma unroll
-                for (int k = 1; k <= MAXK; ++k) {
-                    const int vk = v[k - 1];
-                    const bool blocked = (vk & (OCC_OWN | OCC_OBST)) != 0;        // (also every cell beyond lim)
-                    // two-square veto: this cell is skipped but the ray goes on (impl:439-445)
-                    const bool vetoed = pinned && (vk & OCC_CAME_FROM) && !(vk & OCC_ENEMY);
-                    if (open && !blocked && !vetoed) steps |= 1u << k;
-                    open = open && !blocked && !(vk & OCC_ENEMY);                 // an attacked piece ends the ray
-                }
-                n = __popc(steps);
-                if (steps) {
-                    const int b1 = bit0 + 1;                                      // bit position of step 1 (>= 0)
-                    const unsigned long long m = (unsigned long long)(steps >> 1) << (b1 & 31);
-                    if ((uint32_t)m) atomicOr(&L.mbits[b1 >> 5], (uint32_t)m);
-                    if (m >> 32) atomicOr(&L.mbits[(b1 >> 5) + 1], (uint32_t)(m >> 32));
-                }
-            } else {
-            int e = i;
-            for (int k = 1; k <= MAXK; ++k) {
+            int e = i, n = 0;
+            for (int k = 1; k < (R > C ? R : C); ++k) {
                 if (!__any(k <= lim)) break;
                 if (k <= lim) {
                     e += delta;
@@ -118,7 +87,6 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over
                         if (v & OCC_ENEMY) lim = 0;                               // an attacked piece ends the ray
                     }
                 }
-            }
             }
             n = quad_sum(n);                                                      // moves of the piece = its 4 rays
             if (act && d == 0) { L.cnt[pcell] = (uint8_t)n; mine += n; }
