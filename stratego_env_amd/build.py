@@ -65,7 +65,14 @@ def build_geometry(rows, columns, force=False, verbose=False):
         return path
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
-        raise RuntimeError("hipcc not found: cannot build the %dx%d kernels" % (rows, columns))
+        if os.path.exists(path) and not force:
+            # a deployment box without the ROCm compiler: the library that was shipped is the one to use (file times do not survive
+            # every way of copying a tree); sizes that were not prebuilt cannot be played there
+            import warnings
+            warnings.warn("%s may be older than its sources and hipcc is not available: using it as it is" % path, RuntimeWarning)
+            return path
+        raise RuntimeError("hipcc not found: cannot build the %dx%d kernels; prebuild them where the ROCm compiler is installed with "
+                           "`python -m stratego_env_amd.build %dx%d` and ship stratego_env_amd/_build/" % (rows, columns, rows, columns))
     os.makedirs(OUT_DIR, exist_ok=True)
     tmp = '%s.%d.tmp' % (path, os.getpid())
     cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-fvisibility=hidden', '-Wall',
@@ -78,4 +85,12 @@ def build_geometry(rows, columns, force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    # python -m stratego_env_amd.build            rebuilds the main library (every board size of the reference's variants)
+    # python -m stratego_env_amd.build 7x7 12x12  prebuilds the libraries of other board sizes (for boxes without hipcc)
+    import sys
+    sizes = [a for a in sys.argv[1:] if 'x' in a]
+    if not sizes:
+        print(build(force=True, verbose=True))
+    for a in sizes:
+        r, c = a.lower().split('x')
+        print(build_geometry(int(r), int(c), force=True, verbose=True))
