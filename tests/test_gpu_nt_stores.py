@@ -175,6 +175,14 @@ def test_standard_262144_mid_game_nt_with_uncoded_entries():
     _full_size_check('standard', 262144, 220, 8, 10)
 
 
+def test_standard_both_mode_mid_game_nt_mixed_lines():
+    """Standard in BOTH_OBSERVATIONS mode past the Infinity Cache size, 220 steps into the games: both renderings take
+    emit_codes<CHECKED, NT>, where the lines that hold a left-out quad leave as plain stores and are completed by patch_uncoded;
+    and 6x6 Standard (medium_standard), whose lines are shared between neighbouring games more often."""
+    _full_size_check('standard', 32768, 220, 8, 10, both=True)
+    _full_size_check('medium_standard', 131072, 120, 8, 8)
+
+
 def test_two_chains_full_size_equal_one_chain_and_the_oracle():
     """sgx_rollout(chains = 2) at 65,536 Barrage games (NT by size, the two ranges on streams of their own): oracle digests of
     sampled envs from both ranges, and the final state equals a single-chain run's."""

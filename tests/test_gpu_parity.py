@@ -33,7 +33,7 @@ def _oracle_batch(name, seed, g0, n):
     ('medium', 32, 300, 0.1), ('fives', 32, 200, 0.1), ('tiny', 64, 200, 0.1), ('micro', 64, 120, 0.1),
     ('short_barrage', 32, 250, 0.1), ('standard2', 4, 150, 0.05),
 ])
-def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0):
+def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0, require_endings=True):
     """Random-valid-action rollouts with auto-reset (+ injected garbage actions): every output of every step.
     (tools/soak_parity.py re-runs this with other seeds, batch sizes and garbage rates for minutes.)"""
     import torch
@@ -101,7 +101,7 @@ def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0):
             st, pl = env.export_state()
             assert np.array_equal(st.cpu().numpy(), np.stack([oe.state for oe in oenvs])), (name, t, 'state export')
             assert np.array_equal(pl.cpu().numpy(), np.asarray([oe.player for oe in oenvs], dtype=np.int8))
-    assert games_done > 0 or name in ('standard', 'standard2', 'medium_standard', 'short_standard', 'c12x12', 'c20x20', 'c17x16', 'c32x32')
+    assert games_done > 0 or not require_endings or name in ('standard', 'standard2', 'medium_standard', 'short_standard', 'c12x12', 'c20x20', 'c17x16', 'c32x32')
     env.close()
 
 

@@ -29,7 +29,7 @@ def main():
         t0, salt, runs, steps = time.time(), 1, 0, 0
         while time.time() - t0 < budget:
             for name, n, t, g in CUSTOM_PLAN:
-                T.test_step_bit_exact_vs_oracle(name, n + salt % 3, t, g, seed_salt=salt)
+                T.test_step_bit_exact_vs_oracle(name, n + salt % 3, t, g, seed_salt=salt, require_endings=False)
                 runs += 1
                 steps += (n + salt % 3) * t
                 if time.time() - t0 > budget:
