@@ -328,11 +328,14 @@ def shard_of(rk, per_gpu, total_envs):
     return shard_range(total, rk.rank, rk.world) + (total,)
 
 
-def timed_steps(rk, run_warmup, run_timed, counters):
+def timed_steps(rk, run_warmup, run_timed, counters, settle=None):
     """Warm up, then time run_timed() between barrier + synchronize brackets.  Returns (elapsed seconds MAX over ranks,
-    device ms MAX over ranks or None, elapsed seconds MIN over ranks, summed counter deltas)."""
+    device ms MAX over ranks or None, elapsed seconds MIN over ranks, summed counter deltas).  settle(): untimed, state-preserving GPU
+    work that directly precedes the bracket (gpu_settle)."""
     run_warmup()
     before = counters()
+    if settle:
+        settle()
     ev = None
     if rk.use_cuda:
         import torch
@@ -378,6 +381,27 @@ def make_env(version, n, first, device_index, full_obs=False):
     return env
 
 
+SETTLE_SECONDS = 0.1
+
+
+def gpu_settle(env, seconds):
+    """Untimed and state-preserving: `seconds` of back-to-back sgx_observe launches (the step kernel's own stores into the same buffers;
+    nothing is played) directly before the barrier + synchronize bracket of the timed region.  A short run does not reach the steady
+    rate otherwise: after 5 to 20 warm-up steps (and the few small kernels and the device-to-host copy of the counters read) the next 20
+    launches take 277-297 us instead of the 259-262 us of launches 64 ... 512 -- a burst of step launches that starts from a lightly
+    loaded GPU runs ~10 launches fast, ~15-40 slow, then settles (kernel trace: tools/trace_series.py; idle time before a burst:
+    tools/idle_burst.py, <= 3 ms harmless, >= 10 ms +5 %; tools/early_burst.py: the same 20 launches at turns 6-25 take 260 us directly
+    after a series of observe launches, 286 us after 5 step launches).  With this, `--steps 20 --warmup 5` reads 263.0 us per launch
+    (247 M steps/s; 277-286 us = 227-236 M without) and the default 512 / 64 259.5 us (260.5-262.1 us without): the steady rate either
+    way.  The timed region is still exactly K steps after W warm-up steps."""
+    import torch
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            env.observe()
+        torch.cuda.synchronize()
+
+
 def time_workload(rk, env, steps, warmup, unfused=False, chains=1):
     """(elapsed s, device ms, (min, max) of the ranks' own seconds, games finished, invalid actions) of `steps` batched steps on
     `env`, MAX / SUM over ranks."""
@@ -394,9 +418,9 @@ def time_workload(rk, env, steps, warmup, unfused=False, chains=1):
         env.sample_valid_actions()
         if chains > 1 and not unfused:       # (the chains' streams are created on first use: not inside the timed region)
             env.rollout_steps(warmup, chains=chains)
-            return
-        for _ in range(warmup):
-            one_step()
+        else:
+            for _ in range(warmup):
+                one_step()
 
     def run_timed():
         if unfused:
@@ -408,7 +432,7 @@ def time_workload(rk, env, steps, warmup, unfused=False, chains=1):
     def counters():
         return [int(env.env_info()[:, 1].to(torch.int64).sum()), 0]
 
-    elapsed, dev_ms, own, (games, _) = timed_steps(rk, run_warmup, run_timed, counters)
+    elapsed, dev_ms, own, (games, _) = timed_steps(rk, run_warmup, run_timed, counters, settle=lambda: gpu_settle(env, SETTLE_SECONDS))
     env.bench_steps_played += warmup + steps
     _, (invalid,) = rk.reduce([], [int(env.invalid_action.sum())])
     return elapsed, dev_ms, own, games, invalid
