@@ -354,19 +354,24 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
     for (int i = tid; i < P.rec_bytes / 16; i += 256) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(W.img)[i];
 }
 
-// sgx_step_states: import -> env.step() -> export of one state by one 128-thread block, the record never leaving LDS in between.
+// sgx_step_states: import -> env.step() -> export of one state by one 128- or 192-thread block (states_threads), the record never leaving LDS in between.
 // The step is one wave's work (sgx_step.h: env_step, ~10 us of dependent LDS round trips); the other wave waits at the barrier while
 // the CU's other blocks keep the memory pipes busy with their loads and stores, so the step costs no launch of its own (88 us per
 // 65,536 states as a separate launch between a 300 us import and a 330 us export).  Small blocks = many of them per CU = many
 // steps in flight beside the streaming.  OBS = false: no observation is rendered (get_next_state, is_move_valid_*, masks): no code
 // buffer and no templates in LDS (the step runs as the value-channel kind, whose Lds has no code buffer -- the game logic does
 // not depend on the observation kind), 16 blocks per CU instead of 11.  Partial-observation 'extended' kind only.
+// Threads per state: 128 / 192 / 256 measured 654 / 628 / 636 us per 65,536 Barrage states in one process (tools/states_ab.py).
+// (get_next_state / is_move_valid_*: three waves per state; the variants whose ONE stepping wave also emits a mask or an observation
+// want more blocks per CU instead: 1-D masks 463 us with 128 threads, 592 us with 192)
+template <bool MAPPED, bool OBS>
+constexpr int states_threads() { return (!MAPPED && !OBS) ? 192 : 128; }
 template <int R_, int C_, bool MAPPED, bool OBS>
-__global__ __launch_bounds__(128) void states_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in,
+__global__ __launch_bounds__((states_threads<MAPPED, OBS>())) void states_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in,
                                                      uint8_t *__restrict__ sanitised, int64_t *__restrict__ out, int8_t *__restrict__ player_out, const int nt) {
     using G = Geo<R_, C_>;
     static_assert(G::LPG == 64, "one game per wave");
-    constexpr int NT = 128, KIND = OBS ? 0 : 2;
+    constexpr int NT = states_threads<MAPPED, OBS>(), KIND = OBS ? 0 : 2;
     __shared__ StateLds<G, NT> W;
     __shared__ Lds<G, ObsKind<KIND>::NIB_CH> L;
     __shared__ alignas(16) uint8_t shared[OBS ? shared_table_bytes<G, 0>() : 16];

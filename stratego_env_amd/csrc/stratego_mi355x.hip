@@ -994,7 +994,7 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
         p.nt_stores = h->nt_mode < 0 ? (launch_streams_past_cache(h, p) ? 1 : 0) : h->nt_mode;
         const bool mapped = (io->flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) != 0;
         const bool obs = io->obs_dev || io->final_obs_dev;
-#define CALL_STATES_K(R, C, M, O) states_kernel<R, C, M, O><<<grid, 128, 0, (hipStream_t)stream>>>(p, state_in_dev, player_in_dev, sanitised_dev, state_out_dev, player_out_dev, nt)
+#define CALL_STATES_K(R, C, M, O) states_kernel<R, C, M, O><<<grid, states_threads<M, O>(), 0, (hipStream_t)stream>>>(p, state_in_dev, player_in_dev, sanitised_dev, state_out_dev, player_out_dev, nt)
 #define CALL_STATES(R, C)                                                                                                   \
     do {                                                                                                                    \
         if constexpr (Geo<R, C>::LPG == 64 && !Geo<R, C>::WIDE) {                                                           \
