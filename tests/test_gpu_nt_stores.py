@@ -175,6 +175,12 @@ def test_standard_262144_mid_game_nt_with_uncoded_entries():
     _full_size_check('standard', 262144, 220, 8, 10)
 
 
+def test_barrage_262144_games_config5_per_gpu_size():
+    """BASELINE config 5's per-GPU share (262,144 Barrage games; `bench.py --gpus N > 1` runs this size on every rank): oracle digests of
+    sampled envs and their final states, 150 steps into the games."""
+    _full_size_check('barrage', 262144, 150, 8, 12)
+
+
 def test_standard_both_mode_mid_game_nt_mixed_lines():
     """Standard in BOTH_OBSERVATIONS mode past the Infinity Cache size, 220 steps into the games: both renderings take
     emit_codes<CHECKED, NT>, where the lines that hold a left-out quad leave as plain stores and are completed by patch_uncoded;
