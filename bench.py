@@ -150,6 +150,8 @@ def parse_args(argv=None):
                     help="output buffers: 'trial' = library-owned, picked by sgx_alloc_outputs' bounded placement trial; "
                          "'plain' = the torch.empty tensors of VecStrategoEnv")
     ap.add_argument('--placement-trials', type=int, default=None, help='most candidate allocations (default: what --placement-gb allows)')
+    ap.add_argument('--placement-wide-gb', type=float, default=64.0,
+                    help='budget of the second, wide placement pass that runs when the first found no fast candidate (0: no second pass)')
     ap.add_argument('--placement-gb', type=float, default=8.0,
                     help='most extra device memory the placement trial may hold at any time')
     ap.add_argument('--wake-seconds', type=float, default=2.0,
@@ -501,6 +503,23 @@ def place_outputs(env, args):
                     "max_us": round(max(t), 1)})
     if rep.get('fobs'):
         out["fobs_plain_us"], out["fobs_kept_us"] = round(rep['fobs'][0], 1), round(min(rep['fobs']), 1)
+    # No candidate of the fast class (>= 14 % below the slowest) in the first budget: a second pass samples a much
+    # wider range with the same number of candidates (the library spreads them over the budget it is given) and is kept only if it
+    # found something faster.  (One box: 295 us after 11 candidates in 8 GiB, 283 us as the third candidate of a 64 GB pass.)
+    wide = getattr(args, 'placement_wide_gb', 0.0)
+    streams = env.obs.numel() * 4 > 300e6            # (a launch that fits the Infinity Cache has no placement classes: the toy boards)
+    if t and streams and wide > args.placement_gb and min(t) > 0.86 * max(t) and env.fobs is None:
+        first = (env.obs, env.mask, env._outputs_owner, env._outputs, env.placement_peak_extra_bytes)
+        rep2 = env.tune_placement(args.placement_trials, max_extra_bytes=int(wide * (1 << 30)))
+        t2 = rep2.get('obs') or []
+        out["wide_pass"] = {"budget_gb": wide, "candidates": len(t2), "kept_us": round(min(t2), 1) if t2 else None,
+                            "max_us": round(max(t2), 1) if t2 else None,
+                            "peak_extra_gb": round(env.placement_peak_extra_bytes / 2.0 ** 30, 2), "used": bool(t2) and min(t2) < min(t)}
+        if not out["wide_pass"]["used"]:
+            env.obs, env.mask, env._outputs_owner, env._outputs, env.placement_peak_extra_bytes = first
+            env.observe()
+        else:
+            out["kept_us"] = round(min(t2), 1)
     return out
 
 

@@ -679,6 +679,9 @@ int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t 
     const size_t room = (size_t)max_extra - bytes;                        // what the padding may take
     size_t step = bytes / 8;                                              // (a big buffer leaves little room: smaller steps then)
     if (step * 12 > room) step = room / 12;
+    // a generous budget is spread over all of it: with max_extra_bytes far beyond 32 x bytes / 8 the candidates sample the whole range
+    const int32_t n_cand = (max_trials < SGX_OUT_MAX_TRIALS ? max_trials : SGX_OUT_MAX_TRIALS) - 1;
+    if (n_cand > 0 && room / (size_t)n_cand > step) step = room / (size_t)n_cand;
     step = (step + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
     int first_good = -1;
     for (int k = 1; k < max_trials && k < SGX_OUT_MAX_TRIALS; ++k) {
