@@ -495,7 +495,11 @@ def place_outputs(env, args):
     -> {'candidates', 'plain_us' (the allocation a caller would have got first), 'kept_us', 'median_us', 'max_us', 'peak_extra_gb'}."""
     if args.placement != 'trial':
         return None
-    rep = env.tune_placement(args.placement_trials, max_extra_bytes=int(args.placement_gb * (1 << 30)))
+    # No candidate of the fast class (>= 14 % below the slowest, DESIGN.md section 4) in the first budget: tune_placement's second pass
+    # samples a much wider range with the same number of candidates and is kept only if it found something faster.  (One box: 32
+    # candidates at 338-340 us within 8 GiB, 275.9 us in the 64 GB pass.)
+    rep = env.tune_placement(args.placement_trials, max_extra_bytes=int(args.placement_gb * (1 << 30)),
+                             wide_extra_bytes=int(getattr(args, 'placement_wide_gb', 0.0) * (1 << 30)))
     t = rep.get('obs') or []
     out = {"candidates": len(t), "peak_extra_gb": round(getattr(env, 'placement_peak_extra_bytes', 0) / 2.0 ** 30, 2)}
     if t:
@@ -503,22 +507,13 @@ def place_outputs(env, args):
                     "max_us": round(max(t), 1)})
     if rep.get('fobs'):
         out["fobs_plain_us"], out["fobs_kept_us"] = round(rep['fobs'][0], 1), round(min(rep['fobs']), 1)
-    # No candidate of the fast class (>= 14 % below the slowest) in the first budget: a second pass samples a much
-    # wider range with the same number of candidates (the library spreads them over the budget it is given) and is kept only if it
-    # found something faster.  (One box: 295 us after 11 candidates in 8 GiB, 283 us as the third candidate of a 64 GB pass.)
-    wide = getattr(args, 'placement_wide_gb', 0.0)
-    streams = env.obs.numel() * 4 > 300e6            # (a launch that fits the Infinity Cache has no placement classes: the toy boards)
-    if t and streams and wide > args.placement_gb and min(t) > 0.86 * max(t) and env.fobs is None:
-        first = (env.obs, env.mask, env._outputs_owner, env._outputs, env.placement_peak_extra_bytes)
-        rep2 = env.tune_placement(args.placement_trials, max_extra_bytes=int(wide * (1 << 30)))
-        t2 = rep2.get('obs') or []
-        out["wide_pass"] = {"budget_gb": wide, "candidates": len(t2), "kept_us": round(min(t2), 1) if t2 else None,
-                            "max_us": round(max(t2), 1) if t2 else None,
-                            "peak_extra_gb": round(env.placement_peak_extra_bytes / 2.0 ** 30, 2), "used": bool(t2) and min(t2) < min(t)}
-        if not out["wide_pass"]["used"]:
-            env.obs, env.mask, env._outputs_owner, env._outputs, env.placement_peak_extra_bytes = first
-            env.observe()
-        else:
+    w = rep.get('wide')
+    if w:
+        t2 = w['obs']
+        out["wide_pass"] = {"budget_gb": args.placement_wide_gb, "candidates": len(t2), "kept_us": round(min(t2), 1) if t2 else None,
+                            "max_us": round(max(t2), 1) if t2 else None, "peak_extra_gb": round(w['peak_extra_bytes'] / 2.0 ** 30, 2),
+                            "used": w['used']}
+        if w['used']:
             out["kept_us"] = round(min(t2), 1)
     return out
 

@@ -197,7 +197,9 @@ int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t launches, vo
  * only a buffer whose pages MIX both kinds reaches the fast class (313-325 us).  Which one a plain allocation gets depends
  * on what was allocated before it.  sgx_alloc_outputs allocates the mask buffer, then tries up to `max_trials` candidate
  * allocations of the observation buffer (and of the fully-observable one with SGX_OUT_FULL_OBS): before each candidate a
- * padding allocation of growing size is made and released again afterwards, which moves the candidate to other buddy blocks;
+ * padding allocation of growing size (steps of an eighth of the buffer, or -- under a budget wider than `max_trials` such steps -- of
+ * the budget divided by the number of candidates, so that a generous budget is sampled evenly) is made and released again afterwards,
+ * which moves the candidate to other buddy blocks;
  * each candidate is timed with a few sgx_observe launches (no state change) and only the fastest so far is kept.  The trial
  * stops early once the kept candidate is >= 14 % faster than the slowest one seen (the fast class), or eight candidates after the first one
  * that is >= 9 % faster.  At no time does the trial hold more than `max_extra_bytes`

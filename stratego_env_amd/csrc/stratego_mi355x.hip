@@ -681,8 +681,10 @@ int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t 
     if (step * 12 > room) step = room / 12;
     // a generous budget is spread over all of it: with max_extra_bytes far beyond 32 x bytes / 8 the candidates sample the whole range
     const int32_t n_cand = (max_trials < SGX_OUT_MAX_TRIALS ? max_trials : SGX_OUT_MAX_TRIALS) - 1;
-    if (n_cand > 0 && room / (size_t)n_cand > step) step = room / (size_t)n_cand;
+    const bool spread = n_cand > 0 && room / (size_t)n_cand > step;
+    if (spread) step = room / (size_t)n_cand;
     step = (step + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (spread && step > ((size_t)2 << 20) && step * (size_t)n_cand > room) step -= (size_t)2 << 20;      // (the last candidate must fit too)
     int first_good = -1;
     for (int k = 1; k < max_trials && k < SGX_OUT_MAX_TRIALS; ++k) {
         const size_t pad_bytes = (size_t)k * step;

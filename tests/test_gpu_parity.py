@@ -384,6 +384,21 @@ def test_tune_placement_keeps_outputs():
     assert torch.equal(obs_kept, want_obs) and torch.equal(mask_kept, want_mask)
     del junk, obs_kept, mask_kept
     gc.collect()
+    # the wide second pass (taken when the first budget held no candidate >= 14 % below its slowest one, streaming launches only):
+    # whichever pass is kept, the env goes on with valid buffers that hold the current outputs
+    env = VecStrategoEnv('barrage', 16384, seed=6, auto_reset=True)         # 439 MB of observations: past the Infinity Cache
+    twin = VecStrategoEnv('barrage', 16384, seed=6, auto_reset=True)
+    env.reset()
+    twin.reset()
+    rep = env.tune_placement(trials=2, max_extra_bytes=1 << 30, wide_extra_bytes=3 << 30)
+    if 'wide' in rep:
+        assert len(rep['wide']['obs']) == 2 and rep['wide']['used'] == (min(rep['wide']['obs']) < min(rep['obs']))
+    assert env.obs.data_ptr() == env._outputs.obs_dev and torch.equal(env.obs, twin.obs) and torch.equal(env.mask, twin.mask)
+    env.rollout_steps(5)
+    twin.rollout_steps(5)
+    assert torch.equal(env.obs, twin.obs) and torch.equal(env.mask, twin.mask)
+    env.close()
+    twin.close()
     env = VecStrategoEnv('tiny', 1024, seed=5, auto_reset=True, full_obs=True)       # BOTH mode: the full observation is placed too
     env.reset()
     fobs0 = env.fobs.clone()
