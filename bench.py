@@ -670,6 +670,7 @@ def run_rank(args):
                                                        "separate" if args.unfused else "fused"),
                        "games_per_gpu": n, "total_games": total, "version": args.version, "seed": BASE_SEED,
                        "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns, args.full_obs),
+                       "untimed_before_bracket": "%d warm-up steps, then %.2f s of state-preserving sgx_observe launches (gpu_settle)" % (args.warmup, SETTLE_SECONDS),
                        "concurrent_chains": args.chains, "two_chains": two_chains,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),
                        "reduction_backend": backend if rk.world > 1 else None, "devices": args.devices,
