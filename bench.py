@@ -154,6 +154,8 @@ def parse_args(argv=None):
                     help='budget of the second, wide placement pass that runs when the first found no fast candidate (0: no second pass)')
     ap.add_argument('--placement-gb', type=float, default=8.0,
                     help='most extra device memory the placement trial may hold at any time')
+    ap.add_argument('--settle-seconds', type=float, default=0.1,
+                    help='untimed, state-preserving sgx_observe launches directly before the timed bracket (gpu_settle); 0 = none')
     ap.add_argument('--wake-seconds', type=float, default=2.0,
                     help='untimed GPU wake-up before the warmup steps (a fresh box runs its first ~second at idle clocks)')
     ap.add_argument('--chains', type=int, default=1,
@@ -625,6 +627,8 @@ def run_rank(args):
         return
 
     import torch
+    global SETTLE_SECONDS
+    SETTLE_SECONDS = args.settle_seconds
     if args.wake_seconds > 0:   # bring the GPU out of its idle power state; touches no env state
         scratch = torch.empty(1 << 28, dtype=torch.float32, device='cuda')
         t_wake = time.perf_counter()
