@@ -339,6 +339,8 @@ def timed_steps(rk, run_warmup, run_timed, counters, settle=None):
     run_warmup()
     before = counters()
     if settle:
+        if rk.world > 1:
+            rk.barrier()        # the ranks settle side by side, so that none of them idles at the bracket's barrier for long
         settle()
     ev = None
     if rk.use_cuda:
