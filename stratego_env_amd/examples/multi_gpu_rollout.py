@@ -34,7 +34,7 @@ def main():
     first, n = shard_range(args.total_envs, rank, world)
     env = VecStrategoEnv(args.version, n, device=local_rank, seed=args.seed, env_id_offset=first, auto_reset=True)
     env.reset()
-    env.tune_placement()
+    env.tune_placement(wide_extra_bytes=64 << 30)          # second, wide pass if the first 8 GiB hold no fast memory
     games0 = env.env_info()[:, 1].to(torch.int64).sum()
     invalid_endings = torch.zeros((), dtype=torch.int64, device=env.device)
     torch.cuda.synchronize()
