@@ -201,7 +201,7 @@ int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t launches, vo
  * the budget divided by the number of candidates, so that a generous budget is sampled evenly) is made and released again afterwards,
  * which moves the candidate to other buddy blocks;
  * each candidate is timed with a few sgx_observe launches (no state change) and only the fastest so far is kept.  The trial
- * stops early once the kept candidate is >= 14 % faster than the slowest one seen (the fast class), or eight candidates after the first one
+ * stops early once the kept candidate is >= 17 % faster than the slowest one seen (the fast class), or eight candidates after the first one
  * that is >= 9 % faster.  At no time does the trial hold more than `max_extra_bytes`
  * beyond the buffers it returns (0 or max_trials <= 1: no trial, first allocation).  Channel counts follow `flags` (SGX_STEP_ORIGINAL_CHANNELS).  Waits for the device.  No reference counterpart. */
 #define SGX_OUT_FULL_OBS 1024         /* also allocate fobs_dev [N,R,C,79] (or 33) */

@@ -706,10 +706,11 @@ int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t 
         // that much the fast class has been found and more candidates would only cost start-up time.  (A run of equally slow
         // candidates is no reason to stop: fast memory was found behind six and more slow candidates on several boxes.)
         // Two steps: the classes are ~255-265 / 300-310 / 320-330 / ~345 us (65,536 Barrage games): a candidate 9 % below the slowest may
-        // be the middle class only, so the search goes on for up to eight more candidates and stops at once at 14 % (fast class).
+        // be the middle class only, so the search goes on for up to eight more candidates and stops at once at 17 % (fast class: 272-277 us after 335-340 us;
+        // 282 us, 16 %, is not the best a box has).
         float worst = 0.f;
         for (int j = 0; j <= k; ++j) worst = trial_us[j] > worst ? trial_us[j] : worst;
-        if (k >= 2 && best_us < 0.86f * worst) break;
+        if (k >= 2 && best_us < 0.83f * worst) break;
         if (k >= 2 && best_us < 0.91f * worst && first_good < 0) first_good = k;
         if (first_good >= 0 && k - first_good >= 8) break;
     }
