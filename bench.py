@@ -502,7 +502,9 @@ def place_outputs(env, args):
     # No candidate of the fast class (>= 14 % below the slowest) in the first budget: tune_placement's second pass
     # samples a much wider range with the same number of candidates and is kept only if it found something faster.  (One box: 32
     # candidates at 338-340 us within 8 GiB, 275.9 us in the 64 GB pass.)
-    rep = env.tune_placement(args.placement_trials, max_extra_bytes=int(args.placement_gb * (1 << 30)),
+    # (a 7 GB observation buffer -- 262,144 games -- would have 1 GB of the default budget left for its candidates: four buffer sizes then)
+    budget = max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if args.placement_gb > 0 else 0
+    rep = env.tune_placement(args.placement_trials, max_extra_bytes=budget,
                              wide_extra_bytes=int(getattr(args, 'placement_wide_gb', 0.0) * (1 << 30)))
     t = rep.get('obs') or []
     out = {"candidates": len(t), "peak_extra_gb": round(getattr(env, 'placement_peak_extra_bytes', 0) / 2.0 ** 30, 2)}
