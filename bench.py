@@ -22,7 +22,8 @@ Prints ONE JSON line (rank 0) with
   `roofline`      HBM; `frac` = HBM bytes per launch by the rocprofv3 counters (profiles/traffic.json, committed next to the
                   rocprof summaries they come from) / launch time measured live with HIP events on the launch stream / 8 TB/s;
                   `frac_algorithmic` = SURVEY 8d's B_alg x games per launch over the same time (the kernel moves fewer bytes than
-                  B_alg assumes, so this one can exceed 1); `frac_untuned` = the same on the process's plain first allocation;
+                  B_alg assumes, so this one can exceed 1); `frac_untuned` = the same on the process's plain first allocation; `frac_dram_min` = the
+                  counter bytes without the mask when the 256 MiB Infinity Cache can hold it (the DRAM side lies between it and `frac`);
   `verified_envs` sampled envs of the very env object that was timed, checked after the timed region against the CPU oracle
                   replaying the same number of steps (outputs of the last step, turn and game counters);
   `config.other_workloads`  BASELINE configs 3 and 4 and the reference's default BOTH_OBSERVATIONS mode (1-GPU run only);
