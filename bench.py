@@ -576,7 +576,7 @@ def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, 
         return {"workload": "%d concurrent %s games (%dx%d)%s, same rollout" % (n, version, v.rows, v.columns,
                                                                                  ", BOTH_OBSERVATIONS (67 + 79 channels)" if full_obs else ""),
                 "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
-                "frac": rf["frac"], "frac_basis": rf["frac_basis"], "frac_algorithmic": rf["frac_algorithmic"],
+                "frac": rf["frac"], "frac_dram_min": rf["frac_dram_min"], "frac_basis": rf["frac_basis"], "frac_algorithmic": rf["frac_algorithmic"],
                 "frac_untuned": rf["frac_untuned"], "traffic": rf["traffic"],
                 "b_alg_bytes_per_step": b_alg(v.rows, v.columns, full_obs), "kernel": rf["kernel"],
                 "games_finished_in_timed_region": games, "concurrent_chains": two, "verified_envs": checked,
