@@ -232,7 +232,8 @@ int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);
  * complete) makes env.step() ONE library call: no upload, no download, no second launch.  Meant for a handful of games; batches
  * belong in HBM.  Up to 8 games on a board of more than 32 cells with a multiple of 4 cells, 'extended' channel modes, are played by a
  * kernel of their own -- one workgroup per game: one wave plays the move, all eight emit the mask and the observations -- which
- * publishes its completion in a host-mapped word that sgx_step_sync polls: the call returns when the outputs are visible to the host,
+ * publishes its completion in a host-mapped word that sgx_step_sync polls (a busy wait on the calling thread, like a spinning stream
+ * synchronisation; it looks at the stream now and then so that a failed launch ends it): the call returns when the outputs are visible to the host,
  * typically before `stream` has retired the kernel (later work on `stream` is ordered behind it as usual).  Every other case is
  * sgx_step + hipStreamSynchronize.  Same results either way (tests/test_gpu_step_sync.py).
  * No reference counterpart (the reference is one game per object on the host, maenv:659-828). */

@@ -805,7 +805,7 @@ int step_single(sgx_env *h, const KParams &p, bool full, hipStream_t stream, boo
     *launched = false;
     if (!h->sync_flag_host) {
         void *hp = nullptr, *dp = nullptr;
-        HIP_TRY(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));   // (fine-grained whatever HIP_HOST_COHERENT says: the kernel's release store must be visible while it still runs)
         if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(hp); return fail(SGX_EDEVICE, "hipHostGetDevicePointer failed%s"); }
         memset(hp, 0, 64);
         h->sync_flag_host = (uint32_t *)hp;
