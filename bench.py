@@ -505,6 +505,8 @@ def place_outputs(env, args):
     # candidates at 338-340 us within 8 GiB, 275.9 us in the 64 GB pass.)
     # (a 7 GB observation buffer -- 262,144 games -- would have 1 GB of the default budget left for its candidates: four buffer sizes then)
     budget = max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if args.placement_gb > 0 else 0
+    if env.obs.numel() * 4 <= 300e6 and env.fobs is None:
+        budget = 0     # a launch whose observations fit the Infinity Cache has no placement classes (toy boards: 64 candidates within 1 %): no search
     rep = env.tune_placement(args.placement_trials, max_extra_bytes=budget,
                              wide_extra_bytes=int(getattr(args, 'placement_wide_gb', 0.0) * (1 << 30)))
     t = rep.get('obs') or []
