@@ -19,13 +19,21 @@ contiguously across the ranks (stratego_env_amd.sharding.shard_range), no collec
 of the timed region and one MAX / SUM all-reduce for reporting.
 
 Prints ONE JSON line (rank 0) with
-  `roofline`      HBM; `frac` = HBM bytes per launch by the rocprofv3 counters (profiles/traffic.json, committed next to the
-                  rocprof summaries they come from) / launch time measured live with HIP events on the launch stream / 8 TB/s;
-                  `frac_algorithmic` = SURVEY 8d's B_alg x games per launch over the same time (the kernel moves fewer bytes than
-                  B_alg assumes, so this one can exceed 1); `frac_untuned` = the same on the process's plain first allocation; `frac_dram_min` = the
-                  counter bytes without the mask when the 256 MiB Infinity Cache can hold it (the DRAM side lies between it and `frac`);
+  `roofline`      HBM.  `achieved` = B_min x games per launch / launch time (HIP events on the launch stream over the timed region),
+                  B_min = the packed layout's own byte minimum per env step (record in + record out + action in + next action out +
+                  float32 observation + uint8 mask + results: 31,544 B for Barrage) -- what the kernel cannot avoid
+                  moving; `frac` = achieved / 8 TB/s.  The headline writes ONE set of output tensors in place, so part of it (the 242 MB
+                  mask) can be absorbed by the 256 MiB Infinity Cache: `frac_dram` is the same arithmetic on the ROTATING-OUTPUTS leg
+                  (config.rotating_outputs: >= 3 output sets written round-robin, sgx_step_ring, so that no line written by launch k can
+                  still sit in that cache at launch k+1) -- the DRAM-side figure.  `traffic` = counter bytes per launch from the
+                  committed rocprofv3 --pmc passes (profiles/traffic.json; `traffic_source` says which binary they were measured on:
+                  "static" unless the build id matches); `frac_untuned` = `frac` on the process's plain first allocation;
+                  `survey_8d` = SURVEY 8d's 33,848 B per step x games / launch time, a labelled comparison only (the kernel moves
+                  fewer bytes than that formula assumes, so it is not a fraction of anything);
   `verified_envs` sampled envs of the very env object that was timed, checked after the timed region against the CPU oracle
                   replaying the same number of steps (outputs of the last step, turn and game counters);
+  `config.rotating_outputs`   the rotating-outputs leg; `config.consumer_in_loop`  sgx_step alternating with a device policy that READS
+                  the observation and the mask (examples/batched_policy_loop.py), non-temporal against plain stores under that reader;
   `config.other_workloads`  BASELINE configs 3 and 4 and the reference's default BOTH_OBSERVATIONS mode (1-GPU run only);
   `cpu_baseline`  the CPU oracle (a port of the reference's algorithm) timed on this box's host cores on a bounded sample.
 
@@ -58,6 +66,30 @@ def b_alg(rows, cols, full_obs=False):
     return (32 * rc + 16) + (rc + 16) + 4 + 4 * 67 * rc + rc * k + 12 + (4 * 79 * rc if full_obs else 0)
 
 
+def record_bytes(v):
+    """Bytes of one game's packed record in HBM -- the arithmetic of sgx_create (sgx_record_bytes(h) returns the same for a live
+    handle; tests/test_gpu_parity.py compares the two): 4 dense int8 boards, two never-moved bitmaps, 32 B of scalars, the
+    capture-event list (2 x pieces entries, at most one per cell), rounded up to whole 128-byte lines."""
+    rc = v.rows * v.columns
+    s4 = (rc + 3) & ~3
+    st_off = (4 * s4 + 15) & ~15
+    sb = (((rc + 7) // 8) + 15) & ~15
+    pieces = max(sum(v.piece_counts), int(getattr(v, 'capture_capacity', 0)))
+    max_events = min(2 * pieces, rc)
+    return (st_off + 2 * sb + 32 + (4 if rc > 256 else 2) * max_events + 127) & ~127
+
+
+def b_min(v, full_obs=False, rec_bytes=None):
+    """The packed layout's own byte minimum of one env step -- what `roofline` is priced on: the record read
+    once and written once, the action read (4) and the next action written (4), the float32 observation(s), the uint8 mask and
+    12 B of results (two float32 rewards, done, invalid_action, ending_invalid, player).  Barrage 31,544 B, Standard 31,800 B,
+    Micro 3,624 B."""
+    rc = v.rows * v.columns
+    k = 2 * (v.rows - 1) + 2 * (v.columns - 1) + 1
+    rb = rec_bytes if rec_bytes else record_bytes(v)
+    return 2 * rb + 4 + 4 + 4 * 67 * rc + rc * k + 12 + (4 * 79 * rc if full_obs else 0)
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU boxes show
     256 logical CPUs but run under a 16-CPU quota)."""
@@ -71,16 +103,20 @@ def usable_cores():
     return n
 
 
-def measured_traffic(key, n_envs):
-    """(HBM bytes per launch, source) from the committed rocprofv3 --pmc passes (profiles/traffic.json), or (None, None).
+def measured_traffic(key, n_envs, build_id=None):
+    """(counter bytes per launch, source) from the committed rocprofv3 --pmc passes (profiles/traffic.json), or (None, None).
     The kernel moves the same bytes for every game, so an entry measured at another batch size is scaled by the game count
-    (and labelled as such)."""
+    (and labelled as such).  The file is STATIC: bench.py cannot run itself under the profiler; the source string says whether
+    the entry was measured on the binary that is running now (same build id) or on an earlier one."""
     try:
         t = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
         e = t.get(key)
         if not e:
             return None, None
-        src = "profiles/traffic.json[%s]: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of %s" % (key, e.get('source', 'the committed pmc summary'))
+        same = bool(build_id) and e.get('build_id') == build_id
+        src = "%s: profiles/traffic.json[%s], rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of %s (build id %s)" % (
+            "static, measured on this binary" if same else "static, measured on an EARLIER binary", key,
+            e.get('source', 'the committed pmc summary'), e.get('build_id', 'not recorded'))
         if e['games_per_launch'] == n_envs:
             return e['hbm_bytes_per_launch'], src
         return e['hbm_bytes_per_launch'] * (n_envs / e['games_per_launch']), src + " (measured at %d games per launch, scaled per game)" % e['games_per_launch']
@@ -153,12 +189,19 @@ def parse_args(argv=None):
     ap.add_argument('--placement-trials', type=int, default=None, help='most candidate allocations (default: what --placement-gb allows)')
     ap.add_argument('--placement-wide-gb', type=float, default=64.0,
                     help='budget of the second, wide placement pass that runs when the first found no fast candidate (0: no second pass)')
+    ap.add_argument('--placement-free-fraction', type=float, default=0.4,
+                    help='cap of both placement budgets: this fraction of the FREE device memory, divided by the ranks sharing the device')
     ap.add_argument('--placement-gb', type=float, default=8.0,
                     help='most extra device memory the placement trial may hold at any time')
     ap.add_argument('--settle-seconds', type=float, default=0.1,
                     help='untimed, state-preserving sgx_observe launches directly before the timed bracket (gpu_settle); 0 = none')
     ap.add_argument('--wake-seconds', type=float, default=2.0,
                     help='untimed GPU wake-up before the warmup steps (a fresh box runs its first ~second at idle clocks)')
+    ap.add_argument('--rotate-outputs', type=int, default=0,
+                    help='R >= 2: the HEADLINE writes a ring of R output sets round-robin (sgx_step_ring) instead of one set in place -- for '
+                         'profiling the rotating-outputs workload under rocprofv3; 0 (default): headline in place, rotating leg after it')
+    ap.add_argument('--rotate-sets', type=int, default=3, help='output sets of the rotating-outputs leg after the headline (0 = skip the leg)')
+    ap.add_argument('--no-consumer-leg', action='store_true', help='skip the consumer-in-the-loop leg (sgx_step alternating with a device policy)')
     ap.add_argument('--chains', type=int, default=1,
                     help='sgx_rollout: split the batch into this many ranges of games whose launches overlap on streams of their own '
                          '(1 = sgx_step_n, one launch per step: what the headline uses, so that the per-launch figures are per step)')
@@ -409,9 +452,9 @@ def gpu_settle(env, seconds):
         torch.cuda.synchronize()
 
 
-def time_workload(rk, env, steps, warmup, unfused=False, chains=1):
+def time_workload(rk, env, steps, warmup, unfused=False, chains=1, ring=False):
     """(elapsed s, device ms, (min, max) of the ranks' own seconds, games finished, invalid actions) of `steps` batched steps on
-    `env`, MAX / SUM over ranks."""
+    `env`, MAX / SUM over ranks.  ring: the steps write the env's ring of output sets in turn (env.alloc_output_ring)."""
     import torch
 
     def one_step():
@@ -423,7 +466,9 @@ def time_workload(rk, env, steps, warmup, unfused=False, chains=1):
 
     def run_warmup():
         env.sample_valid_actions()
-        if chains > 1 and not unfused:       # (the chains' streams are created on first use: not inside the timed region)
+        if ring:
+            env.rollout_steps(warmup, ring=True)
+        elif chains > 1 and not unfused:       # (the chains' streams are created on first use: not inside the timed region)
             env.rollout_steps(warmup, chains=chains)
         else:
             for _ in range(warmup):
@@ -434,7 +479,7 @@ def time_workload(rk, env, steps, warmup, unfused=False, chains=1):
             for _ in range(steps):
                 one_step()
         else:
-            env.rollout_steps(steps, chains=chains)    # the same K batched steps, enqueued by one C-ABI call (sgx_step_n / sgx_rollout)
+            env.rollout_steps(steps, chains=chains, ring=ring)    # the same K batched steps, enqueued by one C-ABI call (sgx_step_n / sgx_rollout / sgx_step_ring)
 
     def counters():
         return [int(env.env_info()[:, 1].to(torch.int64).sum()), 0]
@@ -495,6 +540,27 @@ def outputs_checksum(env):
     return int(tot)
 
 
+def ranks_sharing_device(args):
+    """How many local ranks allocate on this rank's GPU: 1 unless --devices maps several ranks onto one device."""
+    if not args.devices:
+        return 1
+    dmap = [int(x) for x in args.devices.split(',')]
+    me = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+    return max(1, dmap.count(dmap[me])) if me < len(dmap) else 1
+
+
+def placement_budgets(args, budget):
+    """(first-pass budget, wide-pass budget) of the placement search in bytes, both capped by what is FREE on this rank's device:
+    every rank searches on its own and, while it does, holds up to its budget beyond the buffers it keeps (the wide pass' pads
+    reached 54 GB for a moment in round 3) -- at most --placement-free-fraction (default 0.4) of the free device memory divided by the
+    ranks that share the device, so that eight ranks' searches cannot exhaust a GPU between them whatever else lives on it."""
+    import torch
+    free, _total = torch.cuda.mem_get_info()
+    cap = int(free * args.placement_free_fraction / ranks_sharing_device(args))
+    wide = int(getattr(args, 'placement_wide_gb', 0.0) * (1 << 30))
+    return min(budget, cap), min(wide, cap)
+
+
 def place_outputs(env, args):
     """Library-owned output buffers from sgx_alloc_outputs' bounded placement trial, unless --placement plain.
     -> {'candidates', 'plain_us' (the allocation a caller would have got first), 'kept_us', 'median_us', 'max_us', 'peak_extra_gb'}."""
@@ -507,8 +573,8 @@ def place_outputs(env, args):
     budget = max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if args.placement_gb > 0 else 0
     if env.obs.numel() * 4 <= 300e6 and env.fobs is None:
         budget = 0     # a launch whose observations fit the Infinity Cache has no placement classes (toy boards: 64 candidates within 1 %): no search
-    rep = env.tune_placement(args.placement_trials, max_extra_bytes=budget,
-                             wide_extra_bytes=int(getattr(args, 'placement_wide_gb', 0.0) * (1 << 30)))
+    budget, wide = placement_budgets(args, budget)
+    rep = env.tune_placement(args.placement_trials, max_extra_bytes=budget, wide_extra_bytes=wide)
     t = rep.get('obs') or []
     out = {"candidates": len(t), "peak_extra_gb": round(getattr(env, 'placement_peak_extra_bytes', 0) / 2.0 ** 30, 2)}
     if t:
@@ -527,29 +593,166 @@ def place_outputs(env, args):
     return out
 
 
-def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, first_us=None):
+def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, first_us=None, rec_bytes=None, build_id=None,
+             rotating=None):
+    """The roofline object of one workload.  Every `frac*` is B_min x games / time / 8 TB/s -- bytes the kernel cannot avoid moving
+    (b_min), so none of them overstates the traffic; `frac_dram` comes from the rotating-outputs leg (`rotating` = its launch
+    seconds), where the Infinity Cache cannot hold anything back from DRAM."""
     key = version + ('+full_obs' if full_obs else '')
-    alg_bytes = b_alg(v.rows, v.columns, full_obs) * n
-    traffic, source = (traffic_override, "--traffic-bytes") if traffic_override is not None else measured_traffic(key, n)
-    alg = alg_bytes / launch_s / 1e9
-    ach = (traffic / launch_s / 1e9) if traffic else alg
-    # The counters count what L2 exchanges with the memory side INCLUDING the 256 MiB Infinity Cache: the mask (plain stores, the same
-    # addresses every launch) can live there as dirty lines that the next launch overwrites, so when it fits, up to that many bytes
-    # never reach DRAM -- `frac` can touch 1.00 on the fastest buffers; the DRAM-side fraction lies between frac_dram_min and frac.
-    mask_bytes = n * v.num_spatial_actions
-    absorbed = mask_bytes if (traffic and mask_bytes <= (256 << 20)) else 0
-    dram_min = ((traffic - absorbed) / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None
-    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "frac_dram_min": dram_min,
-            "frac_basis": "rocprofv3 counter bytes per launch" if traffic else "algorithmic bytes (no counter entry for this workload)",
-            "traffic": traffic, "traffic_source": source,
-            "achieved_algorithmic": alg, "frac_algorithmic": alg / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
-            "kernel": "step_kernel<%d,%d,%d>" % (v.rows, v.columns, 1 if full_obs else 0), "launch_us": launch_s * 1e6,
-            # the same kernel writing the allocation the process got first (observe launch of the placement trial's first candidate):
-            # what an integrator who passes plain torch.empty tensors may get
-            "frac_untuned": ((traffic or alg_bytes) / (first_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if first_us else None}
+    per_step = b_min(v, full_obs, rec_bytes)
+    min_bytes = per_step * n
+    traffic, source = (traffic_override, "--traffic-bytes") if traffic_override is not None else measured_traffic(key, n, build_id)
+    ach = min_bytes / launch_s / 1e9
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "frac_basis": "B_min = %d B per env step (packed record in + out, action in, next action out, float32 observation%s, uint8 mask, "
+                         "results) x %d games per launch / launch time by HIP events; outputs written in place (one set of tensors): "
+                         "memory side including the 256 MiB Infinity Cache" % (per_step, "s" if full_obs else "", n),
+           "bytes_per_launch": min_bytes, "b_min_bytes_per_step": per_step,
+           "kernel": "step_kernel<%d,%d,%d,false>" % (v.rows, v.columns, 1 if full_obs else 0), "launch_us": launch_s * 1e6,
+           "frac_dram": None, "traffic": traffic, "traffic_source": source,
+           "traffic_over_b_min": (traffic / min_bytes) if traffic else None,
+           # the same kernel writing the allocation the process got first (observe launch of the placement trial's first candidate):
+           # what an integrator who passes plain torch.empty tensors may get
+           "frac_untuned": (min_bytes / (first_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if first_us else None,
+           # SURVEY 8d's formula (state as 32 dense int8 boards): a labelled comparison, not a fraction -- the kernel reads a 512-byte
+           # record instead of 3,216 B of boards, so this rate counts bytes that are never moved
+           "survey_8d": {"bytes_per_step": b_alg(v.rows, v.columns, full_obs), "gbps_if_those_bytes_moved": b_alg(v.rows, v.columns, full_obs) * n / launch_s / 1e9}}
+    if rotating:
+        out["frac_dram"] = min_bytes / rotating / 1e9 / HBM_PEAK_GBS
+        out["frac_dram_basis"] = "the same B_min bytes over the launch time of the rotating-outputs leg (config.rotating_outputs)"
+    return out
 
 
-def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, verify=8):
+def rotating_leg(rk, env, args, version, v, steps, warmup, n_sets, full_obs=False, verify=8):
+    """The rotating-outputs leg on the env object that was just timed: n_sets output sets (the env's own + n_sets - 1 more, each from
+    its own placement trial) written round-robin, sgx_step_ring.  With 3 x 2 GB of outputs nothing a launch writes can still be in
+    the 256 MiB Infinity Cache when the same addresses are written again, three launches later: this leg's launch time is DRAM's."""
+    import torch
+    budget = max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if (args.placement == 'trial' and args.placement_gb > 0) else 0
+    budget, _ = placement_budgets(args, budget)
+    tune = budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6
+    reports = env.alloc_output_ring(n_sets, tune=tune, max_extra_bytes=budget, trials=args.placement_trials)
+    elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, warmup, ring=True)
+    assert invalid == 0
+    checked = verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
+    launch_s = dev_ms / 1e3 / steps
+    per_set = [(round(r['obs'][0], 1), round(min(r['obs']), 1)) if (r and r.get('obs')) else None for r in reports]
+    set_bytes = env.obs.numel() * 4 + env.mask.numel() + (env.fobs.numel() * 4 if env.fobs is not None else 0)
+    return {"workload": "the same rollout writing %d output sets round-robin (sgx_step_ring: a trajectory buffer of the last %d steps)" % (n_sets, n_sets),
+            "output_sets": n_sets, "bytes_per_set": set_bytes, "exceeds_infinity_cache": bool((n_sets - 1) * set_bytes > (256 << 20)),
+            "value": env.num_envs * steps / elapsed, "unit": "env steps/s", "steps": steps, "warmup": warmup, "launch_us": launch_s * 1e6,
+            "frac_dram": b_min(v, full_obs, env.record_bytes) * env.num_envs / launch_s / 1e9 / HBM_PEAK_GBS,
+            "placement_plain_and_kept_us_per_extra_set": per_set[1:], "games_finished_in_timed_region": games,
+            "verified_envs": checked, "verified_steps": env.bench_steps_played}, launch_s
+
+
+def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_round=16, n_check=8):
+    """A consumer in the loop (examples/basic_game_loop.py:6-31, 48-63 for a batch): every step is `choose_actions` of
+    stratego_env_amd/examples/batched_policy_loop.py -- logits from the observation, invalid actions masked out, softmax, one sample
+    per game: the observation and the mask are READ on the device -- followed by sgx_step with the chosen actions.  In-process A/B of
+    the observation store policy under that reader: rounds of `steps_per_round` steps alternate between sgx_set_nt_stores(1)
+    (non-temporal interior lines: the default at this size) and (0) (plain stores) on the same env object and buffers; reported per
+    policy: whole-loop env steps/s and the step kernel's own time inside the loop (HIP events around every sgx_step).  The actions of
+    `n_check` sampled envs are logged on the device and replayed on the CPU oracle afterwards (same setups by the counter RNG,
+    auto-reset included): the last step's mask / observation / rewards / flags must match bit for bit."""
+    import numpy as np
+    import torch
+    from stratego_env_amd.config import VARIANTS
+    from stratego_env_amd.examples.batched_policy_loop import choose_actions
+    v = VARIANTS[version]
+    env = make_env(version, n, 0, rk.device_index)
+    try:
+        trial = place_outputs(env, args)
+        dev = env.device
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234)
+        readout = torch.randn(env.obs.shape[-1], env.mask[0].numel(), device=dev, generator=g) * 0.5
+        ids = np.unique(np.linspace(0, n - 1, n_check).astype(np.int64))
+        idx = torch.from_numpy(ids).to(dev)
+        total_steps = 2 * rounds * steps_per_round + 4
+        act_log = torch.zeros((total_steps, len(ids)), dtype=torch.int32, device=dev)
+        done_log = torch.zeros((total_steps, len(ids)), dtype=torch.uint8, device=dev)
+        obs, mask = env.obs, env.mask
+        played = 0
+
+        def loop(k, events=None):
+            nonlocal played, obs, mask
+            for i in range(k):
+                a = choose_actions(obs, mask, readout, g)
+                act_log[played] = a[idx]
+                if events is not None:
+                    events[i][0].record()
+                obs, mask, _, done, _ = env.step(a)
+                if events is not None:
+                    events[i][1].record()
+                done_log[played] = done[idx]
+                played += 1
+
+        loop(4)                                             # untimed: allocator warm-up of the policy's temporaries
+        res = {1: {"s": 0.0, "kernel_ms": 0.0, "steps": 0}, 0: {"s": 0.0, "kernel_ms": 0.0, "steps": 0}}
+        for _ in range(rounds):
+            for mode in (1, 0):
+                env.set_nt_stores(bool(mode))
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps_per_round)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loop(steps_per_round, ev)
+                torch.cuda.synchronize()
+                res[mode]["s"] += time.perf_counter() - t0
+                res[mode]["kernel_ms"] += sum(a.elapsed_time(b) for a, b in ev)
+                res[mode]["steps"] += steps_per_round
+        env.set_nt_stores('auto')
+        assert int(env.invalid_action.sum()) == 0
+        # ---- replay the logged actions of the sampled envs on the CPU oracle
+        orc, cv = oracle_variant(version)
+        acts, dones = act_log.cpu().numpy(), done_log.cpu().numpy()
+        mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
+        rw, dn, pl = env.reward[idx].cpu().numpy(), env.done[idx].cpu().numpy(), env.player[idx].cpu().numpy()
+        ei = env.ending_invalid[idx].cpu().numpy()
+        for c, e in enumerate(ids):
+            oe = orc.OracleEnv(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts)
+            game = 0
+            oe.reset(initial_state_override=orc.reset_state(cv, BASE_SEED, int(e), game))
+            for t in range(played):
+                o, r, d, info = oe.step({oe.player: int(acts[t, c])})
+                if bool(d["__all__"]) != bool(dones[t, c]):
+                    raise SystemExit("bench.py consumer leg: env %d done flag differs from the oracle at step %d" % (int(e), t))
+                last = (o, r, d, info)
+                if d["__all__"]:
+                    game += 1
+                    first = oe.reset(initial_state_override=orc.reset_state(cv, BASE_SEED, int(e), game))
+                    last_obs, last_player = first[1], 1
+                else:
+                    last_player = oe.player
+                    last_obs = o[last_player]
+            o, r, d, info = last
+            want_mask = last_obs[oe.MASK].astype(np.uint8)
+            want_obs = last_obs[oe.POBS]
+            want_rw = np.asarray([r.get(1, 0), r.get(-1, 0)], dtype=np.float32) if d["__all__"] else np.zeros(2, np.float32)
+            want_ei = int(bool(d["__all__"]) and info[1]['game_result_was_invalid'])
+            ok = (np.array_equal(want_mask, mk[c]) and want_obs.tobytes() == ob[c].tobytes() and np.array_equal(want_rw, rw[c])
+                  and int(dn[c]) == int(d["__all__"]) and int(pl[c]) == last_player and int(ei[c]) == want_ei)
+            if not ok:
+                raise SystemExit("bench.py consumer leg: env %d differs from the CPU oracle replaying its %d logged actions" % (int(e), played))
+
+        def rep(m):
+            r = res[m]
+            return {"value": n * r["steps"] / r["s"], "unit": "env steps/s", "ms_per_loop_step": r["s"] / r["steps"] * 1e3,
+                    "step_kernel_us_in_loop": r["kernel_ms"] / r["steps"] * 1e3, "steps": r["steps"]}
+        nt, plain = rep(1), rep(0)
+        return {"workload": "%d concurrent %s games: batched_policy_loop.choose_actions (reads obs + mask; masked softmax over obs-derived logits, "
+                            "multinomial sample) then sgx_step, %d rounds x %d steps per store policy, interleaved" % (n, version, rounds, steps_per_round),
+                "nt_stores": nt, "plain_stores": plain,
+                "default_policy_at_this_size": "nt_stores (observation bytes per launch > 300 MB)",
+                "nt_over_plain_step_kernel": nt["step_kernel_us_in_loop"] / plain["step_kernel_us_in_loop"],
+                "verified_envs": int(len(ids)), "verified_steps": played, "placement": trial}
+    finally:
+        env.close()
+        del env
+        torch.cuda.empty_cache()
+
+
+def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, verify=8, rotate_sets=0):
     """One of the other BASELINE configs on this GPU, about `seconds` of timed steps; output buffers built like the headline's."""
     import torch
     from stratego_env_amd.config import VARIANTS
@@ -565,11 +768,14 @@ def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, 
             e2, d2, _, _, inv2 = time_workload(rk, env, steps, 4, chains=chains)
             assert inv2 == 0
             two = {"chains": chains, "value": n * steps / e2, "us_per_step": d2 / steps * 1e3,
-                   "frac_algorithmic": b_alg(v.rows, v.columns, full_obs) * n / (d2 / 1e3 / steps) / 1e9 / HBM_PEAK_GBS}
+                   "frac": b_min(v, full_obs, env.record_bytes) * n / (d2 / 1e3 / steps) / 1e9 / HBM_PEAK_GBS}
         assert invalid == 0
         checked = verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
         launch_s = dev_ms / 1e3 / steps
-        rf = roofline(version, v, n, launch_s, full_obs=full_obs)
+        rot, rot_s = None, None
+        if rotate_sets >= 2:               # (toy boards: 3 x 248 MB of outputs rotate past the Infinity Cache too)
+            rot, rot_s = rotating_leg(rk, env, args, version, v, steps, 4, rotate_sets, full_obs=full_obs, verify=verify)
+        rf = roofline(version, v, n, launch_s, full_obs=full_obs, rec_bytes=env.record_bytes, build_id=env.build_id, rotating=rot_s)
         # on the plain first allocation: this leg's step time scaled by the trial's observe launches, first candidate / kept one (the
         # observe launch itself is not this leg's step: cheaper on the toy boards, and in BOTH mode the candidates were timed per buffer)
         tr = trial or {}
@@ -578,10 +784,10 @@ def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, 
         return {"workload": "%d concurrent %s games (%dx%d)%s, same rollout" % (n, version, v.rows, v.columns,
                                                                                  ", BOTH_OBSERVATIONS (67 + 79 channels)" if full_obs else ""),
                 "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
-                "frac": rf["frac"], "frac_dram_min": rf["frac_dram_min"], "frac_basis": rf["frac_basis"], "frac_algorithmic": rf["frac_algorithmic"],
-                "frac_untuned": rf["frac_untuned"], "traffic": rf["traffic"],
-                "b_alg_bytes_per_step": b_alg(v.rows, v.columns, full_obs), "kernel": rf["kernel"],
-                "games_finished_in_timed_region": games, "concurrent_chains": two, "verified_envs": checked,
+                "frac": rf["frac"], "frac_dram": rf["frac_dram"], "frac_untuned": rf["frac_untuned"],
+                "b_min_bytes_per_step": rf["b_min_bytes_per_step"], "traffic": rf["traffic"], "traffic_source": rf["traffic_source"],
+                "survey_8d": rf["survey_8d"], "kernel": rf["kernel"],
+                "games_finished_in_timed_region": games, "concurrent_chains": two, "rotating_outputs": rot, "verified_envs": checked,
                 "placement": trial}
     finally:
         env.close()
@@ -653,42 +859,62 @@ def run_rank(args):
     from stratego_env_amd.config import VARIANTS
     v = VARIANTS[args.version]
     env = make_env(args.version, n, first, rk.device_index, full_obs=args.full_obs)
+    build_id, rec_bytes = env.build_id, env.record_bytes
     placement = place_outputs(env, args)
-    elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains)
+    headline_ring = args.rotate_outputs >= 2
+    if headline_ring:      # profiling runs of the rotating-outputs workload: the headline itself writes the ring
+        budget, _ = placement_budgets(args, max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if args.placement == 'trial' else 0)
+        env.alloc_output_ring(args.rotate_outputs, tune=budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6, max_extra_bytes=budget,
+                              trials=args.placement_trials)
+    elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring)
     assert invalid == 0, "rollout produced invalid actions"
     # outside the timed region: the envs that were just timed against the CPU oracle, and the sharding-independent checksum
     checked = verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if args.verify_envs else 0
     verified_steps = env.bench_steps_played
     _, (checked, checksum) = rk.reduce([], [checked, outputs_checksum(env)])
     two_chains = None
-    if rk.world == 1 and args.chains == 1 and not args.unfused and not args.no_two_chains:
+    if rk.world == 1 and args.chains == 1 and not args.unfused and not args.no_two_chains and not headline_ring:
         # The same K steps with the batch split into two ranges of games whose launches overlap (sgx_rollout, chains = 2): reported
         # next to the headline, which stays one launch per step so that its per-launch figures can be checked against a kernel trace.
         e2, d2, _, _, inv2 = time_workload(rk, env, args.steps, args.warmup, False, 2)
         assert inv2 == 0
         two_chains = {"chains": 2, "value": total * args.steps / e2, "us_per_step": d2 / args.steps * 1e3,
-                      "frac_algorithmic": b_alg(v.rows, v.columns, args.full_obs) * n / (d2 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS,
+                      "frac": b_min(v, args.full_obs, rec_bytes) * n / (d2 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS,
                       "verified_envs": verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if args.verify_envs else 0,
                       "verified_steps": env.bench_steps_played}
+    rotating, rot_s = None, None
+    if rk.world == 1 and args.rotate_sets >= 2 and not headline_ring and not args.unfused and args.chains == 1:
+        # the DRAM-side figure: the same env object, the same K / W, outputs written round-robin into rotate_sets sets
+        rotating, rot_s = rotating_leg(rk, env, args, args.version, v, args.steps, args.warmup, args.rotate_sets, full_obs=args.full_obs,
+                                       verify=min(args.verify_envs, 8))
 
     out = None
     if rk.rank == 0:
         total_steps = total * args.steps
         launch_s = dev_ms / 1e3 / args.steps                 # average device time per batched step (HIP events)
+        rf = roofline(args.version, v, n, launch_s, args.traffic_bytes, full_obs=args.full_obs,
+                      first_us=(placement or {}).get('fobs_plain_us' if args.full_obs else 'plain_us'), rec_bytes=rec_bytes, build_id=build_id,
+                      rotating=launch_s if headline_ring else rot_s)
+        if headline_ring:
+            rf["frac_basis"] = rf["frac_basis"].replace("outputs written in place (one set of tensors): memory side including the 256 MiB Infinity Cache",
+                                                        "outputs written round-robin into %d sets (--rotate-outputs): DRAM side" % args.rotate_outputs)
         out = {
             "metric": "env steps/sec", "value": total_steps / elapsed, "unit": "env steps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_envs else "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic", "build_id": build_id,
             "verified_envs": checked, "verified_steps": verified_steps,
             "config": {"workload": "%d concurrent %s games per GPU (%dx%d)%s, random-valid-action rollout with auto-reset, "
-                                   "%s step+sample" % (n, args.version, v.rows, v.columns,
-                                                       ", BOTH_OBSERVATIONS (67 + 79 channels)" if args.full_obs else "",
-                                                       "separate" if args.unfused else "fused"),
+                                   "%s step+sample%s" % (n, args.version, v.rows, v.columns,
+                                                         ", BOTH_OBSERVATIONS (67 + 79 channels)" if args.full_obs else "",
+                                                         "separate" if args.unfused else "fused",
+                                                         ", outputs written round-robin into %d sets" % args.rotate_outputs if headline_ring else ""),
                        "games_per_gpu": n, "total_games": total, "version": args.version, "seed": BASE_SEED,
-                       "games_finished_in_timed_region": games, "b_alg_bytes_per_step": b_alg(v.rows, v.columns, args.full_obs),
+                       "arithmetic": "game logic on int8 / uint8 boards (dtype u8); outputs: float32 observation (85 % of the bytes), uint8 mask",
+                       "games_finished_in_timed_region": games, "b_min_bytes_per_step": b_min(v, args.full_obs, rec_bytes),
+                       "record_bytes": rec_bytes,
                        "untimed_before_bracket": "%d warm-up steps, then %.2f s of state-preserving sgx_observe launches (gpu_settle)" % (args.warmup, SETTLE_SECONDS),
-                       "concurrent_chains": args.chains, "two_chains": two_chains,
+                       "concurrent_chains": args.chains, "two_chains": two_chains, "rotating_outputs": rotating,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),
                        "reduction_backend": backend if rk.world > 1 else None, "devices": args.devices,
                        # the slowest / fastest rank's own K steps (no waiting for the others): weak scaling without a data-path
@@ -697,8 +923,7 @@ def run_rank(args):
                        "outputs_checksum": checksum,
                        # sgx_alloc_outputs' report: observe-launch time on the plain first allocation and on the candidate it kept
                        "placement": placement},
-            "roofline": roofline(args.version, v, n, launch_s, args.traffic_bytes, full_obs=args.full_obs,
-                                 first_us=(placement or {}).get('fobs_plain_us' if args.full_obs else 'plain_us')),
+            "roofline": rf,
         }
     env.close()
     del env
@@ -714,9 +939,12 @@ def run_rank(args):
     if rk.rank == 0:
         out["config"]["scaling_legs"] = legs
         out["config"]["other_workloads"] = None
+        out["config"]["consumer_in_loop"] = None
         if rk.world == 1 and not args.no_other_workloads and args.version == 'barrage':
+            if not args.no_consumer_leg:
+                out["config"]["consumer_in_loop"] = consumer_leg(rk, args)
             out["config"]["other_workloads"] = [other_workload(rk, args, 'standard', 262144, chains=2),
-                                                other_workload(rk, args, 'micro', 65536, chains=2),
+                                                other_workload(rk, args, 'micro', 65536, chains=2, rotate_sets=args.rotate_sets),
                                                 other_workload(rk, args, 'barrage', 65536, full_obs=True)]
         if not args.no_cpu_baseline and rk.world == 1:         # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)

@@ -14,7 +14,9 @@
  *     nothing throws across the ABI; invalid *actions* are not API errors: they are reported per env
  *     in invalid_action[] with that env's state left unchanged (the reference raises ValueError,
  *     stratego_procedural_impl.py:899-902 -- the Python facade turns the flag back into ValueError);
- *   - a handle is bound to one device and is not thread-safe; different handles are independent.
+ *   - a handle is bound to one device and is not thread-safe; different handles are independent.  Every entry point runs on its
+ *     handle's device and restores the calling thread's current HIP device before it returns (also on errors): one process may drive
+ *     handles on several GPUs, and a caller inside a torch.cuda.device(...) scope keeps its device;
  *
  * Data layouts (C order):
  *   obs    float32 [N][R][C][67]   normalised partial observation of the env's NEXT mover, mover's
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 10
+#define SGX_ABI_VERSION 11
 #define SGX_MAX_CELLS 1024       /* rows*cols <= 1024 (largest reference variant: 15x15 = 225; the reference's StrategoProceduralEnv
                                     takes any size, penv:27-36: boards of more than 256 cells use 10-bit cell indices in the record) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
@@ -111,6 +113,11 @@ typedef struct sgx_step_io {
 
 /* Library / geometry queries (penv:32-36: action_size, spatial_action_size). */
 int sgx_abi_version(void);
+/* Hash of the sources the loaded binary was compiled from (the first 16 hex digits of SHA-256 over the files of stratego_env_amd/csrc and this
+ * header, stratego_env_amd/build.py: source_hash; "unknown" for a build outside build.py).  The Python binding refuses a library whose
+ * id differs from the sources next to it, bench.py and smoke() print it: the tested binary is tied to the tested source.  The same
+ * string follows the marker "SGX_BUILD_ID=" in the file, so it can be read without loading the library. */
+const char *sgx_build_id(void);
 /* 1 if kernels for this board size are compiled into the library.  Every reference variant is (10x10, 15x15, 8x8, 6x6, 5x5, 4x4, 3x4);
  * the reference's StrategoProceduralEnv(rows, columns) takes ANY size >= 3 (penv:27-36): for other sizes (rows * cols <= SGX_MAX_CELLS)
  * the same sources are compiled into a library of their own with -DSGX_EXTRA_R=<rows> -DSGX_EXTRA_C=<cols> -DSGX_ONLY_EXTRA
@@ -118,6 +125,10 @@ int sgx_abi_version(void);
 int sgx_supports_geometry(int32_t rows, int32_t cols);
 const char *sgx_last_error(void);
 int64_t sgx_num_envs(const sgx_env *h);
+/* Bytes of one game's packed state record in device memory (a multiple of 128: 512 for Barrage, 640 for
+ * Standard).  One env.step() reads it once and writes it once: with the outputs it is the byte minimum B_min of a step that bench.py's
+ * roofline is priced on.  No reference counterpart (the reference's state is int64 [34,R,C] = 27,200 B at 10x10, impl:69-163). */
+int64_t sgx_record_bytes(const sgx_env *h);
 int sgx_spatial_channels(const sgx_env *h);          /* K */
 int64_t sgx_num_spatial_actions(const sgx_env *h);   /* R*C*K = Discrete(n) of maenv:362 */
 int64_t sgx_action_size_1d(const sgx_env *h);        /* R*C*(R+C)+1 (impl:252-254) */
@@ -247,6 +258,15 @@ int sgx_step_sync(sgx_env *h, const sgx_step_io *io, void *stream);
  * output buffers hold the last step's results afterwards.  (Toy boards finish a batched step in tens of microseconds:
  * driving them one call at a time from Python is launch-bound.) */
 int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void *stream);
+
+/* sgx_step_n over a RING of output sets: step i of the call writes its outputs through ios[(first_set + i) % n_sets] -- a rollout
+ * into a trajectory buffer that keeps the last n_sets steps' observations and masks (what a learner stores per step) instead of
+ * overwriting one set in place.  Every set must name the same actions_dev == next_actions_dev (the one chain of drawn actions) and the
+ * same auto_reset / flags.  With n_sets sets of a size whose sum exceeds the 256 MiB Infinity Cache, no line written by one step can
+ * still sit in that cache when it is written again: bench.py's DRAM-side roofline figure (roofline.frac_dram) is measured this way.
+ * Same game trajectories as sgx_step_n (tests/test_gpu_parity.py).  No reference counterpart beyond the loop of
+ * examples/basic_game_loop.py:34-63. */
+int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, int32_t first_set, int32_t n_steps, void *stream);
 
 /* sgx_step_n with the batch split into `chains` (1..SGX_MAX_CHAINS) contiguous ranges of games, each range playing its n_steps on a
  * stream of its own: games never interact, so the ranges' launches may overlap, and the ramp-up / drain of one range's step is filled

@@ -14,16 +14,16 @@ PO_OBS_CHANNELS = 67
 FO_OBS_CHANNELS = 79
 PO_OBS_CHANNELS_ORIGINAL = 32
 FO_OBS_CHANNELS_ORIGINAL = 33
-ABI_VERSION = 10
+ABI_VERSION = 11
 STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, STEP_ORIGINAL_CHANNELS = 1, 2, 4, 8, 16
 STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
 OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
 
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (
-    'sgx_abi_version', 'sgx_supports_geometry', 'sgx_last_error', 'sgx_num_envs', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
+    'sgx_abi_version', 'sgx_build_id', 'sgx_supports_geometry', 'sgx_last_error', 'sgx_num_envs', 'sgx_record_bytes', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
     'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_nt_stores', 'sgx_set_xcd_skew', 'sgx_set_xcd_shares', 'sgx_get_xcd_shares', 'sgx_set_setup_table', 'sgx_reset',
-    'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_host_alloc', 'sgx_host_free', 'sgx_step_sync', 'sgx_step_n', 'sgx_rollout', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_step_states', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
+    'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_host_alloc', 'sgx_host_free', 'sgx_step_sync', 'sgx_step_n', 'sgx_step_ring', 'sgx_rollout', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_step_states', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
 )
 
 
@@ -59,12 +59,16 @@ def _bind(L):
     vp, i64, u64 = C.c_void_p, C.c_int64, C.c_uint64
     L.sgx_abi_version.restype = C.c_int
     L.sgx_abi_version.argtypes = []
+    L.sgx_build_id.restype = C.c_char_p
+    L.sgx_build_id.argtypes = []
     L.sgx_supports_geometry.restype = C.c_int
     L.sgx_supports_geometry.argtypes = [C.c_int32, C.c_int32]
     L.sgx_last_error.restype = C.c_char_p
     L.sgx_last_error.argtypes = []
     L.sgx_num_envs.restype = i64
     L.sgx_num_envs.argtypes = [vp]
+    L.sgx_record_bytes.restype = i64
+    L.sgx_record_bytes.argtypes = [vp]
     L.sgx_spatial_channels.restype = C.c_int
     L.sgx_spatial_channels.argtypes = [vp]
     L.sgx_num_spatial_actions.restype = i64
@@ -113,6 +117,8 @@ def _bind(L):
     L.sgx_step_sync.argtypes = [vp, C.POINTER(SgxStepIO), vp]
     L.sgx_step_n.restype = C.c_int
     L.sgx_step_n.argtypes = [vp, C.POINTER(SgxStepIO), C.c_int32, vp]
+    L.sgx_step_ring.restype = C.c_int
+    L.sgx_step_ring.argtypes = [vp, C.POINTER(SgxStepIO), C.c_int32, C.c_int32, C.c_int32, vp]
     L.sgx_rollout.restype = C.c_int
     L.sgx_rollout.argtypes = [vp, C.POINTER(SgxStepIO), C.c_int32, C.c_int32, vp]
     L.sgx_sample_valid.restype = C.c_int
@@ -144,11 +150,6 @@ def load(path=None):
     if not os.path.exists(path):
         raise SgxError("libstratego_mi355x.so is not built (%s missing). Run `python -m stratego_env_amd.build` "
                        "or __graft_entry__.build(); there is no CPU fallback." % path)
-    if path == LIB_PATH:
-        from . import build as _build
-        if _build.needs_build():        # (a stale library of the same ABI version still loads; say so)
-            import warnings
-            warnings.warn("%s is older than its sources: rebuild with `python -m stratego_env_amd.build`" % path, RuntimeWarning)
     L = C.CDLL(path)
     missing = [sym for sym in EXPORTED_SYMBOLS if not hasattr(L, sym)]
     if missing:
@@ -158,6 +159,19 @@ def load(path=None):
     if L.sgx_abi_version() != ABI_VERSION:       # struct layouts differ between ABI versions: never bind a stale library
         raise SgxError("%s has ABI version %d, this package needs %d; rebuild with `python -m stratego_env_amd.build`"
                        % (path, L.sgx_abi_version(), ABI_VERSION))
+    # the binary must come from the sources next to it: a stale library of the same ABI version would load and run -- and every parity
+    # claim of the test suite would be about another program.  $SGX_ALLOW_FOREIGN_BUILD=1 lets a kernel experiment built with other
+    # flags or sources through (tools/ A/B runs), loudly.
+    from . import build as _build
+    have, want = L.sgx_build_id().decode('ascii', 'replace'), _build.source_hash()
+    if have != want:
+        msg = ("%s was built from other sources (build id %s, the sources here hash to %s); rebuild with "
+               "`python -m stratego_env_amd.build`" % (path, have, want))
+        if os.environ.get('SGX_ALLOW_FOREIGN_BUILD') != '1':
+            raise SgxError(msg)
+        import warnings
+        warnings.warn(msg + " -- loaded anyway because SGX_ALLOW_FOREIGN_BUILD=1", RuntimeWarning)
+    L.build_id = have
     _libs[path] = L
     return L
 

@@ -15,30 +15,73 @@ OUT_DIR = os.path.join(_PKG, '_build')
 LIB_PATH = os.path.join(OUT_DIR, 'libstratego_mi355x.so')
 
 
-def needs_build():
-    if not os.path.exists(LIB_PATH):
-        return True
+BUILD_ID_MARKER = b'SGX_BUILD_ID='
+
+
+def source_files():
+    """Everything the library is compiled from: the translation unit, the device headers next to it, the ABI header."""
     csrc = os.path.dirname(SRC)
-    deps = [SRC, os.path.join(INCLUDE, 'stratego_mi355x.h')] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.h')]
-    newest = max(os.path.getmtime(f) for f in deps)
-    return os.path.getmtime(LIB_PATH) < newest
+    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(('.h', '.hip'))) + [os.path.join(INCLUDE, 'stratego_mi355x.h')]
+
+
+def source_hash():
+    """First 16 hex digits of SHA-256 over the names and contents of source_files(): the build id compiled into the library
+    (-DSGX_BUILD_ID, returned by sgx_build_id())."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in source_files():
+        h.update(os.path.basename(f).encode() + b'\0')
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+        h.update(b'\0')
+    return h.hexdigest()[:16]
+
+
+def read_build_id(path):
+    """The build id of a library file, read from the bytes after its SGX_BUILD_ID= marker (no dlopen); None if it has none."""
+    try:
+        with open(path, 'rb') as fh:
+            data = fh.read()
+    except OSError:
+        return None
+    at = data.find(BUILD_ID_MARKER)
+    if at < 0:
+        return None
+    end = data.find(b'\0', at)
+    return data[at + len(BUILD_ID_MARKER):end].decode('ascii', 'replace')
+
+
+def is_current(path):
+    """True if `path` was compiled from exactly the sources that are here now (content hash, not file times: file times do not
+    survive every way of copying a tree, and a newer-looking stale binary used to pass)."""
+    return os.path.exists(path) and read_build_id(path) == source_hash()
+
+
+def needs_build():
+    return not is_current(LIB_PATH)
+
+
+def _compile(out_path, extra_flags=(), verbose=False):
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    tmp = '%s.%d.tmp' % (out_path, os.getpid())
+    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-fvisibility=hidden', '-Wall',
+           '-DSGX_BUILD_ID="%s"' % source_hash()] + list(extra_flags) + ['-I', INCLUDE, SRC, '-o', tmp]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, out_path)
+    return out_path
 
 
 def build(force=False, verbose=False):
-    """Compile the library if it is missing or older than its sources.  Returns the .so path."""
+    """Compile the library if it is missing or was built from other sources.  Returns the .so path."""
     if not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libstratego_mi355x.so")
     os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-fvisibility=hidden',
-           '-Wall', '-I', INCLUDE, SRC, '-o', LIB_PATH + '.tmp']
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(LIB_PATH + '.tmp', LIB_PATH)
-    return LIB_PATH
+    return _compile(LIB_PATH, verbose=verbose)
 
 
 BUILTIN_GEOMETRIES = ((10, 10), (15, 15), (8, 8), (6, 6), (5, 5), (4, 4), (3, 4))    # SGX_BUILTIN_GEOMETRIES in the .hip
@@ -59,29 +102,16 @@ def build_geometry(rows, columns, force=False, verbose=False):
     if rows * columns > MAX_CELLS:
         raise ValueError("boards of more than %d cells are not supported (%d x %d)" % (MAX_CELLS, rows, columns))
     path = geometry_lib_path(rows, columns)
-    csrc = os.path.dirname(SRC)
-    deps = [SRC, os.path.join(INCLUDE, 'stratego_mi355x.h')] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith('.h')]
-    if not force and os.path.exists(path) and os.path.getmtime(path) >= max(os.path.getmtime(f) for f in deps):
+    if not force and is_current(path):
         return path
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
-        if os.path.exists(path) and not force:
-            # a deployment box without the ROCm compiler: the library that was shipped is the one to use (file times do not survive
-            # every way of copying a tree); sizes that were not prebuilt cannot be played there
-            import warnings
-            warnings.warn("%s may be older than its sources and hipcc is not available: using it as it is" % path, RuntimeWarning)
-            return path
-        raise RuntimeError("hipcc not found: cannot build the %dx%d kernels; prebuild them where the ROCm compiler is installed with "
-                           "`python -m stratego_env_amd.build %dx%d` and ship stratego_env_amd/_build/" % (rows, columns, rows, columns))
+        raise RuntimeError("hipcc not found: cannot build the %dx%d kernels%s; prebuild them where the ROCm compiler is installed with "
+                           "`python -m stratego_env_amd.build %dx%d` and ship stratego_env_amd/_build/"
+                           % (rows, columns, " (the library that is here was built from other sources)" if os.path.exists(path) else "",
+                              rows, columns))
     os.makedirs(OUT_DIR, exist_ok=True)
-    tmp = '%s.%d.tmp' % (path, os.getpid())
-    cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-fvisibility=hidden', '-Wall',
-           '-DSGX_EXTRA_R=%d' % rows, '-DSGX_EXTRA_C=%d' % columns, '-DSGX_ONLY_EXTRA', '-I', INCLUDE, SRC, '-o', tmp]
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(tmp, path)
-    return path
+    return _compile(path, ['-DSGX_EXTRA_R=%d' % rows, '-DSGX_EXTRA_C=%d' % columns, '-DSGX_ONLY_EXTRA'], verbose)
 
 
 if __name__ == '__main__':

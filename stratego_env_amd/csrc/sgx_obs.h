@@ -136,8 +136,7 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
         // 42 vs 47 us; 16,384 Barrage games 102 vs 87 us, 131,072 Micro games 100 vs 82 us): the host decides per launch.
         const int l0 = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7);               // quads past a 128-byte line
         const int first_line = l0 ? 0 : -1, last_line = ((l0 + NQ) & 7) ? (NQ - 1 + l0) >> 3 : -1;   // lines counted from dst - 16 * l0
-#pragma unroll SGX_OBS_UNROLL
-        for (int q0 = -m0; q0 < NQ; q0 += STRIDE) {
+        auto sweep = [&](const int q0) __attribute__((always_inline)) {
             const int q = q0 + lane;
             const bool in = (unsigned)q < (unsigned)NQ;
             const unsigned x = n16[in ? q : 0];
@@ -162,6 +161,14 @@ __device__ inline void emit_codes(const Lds<G, NB> &L, float *__restrict__ dst, 
             } else {
                 if (in && !esc) base[q] = o;
             }
+        };
+        if constexpr (CHECKED && NT) {
+            // (a ballot per iteration: a convergent operation, which the optimiser cannot unroll under a run-time trip count -- asking for
+            // it only produced a -Wpass-failed warning per instantiation)
+            for (int q0 = -m0; q0 < NQ; q0 += STRIDE) sweep(q0);
+        } else {
+#pragma unroll SGX_OBS_UNROLL
+            for (int q0 = -m0; q0 < NQ; q0 += STRIDE) sweep(q0);
         }
     } else {
         static_assert(!CHECKED, "odd boards patch single floats after a wait (patch_uncoded_floats)");

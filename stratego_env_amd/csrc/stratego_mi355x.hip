@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <sched.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -39,6 +40,38 @@ int fail(int code, const char *fmt, const char *detail = "") {
         hipError_t e_ = (expr);                                                              \
         if (e_ != hipSuccess) return fail(SGX_EDEVICE, #expr ": %s", hipGetErrorString(e_)); \
     } while (0)
+
+// Every entry point that touches the device runs on the handle's device and puts the caller's current device back on every
+// return path: a process that drives several handles on several GPUs (SURVEY 8e's other layout: one thread + stream per GPU), or
+// that sits inside a torch.cuda.device(...) scope, never finds its device switched under it.
+struct DeviceGuard {
+    int prev = -1;
+    bool restore = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            restore = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (restore) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define SGX_ON_DEVICE(dev)                                                                                      \
+    DeviceGuard device_guard_(dev);                                                                             \
+    if (device_guard_.err != hipSuccess) return fail(SGX_EDEVICE, "selecting the handle's device: %s", hipGetErrorString(device_guard_.err))
+
+// Hash of the sources this binary was compiled from (stratego_env_amd/build.py: source_hash() over csrc/* and the ABI header,
+// passed as -DSGX_BUILD_ID): _lib.load() refuses a library whose id differs from the sources next to it, build.needs_build()
+// reads the marker straight from the file.
+#ifndef SGX_BUILD_ID
+#define SGX_BUILD_ID "unknown"
+#endif
+const char g_build_id[] = "SGX_BUILD_ID=" SGX_BUILD_ID;
 
 }  // namespace
 
@@ -167,9 +200,11 @@ static int check_random_setups(const sgx_env *h) {
 }
 
 SGX_API int sgx_abi_version(void) { return SGX_ABI_VERSION; }
+SGX_API const char *sgx_build_id(void) { return g_build_id + 13; }
 SGX_API int sgx_supports_geometry(int32_t rows, int32_t cols) { return supported_geometry(rows, cols) ? 1 : 0; }
 SGX_API const char *sgx_last_error(void) { return g_last_error.c_str(); }
 SGX_API int64_t sgx_num_envs(const sgx_env *h) { return h ? h->n_envs : 0; }
+SGX_API int64_t sgx_record_bytes(const sgx_env *h) { return h ? h->rec_bytes : 0; }
 SGX_API int sgx_spatial_channels(const sgx_env *h) { return h ? h->K : 0; }
 SGX_API int64_t sgx_num_spatial_actions(const sgx_env *h) { return h ? (int64_t)h->cfg.rows * h->cfg.cols * h->K : 0; }
 SGX_API int64_t sgx_action_size_1d(const sgx_env *h) {
@@ -324,7 +359,7 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(SGX_EDEVICE, "no HIP device available: %s", hipGetErrorString(e));
     if (device < 0 || device >= ndev) return fail(SGX_EINVAL, "device index out of range%s");
-    HIP_TRY(hipSetDevice(device));
+    SGX_ON_DEVICE(device);
     sgx_env *h = new sgx_env();
     memset(h, 0, sizeof(*h));
     h->cfg = *cfg;
@@ -348,6 +383,10 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
         for (int i = 0; i < 12; ++i) pieces += cfg->piece_counts[i];
         if (cfg->capture_capacity > pieces) pieces = cfg->capture_capacity;
         h->max_events = 2 * pieces;                                   // every piece can be captured once
+        // ... and both sides together never have more pieces than the board has cells: Geo::EVL_MAX = rows * cols bounds the LDS event
+        // lists and StateIO::IMG (an env_config that overrides 'piece_amounts' for the normalisation only -- Micro with Standard's 40
+        // pieces -- would ask for 80 events on 12 cells otherwise)
+        if (h->max_events > rc_cells) h->max_events = rc_cells;
         const int st_off = (STORED_BOARDS * ((rc_cells + 3) & ~3) + 15) & ~15, sb = (((rc_cells + 7) / 8) + 15) & ~15;
         const int sc_off = st_off + 2 * sb;
         h->sc_off = sc_off;
@@ -396,7 +435,7 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
 SGX_API int sgx_destroy(sgx_env *h) {
     if (!h) return SGX_OK;
     // teardown is best effort: there is nobody to report a failed free to
-    (void)hipSetDevice(h->device);
+    DeviceGuard device_guard_(h->device);
     (void)hipDeviceSynchronize();
     if (h->boards) (void)hipFree(h->boards);
     if (h->tab) (void)hipFree(h->tab);
@@ -447,7 +486,7 @@ SGX_API int sgx_get_xcd_shares(sgx_env *h, int32_t *per_mille, int32_t *calibrat
 
 SGX_API int sgx_set_setup_table(sgx_env *h, const uint8_t *table_host, int64_t n_setups) {
     if (!h || !table_host || n_setups <= 0 || n_setups > 0x7fffffff) return fail(SGX_EINVAL, "bad setup table%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     const size_t bytes = (size_t)n_setups * h->cfg.usable_rows * h->cfg.cols;
     for (size_t i = 0; i < bytes; ++i)
         if (table_host[i] > 12) return fail(SGX_EINVAL, "setup table holds a piece code > 12%s");
@@ -463,7 +502,7 @@ SGX_API int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p
     if ((p1_maps_dev == nullptr) != (p2_maps_dev == nullptr)) return fail(SGX_EINVAL, "pass both piece maps or neither%s");
     if (!p1_maps_dev)
         if (int rc = check_random_setups(h)) return rc;
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     ResetParams rp;
     rp.k = make_params(h);
     rp.select = env_select_dev;
@@ -566,7 +605,7 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream) {
 
 SGX_API int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, int8_t *player_dev, int32_t flags, void *stream) {
     if (!h) return fail(SGX_EINVAL, "handle is NULL%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     KParams p = make_params(h);
     p.mode = 1;
     p.io.obs_dev = obs_dev;
@@ -579,7 +618,7 @@ SGX_API int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *ma
 
 SGX_API int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int32_t launches, void *stream, float *microseconds) {
     if (!h || !microseconds || launches <= 0) return fail(SGX_EINVAL, "bad argument%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -624,7 +663,7 @@ int probe_range(void *ptr, int64_t bytes, int32_t launches, hipStream_t stream, 
 SGX_API int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t launches, void *stream, float *gb_per_s) {
     if (!ptr_dev || !gb_per_s || launches <= 0 || bytes <= 0) return fail(SGX_EINVAL, "sgx_mem_probe: bad argument%s");
     if ((reinterpret_cast<uintptr_t>(ptr_dev) & 1023) != 0) return fail(SGX_EINVAL, "sgx_mem_probe: the range must start on a 1 KiB boundary%s");
-    HIP_TRY(hipSetDevice(device));
+    SGX_ON_DEVICE(device);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -722,7 +761,7 @@ int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t 
 SGX_API int sgx_free_outputs(sgx_env *h, sgx_outputs *out) {
     if (!out) return fail(SGX_EINVAL, "NULL argument%s");
     if (!out->obs_dev && !out->fobs_dev && !out->mask_dev) return SGX_OK;
-    HIP_TRY(hipSetDevice(h ? h->device : out->device));
+    SGX_ON_DEVICE(h ? h->device : out->device);
     HIP_TRY(hipDeviceSynchronize());
     if (out->obs_dev) (void)hipFree(out->obs_dev);
     if (out->fobs_dev) (void)hipFree(out->fobs_dev);
@@ -737,7 +776,7 @@ SGX_API int sgx_alloc_outputs(sgx_env *h, int32_t flags, int64_t max_extra_bytes
     if (flags & ~(SGX_OUT_FULL_OBS | SGX_STEP_ORIGINAL_CHANNELS)) return fail(SGX_EINVAL, "sgx_alloc_outputs: unknown flag%s");
     memset(out, 0, sizeof(*out));
     out->device = h->device;
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     const bool original = (flags & SGX_STEP_ORIGINAL_CHANNELS) != 0, full = (flags & SGX_OUT_FULL_OBS) != 0;
     const int64_t cells = (int64_t)h->cfg.rows * h->cfg.cols;
     out->obs_bytes = h->n_envs * cells * lut_channels(false, original) * 4;
@@ -768,7 +807,7 @@ SGX_API int sgx_alloc_outputs(sgx_env *h, int32_t flags, int64_t max_extra_bytes
 SGX_API int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream) {
     if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
     if (!io->actions_dev) return fail(SGX_EINVAL, "actions_dev is NULL%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     KParams p = make_params(h);
     p.mode = 0;
     p.io = *io;
@@ -778,9 +817,12 @@ SGX_API int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream) {
 // ---- single-game latency (the N = 1 facade): outputs in device-addressable pinned host memory, one call per env.step()
 SGX_API int sgx_host_alloc(sgx_env *h, int64_t bytes, void **host_ptr, void **dev_ptr) {
     if (!h || !host_ptr || !dev_ptr || bytes <= 0) return fail(SGX_EINVAL, "sgx_host_alloc: bad argument%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     void *p = nullptr, *d = nullptr;
-    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return fail(SGX_ENOMEM, "pinned host allocation failed%s"); }
+    // fine-grained (coherent) whatever HIP_HOST_COHERENT says: sgx_step_sync's polled path returns as soon as the kernel has published
+    // its completion word, usually before the kernel has retired -- the outputs in this slab must be visible to the host at that
+    // moment, which coarse-grained host memory guarantees only at the end of the kernel
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return fail(SGX_ENOMEM, "pinned host allocation failed%s"); }
     if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(p); return fail(SGX_EDEVICE, "hipHostGetDevicePointer failed%s"); }
     memset(p, 0, (size_t)bytes);
     *host_ptr = p;
@@ -790,7 +832,10 @@ SGX_API int sgx_host_alloc(sgx_env *h, int64_t bytes, void **host_ptr, void **de
 
 SGX_API int sgx_host_free(sgx_env *h, void *host_ptr) {
     if (!host_ptr) return SGX_OK;
-    if (h) HIP_TRY(hipSetDevice(h->device));
+    int dev = 0;
+    if (h) dev = h->device;
+    else HIP_TRY(hipGetDevice(&dev));
+    SGX_ON_DEVICE(dev);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipHostFree(host_ptr));
     return SGX_OK;
@@ -803,16 +848,25 @@ SGX_API int sgx_host_free(sgx_env *h, void *host_ptr) {
 namespace {
 int step_single(sgx_env *h, const KParams &p, bool full, hipStream_t stream, bool *launched) {
     *launched = false;
-    if (!h->sync_flag_host) {
+    if (!h->sync_count) {
+        // all three resources into locals, published to the handle only when every step has succeeded (a half-initialised handle would
+        // launch single_kernel with a NULL workgroup counter on the next call)
         void *hp = nullptr, *dp = nullptr;
-        HIP_TRY(hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent));   // (fine-grained whatever HIP_HOST_COHERENT says: the kernel's release store must be visible while it still runs)
-        if (hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(hp); return fail(SGX_EDEVICE, "hipHostGetDevicePointer failed%s"); }
-        memset(hp, 0, 64);
+        uint32_t *cnt = nullptr;
+        hipError_t e = hipHostMalloc(&hp, 64, hipHostMallocMapped | hipHostMallocCoherent);   // (fine-grained whatever HIP_HOST_COHERENT says: the kernel's release store must be visible while it still runs)
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&dp, hp, 0);
+        if (e == hipSuccess) { memset(hp, 0, 64); e = hipMalloc((void **)&cnt, 64); }
+        if (e == hipSuccess) e = hipMemset(cnt, 0, 64);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            if (cnt) (void)hipFree(cnt);
+            if (hp) (void)hipHostFree(hp);
+            return fail(SGX_EDEVICE, "sgx_step_sync: completion word: %s", hipGetErrorString(e));
+        }
         h->sync_flag_host = (uint32_t *)hp;
         h->sync_flag_dev = (uint32_t *)dp;
-        HIP_TRY(hipMalloc((void **)&h->sync_count, 64));
-        HIP_TRY(hipMemset(h->sync_count, 0, 64));
-        HIP_TRY(hipDeviceSynchronize());
+        h->sync_count = cnt;
     }
     const uint32_t seq = ++h->sync_seq;
 #define CALL_SINGLE(R, C)                                                                                              \
@@ -830,9 +884,13 @@ int step_single(sgx_env *h, const KParams &p, bool full, hipStream_t stream, boo
     // poll the word the last workgroup writes after a system-scope fence; look at the stream now and then, so that a launch that
     // failed on the device ends the wait with its error instead of hanging
     volatile uint32_t *flag = h->sync_flag_host;
+    // a step is ~6 us of kernel: spin with `pause` for the first ~2^14 polls (about a millisecond), then yield the core between
+    // polls and look at the stream every 256th time, so that a launch that failed on the device -- or a device that hangs -- neither
+    // pins a host core nor waits for ever without noticing
     for (uint32_t spins = 0; *flag != seq; ++spins) {
-        __builtin_ia32_pause();
-        if ((spins & 0xFFFFF) == 0xFFFFF) {
+        const bool slow = spins >= (1u << 14);
+        if (slow) sched_yield(); else __builtin_ia32_pause();
+        if (slow && (spins & 0xFF) == 0) {
             const hipError_t q = hipStreamQuery(stream);
             if (q == hipSuccess) break;                          // the kernel has retired: its stores are visible
             if (q != hipErrorNotReady) return fail(SGX_EDEVICE, "sgx_step_sync: %s", hipGetErrorString(q));
@@ -850,7 +908,7 @@ SGX_API int sgx_step_sync(sgx_env *h, const sgx_step_io *io, void *stream) {
     const bool original = (io->flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
     if (h->n_envs <= SGX_SINGLE_MAX_ENVS && !original && !(io->flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) && h->map_mode == 0 &&
         !h->no_single) {
-        HIP_TRY(hipSetDevice(h->device));
+        SGX_ON_DEVICE(h->device);
         KParams p = make_params(h);
         p.mode = 0;
         p.io = *io;
@@ -864,17 +922,51 @@ SGX_API int sgx_step_sync(sgx_env *h, const sgx_step_io *io, void *stream) {
     return SGX_OK;
 }
 
+// Joins the chains' streams into the caller's: records every chain's join event and makes `stream` wait for it.  Returns `rc` (the
+// error of the launches, which wins) or the first error of the joining itself.
+static int join_chains(sgx_env *h, int chains, hipStream_t stream, int rc) {
+    const std::string keep = g_last_error;
+    hipError_t first = hipSuccess;
+    for (int c = 0; c < chains; ++c) {
+        hipError_t e = hipEventRecord(h->chain_join[c], h->chain_stream[c]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, h->chain_join[c], 0);
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    }
+    if (rc != SGX_OK) { g_last_error = keep; return rc; }
+    if (first != hipSuccess) return fail(SGX_EDEVICE, "joining the chains: %s", hipGetErrorString(first));
+    return SGX_OK;
+}
+
 SGX_API int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void *stream) {
     if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
     if (!io->actions_dev || io->next_actions_dev != io->actions_dev)
         return fail(SGX_EINVAL, "sgx_step_n needs next_actions_dev == actions_dev (each step plays the action the previous one drew)%s");
     if (n_steps < 0) return fail(SGX_EINVAL, "n_steps is negative%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     KParams p = make_params(h);
     p.mode = 0;
     p.io = *io;
     for (int32_t i = 0; i < n_steps; ++i)
         if (int rc = launch_step(h, p, stream)) return rc;
+    return SGX_OK;
+}
+
+SGX_API int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, int32_t first_set, int32_t n_steps, void *stream) {
+    if (!h || !ios) return fail(SGX_EINVAL, "handle or ios is NULL%s");
+    if (n_sets < 1 || first_set < 0 || first_set >= n_sets || n_steps < 0) return fail(SGX_EINVAL, "sgx_step_ring: n_sets, first_set or n_steps out of range%s");
+    for (int32_t k = 0; k < n_sets; ++k) {
+        if (!ios[k].actions_dev || ios[k].next_actions_dev != ios[k].actions_dev || ios[k].actions_dev != ios[0].actions_dev)
+            return fail(SGX_EINVAL, "sgx_step_ring: every set needs next_actions_dev == actions_dev == the first set's (each step plays the action the previous one drew)%s");
+        if (ios[k].auto_reset != ios[0].auto_reset || ios[k].flags != ios[0].flags)
+            return fail(SGX_EINVAL, "sgx_step_ring: the sets differ in auto_reset or flags%s");
+    }
+    SGX_ON_DEVICE(h->device);
+    KParams p = make_params(h);
+    p.mode = 0;
+    for (int32_t i = 0; i < n_steps; ++i) {
+        p.io = ios[(first_set + i) % n_sets];
+        if (int rc = launch_step(h, p, stream)) return rc;
+    }
     return SGX_OK;
 }
 
@@ -888,7 +980,7 @@ SGX_API int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int3
     const int64_t unit = 8 * 8 * (cells <= 16 ? 4 : (cells <= 32 ? 2 : 1));     // 8 workgroups x SGX_WPB waves x Geo::GPW games
     int64_t per = (h->n_envs / chains) / unit * unit;
     if (chains == 1 || per == 0 || n_steps == 0) return sgx_step_n(h, io, n_steps, stream);
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     if (!h->chain_fork) HIP_TRY(hipEventCreateWithFlags(&h->chain_fork, hipEventDisableTiming));
     for (int c = 0; c < chains; ++c) {
         if (!h->chain_stream[c]) HIP_TRY(hipStreamCreateWithFlags(&h->chain_stream[c], hipStreamNonBlocking));
@@ -903,24 +995,22 @@ SGX_API int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int3
     // gains -- 65,536 Micro games: 107 us per step against 44 us with one chain; each switch of the submitting queue is a host
     // round trip.)
     const int block = 32;                                    // (4 ... 1000 measured within 3 % of each other)
-    for (int32_t i0 = 0; i0 < n_steps; i0 += block)
-        for (int c = 0; c < chains; ++c) {
+    int rc = SGX_OK;
+    for (int32_t i0 = 0; i0 < n_steps && rc == SGX_OK; i0 += block)
+        for (int c = 0; c < chains && rc == SGX_OK; ++c) {
             KParams pc = p;
             pc.env_first = c * per;
             pc.n_envs = c == chains - 1 ? h->n_envs : (c + 1) * per;
-            for (int32_t i = i0; i < n_steps && i < i0 + block; ++i)
-                if (int rc = launch_step(h, pc, (void *)h->chain_stream[c])) return rc;
+            for (int32_t i = i0; i < n_steps && i < i0 + block && rc == SGX_OK; ++i) rc = launch_step(h, pc, (void *)h->chain_stream[c]);
         }
-    for (int c = 0; c < chains; ++c) {
-        HIP_TRY(hipEventRecord(h->chain_join[c], h->chain_stream[c]));
-        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->chain_join[c], 0));
-    }
-    return SGX_OK;
+    // the caller's stream waits for every chain that was forked -- also when a launch failed half way: what is already enqueued still
+    // writes the caller's buffers and must stay ordered before whatever the caller enqueues next
+    return join_chains(h, chains, (hipStream_t)stream, rc);
 }
 
 SGX_API int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actions_dev, void *stream) {
     if (!h || !mask_dev || !actions_dev) return fail(SGX_EINVAL, "NULL argument%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     KParams p = make_params(h);
 #define CALL_SAMPLE(R, C) sample_kernel<R, C><<<(unsigned)h->n_envs, 64, 0, (hipStream_t)stream>>>(p, mask_dev, actions_dev)
     DISPATCH_GEOMETRY(h, CALL_SAMPLE);
@@ -967,13 +1057,13 @@ int launch_import(sgx_env *h, const KParams &p_in, const int64_t *state_dev, con
 
 SGX_API int sgx_export_state(sgx_env *h, int64_t *state_dev, int8_t *player_dev, void *stream) {
     if (!h || !state_dev) return fail(SGX_EINVAL, "NULL argument%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     return launch_export(h, make_params(h), state_dev, player_dev, (hipStream_t)stream);
 }
 
 SGX_API int sgx_import_state_checked(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, uint8_t *sanitised_dev, void *stream) {
     if (!h || !state_dev) return fail(SGX_EINVAL, "NULL argument%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     return launch_import(h, make_params(h), state_dev, player_dev, sanitised_dev, (hipStream_t)stream);
 }
 
@@ -984,7 +1074,7 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
     if (!h || !state_in_dev || !io) return fail(SGX_EINVAL, "NULL argument%s");
     if (io->auto_reset || io->next_actions_dev) return fail(SGX_EINVAL, "sgx_step_states: no auto_reset, no sampled next actions%s");
     if (chains < 1 || chains > SGX_MAX_CHAINS) return fail(SGX_EINVAL, "chains out of range%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     const int64_t unit = 64;
     int64_t per = (h->n_envs / chains) / unit * unit;
     if (per == 0) chains = 1;
@@ -1028,20 +1118,16 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
     }
     HIP_TRY(hipEventRecord(h->chain_fork, (hipStream_t)stream));
     for (int c = 0; c < chains; ++c) HIP_TRY(hipStreamWaitEvent(h->chain_stream[c], h->chain_fork, 0));
-    for (int c = 0; c < chains; ++c) {
+    int rc = SGX_OK;
+    for (int c = 0; c < chains && rc == SGX_OK; ++c) {
         KParams pc = p;
         pc.env_first = c * per;
         pc.n_envs = c == chains - 1 ? h->n_envs : (c + 1) * per;
-        if (int rc = launch_import(h, pc, state_in_dev, player_in_dev, sanitised_dev, h->chain_stream[c])) return rc;
-        if (int rc = launch_step(h, pc, (void *)h->chain_stream[c])) return rc;
-        if (state_out_dev)
-            if (int rc = launch_export(h, pc, state_out_dev, player_out_dev, h->chain_stream[c])) return rc;
+        rc = launch_import(h, pc, state_in_dev, player_in_dev, sanitised_dev, h->chain_stream[c]);
+        if (rc == SGX_OK) rc = launch_step(h, pc, (void *)h->chain_stream[c]);
+        if (rc == SGX_OK && state_out_dev) rc = launch_export(h, pc, state_out_dev, player_out_dev, h->chain_stream[c]);
     }
-    for (int c = 0; c < chains; ++c) {
-        HIP_TRY(hipEventRecord(h->chain_join[c], h->chain_stream[c]));
-        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->chain_join[c], 0));
-    }
-    return SGX_OK;
+    return join_chains(h, chains, (hipStream_t)stream, rc);     // (also after a failed launch: see sgx_rollout)
 }
 
 SGX_API int sgx_import_state(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, void *stream) {
@@ -1065,7 +1151,7 @@ SGX_API int sgx_copy_envs(sgx_env *dst, const int32_t *dst_index_dev, sgx_env *s
     if (dst == src && (dst_index_dev || src_index_dev))
         return fail(SGX_EINVAL, "sgx_copy_envs: an indexed copy inside one handle would race; stage through a second handle%s");
     if (n == 0 || dst == src) return SGX_OK;
-    HIP_TRY(hipSetDevice(dst->device));
+    SGX_ON_DEVICE(dst->device);
     copy_records_kernel<<<(unsigned)((n + 3) / 4), 256, 0, (hipStream_t)stream>>>(dst->boards, dst_index_dev, src->boards, src_index_dev, dst->rec_bytes, n);
     HIP_TRY(hipGetLastError());
     return SGX_OK;
@@ -1083,7 +1169,7 @@ SGX_API int sgx_expand(sgx_env *dst, sgx_env *src, const int32_t *src_index_dev,
     if (io->auto_reset) return fail(SGX_EINVAL, "sgx_expand does not auto-reset%s");
     if (io->fobs_dev || io->final_fobs_dev || (io->flags & SGX_STEP_ORIGINAL_CHANNELS))
         return fail(SGX_EINVAL, "sgx_expand renders the 67-channel partial observation only%s");
-    HIP_TRY(hipSetDevice(dst->device));
+    SGX_ON_DEVICE(dst->device);
     KParams p = make_params(dst);
     p.mode = 0;
     p.io = *io;
@@ -1094,7 +1180,7 @@ SGX_API int sgx_expand(sgx_env *dst, sgx_env *src, const int32_t *src_index_dev,
 
 SGX_API int sgx_get_env_info(sgx_env *h, int32_t *info_dev, void *stream) {
     if (!h || !info_dev) return fail(SGX_EINVAL, "NULL argument%s");
-    HIP_TRY(hipSetDevice(h->device));
+    SGX_ON_DEVICE(h->device);
     info_kernel<<<(unsigned)((h->n_envs + 255) / 256), 256, 0, (hipStream_t)stream>>>(h->boards, h->rec_bytes, h->sc_off, info_dev, h->n_envs);
     HIP_TRY(hipGetLastError());
     return SGX_OK;

@@ -41,6 +41,12 @@ class _OutputsOwner:
         self._L, self.out = lib, out
 
     def __del__(self):
+        # Runs wherever the garbage collector drops the last tensor.  sgx_free_outputs selects the buffers' device for the free and
+        # puts the calling thread's device back (DeviceGuard); at interpreter shutdown the HIP runtime may already be gone and the
+        # process's memory is released anyway: nothing to do then.
+        import sys
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self._L.sgx_free_outputs(None, C.byref(self.out))      # (works without the handle: the record names its device)
         except Exception:
@@ -124,6 +130,7 @@ class VecStrategoEnv:
                 # library-owned buffers: the env lets go of its views too, so that the memory is freed now unless the caller still
                 # holds a tensor of it (which then stays valid)
                 self.obs = self.mask = self.fobs = None
+            self._ring = self._ring_owners = None      # (tensors of the ring a caller still holds keep their buffers alive)
             self._release_outputs()
             self._L.sgx_destroy(self._h)
             self._h = None
@@ -237,6 +244,52 @@ class VecStrategoEnv:
         self.observe()
         return report
 
+    @property
+    def record_bytes(self):
+        """Bytes of one game's packed state record in device memory (sgx_record_bytes): read once and written once per step."""
+        return int(self._L.sgx_record_bytes(self._h))
+
+    @property
+    def build_id(self):
+        """Hash of the sources the loaded library was compiled from (sgx_build_id)."""
+        return self._L.sgx_build_id().decode('ascii', 'replace')
+
+    def alloc_output_ring(self, n_sets, tune=False, max_extra_bytes=8 << 30, trials=None):
+        """A ring of `n_sets` output sets (obs, mask[, fobs]) for rollout_steps(..., ring=True): step i writes set i mod n_sets -- a
+        rollout into a trajectory buffer that keeps the last n_sets steps (sgx_step_ring).  Set 0 is the env's current set; the others
+        are torch.empty tensors or, with tune=True, library-owned buffers from the placement trial (one sgx_alloc_outputs each).
+        Returns the per-set trial reports (None for set 0 and for untuned sets)."""
+        n_sets = int(n_sets)
+        if n_sets < 1:
+            raise ValueError("n_sets must be >= 1")
+        N, R, Cc, K, dev = self.num_envs, self.R, self.Cc, self.K, self.device
+        self._ring = [(self.obs, self.mask, self.fobs)]
+        self._ring_owners = [getattr(self, '_outputs_owner', None)]
+        reports = [None]
+        for _ in range(1, n_sets):
+            if tune:
+                out = _lib.SgxOutputs()
+                flags = self._mode_flags | (_lib.OUT_FULL_OBS if self.fobs is not None else 0)
+                with torch.cuda.device(self.device):
+                    _lib.check(self._L.sgx_alloc_outputs(self._h, flags, int(max_extra_bytes), int(trials or _lib.OUT_MAX_TRIALS),
+                                                         self._stream(), C.byref(out)), self._L)
+                owner = _OutputsOwner(self._L, out)
+                obs = _wrap_device(out.obs_dev, (N, R, Cc, self.p_channels), torch.float32, dev, owner)
+                mask = _wrap_device(out.mask_dev, (N, R, Cc, K), torch.uint8, dev, owner)
+                fobs = _wrap_device(out.fobs_dev, (N, R, Cc, self.f_channels), torch.float32, dev, owner) if out.fobs_dev else None
+                reports.append({'obs': [float(x) for x in out.trial_us[:out.n_trials]]})
+                self._ring_owners.append(owner)
+            else:
+                obs = torch.empty((N, R, Cc, self.p_channels), dtype=torch.float32, device=dev)
+                mask = torch.empty((N, R, Cc, K), dtype=torch.uint8, device=dev)
+                fobs = torch.empty((N, R, Cc, self.f_channels), dtype=torch.float32, device=dev) if self.fobs is not None else None
+                reports.append(None)
+                self._ring_owners.append(None)
+            self._ring.append((obs, mask, fobs))
+        self._ring_pos = 1 % n_sets          # set 0 holds the current position's outputs: the next step writes set 1
+        self._ring_ios = (_lib.SgxStepIO * n_sets)()
+        return reports
+
     def _release_outputs(self):
         """Drops the env's own reference to library-owned output buffers; they are freed when the last tensor viewing them goes."""
         self._outputs_owner = None
@@ -293,12 +346,27 @@ class VecStrategoEnv:
             self.sample_valid_actions()
         return self.step(self.next_actions, want_next_actions=True)
 
-    def rollout_steps(self, n_steps, chains=1):
+    def rollout_steps(self, n_steps, chains=1, ring=False):
         """`n_steps` rollout steps enqueued by one library call (sgx_step_n): same results as calling rollout_step()
         n_steps times, without a Python round trip per step (toy boards are launch-bound otherwise).  chains > 1 (sgx_rollout):
-        the batch is split into that many contiguous ranges of games whose launches overlap on streams of their own."""
+        the batch is split into that many contiguous ranges of games whose launches overlap on streams of their own.
+        ring=True (after alloc_output_ring): the steps write the ring's output sets in turn (sgx_step_ring); self.obs / self.mask /
+        self.fobs are the set the LAST step wrote afterwards."""
         if not self._next_actions_fresh:
             self.sample_valid_actions()
+        if ring:
+            n_sets, n_steps = len(self._ring), int(n_steps)
+            for k, (obs, mask, fobs) in enumerate(self._ring):
+                self.obs, self.mask, self.fobs = obs, mask, fobs
+                io = self._fill_io(self.next_actions, True, True, True, 0)
+                C.memmove(C.byref(self._ring_ios[k]), C.byref(io), C.sizeof(_lib.SgxStepIO))
+            first = self._ring_pos
+            with torch.cuda.device(self.device):
+                _lib.check(self._L.sgx_step_ring(self._h, self._ring_ios, n_sets, first, n_steps, self._stream()), self._L)
+            last = (first + n_steps - 1) % n_sets if n_steps > 0 else (first - 1) % n_sets
+            self.obs, self.mask, self.fobs = self._ring[last]
+            self._ring_pos = (first + n_steps) % n_sets
+            return self.obs, self.mask, self.reward, self.done, self.player
         io = self._fill_io(self.next_actions, True, True, True, 0)
         with torch.cuda.device(self.device):
             if chains > 1:

@@ -41,6 +41,29 @@ def test_self_launch_two_ranks():
     assert d['config']['stub_steps_x_games'] == 5 * 2000      # the SUM all-reduce saw both ranks' timed steps
 
 
+def test_self_launch_eight_ranks_with_the_config5_defaults():
+    """BASELINE config 5 as the driver will launch it: --gpus 8 with no size argument = 262,144 games per GPU (2,097,152 in total,
+    weak) plus the strong leg of 2,097,152 games; all eight ranks rendezvous, shard and reduce."""
+    p = _run(['--gpus', '8', '--dry-run', '--steps', '3', '--warmup', '1'], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1
+    d = lines[0]
+    assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['launched_by'] == 'bench.py'
+    assert d['config']['games_per_gpu'] == 262144 and d['config']['total_games'] == 2097152
+    assert d['config']['games_covered_by_ranks'] == 2097152 and d['config']['stub_steps_x_games'] == 3 * 2097152
+    assert d['config']['strong_leg_total_games'] == 2097152
+    # the strong split of the same total over 8 ranks, and one that does not divide evenly
+    p = _run(['--gpus', '8', '--dry-run', '--steps', '2', '--warmup', '1', '--total-envs', '2097152'], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _json_lines(p.stdout)[0]
+    assert d['scaling'] == 'strong' and d['config']['games_per_gpu'] == 262144 and d['config']['games_covered_by_ranks'] == 2097152
+    p = _run(['--gpus', '8', '--dry-run', '--steps', '2', '--warmup', '1', '--total-envs', '65541'], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _json_lines(p.stdout)[0]
+    assert d['config']['games_covered_by_ranks'] == 65541 and d['config']['stub_steps_x_games'] == 2 * 65541
+
+
 def test_self_launch_strong_scaling_keeps_the_remainder():
     # 1001 games over 3 ranks: shard_range gives 334 + 334 + 333; an integer division would drop two games
     p = _run(['--gpus', '3', '--dry-run', '--steps', '4', '--warmup', '1', '--total-envs', '1001'])

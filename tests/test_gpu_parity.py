@@ -733,3 +733,96 @@ def test_rollout_chains_equal_a_single_chain(name, n):
         assert int(env.invalid_action.sum()) == 0
         env.close()
     ref.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,n,full', [('barrage', 1024, False), ('micro', 4096, False), ('fives', 1500, False), ('barrage', 512, True)])
+def test_step_ring_equals_step_n(name, n, full):
+    """sgx_step_ring: the same rollout writing a ring of output sets round-robin leaves exactly the state of sgx_step_n; the set the
+    last step wrote holds sgx_step_n's outputs, and the sets before it hold the outputs of the steps before."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    per_step = []
+    ref = VecStrategoEnv(name, n, seed=91, auto_reset=True, full_obs=full)
+    ref.reset()
+    for _ in range(11):
+        ref.rollout_steps(1)
+        per_step.append((ref.obs.clone(), ref.mask.clone(), ref.fobs.clone() if full else None))
+    want_state, want_player = ref.export_state()
+    for n_sets in (1, 2, 3, 4):
+        env = VecStrategoEnv(name, n, seed=91, auto_reset=True, full_obs=full)
+        env.reset()
+        env.alloc_output_ring(n_sets)
+        env.rollout_steps(4, ring=True)
+        env.rollout_steps(7, ring=True)
+        torch.cuda.synchronize()
+        st, pl = env.export_state()
+        assert torch.equal(st, want_state) and torch.equal(pl, want_player), (name, n_sets)
+        for a, b in ((env.obs, ref.obs), (env.mask, ref.mask), (env.reward, ref.reward), (env.done, ref.done), (env.next_actions, ref.next_actions)):
+            assert torch.equal(a, b), (name, n_sets)
+        if full:
+            assert torch.equal(env.fobs, ref.fobs)
+        # set (1 + i) mod n_sets was written by step i: the last n_sets steps are all still there
+        for back in range(min(n_sets, 11)):
+            i = 10 - back
+            obs, mask, fobs = env._ring[(1 + i) % n_sets]
+            assert torch.equal(obs, per_step[i][0]) and torch.equal(mask, per_step[i][1]), (name, n_sets, back)
+            if full:
+                assert torch.equal(fobs, per_step[i][2])
+        assert int(env.invalid_action.sum()) == 0
+        env.close()
+    ref.close()
+
+
+@pytest.mark.gpu
+def test_record_bytes_match_the_bench_arithmetic():
+    """bench.py prices its roofline on B_min, which contains the packed record twice: its own arithmetic must be the library's."""
+    import bench
+    from stratego_env_amd.config import VARIANTS
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    for name, v in VARIANTS.items():
+        env = VecStrategoEnv(name, 8, seed=1)
+        assert env.record_bytes == bench.record_bytes(v) and env.record_bytes % 128 == 0, name
+        assert len(env.build_id) == 16
+        env.close()
+
+
+@pytest.mark.gpu
+def test_entry_points_leave_the_callers_device_alone():
+    """Every entry point runs on its handle's device and restores the caller's (DeviceGuard).  With one GPU the current device cannot
+    differ from the handle's, so this checks the calls through a second, never-selected ordinal only where the box has one; on any
+    box: the HIP runtime's current device is what it was before each call."""
+    import ctypes
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    hip = ctypes.CDLL('libamdhip64.so')
+    cur = ctypes.c_int(-1)
+
+    def current():
+        assert hip.hipGetDevice(ctypes.byref(cur)) == 0
+        return cur.value
+    ndev = torch.cuda.device_count()
+    home = 0
+    target = 1 if ndev > 1 else 0
+    torch.cuda.set_device(home)
+    assert current() == home
+    env = VecStrategoEnv('barrage', 64, device=target, seed=3, auto_reset=True)
+    assert current() == home
+    env.reset(); assert current() == home
+    env.rollout_steps(5); assert current() == home
+    env.rollout_steps(4, chains=2); assert current() == home
+    st, pl = env.export_state(); assert current() == home
+    env.import_state(st, pl); assert current() == home
+    env.tune_placement(trials=2, max_extra_bytes=1 << 30); assert current() == home
+    keep = env.obs
+    env.close(); assert current() == home
+    del keep, env
+    import gc
+    gc.collect()
+    assert current() == home
+    if ndev > 1:
+        # results on the other device equal results on the home device
+        a = VecStrategoEnv('barrage', 64, device=0, seed=3, auto_reset=True); a.reset(); a.rollout_steps(9)
+        b = VecStrategoEnv('barrage', 64, device=1, seed=3, auto_reset=True); b.reset(); b.rollout_steps(9)
+        assert torch.equal(a.obs.cpu(), b.obs.cpu()) and torch.equal(a.mask.cpu(), b.mask.cpu())
+        a.close(); b.close()
