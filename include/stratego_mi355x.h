@@ -157,6 +157,15 @@ int sgx_destroy(sgx_env *h);
  * mode (tests/test_gpu_nt_stores.py runs the parity suites with the mode forced).  No reference counterpart. */
 int sgx_set_nt_stores(sgx_env *h, int32_t mode);
 
+/* Kernel choice on boards of at most 16 cells with a multiple of 4 cells (Micro 3x4, Tiny 4x4): by default sgx_step / sgx_observe / sgx_step_n /
+ * sgx_rollout / sgx_step_ring play ONE GAME PER LANE there (64 games per wave, boards as nibbles in registers)
+ * whenever the call asks for the 67-channel partial observation of an 'extended' channel mode with masks in the mover's perspective, no
+ * terminal-observation buffers, and 16-byte aligned output tensors; every other call, and every other board size, runs the
+ * wave-per-game kernel.  mode 0 forces the wave-per-game kernel, 1 / -1 (default) the lane kernel where eligible; SGX_LANE=0|1|auto sets
+ * the default of handles created afterwards.  Results are identical either way (tests/test_gpu_lane_kernel.py).  No reference
+ * counterpart. */
+int sgx_set_lane_kernel(sgx_env *h, int32_t mode);
+
 /* Shares of the eight XCDs in a launch of sgx_step / sgx_observe.  Under a saturating write stream the odd XCDs of MI355X drain their
  * eighth of the games ~20 % slower than the even ones, so with equal eighths the even XCDs idle at the end of every launch; the
  * library gives the even XCD of each pair `per_mille` more than the mean share and the odd one as much less (DESIGN.md section 3.1:

@@ -22,7 +22,7 @@ OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_build_id', 'sgx_supports_geometry', 'sgx_last_error', 'sgx_num_envs', 'sgx_record_bytes', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
-    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_nt_stores', 'sgx_set_xcd_skew', 'sgx_set_xcd_shares', 'sgx_get_xcd_shares', 'sgx_set_setup_table', 'sgx_reset',
+    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_nt_stores', 'sgx_set_lane_kernel', 'sgx_set_xcd_skew', 'sgx_set_xcd_shares', 'sgx_get_xcd_shares', 'sgx_set_setup_table', 'sgx_reset',
     'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_host_alloc', 'sgx_host_free', 'sgx_step_sync', 'sgx_step_n', 'sgx_step_ring', 'sgx_rollout', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_step_states', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
 )
 
@@ -87,6 +87,8 @@ def _bind(L):
     L.sgx_destroy.argtypes = [vp]
     L.sgx_set_nt_stores.restype = C.c_int
     L.sgx_set_nt_stores.argtypes = [vp, C.c_int32]
+    L.sgx_set_lane_kernel.restype = C.c_int
+    L.sgx_set_lane_kernel.argtypes = [vp, C.c_int32]
     L.sgx_set_xcd_skew.restype = C.c_int
     L.sgx_set_xcd_skew.argtypes = [vp, C.c_int32]
     L.sgx_set_xcd_shares.restype = C.c_int

@@ -34,6 +34,16 @@ constexpr int FOBS_TAB_DWORDS = LUT_DWORDS + 2 * FOBS_CH * 4;
 constexpr int NIB_ONE = 4, CODE_NONE = 0xFF, CODETAB_REC = 192, CODETAB_BYTES = 208;
 constexpr int COMBAT_BYTES = 16 * 16;
 enum { COMBAT_LOSE = 0, COMBAT_TIE = 1, COMBAT_WIN = 2, COMBAT_WIN_FLAG = 3 };
+// Outcome of piece type `att` attacking piece type `def` (both 1..12): the reference's first-match chain, impl:968-982 (tabulated by
+// the host into DevTables::combat).
+__host__ __device__ inline int combat_outcome(int att, int def) {
+    if (att == 3 /* miner */ && def == 12 /* bomb */) return COMBAT_WIN;      // only the miner defuses
+    if (att == 1 /* spy */ && def == 10 /* marshal */) return COMBAT_WIN;     // the spy wins only when it attacks
+    if (def == 11 /* flag */) return COMBAT_WIN_FLAG;
+    if (def == 12) return COMBAT_LOSE;
+    if (att == def) return COMBAT_TIE;
+    return att > def ? COMBAT_WIN : COMBAT_LOSE;
+}
 constexpr int CODE_ESC = 8;   // (-2.0, never a value of its own) marks an entry whose float has no code: see emit_codes / patch_uncoded
 constexpr int TMPL_MAX_BYTES = ((SGX_MAX_CELLS * FOBS_CH / 2) + 15) & ~15;   // 40,448
 __host__ __device__ constexpr int lut_row(int ch) { return ((ch >> 1) & 1) * LUT_BLK + (ch >> 2) * LUT_ROW_PITCH + (ch & 1) * 16; }
@@ -155,6 +165,7 @@ struct KParams {
     int32_t map_mode, map_arg;   // experiment only: see group_of_block
     int32_t xcd_first[8], xcd_count[8];   // workgroup-groups of this launch played by XCD x: [xcd_first[x], + xcd_count[x]) (group_of_block)
     int32_t nt_stores;  // the launch's observations do not fit the Infinity Cache: whole lines leave as non-temporal stores (sgx_obs.h)
+    int32_t prio_mode;  // experiment (SGX_PRIO): wave priorities by the wave's slot on its SIMD, see stagger_priority
     // functional-API instantiation only (sgx_expand): game i is read from record src_index[i] (i when NULL) of ANOTHER handle's
     // records and written to record i of this one, whether or not the move was valid
     const int8_t *src_boards;
@@ -294,6 +305,20 @@ __device__ inline int64_t group_of_block(const KParams &P) {
     if (P.map_mode == 5) return x * per + ((x & 1) ? per - 1 - i : i);                   // neighbouring XCDs walk towards each other
     if (P.map_mode == 6) { const int64_t f = map_arg, sub = per / f; return x * per + (i % f) * sub + (i / f); }   // f sub-fronts per XCD (f divides nb / 8)
     return x * per + i;
+}
+
+// Experiment (SGX_PRIO=1|2).  All waves of a SIMD start their game logic together and share the issue slots, so the FIRST store of the
+// launch leaves only when the whole cohort is through its logic (Micro: ~11 us of a 41 us launch with nothing on the memory pipes).
+// With priorities by slot (s_setprio: 3 for the waves in slots 0-1, 2 for slots 2-3, ...) the cohort runs staggered: the first pair reaches
+// its stores after a quarter of that time and the later pairs' logic overlaps the earlier pairs' emission.
+__device__ inline void stagger_priority(int mode) {
+    if (mode == 0) return;
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;       // HW_REG_HW_ID[3:0] = wave slot on its SIMD
+    const unsigned level = mode == 1 ? (slot >> 1) : (slot & 3u);
+    if (level == 0) __builtin_amdgcn_s_setprio(3);
+    else if (level == 1) __builtin_amdgcn_s_setprio(2);
+    else if (level == 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
 }
 
 // Orders the LDS phases of ONE wave (each wave owns its game's LDS region; waves of a workgroup never exchange

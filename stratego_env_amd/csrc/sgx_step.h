@@ -502,6 +502,7 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     __shared__ alignas(16) uint8_t obst_s[G::OBST_BYTES + COMBAT_BYTES];    // obstacle map, then the combat outcome table
     const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;     // lane inside the game, game inside the workgroup
     const int64_t env = P.env_first + group_of_block(P) * (G::WPB * G::GPW) + slot;
+    stagger_priority(P.prio_mode);
     // The game's record and action are requested FIRST: the reads fly while the workgroup stages its shared tables (another
     // global round trip) and waits at the barrier -- the two round trips used to follow each other.
     const GameInput in = load_game<G, MAPPED>(P, env, lane);

@@ -80,6 +80,8 @@ const char g_build_id[] = "SGX_BUILD_ID=" SGX_BUILD_ID;
 #include "sgx_mask.h"
 #include "sgx_setup.h"
 #include "sgx_step.h"
+#include "sgx_lane.h"
+#include "sgx_lane_kernel.h"
 #include "sgx_aux_kernels.h"
 #include "sgx_mem.h"
 
@@ -107,6 +109,8 @@ struct sgx_env {
     int xcd_explicit;            // xcd_w was set by sgx_set_xcd_shares: it overrides the skew rule
     int32_t xcd_w[8];            // shares of the eight XCDs, per mille of the mean share (sum 8000)
     int nt_mode;                 // sgx_set_nt_stores: -1 = by the launch's output size, 0 = never, 1 = always
+    int lane_mode;               // sgx_set_lane_kernel: 0 = never the lane-per-game kernel, otherwise wherever it is eligible
+    int prio_mode;               // SGX_PRIO experiment (sgx_layout.h: stagger_priority)
     hipStream_t chain_stream[SGX_MAX_CHAINS];   // sgx_rollout: created on first use
     hipEvent_t chain_fork, chain_join[SGX_MAX_CHAINS];
     // sgx_step_sync on a handful of games (single_kernel): a host-mapped word the kernel publishes its sequence number in, and the
@@ -262,16 +266,6 @@ static void build_lut(const sgx_config *cfg, bool full, float *lut, bool raw_val
     }
 }
 
-// Outcome of piece type `att` attacking piece type `def` (both 1..12): the reference's first-match chain, impl:968-982.
-static int combat_outcome(int att, int def) {
-    if (att == SP_MINER && def == SP_BOMB) return COMBAT_WIN;         // only the miner defuses
-    if (att == SP_SPY && def == SP_MARSHALL) return COMBAT_WIN;       // the spy wins only when it attacks
-    if (def == SP_FLAG) return COMBAT_WIN_FLAG;
-    if (def == SP_BOMB) return COMBAT_LOSE;
-    if (att == def) return COMBAT_TIE;
-    return att > def ? COMBAT_WIN : COMBAT_LOSE;
-}
-
 // 'extended' observations are rendered from 4-bit codes (sgx_obs.h): code c decodes to sext(c) / 4.  Templates of the channel
 // defaults and the codes of captured counts / recent-move codes, derived from the LUTs themselves.
 static int float_code(float f) {
@@ -372,6 +366,9 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
         if (!strcmp(e, "0")) h->nt_mode = 0;
         else if (!strcmp(e, "1")) h->nt_mode = 1;
     }
+    h->lane_mode = -1;
+    if (const char *e = getenv("SGX_LANE")) { if (!strcmp(e, "0")) h->lane_mode = 0; else if (!strcmp(e, "1")) h->lane_mode = 1; }   // SGX_LANE=0|1|auto
+    if (const char *e = getenv("SGX_PRIO")) h->prio_mode = atoi(e);
     h->xcd_skew = -1;
     if (const char *e = getenv("SGX_XCD_SKEW")) { if (strcmp(e, "auto")) h->xcd_skew = atoi(e); }   // SGX_XCD_SKEW=<per mille>|auto
     if (h->xcd_skew > 900) h->xcd_skew = 900;
@@ -458,6 +455,15 @@ SGX_API int sgx_set_nt_stores(sgx_env *h, int32_t mode) {
     return SGX_OK;
 }
 
+// experiment, not part of the ABI header's contract: wave priorities by SIMD slot (0 = off)
+SGX_API int sgx_debug_set_prio(sgx_env *h, int32_t mode) { if (h) h->prio_mode = mode; return SGX_OK; }
+
+SGX_API int sgx_set_lane_kernel(sgx_env *h, int32_t mode) {
+    if (!h || mode < -1 || mode > 1) return fail(SGX_EINVAL, "sgx_set_lane_kernel: mode must be -1 (auto), 0 or 1%s");
+    h->lane_mode = mode;
+    return SGX_OK;
+}
+
 static void launch_shares(const sgx_env *h, bool streaming, int32_t *w);
 
 SGX_API int sgx_set_xcd_skew(sgx_env *h, int32_t per_mille) {
@@ -517,13 +523,15 @@ SGX_API int sgx_reset(sgx_env *h, const uint8_t *env_select_dev, const int8_t *p
 
 // Observation bytes one launch writes; beyond what the 256 MiB Infinity Cache absorbs the kernel uses non-temporal stores for the
 // lines a wave writes whole (measured crossover between 281 and 316 MB on four board sizes, sgx_obs.h).
-static bool launch_streams_past_cache(const sgx_env *h, const KParams &p) {
+// `sets`: output sets written round-robin (sgx_step_ring): a line is written again only after `sets` launches, so what has to fit the
+// cache for plain stores to pay is the observations of all of them.
+static bool launch_streams_past_cache(const sgx_env *h, const KParams &p, int sets = 1) {
     const bool original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
     const int64_t cells = (int64_t)h->cfg.rows * h->cfg.cols;
     int64_t bytes = 0;
     if (p.io.obs_dev) bytes += h->n_envs * cells * lut_channels(false, original) * 4;
     if (p.io.fobs_dev) bytes += h->n_envs * cells * lut_channels(true, original) * 4;
-    return bytes > (int64_t)300 * 1000 * 1000;
+    return bytes * sets > (int64_t)300 * 1000 * 1000;
 }
 
 // Workgroup-groups per XCD for `groups` groups of games from the shares w[8] (per mille of the mean share): KParams::xcd_first /
@@ -553,21 +561,48 @@ static void launch_shares(const sgx_env *h, bool streaming, int32_t *w) {
     for (int x = 0; x < 8; ++x) w[x] = (x & 1) ? 1000 - skew : 1000 + skew;
 }
 
+// The lane-per-game kernel plays this launch?  (sgx_lane_kernel.h: what it covers; everything else is the wave-per-game kernel.)
+static bool lane_eligible(const sgx_env *h, const KParams &p, bool full, bool original) {
+    const int cells = h->cfg.rows * h->cfg.cols;
+    auto aligned = [](const void *ptr, uintptr_t a) { return (reinterpret_cast<uintptr_t>(ptr) & (a - 1)) == 0; };
+    return h->lane_mode != 0 && cells <= 16 && cells % 4 == 0 && !full && !original && h->map_mode == 0 &&
+           !(p.io.flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) && !p.src_boards && !p.io.final_obs_dev && !p.io.final_fobs_dev &&
+           (h->rec_bytes == 128 || h->rec_bytes == 256) && (p.env_first & 63) == 0 &&
+           aligned(p.io.obs_dev, 16) && aligned(p.io.mask_dev, 16) && aligned(p.io.reward_dev, 8) && aligned(p.io.actions_dev, 16);
+}
+
 static int check_step_io(sgx_env *h, const KParams &p) {
     if (p.mode == 0 && p.io.auto_reset) return check_random_setups(h);
     return SGX_OK;
 }
 
-static int launch_step(sgx_env *h, const KParams &p_in, void *stream) {
+static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_sets = 1) {
     KParams p = p_in;
     if (p.mode == 0 && p.io.auto_reset)
         if (int rc = check_random_setups(h)) return rc;
     p.map_mode = h->map_mode; p.map_arg = h->map_arg;
-    const bool streaming = launch_streams_past_cache(h, p);
+    p.prio_mode = h->prio_mode;
+    const bool streaming = launch_streams_past_cache(h, p, ring_sets);
     p.nt_stores = h->nt_mode < 0 ? (streaming ? 1 : 0) : h->nt_mode;
     int32_t skew[8];                     // unequal XCD shares (sgx_layout.h: group_of_block)
     launch_shares(h, streaming, skew);
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
+    if (lane_eligible(h, p, full, original)) {
+        // boards of at most 16 cells: one game per lane, 64 games per wave (sgx_lane_kernel.h)
+#define CALL_LANE(R, C)                                                                                    \
+    do {                                                                                                   \
+        if constexpr (lane_geometry<Geo<R, C>>()) {                                                        \
+            const unsigned grid = shares_for(p, (p.n_envs - p.env_first + 63) / 64, skew);                 \
+            const size_t dyn = 64 * (size_t)(p.rec_bytes + 16);                                            \
+            if (p.mode) lane_kernel<R, C, true><<<grid, 64, dyn, (hipStream_t)stream>>>(p);                \
+            else lane_kernel<R, C, false><<<grid, 64, dyn, (hipStream_t)stream>>>(p);                      \
+        }                                                                                                  \
+    } while (0)
+        DISPATCH_GEOMETRY(h, CALL_LANE);
+#undef CALL_LANE
+        HIP_TRY(hipGetLastError());
+        return SGX_OK;
+    }
 #define CALL_STEP_KIND(R, C, KIND)                                                                 \
     do {                                                                                           \
         using G_ = Geo<R, C>;                                                                      \
@@ -965,7 +1000,7 @@ SGX_API int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, in
     p.mode = 0;
     for (int32_t i = 0; i < n_steps; ++i) {
         p.io = ios[(first_set + i) % n_sets];
-        if (int rc = launch_step(h, p, stream)) return rc;
+        if (int rc = launch_step(h, p, stream, n_sets)) return rc;
     }
     return SGX_OK;
 }

@@ -155,6 +155,12 @@ class VecStrategoEnv:
             raise ValueError("set_nt_stores: 'auto', True or False")
         _lib.check(self._L.sgx_set_nt_stores(self._h, m), self._L)
 
+    def set_lane_kernel(self, mode='auto'):
+        """Kernel choice on boards of at most 16 cells (sgx_set_lane_kernel): 'auto' / True = one game per lane where the call is
+        eligible, False = always the wave-per-game kernel.  Results are identical either way."""
+        m = -1 if mode in ('auto', None) else int(bool(mode))
+        _lib.check(self._L.sgx_set_lane_kernel(self._h, m), self._L)
+
     def set_xcd_skew(self, per_mille='auto'):
         """Shares of the eight XCDs in a launch (sgx_set_xcd_skew): 'auto' (100 per mille more for the even XCDs when the launch streams
         past the Infinity Cache, equal shares otherwise) or 0 .. 900.  Results are identical for every value."""

@@ -1,0 +1,104 @@
+"""The lane-per-game kernel (stratego_env_amd/csrc/sgx_lane_kernel.h: boards of at most 16 cells, one game per lane) on the GPU:
+every output of every step against the CPU oracle -- with the kernel forced, so that the test cannot pass on the wave-per-game
+kernel -- and, output by output, against the wave-per-game kernel on the same inputs."""
+import numpy as np
+import pytest
+
+from stratego_env_amd import config
+from stratego_env_amd.config import custom_variant
+
+pytestmark = pytest.mark.gpu
+
+#                                                              spy scout miner sgt lt cpt maj col gen mar flag bomb
+CUSTOM = {
+    # every rule on 16 cells: scouts, spy / marshal, miner / bomb, a lake
+    'zoo44': custom_variant(4, 4, max_turns=60, obstacle_locations=((1, 1),), piece_counts=(1, 2, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1),
+                            initial_state_usable_rows=2, name='zoo44'),
+    # three sergeants: captured counts normalise to thirds -- values without a 4-bit code (the patched floats of the lane kernel)
+    'thirds44': custom_variant(4, 4, max_turns=80, piece_counts=(0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 1, 0), initial_state_usable_rows=1, name='thirds44'),
+    'tall43': custom_variant(4, 3, max_turns=50, piece_counts=(0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 1, 1), initial_state_usable_rows=2, name='tall43'),
+}
+
+
+@pytest.fixture(autouse=True)
+def _custom_names():
+    config.VARIANTS.update(CUSTOM)
+    yield
+    for k in CUSTOM:
+        config.VARIANTS.pop(k, None)
+
+
+@pytest.mark.parametrize('name,n_envs,n_steps', [('micro', 64, 150), ('micro', 200, 60), ('tiny', 64, 250), ('tiny', 130, 120),
+                                                 ('zoo44', 96, 250), ('thirds44', 96, 300), ('tall43', 70, 200)])
+def test_lane_kernel_step_bit_exact_vs_oracle(name, n_envs, n_steps):
+    """tests/test_gpu_parity.py's step-by-step comparison (mask, observation, rewards, flags, sampler, int64 state; 10 % garbage
+    actions; auto-reset) without terminal-observation buffers, i.e. on the lane kernel."""
+    from tests.test_gpu_parity import test_step_bit_exact_vs_oracle
+    test_step_bit_exact_vs_oracle(name, n_envs, n_steps, 0.1, seed_salt=3, final_obs=False, lane_kernel=True)
+
+
+@pytest.mark.parametrize('name,n', [('micro', 1), ('micro', 63), ('micro', 65), ('micro', 4097), ('tiny', 1000), ('zoo44', 777), ('thirds44', 513)])
+def test_lane_and_wave_kernels_agree(name, n):
+    """Same seed, same actions (garbage included), one env on each kernel: identical outputs and int64 states after every step,
+    for ragged batch sizes (partial waves, partial sub-batches)."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    a = VecStrategoEnv(name, n, seed=4242, env_id_offset=17, auto_reset=True)
+    b = VecStrategoEnv(name, n, seed=4242, env_id_offset=17, auto_reset=True)
+    a.set_lane_kernel(True)
+    b.set_lane_kernel(False)
+    a.reset(); b.reset()
+    rs = np.random.RandomState(5)
+    NA = a.variant.num_spatial_actions
+    for t in range(70):
+        for x, y in ((a.obs, b.obs), (a.mask, b.mask), (a.player, b.player)):
+            assert torch.equal(x, y), (name, n, t)
+        acts = a.sample_valid_actions().clone()
+        assert torch.equal(acts, b.sample_valid_actions())
+        bad = torch.from_numpy(rs.rand(n) < 0.08).to(acts.device)
+        acts = torch.where(bad, torch.from_numpy(rs.randint(-2, NA + 2, size=n).astype(np.int32)).to(acts.device), acts)
+        a.step(acts, want_next_actions=True)
+        b.step(acts, want_next_actions=True)
+        for x, y in ((a.reward, b.reward), (a.done, b.done), (a.invalid_action, b.invalid_action), (a.ending_invalid, b.ending_invalid),
+                     (a.next_actions, b.next_actions)):
+            assert torch.equal(x, y), (name, n, t)
+        if t % 10 == 9:
+            sa, pa = a.export_state()
+            sb, pb = b.export_state()
+            assert torch.equal(sa, sb) and torch.equal(pa, pb), (name, n, t)
+    assert int(a.done.sum()) >= 0 and int(a.invalid_action.sum()) == int(b.invalid_action.sum())
+    # the raw (un-normalised) observation and a forced non-temporal sweep
+    a.observe(raw=True); b.observe(raw=True)
+    assert torch.equal(a.obs, b.obs)
+    a.set_nt_stores(True)
+    a.observe(); b.observe()
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.mask, b.mask)
+    a.close(); b.close()
+
+
+def test_lane_kernel_rollout_digests_at_full_size():
+    """65,536 + 17 Micro games, 64 fused steps on the lane kernel (sgx_step_n), then sampled games against the oracle's digests of the
+    last step and its counters (so_rollout_ex)."""
+    import torch
+    from oracle import oracle as orc
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    from tests.helpers import oracle_cvariant
+    N, T, seed = 65536 + 17, 64, 0xBEEF
+    for name in ('micro', 'tiny'):
+        env = VecStrategoEnv(name, N, seed=seed, auto_reset=True)
+        env.set_lane_kernel(True)
+        env.reset()
+        env.rollout_steps(T)
+        torch.cuda.synchronize()
+        assert int(env.invalid_action.sum()) == 0
+        cv = oracle_cvariant(name)
+        ids = [0, 1, 63, 64, 65, 4095, 40000, 65535, 65536, N - 1]
+        idx = torch.tensor(ids, device=env.device)
+        mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
+        rw, dn, pl = env.reward[idx].cpu().numpy(), env.done[idx].cpu().numpy(), env.player[idx].cpu().numpy()
+        ei, info = env.ending_invalid[idx].cpu().numpy(), env.env_info()[idx].cpu().numpy()
+        for i, e in enumerate(ids):
+            r = orc.rollout_ex(cv, seed, e, 1, T, threads=1)
+            assert int(r['last_digests'][0]) == orc.step_digest(mk[i], ob[i], rw[i], dn[i], pl[i], ei[i]), (name, e)
+            assert np.array_equal(r['info'][0], info[i]), (name, e)
+        env.close()
