@@ -44,6 +44,8 @@ extern "C" {
 #define SGX_FO_OBS_CHANNELS_ORIGINAL 33   /* impl:1070 */
 #define SGX_STATE_LAYERS 34      /* impl:109 */
 #define SGX_OBS_LUT_STRIDE 16    /* entries per channel in the normalisation LUT */
+#define SGX_MAX_PIECES_PER_TYPE 127   /* config 'piece_amounts' per piece type (the reference's dict is unbounded, config.py:3-23; a side
+                                         never has more pieces than usable cells anyway) */
 
 enum {
     SGX_OK = 0,
@@ -58,7 +60,7 @@ typedef struct sgx_config {
     int32_t rows, cols;               /* >= 3 each (penv:28-30), rows*cols <= SGX_MAX_CELLS */
     int32_t max_turns;                /* config 'max_turns' -> StateData.MAX_TURNS (impl:247) */
     int32_t usable_rows;              /* config 'initial_state_usable_rows' */
-    int32_t piece_counts[12];         /* config 'piece_amounts' for piece codes 1..12 (SPY..BOMB), <= 8 each */
+    int32_t piece_counts[12];         /* config 'piece_amounts' for piece codes 1..12 (SPY..BOMB), <= SGX_MAX_PIECES_PER_TYPE each */
     int32_t capture_capacity;         /* most pieces ONE side can have on the board, 0 = sum of piece_counts.  An env_config that
                                          overrides 'piece_amounts' changes the normalisation constants only (maenv:323-326, 370-382)
                                          while the setups keep the version's pieces: sizes the capture-event list */
@@ -157,13 +159,14 @@ int sgx_destroy(sgx_env *h);
  * mode (tests/test_gpu_nt_stores.py runs the parity suites with the mode forced).  No reference counterpart. */
 int sgx_set_nt_stores(sgx_env *h, int32_t mode);
 
-/* Kernel choice on boards of at most 16 cells with a multiple of 4 cells (Micro 3x4, Tiny 4x4): by default sgx_step / sgx_observe / sgx_step_n /
- * sgx_rollout / sgx_step_ring play ONE GAME PER LANE there (64 games per wave, boards as nibbles in registers)
- * whenever the call asks for the 67-channel partial observation of an 'extended' channel mode with masks in the mover's perspective, no
- * terminal-observation buffers, and 16-byte aligned output tensors; every other call, and every other board size, runs the
- * wave-per-game kernel.  mode 0 forces the wave-per-game kernel, 1 / -1 (default) the lane kernel where eligible; SGX_LANE=0|1|auto sets
- * the default of handles created afterwards.  Results are identical either way (tests/test_gpu_lane_kernel.py).  No reference
- * counterpart. */
+/* Kernel choice on boards of at most 16 cells with a multiple of 4 cells (Micro 3x4, Tiny 4x4).  A second kernel plays ONE GAME PER LANE
+ * there (64 games per wave, boards as nibbles in registers).  It is eligible for sgx_step / sgx_observe / sgx_step_n /
+ * sgx_rollout / sgx_step_ring calls that ask for the 67-channel partial observation of an 'extended' channel mode (or none), masks in the
+ * mover's perspective, no terminal-observation buffers and 16-byte aligned output tensors.  Measured: its game logic is twice as fast
+ * (65,536 Micro games without outputs 13 against 26 us, mask only 15 against 30 us), but with the observation emitted one launch is slower
+ * (51 against 42 us: one wave per SIMD, nothing overlaps its logic with its stores).  mode -1 (default): the lane kernel for eligible
+ * calls that emit NO observation, the wave-per-game kernel otherwise; 0: never; 1: for every eligible call.  SGX_LANE=0|1|auto sets the
+ * default of handles created afterwards.  Results are identical either way (tests/test_gpu_lane_kernel.py).  No reference counterpart. */
 int sgx_set_lane_kernel(sgx_env *h, int32_t mode);
 
 /* Shares of the eight XCDs in a launch of sgx_step / sgx_observe.  Under a saturating write stream the odd XCDs of MI355X drain their
@@ -311,6 +314,17 @@ int sgx_import_state_checked(sgx_env *h, const int64_t *state_dev, const int8_t 
  * LDS): 65,536 Barrage states 745 -> ~640 us; `chains` only matters on the other paths. */
 int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_t *player_in_dev, uint8_t *sanitised_dev,
                     const sgx_step_io *io, int64_t *state_out_dev, int8_t *player_out_dev, int32_t chains, void *stream);
+
+/* General states in sgx_step_states.  The reference's pure functions accept ANY int64 [34,R,C] (penv:74-155); the packed record carries what
+ * play can produce.  On boards of 33 .. 256 cells with the 67-channel observation kind (the one-launch path above) sgx_step_states runs a
+ * second pass over the states its import had to alter: they are redone from the caller's int64 input on a general-state variant of the
+ * kernels -- dense recent-move layers, a capture event for every (layer, cell) pair, counts up to 32,768, captured-count channels beyond the
+ * 16-entry table normalised by the reference's own float32 arithmetic (maenv:506-508) -- so that get_next_state, is_move_valid_*, the
+ * masks and the partial observation of such states equal the reference's; sanitised_dev then reports only what still had to be altered
+ * (values outside their layer's range, an obstacle layer that differs from the variant's, a player that is not +1 / -1).  mode 1 (default):
+ * on; 0: off (flagged states keep the first pass' sanitised results).  SGX_GENERAL_STATES=0|1 sets the default of handles created
+ * afterwards.  Costs one launch of early-exit blocks (~2 % of a get_next_state call) when no state is flagged. */
+int sgx_set_general_states(sgx_env *h, int32_t mode);
 
 /* Search callers (MCTS on get_next_state, penv:148-155) keep their nodes in the packed records instead of paying the 27 KB
  * int64 import / export per state: handles of the same variant on the same device act as node pools.

@@ -23,7 +23,7 @@ OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_build_id', 'sgx_supports_geometry', 'sgx_last_error', 'sgx_num_envs', 'sgx_record_bytes', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
     'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_nt_stores', 'sgx_set_lane_kernel', 'sgx_set_xcd_skew', 'sgx_set_xcd_shares', 'sgx_get_xcd_shares', 'sgx_set_setup_table', 'sgx_reset',
-    'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_host_alloc', 'sgx_host_free', 'sgx_step_sync', 'sgx_step_n', 'sgx_step_ring', 'sgx_rollout', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_step_states', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
+    'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_alloc_outputs', 'sgx_free_outputs', 'sgx_step', 'sgx_host_alloc', 'sgx_host_free', 'sgx_step_sync', 'sgx_step_n', 'sgx_step_ring', 'sgx_rollout', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_step_states', 'sgx_set_general_states', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
 )
 
 
@@ -133,6 +133,8 @@ def _bind(L):
     L.sgx_import_state_checked.argtypes = [vp, vp, vp, vp, vp]
     L.sgx_step_states.restype = C.c_int
     L.sgx_step_states.argtypes = [vp, vp, vp, vp, C.POINTER(SgxStepIO), vp, vp, C.c_int32, vp]
+    L.sgx_set_general_states.restype = C.c_int
+    L.sgx_set_general_states.argtypes = [vp, C.c_int32]
     L.sgx_copy_envs.restype = C.c_int
     L.sgx_copy_envs.argtypes = [vp, vp, vp, vp, i64, vp]
     L.sgx_expand.restype = C.c_int

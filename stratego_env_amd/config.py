@@ -113,7 +113,7 @@ VARIANTS: Dict[str, Variant] = {
 }
 
 
-MAX_PIECES_PER_TYPE = 8       # EV_COUNT_MAX of the packed record (csrc/sgx_layout.h)
+MAX_PIECES_PER_TYPE = 127     # SGX_MAX_PIECES_PER_TYPE (a capture event counts to 8; more pieces of a type chain events)
 
 
 def custom_variant(rows, columns, max_turns=2000, obstacle_locations=(), piece_counts=None, initial_state_usable_rows=None,
@@ -132,9 +132,8 @@ def custom_variant(rows, columns, max_turns=2000, obstacle_locations=(), piece_c
         for t in (1, 2, 3, 4, 5, 6, 7, 8, 9, 0, 11):           # scout .. marshal, spy, bomb; then more scouts
             if sum(piece_counts) < room:
                 piece_counts[t] = 1
-        # more scouts, at most MAX_PIECES_PER_TYPE of them (a captured-count entry of the packed record counts to 8, the most
-        # numerous piece type of any reference variant): the remaining setup cells stay empty
-        piece_counts[1] += min(room - sum(piece_counts), MAX_PIECES_PER_TYPE - piece_counts[1])
+        # more scouts, at most 8 of them like Standard: the remaining setup cells stay empty
+        piece_counts[1] += min(room - sum(piece_counts), 8 - piece_counts[1])
     if max(piece_counts) > MAX_PIECES_PER_TYPE:
         raise ValueError("at most %d pieces of one type per side (got %s)" % (MAX_PIECES_PER_TYPE, list(piece_counts)))
     return Variant(name or 'custom_%dx%d' % (rows, columns), rows, columns, int(max_turns), tuple(tuple(x) for x in obstacle_locations),

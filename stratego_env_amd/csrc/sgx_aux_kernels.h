@@ -112,8 +112,11 @@ __global__ __launch_bounds__(64) void sample_kernel(const KParams P, const uint8
 template <class G, int NT_ = 256>
 struct StateIO {
     static constexpr int RC = G::RC, NT = NT_, NX = SGX_STATE_LAYERS * RC, NQ = NX / 2;
-    static constexpr int IMG = (G::EVL_OFF + G::EV_BYTES * G::EVL_MAX + 127) & ~127;   // >= rec_bytes of any piece set on this board
+    static constexpr int IMG = (G::ST_OFF + G::TAIL_BYTES + 127) & ~127;   // >= rec_bytes of any piece set on this board (BIG: + the dense recent boards)
     static constexpr int DENSE = (NX + 15) & ~15;
+    // one entry per (layer, cell): a byte normally; the general-state variant counts up to 32,768 captures on a cell
+    using dense_t = std::conditional_t<G::BIG, int16_t, int8_t>;
+    using cap_t = std::conditional_t<G::BIG, uint16_t, uint8_t>;
     static constexpr int NE = 24 * RC, PER = (NE + NT - 1) / NT, NEP = (NE + 3) & ~3;
     static constexpr int ITER = (NQ + NT - 1) / NT;
 };
@@ -123,7 +126,7 @@ template <class G, int NT_ = 256>
 struct alignas(16) StateLds {
     using IO = StateIO<G, NT_>;
     alignas(16) uint8_t img[IO::IMG];
-    alignas(16) int8_t dense[IO::DENSE];               // export: [layer][cell] as bytes; import: cap[] at 8 * RC, recent[] at 6 * RC
+    alignas(16) typename IO::dense_t dense[IO::DENSE]; // export: [layer][cell]; import: cap[] at 8 * RC, recent[] at 6 * RC
     int scan[IO::NT / 64];
     int scal[5];       // layer 5: turn count, game over, winner, max turns, ending invalid
     int pairs[2];
@@ -140,9 +143,10 @@ __device__ __forceinline__ void export_from_image(const KParams &P, StateLds<G, 
                                                   const int64_t env, const int tid, const int nt) {
     using IO = StateIO<G, NT_>;
     constexpr int RC = G::RC, C = G::C, S = G::S, NT = IO::NT, NX = IO::NX, NQ = IO::NQ;
+    using dense_t = typename IO::dense_t;
     const uint8_t *img = W.img;
-    int8_t *dense = W.dense;
-    for (int i = tid; i < IO::DENSE / 4; i += NT) reinterpret_cast<int *>(dense)[i] = 0;
+    dense_t *dense = W.dense;
+    for (int i = tid; i < IO::DENSE * (int)sizeof(dense_t) / 4; i += NT) reinterpret_cast<int *>(dense)[i] = 0;
     __syncthreads();
     const int4 sc = reinterpret_cast<const int4 *>(img + G::SC_OFF)[0], sc2 = reinterpret_cast<const int4 *>(img + G::SC_OFF)[1];
     for (int i = tid; i < RC; i += NT) {
@@ -154,8 +158,12 @@ __device__ __forceinline__ void export_from_image(const KParams &P, StateLds<G, 
         const uint32_t *stb = reinterpret_cast<const uint32_t *>(img + G::ST_OFF);
         dense[32 * RC + i] = (int8_t)((stb[i >> 5] >> (i & 31)) & 1u);
         dense[33 * RC + i] = (int8_t)((stb[G::SB / 4 + (i >> 5)] >> (i & 31)) & 1u);
+        if constexpr (G::BIG) {
+            dense[6 * RC + i] = (int8_t)img[G::RECB_OFF + i];
+            dense[7 * RC + i] = (int8_t)img[G::RECB_OFF + G::S_PAD + i];
+        }
     }
-    if (tid < 4) {
+    if (!G::BIG && tid < 4) {
         const int pr = (((tid >> 1) ? sc2.z : sc2.y) >> (16 * (tid & 1))) & 0xFFFF;
         if (pr >> G::CELL_BITS) dense[(6 + (tid >> 1)) * RC + G::pair_cell(pr)] = (int8_t)G::pair_code(pr);
     }
@@ -164,7 +172,13 @@ __device__ __forceinline__ void export_from_image(const KParams &P, StateLds<G, 
         const int n_events = min(sc2.x, (int)G::EVL_MAX);
         for (int i = tid; i < n_events; i += NT) {
             const int e = (int)ev[i], key = (e >> G::CELL_BITS) & 31, cell = e & G::CELL_MASK;
-            if (key < 24 && cell < RC) dense[(8 + key) * RC + cell] = (int8_t)((e >> G::EV_COUNT_SHIFT) + 1);
+            // (a variant with more than 8 pieces of a type may hold several events of one key: their counts add up -- 32-bit LDS atomics on
+            //  the word that holds the entry; sums stay below the entry's width: <= 127 pieces of a type, 32,768 in a general-state image)
+            if (key < 24 && cell < RC) {
+                const int idx = (8 + key) * RC + cell, cnt = (e >> G::EV_COUNT_SHIFT) + 1;
+                constexpr int PERW = 4 / (int)sizeof(dense_t);
+                atomicAdd(reinterpret_cast<int *>(dense) + idx / PERW, cnt << (8 * (int)sizeof(dense_t) * (idx % PERW)));
+            }
         }
     }
     __syncthreads();
@@ -211,9 +225,10 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
                                                 uint8_t *__restrict__ sanitised, const int64_t env, const int tid) {
     using IO = StateIO<G, NT_>;
     constexpr int RC = G::RC, C = G::C, S = G::S, NT = IO::NT, NX = IO::NX, NQ = IO::NQ, NE = IO::NE, PER = IO::PER, ITER = IO::ITER;
+    using cap_t = typename IO::cap_t;
     uint8_t *img = W.img;
-    uint8_t *cap = reinterpret_cast<uint8_t *>(W.dense) + 8 * RC;             // [24][RC] captured counts
-    int8_t *recent = W.dense + 6 * RC;                                        // [2][RC] recent-move codes
+    cap_t *cap = reinterpret_cast<cap_t *>(W.dense) + 8 * RC;                 // [24][RC] captured counts
+    typename IO::dense_t *recent = W.dense + 6 * RC;                          // [2][RC] recent-move codes
     const int lane = tid & 63, wave = tid >> 6;
     typedef long long i64x2 __attribute__((ext_vector_type(2)));
     const i64x2 *s = reinterpret_cast<const i64x2 *>(in + env * (int64_t)NX);
@@ -258,8 +273,17 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
                 const int b = l < 2 ? B_PIECES + l : B_PO + (l - 3), hi = l < 2 ? SP_BOMB : SP_UNKNOWN;
                 ok = raw >= 0 && raw <= hi;
                 img[b * S + cell] = (uint8_t)(ok ? (int)raw : 0);
-            } else if (l == 6 || l == 7) { ok = raw >= -3 && raw <= 1; recent[(l - 6) * RC + cell] = (int8_t)(ok ? (int)raw : 0); }
-            else if (l < 32) { ok = raw >= 0 && raw <= EV_COUNT_MAX; cap[(l - 8) * RC + cell] = (uint8_t)(raw <= 0 ? 0 : (raw > EV_COUNT_MAX ? EV_COUNT_MAX : (int)raw)); }
+            } else if (l == 6 || l == 7) {
+                ok = raw >= -3 && raw <= 1;
+                recent[(l - 6) * RC + cell] = (int8_t)(ok ? (int)raw : 0);
+                if constexpr (G::BIG) img[G::RECB_OFF + (l - 6) * G::S_PAD + cell] = (uint8_t)(int8_t)(ok ? (int)raw : 0);   // dense in the image
+            }
+            else if (l < 32) {
+                // (multi_ev: a count beyond 8 is laid out as several events of the same key, 8 + 8 + ... + rest)
+                const int cmax = (!G::BIG && P.multi_ev) ? 127 : (int)G::COUNT_MAX;
+                ok = raw >= 0 && raw <= cmax;
+                cap[(l - 8) * RC + cell] = (cap_t)(raw <= 0 ? 0 : (raw > cmax ? cmax : (int)raw));
+            }
             else {
                 ok = raw == 0 || raw == 1;
                 if (raw == 1) atomicOr(reinterpret_cast<uint32_t *>(img + G::ST_OFF) + (l - 32) * (G::SB / 4) + (cell >> 5), 1u << (cell & 31));
@@ -271,10 +295,11 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
     if (bad) W.altered = 1;
     __syncthreads();
     // capture events (one per non-zero count) in (layer, cell) order: thread t owns entries [t*PER, (t+1)*PER) of the count table
+    const bool split = !G::BIG && P.multi_ev;                               // counts beyond 8 become several events of one key
     int cnt = 0;
     for (int k = 0; k < PER; ++k) {
         const int e = tid * PER + k;
-        if (e < NE) cnt += cap[e] != 0;
+        if (e < NE) cnt += split ? ((int)cap[e] + (int)G::COUNT_MAX - 1) / (int)G::COUNT_MAX : (cap[e] != 0);
     }
     // block-wide inclusive scan: DPP scan inside each wave, then the four wave totals through LDS
     const int incl = gscan_incl<Geo<10, 10>>(cnt);                            // (any one-game-per-wave geometry: a 64-lane scan)
@@ -293,7 +318,7 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
                 bal &= bal - 1;
             }
         }
-        if (lane == 0) { W.pairs[wave] = pair; if (total > 2) W.altered = 1; }
+        if (lane == 0) { W.pairs[wave] = pair; if (total > 2 && !G::BIG) W.altered = 1; }
     }
     __syncthreads();
     int wave_base = 0;
@@ -307,8 +332,13 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
         for (int k = 0; k < PER; ++k) {
             const int e = tid * PER + k;
             if (e < NE && cap[e] != 0) {
-                if (at < P.max_events) ev[at] = (typename G::ev_t)(((cap[e] - 1) << G::EV_COUNT_SHIFT) | ((e / RC) << G::CELL_BITS) | (e % RC));
-                ++at;
+                int left = cap[e];
+                do {
+                    const int c = (split && left > (int)G::COUNT_MAX) ? (int)G::COUNT_MAX : left;
+                    if (at < max_events_of<G>(P)) ev[at] = (typename G::ev_t)(((c - 1) << G::EV_COUNT_SHIFT) | ((e / RC) << G::CELL_BITS) | (e % RC));
+                    ++at;
+                    left -= c;
+                } while (split && left > 0);
             }
         }
     }
@@ -318,13 +348,13 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
         if (W.scal[2] > 0) flags |= F_WIN_P1; else if (W.scal[2] < 0) flags |= F_WIN_M1;
         if (W.scal[4] != 0) flags |= F_END_INVALID;
         if (player_in && player_in[env] < 0) flags |= F_PLAYER_M1;
-        bool dropped = total_events > P.max_events;
+        bool dropped = total_events > max_events_of<G>(P);
         if (player_in && player_in[env] != 1 && player_in[env] != -1) dropped = true;
         if (sanitised) sanitised[env] = (W.altered || dropped) ? 1 : 0;
         const int old_game = rec_scal<G>(P.boards, P.rec_bytes, env)[0].w;
         int4 *scg = reinterpret_cast<int4 *>(img + G::SC_OFF);
         scg[0] = make_int4(W.scal[0], flags, W.scal[3], old_game < 0 ? 0 : old_game);
-        scg[1] = make_int4(min(total_events, P.max_events), W.pairs[0], W.pairs[1], 0);
+        scg[1] = make_int4(min(total_events, max_events_of<G>(P)), W.pairs[0], W.pairs[1], 0);
     }
     __syncthreads();
 }
@@ -366,10 +396,14 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
 // want more blocks per CU instead: 1-D masks 463 us with 128 threads, 592 us with 192)
 template <bool MAPPED, bool OBS>
 constexpr int states_threads() { return (!MAPPED && !OBS) ? 192 : 128; }
-template <int R_, int C_, bool MAPPED, bool OBS>
+// VAR = 1: the second pass of sgx_step_states over the states the first pass had to alter (sanitised[env] != 0; every other block leaves at
+// once): the same import -> env_step -> export on the general-state variant of the geometry (Geo<R, C, 1>: dense recent-move boards, an
+// event for every (layer, cell) pair, counts to 32,768), whose record image exists only here in LDS; the outputs of the first pass are
+// overwritten and the flag is cleared unless the state holds values outside its layers' ranges.
+template <int R_, int C_, bool MAPPED, bool OBS, int VAR = 0>
 __global__ __launch_bounds__((states_threads<MAPPED, OBS>())) void states_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in,
                                                      uint8_t *__restrict__ sanitised, int64_t *__restrict__ out, int8_t *__restrict__ player_out, const int nt) {
-    using G = Geo<R_, C_>;
+    using G = Geo<R_, C_, VAR>;
     static_assert(G::LPG == 64, "one game per wave");
     constexpr int NT = states_threads<MAPPED, OBS>(), KIND = OBS ? 0 : 2;
     __shared__ StateLds<G, NT> W;
@@ -379,6 +413,8 @@ __global__ __launch_bounds__((states_threads<MAPPED, OBS>())) void states_kernel
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t env = P.env_first + group_of_block(P);
     if (env >= P.n_envs) return;
+    if constexpr (G::BIG)
+        if (sanitised[env] == 0) return;                                     // (block-uniform) nothing to redo for this state
     {   // the step's workgroup-shared tables (game_kernel_body): default-code templates, code table, obstacle map, combat outcomes
         if constexpr (OBS) {
             const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
@@ -394,11 +430,13 @@ __global__ __launch_bounds__((states_threads<MAPPED, OBS>())) void states_kernel
     import_to_image(P, W, in, player_in, sanitised, env, tid);              // (ends with a barrier: image and tables are in place)
     if (tid < 64) {
         const GameInput gin = load_game_from<G>(P, reinterpret_cast<const int4 *>(W.img), env, lane);
-        env_step<R_, C_, KIND, MAPPED>(P, L, shared, obst_s, env, lane, gin, reinterpret_cast<int8_t *>(W.img));
+        env_step<R_, C_, KIND, MAPPED, false, VAR>(P, L, shared, obst_s, env, lane, gin, reinterpret_cast<int8_t *>(W.img));
     }
     __syncthreads();
-    int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;                       // the handle keeps the successor, like after sgx_step
-    for (int i = tid; i < P.rec_bytes / 16; i += NT) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(W.img)[i];
+    if constexpr (!G::BIG) {                                                   // (a general-state image does not fit the handle's packed records)
+        int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;                   // the handle keeps the successor, like after sgx_step
+        for (int i = tid; i < P.rec_bytes / 16; i += NT) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(W.img)[i];
+    }
     if (out) export_from_image(P, W, out, player_out, env, tid, nt);
 }
 

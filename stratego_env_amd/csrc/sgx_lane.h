@@ -182,12 +182,13 @@ SGX_HD LaneMove lane_decode(int a, int4 pos, int flags, int player) {
 // One more captured piece on (layer, cell) `key`: the count of its event goes up, or a new event is appended (sgx_step.h:
 // add_capture).  `ev`: the game's event list.
 template <class G>
-SGX_HD int lane_add_capture(uint16_t *ev, int n_events, int max_events, int key) {
+SGX_HD int lane_add_capture(uint16_t *ev, int n_events, int max_events, int key, bool multi = false) {
     bool found = false;
     for (int i = 0; i < G::EVL_MAX; ++i) {
         if (i < n_events && (int)(ev[i] & G::EV_KEY_MASK) == key) {
-            if ((int)(ev[i] >> G::EV_COUNT_SHIFT) < EV_COUNT_MAX - 1) ev[i] = (uint16_t)(ev[i] + (1 << G::EV_COUNT_SHIFT));
-            found = true;
+            const bool room = (int)(ev[i] >> G::EV_COUNT_SHIFT) < EV_COUNT_MAX - 1;
+            if (room) ev[i] = (uint16_t)(ev[i] + (1 << G::EV_COUNT_SHIFT));
+            if (room || !multi) found = true;             // (multi: a full event does not count -- the capture opens another one)
         }
     }
     if (!found && n_events < max_events) { ev[n_events] = (uint16_t)key; n_events += 1; }
@@ -204,7 +205,7 @@ struct LaneApplied {
 };
 template <class G, class CombatPtr>
 SGX_HD LaneApplied lane_apply(LaneGame &g, uint16_t *ev, const LaneMove &m, int player, uint32_t obst_abs, CombatPtr combat, int max_events,
-                              int step_flags, bool mover_has_moves) {
+                              int step_flags, bool mover_has_moves, bool multi = false) {
     constexpr int R = G::R, C = G::C;
     const int pi = player == 1 ? 0 : 1;
     const bool over = (g.flags & F_OVER) != 0;
@@ -273,8 +274,8 @@ SGX_HD LaneApplied lane_apply(LaneGame &g, uint16_t *ev, const LaneMove &m, int 
         if (wins) { own_pc = lg_set(own_pc, e, moved); own_po = lg_set(own_po, e, moved); }
         if (!wins && !tied) en_po = lg_set(en_po, e, dest);
         // captured counts (impl:999-1009): the attacker's own layer unless it won, the defender's if it lost or tied
-        if (!wins) g.n_events = lane_add_capture<G>(ev, g.n_events, max_events, ((12 * pi + moved - 1) << G::CELL_BITS) | e);
-        if (wins || tied) g.n_events = lane_add_capture<G>(ev, g.n_events, max_events, ((12 * (1 - pi) + dest - 1) << G::CELL_BITS) | e);
+        if (!wins) g.n_events = lane_add_capture<G>(ev, g.n_events, max_events, ((12 * pi + moved - 1) << G::CELL_BITS) | e, multi);
+        if (wins || tied) g.n_events = lane_add_capture<G>(ev, g.n_events, max_events, ((12 * (1 - pi) + dest - 1) << G::CELL_BITS) | e, multi);
     }
     g.pc[0] = pi ? en_pc : own_pc; g.pc[1] = pi ? own_pc : en_pc;
     g.po[0] = pi ? en_po : own_po; g.po[1] = pi ? own_po : en_po;

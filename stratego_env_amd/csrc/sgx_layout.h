@@ -73,14 +73,20 @@ constexpr int F_OVER = 1, F_WIN_P1 = 2, F_WIN_M1 = 4, F_END_INVALID = 8, F_PLAYE
 
 enum { SP_SPY = 1, SP_SCOUT = 2, SP_MINER = 3, SP_MARSHALL = 10, SP_FLAG = 11, SP_BOMB = 12, SP_UNKNOWN = 13 };
 
-template <int R_, int C_>
+// VAR_ = 1 ("BIG"): the general-state variant of a geometry, used ONLY inside sgx_step_states' second pass for states the packed record
+// cannot carry (more than two recent-move cells per player, more capture cells than pieces, more than 8 captures on one cell): 32-bit
+// capture events with room for every (layer, cell) pair and counts up to 32,768, and the two recent-move layers kept DENSE in the
+// record image.  Such records never exist in HBM -- the image lives in the LDS of the fused states_kernel between import and export.
+template <int R_, int C_, int VAR_ = 0>
 struct Geo {
     static constexpr int R = R_, C = C_;
     static constexpr int RC = R * C;
+    static constexpr bool BIG = VAR_ == 1;
     // cell-index width of the packed record: 8 bits up to 256 cells, 10 bits beyond (up to SGX_MAX_CELLS = 1024)
     static constexpr bool WIDE = RC > 256;
     static constexpr int CELL_BITS = WIDE ? 10 : 8, CELL_MASK = (1 << CELL_BITS) - 1, CODE_BITS = 16 - CELL_BITS;
-    using ev_t = std::conditional_t<WIDE, uint32_t, uint16_t>;        // capture event: (count - 1) << EV_COUNT_SHIFT | key << CELL_BITS | cell
+    using ev_t = std::conditional_t<(WIDE || BIG), uint32_t, uint16_t>;   // capture event: (count - 1) << EV_COUNT_SHIFT | key << CELL_BITS | cell
+    static constexpr int COUNT_MAX = BIG ? (1 << 15) : EV_COUNT_MAX;     // most captured pieces one event counts
     using cell_t = std::conditional_t<WIDE, uint16_t, uint8_t>;       // a cell index in LDS scratch lists
     using entry_t = std::conditional_t<WIDE, uint32_t, uint16_t>;     // an observation entry index (cell * channels + channel)
     static constexpr int EV_COUNT_SHIFT = CELL_BITS + 5, EV_KEY_MASK = (1 << EV_COUNT_SHIFT) - 1;
@@ -97,9 +103,14 @@ struct Geo {
     static constexpr int ST_OFF = (STORED_BOARDS * S + 15) & ~15;
     static constexpr int SB = (((RC + 7) / 8) + 15) & ~15;           // bytes of one never-moved bitmap (bit i = cell i)
     static constexpr int SC_OFF = ST_OFF + 2 * SB, EVL_OFF = SC_OFF + 32;
-    static constexpr int EVL_MAX = RC;                               // 2 * pieces per side <= cells
+    static constexpr int EVL_MAX = BIG ? 24 * RC : RC;               // 2 * pieces per side <= cells; BIG: every (layer, cell) pair
     static constexpr int EV_BYTES = (int)sizeof(ev_t);
-    static constexpr int TAIL_BYTES = 2 * SB + 32 + ((EV_BYTES * EVL_MAX + 15) & ~15);   // LDS image of the record from ST_OFF on
+    static constexpr int EVB = (EV_BYTES * EVL_MAX + 15) & ~15;      // bytes of the event list, padded to 16
+    static constexpr int S_PAD = (S + 15) & ~15;
+    static constexpr int RECB_OFF = EVL_OFF + EVB;                   // BIG only: the two recent-move boards, dense, S_PAD bytes each
+    static constexpr int TAIL_BYTES = 2 * SB + 32 + EVB + (BIG ? 2 * S_PAD : 0);   // LDS image of the record from ST_OFF on
+    static constexpr int IMG_BYTES = ST_OFF + TAIL_BYTES;            // the whole record image
+    static constexpr int SPECIAL_EXTRA = BIG ? 2 * RC : 4;           // observation entries of the recent-move layers: four pairs, or every cell
     static constexpr int K = 2 * (R - 1) + 2 * (C - 1) + 1;
     static constexpr int NA = RC * K;                 // spatial actions
     static constexpr int NA_PAD = (NA + 15) & ~15;
@@ -120,7 +131,7 @@ struct Geo {
     static constexpr int CNT_PAD = CPL * LPG;
     // upper estimate of one game's LDS region (struct Lds with the widest code buffer) + the workgroup's shared tables
     static constexpr int LDS_GAME_EST = N_LDS_BOARDS * S + (RC * FOBS_CH / 2 + 64) + 4 * MB_WORDS + (1 + (int)sizeof(cell_t)) * CNT_PAD + S + TAIL_BYTES +
-                                        (4 + (int)sizeof(entry_t)) * (EVL_MAX + 12) + 64;
+                                        (4 + (int)sizeof(entry_t)) * (EVL_MAX + SPECIAL_EXTRA + 8) + 64;
     // the workgroup's shared tables; WIDE boards read the default-code templates from global memory (L2) instead of an LDS copy
     static constexpr int LDS_SHARED_EST = (WIDE ? 0 : 2 * (RC * FOBS_CH / 2 + 32)) + 1024 + S;
     static constexpr int WPB = (SGX_WPB * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? SGX_WPB
@@ -166,6 +177,10 @@ struct KParams {
     int32_t xcd_first[8], xcd_count[8];   // workgroup-groups of this launch played by XCD x: [xcd_first[x], + xcd_count[x]) (group_of_block)
     int32_t nt_stores;  // the launch's observations do not fit the Infinity Cache: whole lines leave as non-temporal stores (sgx_obs.h)
     int32_t prio_mode;  // experiment (SGX_PRIO): wave priorities by the wave's slot on its SIMD, see stagger_priority
+    // A variant with more than 8 pieces of one type (the reference's piece_amounts is unbounded, config.py:3-23): a capture event counts to
+    // 8, so a ninth capture of one type on one cell opens ANOTHER event with the same (layer, cell) key.  Every reader of the list then
+    // sums the events of a key (the first one speaks for all); 0 for every variant of the reference, whose lists never hold duplicates.
+    int32_t multi_ev;
     // functional-API instantiation only (sgx_expand): game i is read from record src_index[i] (i when NULL) of ANOTHER handle's
     // records and written to record i of this one, whether or not the move was valid
     const int8_t *src_boards;
@@ -204,8 +219,8 @@ struct alignas(16) Lds {
     alignas(16) uint8_t occ[G::S];                     // gen_mask scratch: combined occupancy byte per cell
     alignas(16) typename G::cell_t plist[G::CNT_PAD];  // gen_mask scratch: compacted list of movable cells (also setup-shuffle scratch)
     alignas(16) uint8_t tail[G::TAIL_BYTES];           // record image from ST_OFF on: bitmaps, 32 B scalars, capture-event list
-    alignas(16) float unc_val[G::EVL_MAX + 4];         // entries of the observation being rendered whose value has no code:
-    alignas(16) typename G::entry_t unc_entry[(G::EVL_MAX + 4 + 7) & ~7];   //   the float / the entry index
+    alignas(16) float unc_val[G::EVL_MAX + G::SPECIAL_EXTRA];         // entries of the observation being rendered whose value has no code:
+    alignas(16) typename G::entry_t unc_entry[(G::EVL_MAX + G::SPECIAL_EXTRA + 7) & ~7];   //   the float / the entry index
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -232,6 +247,10 @@ template <class G>
 __device__ inline int4 *rec_scal(int8_t *boards, int rec_bytes, int64_t env) {
     return reinterpret_cast<int4 *>(boards + env * (int64_t)rec_bytes + G::SC_OFF);
 }
+
+// capacity of a game's capture-event list: the handle's (2 x pieces, at most one per cell), or every (layer, cell) pair in a general-state image
+template <class G>
+__device__ inline int max_events_of(const KParams &P) { return G::BIG ? (int)G::EVL_MAX : P.max_events; }
 
 // A value that is the same in every lane of a game: an SGPR when the game is the whole wave, left alone otherwise.
 template <class G>

@@ -47,6 +47,14 @@ __device__ inline bool special_entry(const Lds<G, NB> &L, int i, int n_events, i
         ch = Spec::CAP0 + (pi == qi ? 0 : 12) + t;
         v = (ev >> G::EV_COUNT_SHIFT) + 1;
         tab_idx = 16 * t + v;
+    } else if constexpr (G::BIG) {                // general-state image: every cell of the two dense recent-move boards
+        const int k = i - n_events, pl = k >= G::RC ? 1 : 0;
+        cell = k - pl * G::RC;
+        const int code = L.b[B_RECENT + pl][cell];
+        if (code == 0) return false;
+        ch = Spec::REC0 + (pl == qi ? 0 : 1);
+        v = code + 3;
+        tab_idx = CODETAB_REC + v;
     } else {
         const int k = i - n_events, pl = k >> 1, pr = (((pl ? rp1 : rp0) >> (16 * (k & 1))) & 0xFFFF);
         const int code = G::pair_code(pr);
@@ -60,12 +68,25 @@ __device__ inline bool special_entry(const Lds<G, NB> &L, int i, int n_events, i
     return true;
 }
 
+// Events of one (layer, cell) key when a variant has more than 8 pieces of a type (KParams::multi_ev): event i speaks for its key if no
+// earlier event has it; its count then is the sum over all events of the key.  Returns false for a later duplicate.
+template <class G, int NB>
+__device__ inline bool merged_event(const Lds<G, NB> &L, int i, int n_events, int &v) {
+    const typename G::ev_t *evl = reinterpret_cast<const typename G::ev_t *>(L.tail + 2 * G::SB + 32);
+    const int key = (int)(evl[i] & G::EV_KEY_MASK);
+    for (int j = 0; j < i; ++j)
+        if ((int)(evl[j] & G::EV_KEY_MASK) == key) return false;
+    for (int j = i + 1; j < n_events; ++j)
+        if ((int)(evl[j] & G::EV_KEY_MASK) == key) v += (int)(evl[j] >> G::EV_COUNT_SHIFT) + 1;
+    return true;
+}
+
 // Fills L.nib with the codes of Spec's observation from player index qi's perspective.  tmpl = the variant's default codes,
 // codetab = codes of captured counts / recent-move codes (both workgroup-shared LDS copies), glut = this kind's LUT in global
 // memory.  Returns the number of entries whose value has no code (L.unc_entry / L.unc_val; the same for every lane of the game).
 template <class G, class Spec, int NB>
 __device__ inline int build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uint8_t *codetab, const float *__restrict__ glut, int qi, int n_events,
-                                  int rp0, int rp1, int lane) {
+                                  int rp0, int rp1, int lane, const int32_t *piece_counts = nullptr, bool raw = false, bool multi = false) {
     constexpr int RC = G::RC, NCH = Spec::NCH, NBYTES = ((RC * NCH + 1) / 2 + 15) & ~15;
     static_assert(NBYTES <= Lds<G, NB>::NIB_BYTES, "code buffer too small for this observation kind");
     for (int i = lane; i < NBYTES / 16; i += G::LPG) reinterpret_cast<int4 *>(L.nib)[i] = reinterpret_cast<const int4 *>(tmpl)[i];
@@ -90,15 +111,32 @@ __device__ inline int build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uint
     // captured counts / recent-move codes: their code replaces the channel default; a value without a code gets CODE_ESC and
     // goes on the game's list of uncoded entries (float from the LUT in global memory: a few lanes, once per step)
     int n_unc = 0;
-    for (int i0 = 0; i0 < n_events + 4; i0 += G::LPG) {
+    for (int i0 = 0; i0 < n_events + G::SPECIAL_EXTRA; i0 += G::LPG) {
         const int i = i0 + lane;
         int entry = 0, ch, v, ti;
         bool unc = false;
         float val = 0.f;
-        if (i < n_events + 4 && special_entry<G, Spec>(L, i, n_events, rp0, rp1, qi, entry, ch, v, ti)) {
-            int now = codetab[ti];
-            const int was = codetab[i < n_events ? (ti & ~15) : CODETAB_REC + 3];   // the default: count 0 / code 0
-            if (now == CODE_NONE) { unc = true; now = CODE_ESC; val = glut[lut_row(ch) + v]; }
+        bool have = i < n_events + G::SPECIAL_EXTRA && special_entry<G, Spec>(L, i, n_events, rp0, rp1, qi, entry, ch, v, ti);
+        if (multi && have && i < n_events) {                       // (variants with more than 8 pieces of a type only)
+            have = merged_event(L, i, n_events, v);
+            ti = (ti & ~15) + (v < LUT_STRIDE ? v : 0);
+        }
+        if (have) {
+            int now, was;
+            if ((G::BIG || multi) && i < n_events && v >= LUT_STRIDE) {
+                // a count beyond the 16-entry LUT (general states only): the reference's arithmetic itself, (x - mid) / range in float32 with
+                // mid = range = hi / 2, hi = the type's piece count if > 1 else 8 (maenv:288-298, 506-508); raw observations hold the count
+                const int t = (ch - Spec::CAP0) % 12, pc = piece_counts[t];
+                const float hi = pc > 1 ? (float)pc : 8.0f, half = hi / 2.0f;
+                val = raw ? (float)v : __fdiv_rn(__fsub_rn((float)v, half), half);
+                now = CODE_NONE;
+                was = codetab[16 * t];
+            } else {
+                now = codetab[ti];
+                was = codetab[i < n_events ? (ti & ~15) : CODETAB_REC + 3];   // the default: count 0 / code 0
+                if (now == CODE_NONE) val = glut[lut_row(ch) + v];
+            }
+            if (now == CODE_NONE) { unc = true; now = CODE_ESC; }
             swap_code(L, entry, was, now);
         }
         const unsigned long long bal = gballot<G>(unc);
@@ -242,11 +280,24 @@ __device__ inline void patch_uncoded_floats(const Lds<G, NB> &L, float *__restri
 // 'original' kinds: the LUT path leaves the captured-count channels at their default; every capture event is written as a single
 // float afterwards (`lut` = this kind's LUT in global memory).  The caller has waited for the bulk stores of `dst`.
 template <class G, class Spec, int NB>
-__device__ inline void emit_obs_patches(const Lds<G, NB> &L, const float *__restrict__ lut, int qi, float *__restrict__ dst, int n_events, int lane) {
+__device__ inline void emit_obs_patches(const Lds<G, NB> &L, const float *__restrict__ lut, int qi, float *__restrict__ dst, int n_events, int lane,
+                                        bool raw = false, bool multi = false, const int32_t *piece_counts = nullptr) {
     static_assert(!Spec::CODES, "");
     for (int i = lane; i < n_events; i += G::LPG) {
         int entry, ch, v, ti;
-        if (special_entry<G, Spec>(L, i, n_events, 0, 0, qi, entry, ch, v, ti)) dst[entry] = lut[lut_row(ch) + v];
+        if (special_entry<G, Spec>(L, i, n_events, 0, 0, qi, entry, ch, v, ti)) {
+            if (multi && !merged_event(L, i, n_events, v)) continue;
+            float val;
+            if (v < LUT_STRIDE) val = lut[lut_row(ch) + v];
+            else {
+                // beyond the 16-entry LUT (more than 8 pieces of a type only): the reference's arithmetic, (x - mid) / range with
+                // mid = range = hi / 2, hi = the type's piece count if > 1 else 2 in the 'original' channel modes (maenv:87-199)
+                const int pc = piece_counts[(ch - Spec::CAP0) % 12];
+                const float half = (pc > 1 ? (float)pc : 2.0f) / 2.0f;
+                val = raw ? (float)v : __fdiv_rn(__fsub_rn((float)v, half), half);
+            }
+            dst[entry] = val;
+        }
     }
 }
 

@@ -34,16 +34,18 @@ constexpr int waves_per_simd() {
 
 // One more captured piece on layer / cell `key` ((12 * pi + type - 1) << CELL_BITS | cell): the count of its event goes up, or a new event
 // is appended.  Returns the new number of events.
+// multi (KParams::multi_ev): a full event of the key does not count as found -- the capture opens another event with the same key
 template <class G, int NB>
-__device__ inline int add_capture(Lds<G, NB> &L, int n_events, int max_events, int key, int lane) {
+__device__ inline int add_capture(Lds<G, NB> &L, int n_events, int max_events, int key, int lane, bool multi = false) {
     using ev_t = typename G::ev_t;
     ev_t *evl = reinterpret_cast<ev_t *>(L.tail + 2 * G::SB + 32);
     bool found = false;
     for (int i0 = 0; i0 < n_events; i0 += G::LPG) {                    // (wave-uniform bound for a 64-lane game)
         const int i = i0 + lane;
-        const bool hit = i < n_events && (int)(evl[i] & G::EV_KEY_MASK) == key;
-        if (hit && (int)(evl[i] >> G::EV_COUNT_SHIFT) < EV_COUNT_MAX - 1) evl[i] = (ev_t)(evl[i] + (1 << G::EV_COUNT_SHIFT));
-        found = found || gballot<G>(hit) != 0ull;
+        const bool match = i < n_events && (int)(evl[i] & G::EV_KEY_MASK) == key;
+        const bool room = match && (int)(evl[i] >> G::EV_COUNT_SHIFT) < G::COUNT_MAX - 1;
+        if (room) evl[i] = (ev_t)(evl[i] + (1 << G::EV_COUNT_SHIFT));
+        found = found || gballot<G>(multi ? room : match) != 0ull;
     }
     if (!found && n_events < max_events) {
         if (lane == 0) evl[n_events] = (ev_t)key;
@@ -74,10 +76,17 @@ __device__ inline void write_record(Lds<G, NB> &L, int8_t *rec_g, int rec_bytes,
         reinterpret_cast<int4 *>(L.tail + 2 * G::SB)[0] = sc0;
         reinterpret_cast<int4 *>(L.tail + 2 * G::SB)[1] = sc1;
     }
+    if constexpr (G::BIG) {                          // the recent-move boards stay dense in a general-state record image
+        for (int i = lane; i < G::S_PAD; i += G::LPG) {
+            L.tail[G::RECB_OFF - G::ST_OFF + i] = i < S ? (uint8_t)L.b[B_RECENT][i] : 0;
+            L.tail[G::RECB_OFF - G::ST_OFF + G::S_PAD + i] = i < S ? (uint8_t)L.b[B_RECENT + 1][i] : 0;
+        }
+        for (int i = n_events + lane; i < G::EVL_MAX; i += G::LPG) reinterpret_cast<typename G::ev_t *>(L.tail + 2 * G::SB + 32)[i] = 0;
+    }
     wave_sync<G>();
     const int4 *bsrc = reinterpret_cast<const int4 *>(&L.b[0][0]), *tsrc = reinterpret_cast<const int4 *>(L.tail);
     int4 *dst = reinterpret_cast<int4 *>(rec_g);
-    const int n_tail_q = (2 * G::SB + 32 + G::EV_BYTES * n_events + 15) >> 4;  // tail int4s that carry data
+    const int n_tail_q = G::BIG ? G::TAIL_BYTES / 16 : (2 * G::SB + 32 + G::EV_BYTES * n_events + 15) >> 4;  // tail int4s that carry data
     for (int i = lane; i < rec_bytes / 16; i += G::LPG) {
         int4 v = make_int4(0, 0, 0, 0);
         if (i < G::ST_OFF / 16) {
@@ -101,10 +110,10 @@ struct GameInput {
 template <class G>
 __device__ __forceinline__ GameInput load_game_from(const KParams &P, const int4 *src, const int64_t env, const int lane) {
     constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + G::LPG - 1) / G::LPG;
-    static_assert(G::TAIL_BYTES % 16 == 0 && (NLOAD <= 2 || G::WIDE), "record image must fit two int4 per lane");
+    static_assert(G::TAIL_BYTES % 16 == 0 && (NLOAD <= 2 || G::WIDE || G::BIG), "record image must fit two int4 per lane");
     const int4 zero4 = make_int4(0, 0, 0, 0);
     GameInput in{zero4, zero4, zero4, 0, src};
-    const int nq = min(P.rec_bytes >> 4, Q_REC);
+    const int nq = G::BIG ? Q_REC : min(P.rec_bytes >> 4, Q_REC);
     if constexpr (NLOAD <= 2) {
         if (lane < nq) in.rq0 = src[lane];
         if constexpr (NLOAD > 1)
@@ -134,10 +143,10 @@ struct StepOut {
 // `shared` = the workgroup's tables (shared_table_bytes): templates + code table, or LUTs + quad tables
 // SPLIT: the next mover's mask and observations are NOT emitted here -- the caller does it with the whole workgroup from the LDS
 // state this function leaves behind and the scalars in *so.
-template <int R_, int C_, int KIND, bool MAPPED, bool SPLIT = false>
-__device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsKind<KIND>::NIB_CH> &L, const uint8_t *shared, const uint8_t *obst_s,
+template <int R_, int C_, int KIND, bool MAPPED, bool SPLIT = false, int VAR = 0>
+__device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>, ObsKind<KIND>::NIB_CH> &L, const uint8_t *shared, const uint8_t *obst_s,
                                          const int64_t env, const int lane, const GameInput &in, int8_t *rec_out = nullptr, StepOut *so = nullptr) {
-    using G = Geo<R_, C_>;
+    using G = Geo<R_, C_, VAR>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
     constexpr bool ORIG = ObsKind<KIND>::ORIG, FULL = ObsKind<KIND>::FULL;
@@ -172,7 +181,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
                 else if (lane + G::LPG < Q_REC) tl[lane + G::LPG - Q_BOARDS] = rq1;
             }
         } else {                                              // WIDE boards: the record is several KiB, staged in a loop
-            const int nq = min(P.rec_bytes >> 4, Q_REC);
+            const int nq = G::BIG ? Q_REC : min(P.rec_bytes >> 4, Q_REC);
             for (int i = lane; i < Q_REC; i += G::LPG) {
                 const int4 v = i < nq ? in.src[i] : make_int4(0, 0, 0, 0);
                 if (i < Q_BOARDS) dst[i] = v;
@@ -197,7 +206,12 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
                 L.b[B_STILL + 1][i] = (int8_t)((stb[G::SB / 4 + (i >> 5)] >> (i & 31)) & 1u);
             }
         }
-        if (lane < 4) {
+        if constexpr (G::BIG) {                      // general-state image: the recent-move boards are dense
+            for (int i = lane; i < S; i += G::LPG) {
+                L.b[B_RECENT][i] = (int8_t)L.tail[G::RECB_OFF - G::ST_OFF + i];
+                L.b[B_RECENT + 1][i] = (int8_t)L.tail[G::RECB_OFF - G::ST_OFF + G::S_PAD + i];
+            }
+        } else if (lane < 4) {
             const int pr = (((lane >> 1) ? rp1 : rp0) >> (16 * (lane & 1))) & 0xFFFF;
             if (pr >> G::CELL_BITS) L.b[B_RECENT + (lane >> 1)][G::pair_cell(pr)] = (int8_t)G::pair_code(pr);
         }
@@ -334,8 +348,8 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
                 }
                 if (dest != 0) {
                     // captured counts (impl:999-1009): the attacker's own layer unless it won, the defender's if it lost or tied
-                    if (!wins) n_events = add_capture(L, n_events, P.max_events, ((12 * pi + moved - 1) << G::CELL_BITS) | e, lane);
-                    if (wins || tied) n_events = add_capture(L, n_events, P.max_events, ((12 * (1 - pi) + dest - 1) << G::CELL_BITS) | e, lane);
+                    if (!wins) n_events = add_capture(L, n_events, max_events_of<G>(P), ((12 * pi + moved - 1) << G::CELL_BITS) | e, lane, P.multi_ev != 0);
+                    if (wins || tied) n_events = add_capture(L, n_events, max_events_of<G>(P), ((12 * (1 - pi) + dest - 1) << G::CELL_BITS) | e, lane, P.multi_ev != 0);
                     if (pi) rp1 = 0; else rp0 = 0;                                       // an attack wipes the mover's layer
                 } else {
                     const int code = old_end == 1 ? (old_start == -2 ? -3 : -2) : -1;
@@ -396,7 +410,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
             const uint8_t *tmpl = full ? shared + tmpl_lds_bytes<G, KIND>(false) : shared;
             if constexpr (G::WIDE) tmpl = P.tab->tmpl[(raw ? 2 : 0) + (full ? 1 : 0)];           // (global memory, L2-resident)
             const int n_unc = build_codes<G, Spec>(L, tmpl, codetab, full ? glut_f : glut_p, q,
-                                                   n_events, rp0, rp1, lane);
+                                                   n_events, rp0, rp1, lane, P.piece_counts, raw, P.multi_ev != 0);
             if constexpr (RC % 4 == 0) {
                 if (n_unc == 0) {
                     if (P.nt_stores) emit_codes<G, Spec, false, true>(L, dst, lane);
@@ -420,7 +434,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
             emit_obs_lut<G, Spec>(L, reinterpret_cast<const float *>(shared) + (full ? OBS_TAB_DWORDS : 0), q, dst, lane);
             if (n_events > 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                emit_obs_patches<G, Spec>(L, full ? glut_f : glut_p, q, dst, n_events, lane);
+                emit_obs_patches<G, Spec>(L, full ? glut_f : glut_p, q, dst, n_events, lane, raw, P.multi_ev != 0, P.piece_counts);
             }
             return 0;
         }
@@ -481,7 +495,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_>, ObsK
     // ---- write the record back as whole 128-byte lines: dense boards, scalars, capture events.  (Scattered stores
     //      of only the <= 9 touched bytes + 32 B of scalars are partial-line writes: measured 7 % slower.)
     if (applied || wrote_reset || (MAPPED && P.src_boards))
-        write_record(L, rec_g, P.rec_bytes, make_int4(turn, flags, max_turns, game_no), make_int4(n_events, rp0, rp1, 0), n_events, lane);
+        write_record(L, rec_g, G::BIG ? (int)G::IMG_BYTES : P.rec_bytes, make_int4(turn, flags, max_turns, game_no), make_int4(n_events, rp0, rp1, 0), n_events, lane);
     STAMP(8);   // write-back issued
 #ifdef SGX_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -594,7 +608,7 @@ __global__ __launch_bounds__(64 * SINGLE_WAVES) void single_kernel(const KParams
         using Spec = decltype(spec);
         if (wave == 0) {
             const int n_unc = build_codes<G, Spec>(L, full ? shared + NP : shared, codetab, P.tab->lut[(raw ? 2 : 0) + (full ? 1 : 0)], so.qi,
-                                                   so.n_events, so.rp0, so.rp1, lane);
+                                                   so.n_events, so.rp0, so.rp1, lane, P.piece_counts, raw, P.multi_ev != 0);
             if (lane == 0) so.n_unc = n_unc;
         }
         __syncthreads();

@@ -118,6 +118,8 @@ struct sgx_env {
     uint32_t *sync_flag_host, *sync_flag_dev, *sync_count;
     uint32_t sync_seq;
     int no_single;               // SGX_NO_SINGLE=1: sgx_step_sync never takes the single_kernel path (A/B measurements)
+    uint8_t *san_flags;          // sgx_step_states: per-state "had to be altered" flags when the caller passes none (created on first use)
+    int general_states;          // sgx_set_general_states: 0 = flagged states stay sanitised, otherwise the second, general-state pass redoes them
 };
 
 namespace {
@@ -167,6 +169,8 @@ KParams make_params(const sgx_env *h) {
     for (int i = 0; i < 12; ++i) p.piece_counts[i] = h->cfg.piece_counts[i];
     p.rec_bytes = h->rec_bytes;
     p.max_events = h->max_events;
+    for (int i = 0; i < 12; ++i)
+        if (h->cfg.piece_counts[i] > EV_COUNT_MAX) p.multi_ev = 1;
     p.n_envs = h->n_envs;
     p.seed = h->seed;
     p.env_id_offset = h->env_id_offset;
@@ -183,8 +187,8 @@ int check_cfg(const sgx_config *cfg) {
     if (cfg->usable_rows < 1 || cfg->usable_rows * 2 > cfg->rows) return fail(SGX_EINVAL, "usable_rows out of range%s");
     for (int i = 0; i < 12; ++i) {
         if (cfg->piece_counts[i] < 0) return fail(SGX_EINVAL, "negative piece count%s");
-        // a capture event counts the pieces of one type captured on one cell in 3 bits (sgx_layout.h): 8 = the scouts of Standard
-        if (cfg->piece_counts[i] > EV_COUNT_MAX) return fail(SGX_EINVAL, "more than 8 pieces of one type per side%s");
+        // (a capture event counts to 8 = the scouts of Standard; a variant with more pieces of one type chains events: KParams::multi_ev)
+        if (cfg->piece_counts[i] > SGX_MAX_PIECES_PER_TYPE) return fail(SGX_EINVAL, "more than 127 pieces of one type per side%s");
     }
     // (more pieces than usable cells is legal for a handle that never samples random setups: an env_config that overrides
     //  'piece_amounts' changes the normalisation only; sgx_reset checks it where it matters)
@@ -367,6 +371,8 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
         else if (!strcmp(e, "1")) h->nt_mode = 1;
     }
     h->lane_mode = -1;
+    h->general_states = 1;
+    if (const char *e = getenv("SGX_GENERAL_STATES")) h->general_states = atoi(e);
     if (const char *e = getenv("SGX_LANE")) { if (!strcmp(e, "0")) h->lane_mode = 0; else if (!strcmp(e, "1")) h->lane_mode = 1; }   // SGX_LANE=0|1|auto
     if (const char *e = getenv("SGX_PRIO")) h->prio_mode = atoi(e);
     h->xcd_skew = -1;
@@ -445,6 +451,7 @@ SGX_API int sgx_destroy(sgx_env *h) {
     if (h->chain_fork) (void)hipEventDestroy(h->chain_fork);
     if (h->sync_flag_host) (void)hipHostFree(h->sync_flag_host);
     if (h->sync_count) (void)hipFree(h->sync_count);
+    if (h->san_flags) (void)hipFree(h->san_flags);
     delete h;
     return SGX_OK;
 }
@@ -457,6 +464,12 @@ SGX_API int sgx_set_nt_stores(sgx_env *h, int32_t mode) {
 
 // experiment, not part of the ABI header's contract: wave priorities by SIMD slot (0 = off)
 SGX_API int sgx_debug_set_prio(sgx_env *h, int32_t mode) { if (h) h->prio_mode = mode; return SGX_OK; }
+
+SGX_API int sgx_set_general_states(sgx_env *h, int32_t mode) {
+    if (!h || mode < 0 || mode > 1) return fail(SGX_EINVAL, "sgx_set_general_states: mode must be 0 or 1%s");
+    h->general_states = mode;
+    return SGX_OK;
+}
 
 SGX_API int sgx_set_lane_kernel(sgx_env *h, int32_t mode) {
     if (!h || mode < -1 || mode > 1) return fail(SGX_EINVAL, "sgx_set_lane_kernel: mode must be -1 (auto), 0 or 1%s");
@@ -565,7 +578,9 @@ static void launch_shares(const sgx_env *h, bool streaming, int32_t *w) {
 static bool lane_eligible(const sgx_env *h, const KParams &p, bool full, bool original) {
     const int cells = h->cfg.rows * h->cfg.cols;
     auto aligned = [](const void *ptr, uintptr_t a) { return (reinterpret_cast<uintptr_t>(ptr) & (a - 1)) == 0; };
-    return h->lane_mode != 0 && cells <= 16 && cells % 4 == 0 && !full && !original && h->map_mode == 0 &&
+    // -1 (auto): only where it is the faster kernel -- launches that emit no observation (2 x on Micro / Tiny)
+    if (h->lane_mode < 0 && p.io.obs_dev) return false;
+    return h->lane_mode != 0 && !p.multi_ev && cells <= 16 && cells % 4 == 0 && !full && !original && h->map_mode == 0 &&
            !(p.io.flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) && !p.src_boards && !p.io.final_obs_dev && !p.io.final_fobs_dev &&
            (h->rec_bytes == 128 || h->rec_bytes == 256) && (p.env_first & 63) == 0 &&
            aligned(p.io.obs_dev, 16) && aligned(p.io.mask_dev, 16) && aligned(p.io.reward_dev, 8) && aligned(p.io.actions_dev, 16);
@@ -1125,20 +1140,38 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
         p.nt_stores = h->nt_mode < 0 ? (launch_streams_past_cache(h, p) ? 1 : 0) : h->nt_mode;
         const bool mapped = (io->flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) != 0;
         const bool obs = io->obs_dev || io->final_obs_dev;
-#define CALL_STATES_K(R, C, M, O) states_kernel<R, C, M, O><<<grid, states_threads<M, O>(), 0, (hipStream_t)stream>>>(p, state_in_dev, player_in_dev, sanitised_dev, state_out_dev, player_out_dev, nt)
-#define CALL_STATES(R, C)                                                                                                   \
+        // Second pass (sgx_set_general_states, on by default): the states the first pass had to alter -- more than two recent-move cells per
+        // player, more capture cells than pieces, more than 8 captures on a cell: things play cannot produce but penv's pure functions
+        // accept -- are redone from the caller's int64 input on the general-state variant of the geometry (Geo<R, C, 1>); every other
+        // block of that launch leaves at once.  It needs the flags even when the caller did not ask for them.
+        const bool general = h->general_states != 0;
+        uint8_t *flags_dev = sanitised_dev;
+        if (general && !flags_dev) {
+            if (!h->san_flags) HIP_TRY(hipMalloc((void **)&h->san_flags, (size_t)h->n_envs));
+            flags_dev = h->san_flags;
+        }
+#define CALL_STATES_K(R, C, M, O, V) states_kernel<R, C, M, O, V><<<grid, states_threads<M, O>(), 0, (hipStream_t)stream>>>(p, state_in_dev, player_in_dev, flags_dev, state_out_dev, player_out_dev, nt)
+#define CALL_STATES_V(R, C, V)                                                                                              \
     do {                                                                                                                    \
         if constexpr (Geo<R, C>::LPG == 64 && !Geo<R, C>::WIDE) {                                                           \
-            if (mapped && obs) CALL_STATES_K(R, C, true, true);                                                             \
-            else if (mapped) CALL_STATES_K(R, C, true, false);                                                              \
-            else if (obs) CALL_STATES_K(R, C, false, true);                                                                 \
-            else CALL_STATES_K(R, C, false, false);                                                                         \
+            if (mapped && obs) CALL_STATES_K(R, C, true, true, V);                                                          \
+            else if (mapped) CALL_STATES_K(R, C, true, false, V);                                                           \
+            else if (obs) CALL_STATES_K(R, C, false, true, V);                                                              \
+            else CALL_STATES_K(R, C, false, false, V);                                                                      \
         }                                                                                                                   \
     } while (0)
+#define CALL_STATES(R, C) CALL_STATES_V(R, C, 0)
+#define CALL_STATES_BIG(R, C) CALL_STATES_V(R, C, 1)
         DISPATCH_GEOMETRY(h, CALL_STATES);
-#undef CALL_STATES
-#undef CALL_STATES_K
         HIP_TRY(hipGetLastError());
+        if (general) {
+            DISPATCH_GEOMETRY(h, CALL_STATES_BIG);
+            HIP_TRY(hipGetLastError());
+        }
+#undef CALL_STATES
+#undef CALL_STATES_BIG
+#undef CALL_STATES_V
+#undef CALL_STATES_K
         return SGX_OK;
     }
     if (chains == 1) {

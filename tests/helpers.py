@@ -109,3 +109,35 @@ def directed_positions():
             states.append(st); players.append(mover)
             actions.append(ru.action_size - 1)
     return np.stack(states), np.asarray(players, dtype=np.int8), np.asarray(actions, dtype=np.int64)
+
+
+def general_states(name, n, rs):
+    """Random int64 states whose values stay inside each layer's legal range but that play cannot produce: many recent-move cells,
+    captured counts far beyond the pieces (up to 40 on a cell), capture cells everywhere, stale flags, pieces of both players mixed
+    over the whole board (never two on one cell, never on a lake)."""
+    v = VARIANTS[name]
+    R, C = v.rows, v.columns
+    obst = np.zeros((R, C), dtype=np.int64)
+    for r, c in v.obstacle_locations:
+        obst[r, c] = 1
+    states = np.zeros((n, 34, R, C), dtype=np.int64)
+    players = rs.choice([1, -1], size=n).astype(np.int8)
+    for e in range(n):
+        st = states[e]
+        st[2] = obst
+        owner = rs.choice([0, 1, 2], size=(R, C), p=[0.55, 0.225, 0.225]) * (1 - obst)
+        types = rs.choice(np.arange(1, 13), size=(R, C), p=[.06, .2, .1, .08, .08, .08, .08, .08, .06, .06, .06, .06])
+        for pi in (0, 1):
+            mine = owner == pi + 1
+            st[pi] = np.where(mine, types, 0)
+            st[3 + pi] = np.where(mine, np.where(rs.rand(R, C) < 0.5, 13, types), 0)
+            st[32 + pi] = np.where(mine, rs.randint(0, 2, size=(R, C)), rs.rand(R, C) < 0.05)
+            st[6 + pi] = np.where(rs.rand(R, C) < 0.15, rs.choice([-3, -2, -1, 1], size=(R, C)), 0)
+        st[8:32] = np.where(rs.rand(24, R, C) < 0.08, rs.choice([1, 2, 3, 5, 8, 9, 15, 16, 17, 40], size=(24, R, C)), 0)
+        st[5, 0, 0] = rs.randint(0, v.max_turns - 1)
+        st[5, 1, 0] = v.max_turns
+        if rs.rand() < 0.1:
+            st[5, 0, 1] = 1
+            st[5, 0, 2] = rs.choice([1, -1, 0])
+            st[5, 1, 1] = int(st[5, 0, 2] == 0)
+    return states, players

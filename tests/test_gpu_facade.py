@@ -388,5 +388,10 @@ def test_facade_env_config_overrides_replay_reference_goldens():
     with pytest.raises(ValueError):
         env.reset()
     env.close()
-    with pytest.raises(ValueError):     # more than 8 pieces of one type: outside the packed record's capture counts
-        StrategoMultiAgentEnv({'version': GameVersions.STANDARD, 'piece_amounts': {SP.SCOUT: 9, SP.FLAG: 1}})
+    # more than 8 pieces of one type (the reference's dict is unbounded): accepted -- here, as in the reference, only the normalisation changes
+    env = StrategoMultiAgentEnv({'version': GameVersions.STANDARD, 'piece_amounts': {SP.SCOUT: 9, SP.FLAG: 1},
+                                 'observation_mode': ObservationModes.PARTIALLY_OBSERVABLE})
+    assert float(np.asarray(env._p_obs_ranges).reshape(-1)[41 + 1]) == 4.5 and float(np.asarray(env._p_obs_mids).reshape(-1)[53 + 1]) == 4.5
+    obs = env.reset()
+    assert obs[1]['partial_observation'].shape == (10, 10, 67)
+    env.close()

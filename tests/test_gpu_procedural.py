@@ -5,7 +5,7 @@ import pytest
 
 from oracle import oracle as orc
 from stratego_env_amd.config import VARIANTS
-from tests.helpers import load_games, oracle_cvariant, oracle_env
+from tests.helpers import general_states, load_games, oracle_cvariant, oracle_env
 from tests.test_gpu_parity import _table
 
 pytestmark = pytest.mark.gpu
@@ -251,13 +251,18 @@ def test_import_reports_sanitised_states_and_strict_mode_raises():
     bad[4, 10] = 3                       # 300 captured pieces
     bad[5, 33, 2, 2] = 7                 # never-moved flag that is not 0 / 1
     penv = BatchedStrategoProceduralEnv('barrage', n)
-    penv.get_valid_moves_as_1d_mask(bad, players)
+    m = penv.get_valid_moves_as_1d_mask(bad, players).cpu().numpy()
     flags = penv.last_sanitised.cpu().numpy()
-    assert flags.tolist() == [0, 1, 1, 1, 1, 1] + [0] * (n - 6)
+    # round 4: the one-call functional API redoes states 2 and 4 on the general-state kernels (legal values, impossible structure) -- they
+    # come back exact and unflagged; values outside a layer's range and a foreign obstacle stay flagged
+    assert flags.tolist() == [0, 1, 0, 1, 0, 1] + [0] * (n - 6)
+    ru = orc.OracleRules(10, 10)
+    for e in (2, 4):
+        assert np.array_equal(m[e], ru.get_valid_moves_as_1d_mask(bad[e].cpu().numpy(), int(players[e])))
     penv.get_valid_moves_as_1d_mask(states, players)
     assert int(penv.last_sanitised.sum()) == 0
-    packed = penv.pack(bad, players)
-    assert packed.sanitised.cpu().numpy().tolist() == flags.tolist()
+    packed = penv.pack(bad, players)            # packed records (search pools) still carry reachable states only: all five flagged
+    assert packed.sanitised.cpu().numpy().tolist() == [0, 1, 1, 1, 1, 1] + [0] * (n - 6)
     penv.strict = True
     with pytest.raises(ValueError):
         penv.get_valid_moves_as_1d_mask(bad, players)
@@ -359,3 +364,70 @@ def test_heuristic_rewards_match_reference_golden():
     got = penv.get_heuristic_rewards_from_move(states, players, actions, rm).cpu().numpy()
     assert np.array_equal(got, np.asarray(g['rewards'], dtype=np.float32))
     penv.close()
+
+
+@pytest.mark.parametrize('name', ['barrage', 'medium', 'octa_barrage', 'standard2'])
+def test_general_states_are_reproduced_not_sanitised(name):
+    """penv's pure functions accept ANY int64 [34,R,C] (penv:74-155).  States the packed record cannot carry are redone by
+    sgx_step_states' second pass on the general-state variant of the kernels: next state, validity, both mask encodings and the raw
+    partial observation equal OracleRules', and no state comes back flagged."""
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    v = VARIANTS[name]
+    rs = np.random.RandomState(23)
+    n = 64 if name != 'standard2' else 24
+    states, players = general_states(name, n, rs)
+    ru = orc.OracleRules(v.rows, v.columns)
+    pe = BatchedStrategoProceduralEnv(name, n)
+    # the first pass alone would have flagged every one of them
+    san = __import__('torch').zeros(n, dtype=__import__('torch').uint8, device=pe.device)
+    pe._vec.import_state_checked(states, players, san)
+    assert int(san.sum()) == n
+    for pl_all in (players, -players):
+        m1 = pe.get_valid_moves_as_1d_mask(states, pl_all).cpu().numpy()
+        assert int(pe.last_sanitised.sum()) == 0
+        ms = pe.get_valid_moves_as_spatial_mask(states, pl_all).cpu().numpy()
+        assert int(pe.last_sanitised.sum()) == 0
+        po = pe.get_partially_observable_observation_extended_channels(states, pl_all).cpu().numpy()
+        assert int(pe.last_sanitised.sum()) == 0
+        for e in range(n):
+            p = int(pl_all[e])
+            assert np.array_equal(m1[e], ru.get_valid_moves_as_1d_mask(states[e], p)), (name, e, '1d mask')
+            assert np.array_equal(ms[e], ru.get_valid_moves_as_spatial_mask(states[e], p)), (name, e, 'spatial mask')
+            assert po[e].tobytes() == ru.get_partially_observable_observation_extended_channels(states[e], p).tobytes(), (name, e, 'obs')
+    n_valid = 0
+    for rnd in range(5):
+        acts = np.zeros(n, dtype=np.int64)
+        for e in range(n):
+            mask = ru.get_valid_moves_as_1d_mask(states[e], int(players[e]))
+            acts[e] = rs.choice(np.flatnonzero(mask)) if rs.rand() < 0.7 else rs.randint(-3, ru.action_size + 3)
+        for osc in (False, True):
+            ns, npl, valid = pe.get_next_state(states, players, acts, allow_piece_oscillation=osc)
+            assert int(pe.last_sanitised.sum()) == 0
+            ns, npl, valid = ns.cpu().numpy(), npl.cpu().numpy(), valid.cpu().numpy()
+            v2 = pe.is_move_valid_by_1d_index(states, players, acts, allow_piece_oscillation=osc).cpu().numpy()
+            for e in range(n):
+                want_valid = ru.is_move_valid_by_1d_index(states[e], int(players[e]), int(acts[e]), allow_piece_oscillation=osc)
+                assert bool(valid[e]) == want_valid == bool(v2[e]), (name, rnd, e, acts[e], osc)
+                if want_valid:
+                    n_valid += 1
+                    w, wp = ru.get_next_state(states[e], int(players[e]), int(acts[e]), allow_piece_oscillation=osc)
+                    assert np.array_equal(ns[e], w) and npl[e] == wp, (name, rnd, e, 'next state', np.argwhere(ns[e] != w)[:4])
+                else:
+                    assert np.array_equal(ns[e], states[e]) and npl[e] == players[e]
+    assert n_valid > n
+    pos = rs.randint(-1, max(v.rows, v.columns) + 1, size=(n, 4))
+    got = pe.is_move_valid_by_position(states, players, pos[:, 0], pos[:, 1], pos[:, 2], pos[:, 3]).cpu().numpy()
+    for e in range(n):
+        assert bool(got[e]) == ru.is_move_valid_by_position(states[e], int(players[e]), *[int(x) for x in pos[e]])
+    # values outside a layer's range stay flagged (and only those)
+    bad = states.copy()
+    bad[0, 0, 0, 0] = 14
+    bad[1, 9, 1, 1] = -1
+    pe.get_valid_moves_as_1d_mask(bad, players)
+    flagged = pe.last_sanitised.cpu().numpy()
+    assert flagged[0] == 1 and flagged[1] == 1 and int(flagged.sum()) == 2
+    # switched off, every such state is flagged again
+    pe._vec._L.sgx_set_general_states(pe._vec._h, 0)
+    pe.get_valid_moves_as_1d_mask(states, players)
+    assert int(pe.last_sanitised.sum()) == n
+    pe.close()
