@@ -50,11 +50,13 @@ def test_custom_variants_and_geometry_libraries():
     from stratego_env_amd.config import custom_variant, get_variant, VARIANTS
     v = custom_variant(7, 9)
     assert (v.rows, v.columns, v.initial_state_usable_rows) == (7, 9, 3) and v.piece_counts[10] == 1
-    # one of every type, then scouts up to 8 per type (what a capture event of the packed record counts to): 19 of the 27 cells
+    # one of every type, then scouts up to 8 like Standard: 19 of the 27 cells
     assert sum(v.piece_counts) == 19 and max(v.piece_counts) == v.piece_counts[1] == 8
     assert sum(custom_variant(5, 5).piece_counts) == 10
+    # more than 8 pieces of one type are accepted (chained capture events, round 4); 128 are not
+    assert custom_variant(10, 10, piece_counts=(0, 9, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0)).piece_counts[1] == 9
     with pytest.raises(ValueError):
-        custom_variant(10, 10, piece_counts=(0, 9, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0))
+        custom_variant(32, 32, piece_counts=(0, 128, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0))
     assert v.spatial_channels == 2 * 6 + 2 * 8 + 1 and v.action_size == 63 * 16 + 1 and get_variant(v) is v
     w = custom_variant(3, 3, max_turns=10, obstacle_locations=[(1, 1)], piece_counts=(0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0))
     assert w.obstacle_map()[1, 1] == 1 and w.pieces_per_side == 2 and w.max_turns == 10

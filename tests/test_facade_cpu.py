@@ -89,5 +89,6 @@ def test_env_config_overrides_follow_the_reference_merge():
     assert v.captured_count_highs()[1] == 3 and v.captured_count_highs()[0] == 8
     v, setup = resolve_variant({'version': GameVersions.TINY, 'rows': 5, 'columns': 4})
     assert (v.rows, v.columns) == (5, 4) and (setup.rows, setup.columns) == (4, 4)
-    with pytest.raises(ValueError):
-        resolve_variant({'version': GameVersions.STANDARD, 'piece_amounts': {SP.SCOUT: 9, SP.FLAG: 1}})
+    # more than 8 pieces of one type: accepted since round 4 (chained capture events); the reference's dict is unbounded
+    v, setup = resolve_variant({'version': GameVersions.STANDARD, 'piece_amounts': {SP.SCOUT: 9, SP.FLAG: 1}})
+    assert v.piece_counts[1] == 9 and v.captured_count_highs()[1] == 9 and setup.piece_counts == VARIANTS['standard'].piece_counts
