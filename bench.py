@@ -423,9 +423,10 @@ class _StubEnv:
         return [self.steps_done * self.n, 0]
 
 
-def make_env(version, n, first, device_index, full_obs=False):
+def make_env(version, n, first, device_index, full_obs=False, compact=False):
     from stratego_env_amd.vec_env import VecStrategoEnv
-    env = VecStrategoEnv(version, n, device=device_index, seed=BASE_SEED, env_id_offset=first, auto_reset=True, full_obs=full_obs)
+    env = VecStrategoEnv(version, n, device=device_index, seed=BASE_SEED, env_id_offset=first, auto_reset=True, full_obs=full_obs,
+                         compact_outputs=compact)
     env.reset()
     env.bench_steps_played = 0               # rollout steps since reset(): what the oracle replays in verify_against_oracle
     return env
@@ -504,7 +505,10 @@ def verify_against_oracle(env, version, n_check, both=False):
     orc, cv = oracle_variant(version)
     ids = np.unique(np.concatenate([[0, env.num_envs - 1], np.linspace(0, env.num_envs - 1, n_check).astype(np.int64)]))[:max(n_check, 2)]
     idx = torch.from_numpy(ids).to(env.device)
-    mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
+    if getattr(env, 'compact', False):             # compact outputs: what the decode ops make of them is what must equal the oracle
+        mk, ob = env.decode_mask()[idx].cpu().numpy(), env.decode_obs()[idx].cpu().numpy()
+    else:
+        mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
     fo = env.fobs[idx].cpu().numpy() if both else None
     rw, dn, pl = env.reward[idx].cpu().numpy(), env.done[idx].cpu().numpy(), env.player[idx].cpu().numpy()
     ei, info = env.ending_invalid[idx].cpu().numpy(), env.env_info()[idx].cpu().numpy()
@@ -564,7 +568,7 @@ def placement_budgets(args, budget):
 def place_outputs(env, args):
     """Library-owned output buffers from sgx_alloc_outputs' bounded placement trial, unless --placement plain.
     -> {'candidates', 'plain_us' (the allocation a caller would have got first), 'kept_us', 'median_us', 'max_us', 'peak_extra_gb'}."""
-    if args.placement != 'trial':
+    if args.placement != 'trial' or getattr(env, 'compact', False):
         return None
     # No candidate of the fast class (>= 14 % below the slowest, DESIGN.md section 4) in the first budget: tune_placement's second pass
     # samples a much wider range with the same number of candidates and is kept only if it found something faster.  (One box: 32
@@ -746,6 +750,47 @@ def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_
                 "default_policy_at_this_size": "nt_stores (observation bytes per launch > 300 MB)",
                 "nt_over_plain_step_kernel": nt["step_kernel_us_in_loop"] / plain["step_kernel_us_in_loop"],
                 "verified_envs": int(len(ids)), "verified_steps": played, "placement": trial}
+    finally:
+        env.close()
+        del env
+        torch.cuda.empty_cache()
+
+
+def compact_leg(rk, args, version='barrage', n=GAMES_1GPU, seconds=0.5, verify=8):
+    """Opt-in compact outputs (SGX_STEP_COMPACT_OBS / _MASK; never the headline): the same rollout writing 4-bit codes + mask bits -- 1/8 of
+    the bytes per step -- and, separately, the decode ops that expand a batch to the contract's float32 observation / uint8 mask.
+    Verified like every leg (the DECODED last step against the oracle)."""
+    import torch
+    from stratego_env_amd.config import VARIANTS
+    v = VARIANTS[version]
+    env = make_env(version, n, 0, rk.device_index, compact=True)
+    try:
+        _, probe_ms, _, _, _ = time_workload(rk, env, 8, 8)
+        steps = int(max(16, min(4096, seconds * 1e3 / max(probe_ms / 8, 1e-3))))
+        elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, 4)
+        assert invalid == 0
+        checked = verify_against_oracle(env, version, verify) if verify else 0
+        launch_s = dev_ms / 1e3 / steps
+        per_step = 2 * env.record_bytes + 8 + env.compact_obs_stride + 4 * env.compact_mask_words + 12
+        obs_out, mask_out = env.decode_obs(), env.decode_mask()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(20):
+            env.decode_obs(obs_out)
+        ev[1].record()
+        for _ in range(20):
+            env.decode_mask(mask_out)
+        ev[2].record()
+        torch.cuda.synchronize()
+        dec_obs_us, dec_mask_us = ev[0].elapsed_time(ev[1]) / 20 * 1e3, ev[1].elapsed_time(ev[2]) / 20 * 1e3
+        return {"workload": "%d concurrent %s games, same rollout with COMPACT outputs (opt-in: uint8 codes [N,%d] + int32 mask bits [N,%d])"
+                            % (n, version, env.compact_obs_stride, env.compact_mask_words),
+                "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
+                "bytes_per_step": per_step, "frac": per_step * n / launch_s / 1e9 / HBM_PEAK_GBS,
+                "decode_obs_us_per_batch": dec_obs_us, "decode_mask_us_per_batch": dec_mask_us,
+                "decode_obs_frac": (env.compact_obs_stride + 4 * 67 * v.rows * v.columns) * n / (dec_obs_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "games_finished_in_timed_region": games, "verified_envs": checked}
     finally:
         env.close()
         del env
@@ -946,6 +991,7 @@ def run_rank(args):
             out["config"]["other_workloads"] = [other_workload(rk, args, 'standard', 262144, chains=2),
                                                 other_workload(rk, args, 'micro', 65536, chains=2, rotate_sets=args.rotate_sets),
                                                 other_workload(rk, args, 'barrage', 65536, full_obs=True)]
+            out["config"]["compact_outputs"] = compact_leg(rk, args)
         if not args.no_cpu_baseline and rk.world == 1:         # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
         else:

@@ -113,6 +113,25 @@ typedef struct sgx_step_io {
 #define SGX_STEP_MASK_1D 32
 #define SGX_STEP_MASK_STATE_COORDS 64
 
+/* Compact outputs (opt-in; never the default).  The float32 observation is 85 % of a step's bytes and the step kernel already sits on
+ * the write roofline, so the only way past it is to write less: with SGX_STEP_COMPACT_OBS obs_dev receives, per game, the kernel's own
+ * 4-bit code buffer -- uint8 [N][sgx_compact_obs_stride(h)]: ceil(R*C*67 / 2) bytes of codes (nibble e = float e of the [R,C,67]
+ * observation, low nibble first; code c decodes to sext(c) / 4, code 8 marks an entry without a code), padded to 16 bytes; a 16-byte
+ * header {int32 n, 0, 0, 0}; n x {uint32 entry, float32 value} for the marked entries (captured counts that normalise to thirds /
+ * fifths); padded to whole 128-byte lines (10x10: 3,584 B for Barrage instead of 26,800 B).  With SGX_STEP_COMPACT_MASK mask_dev
+ * receives the mask as bits, uint32 [N][sgx_compact_mask_words(h)], bit a of the game's words = flat action a (10x10: 480 B instead of
+ * 3,700 B).  sgx_decode_obs / sgx_decode_mask expand a batch of them with the step kernel's own emission code: the float32 / uint8
+ * results are byte-identical to what the step writes without the flags (tests/test_gpu_compact.py).  Accepted by sgx_step, sgx_observe,
+ * sgx_step_n, sgx_rollout and sgx_step_ring for the 67-channel partial observation of an 'extended' channel mode and masks in the
+ * mover's perspective (no fobs_dev / final_obs_dev / original channels / state-coordinate masks; 16-byte aligned buffers).  No reference
+ * counterpart: the reference's contract is the float32 observation (impl:1335-1397 + maenv:506-508), which the decode ops deliver. */
+#define SGX_STEP_COMPACT_OBS 128
+#define SGX_STEP_COMPACT_MASK 256
+int64_t sgx_compact_obs_stride(const sgx_env *h);
+int64_t sgx_compact_mask_words(const sgx_env *h);
+int sgx_decode_obs(sgx_env *h, const uint8_t *compact_dev, float *obs_dev /* [N,R,C,67] */, void *stream);
+int sgx_decode_mask(sgx_env *h, const uint32_t *bits_dev, uint8_t *mask_dev /* [N,R,C,K] */, void *stream);
+
 /* Library / geometry queries (penv:32-36: action_size, spatial_action_size). */
 int sgx_abi_version(void);
 /* Hash of the sources the loaded binary was compiled from (the first 16 hex digits of SHA-256 over the files of stratego_env_amd/csrc and this

@@ -440,6 +440,56 @@ __global__ __launch_bounds__((states_threads<MAPPED, OBS>())) void states_kernel
     if (out) export_from_image(P, W, out, player_out, env, tid, nt);
 }
 
+// ---------------------------------------------------------------------------------------------
+// sgx_decode_obs / sgx_decode_mask: compact outputs (SGX_STEP_COMPACT_OBS / _MASK) -> the contract's float32 observation / uint8 mask.
+// The same lanes-per-game geometry and the very emit_codes / patch_uncoded / emit_mask functions of the step kernel, fed from the compact
+// records instead of a freshly built code buffer: the result is byte-identical to what the step would have written.
+// ---------------------------------------------------------------------------------------------
+template <int R_, int C_>
+__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB)) void decode_obs_kernel(const uint8_t *__restrict__ compact, int stride, int capacity, float *__restrict__ obs,
+                                                                           int64_t n_envs, int nt) {
+    using G = Geo<R_, C_>;
+    using Spec = PartialObs;
+    __shared__ Lds<G> LW[G::WPB * G::GPW];
+    const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;
+    const int64_t env = blockIdx.x * (int64_t)(G::WPB * G::GPW) + slot;
+    if (env >= n_envs) return;
+    Lds<G> &L = LW[slot];
+    const int n_unc = load_compact<G, Spec>(L, compact + env * (int64_t)stride, capacity, lane);
+    float *dst = obs + env * (int64_t)(G::RC * Spec::NCH);
+    if constexpr (G::RC % 4 == 0) {
+        if (n_unc == 0) {
+            if (nt) emit_codes<G, Spec, false, true>(L, dst, lane);
+            else emit_codes<G, Spec, false, false>(L, dst, lane);
+        } else {
+            if (nt) emit_codes<G, Spec, true, true>(L, dst, lane);
+            else emit_codes<G, Spec, true, false>(L, dst, lane);
+            patch_uncoded<G, Spec>(L, dst, n_unc, lane);
+        }
+    } else {
+        if (nt) emit_codes<G, Spec, false, true>(L, dst, lane);
+        else emit_codes<G, Spec, false, false>(L, dst, lane);
+        if (n_unc) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            patch_uncoded_floats(L, dst, n_unc, lane);
+        }
+    }
+}
+
+template <int R_, int C_>
+__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB)) void decode_mask_kernel(const uint32_t *__restrict__ bits, uint8_t *__restrict__ mask, int64_t n_envs) {
+    using G = Geo<R_, C_>;
+    __shared__ Lds<G> LW[G::WPB * G::GPW];
+    const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;
+    const int64_t env = blockIdx.x * (int64_t)(G::WPB * G::GPW) + slot;
+    if (env >= n_envs) return;
+    Lds<G> &L = LW[slot];
+    const int4 *src = reinterpret_cast<const int4 *>(bits + env * (int64_t)G::MB_WORDS);
+    for (int i = lane; i < G::MB_WORDS / 4; i += G::LPG) reinterpret_cast<int4 *>(L.mbits)[i] = src[i];
+    wave_sync<G>();
+    emit_mask(L, mask + env * (int64_t)G::NA, lane);
+}
+
 // sgx_copy_envs: packed records between two handles of the same variant, one wave per record
 __global__ __launch_bounds__(256) void copy_records_kernel(int8_t *__restrict__ dst, const int32_t *__restrict__ dst_idx, const int8_t *__restrict__ src,
                                                            const int32_t *__restrict__ src_idx, int rec_bytes, int64_t n) {

@@ -151,6 +151,35 @@ __device__ inline int build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uint
     return n_unc;
 }
 
+// Compact observation (SGX_STEP_COMPACT_OBS): the game's code buffer itself instead of the floats it decodes to -- NIB_BYTES of 4-bit codes,
+// a 16-byte header {n_unc, 0, 0, 0}, then n_unc x {uint32 entry, float value} for the entries whose value has no code (CODE_ESC in
+// the buffer).  sgx_decode_obs expands it with the very emit_codes / patch path below, so the float32 result is byte-identical to what
+// the step would have written.  `dst` is 16-byte aligned (the record stride is a multiple of 128).
+template <class G, class Spec, int NB>
+__device__ inline void store_compact(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int n_unc, int lane) {
+    constexpr int NBYTES = ((G::RC * Spec::NCH + 1) / 2 + 15) & ~15;
+    for (int i = lane; i < NBYTES / 16; i += G::LPG) reinterpret_cast<int4 *>(dst)[i] = reinterpret_cast<const int4 *>(L.nib)[i];
+    if (lane == 0) *reinterpret_cast<int4 *>(dst + NBYTES) = make_int4(n_unc, 0, 0, 0);
+    uint2 *ent = reinterpret_cast<uint2 *>(dst + NBYTES + 16);
+    for (int k = lane; k < n_unc; k += G::LPG) ent[k] = make_uint2((uint32_t)L.unc_entry[k], __float_as_uint(L.unc_val[k]));
+}
+// the reverse: compact record -> L.nib / L.unc_*; returns n_unc
+template <class G, class Spec, int NB>
+__device__ inline int load_compact(Lds<G, NB> &L, const uint8_t *__restrict__ src, int capacity, int lane) {
+    constexpr int NBYTES = ((G::RC * Spec::NCH + 1) / 2 + 15) & ~15;
+    for (int i = lane; i < NBYTES / 16; i += G::LPG) reinterpret_cast<int4 *>(L.nib)[i] = reinterpret_cast<const int4 *>(src)[i];
+    int n_unc = reinterpret_cast<const int4 *>(src + NBYTES)->x;
+    n_unc = n_unc < 0 ? 0 : (n_unc > capacity ? capacity : n_unc);
+    const uint2 *ent = reinterpret_cast<const uint2 *>(src + NBYTES + 16);
+    for (int k = lane; k < n_unc; k += G::LPG) {
+        const uint2 e = ent[k];
+        L.unc_entry[k] = (typename G::entry_t)e.x;
+        L.unc_val[k] = __uint_as_float(e.y);
+    }
+    wave_sync<G>();
+    return n_unc;
+}
+
 // L.nib -> global.  The observation is written in 1 KiB chunks aligned to 1 KiB ADDRESS boundaries (whole 128-byte lines per
 // store instruction; chunking by cell group left two partial lines per store and ran 1.5x slower in the store-pattern probe).
 // CHECKED (games with uncoded entries, 4-aligned boards): a quad that holds a CODE_ESC entry is not stored here -- patch_uncoded

@@ -411,6 +411,10 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
             if constexpr (G::WIDE) tmpl = P.tab->tmpl[(raw ? 2 : 0) + (full ? 1 : 0)];           // (global memory, L2-resident)
             const int n_unc = build_codes<G, Spec>(L, tmpl, codetab, full ? glut_f : glut_p, q,
                                                    n_events, rp0, rp1, lane, P.piece_counts, raw, P.multi_ev != 0);
+            if (!full && (P.io.flags & SGX_STEP_COMPACT_OBS)) {      // the codes themselves: 1/8 of the bytes (sgx_decode_obs expands them)
+                store_compact<G, Spec>(L, reinterpret_cast<uint8_t *>(dst), n_unc, lane);
+                return 0;
+            }
             if constexpr (RC % 4 == 0) {
                 if (n_unc == 0) {
                     if (P.nt_stores) emit_codes<G, Spec, false, true>(L, dst, lane);
@@ -475,11 +479,19 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
         // 16 index computations per lane cost 30 VGPRs)
         if (MAPPED && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
         else if (MAPPED && qi) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
+        else if (P.io.flags & SGX_STEP_COMPACT_MASK) {               // the mask as bits: uint32 [MB_WORDS] per game, bit a = action a
+            int4 *mdst = reinterpret_cast<int4 *>(reinterpret_cast<uint32_t *>(P.io.mask_dev) + env * (int64_t)G::MB_WORDS);
+            for (int i = lane; i < G::MB_WORDS / 4; i += G::LPG) mdst[i] = reinterpret_cast<const int4 *>(L.mbits)[i];
+        }
         else emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
     }
     STAMP(5);   // mask stores issued
     // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
-    if (P.io.obs_dev) render(PS{}, false, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH));
+    if (P.io.obs_dev) {
+        float *odst = (P.io.flags & SGX_STEP_COMPACT_OBS) ? reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(P.io.obs_dev) + env * (int64_t)P.compact_stride)
+                                                          : P.io.obs_dev + env * (int64_t)(RC * PS::NCH);
+        render(PS{}, false, qi, odst);
+    }
     if constexpr (FULL)
         if (P.io.fobs_dev) render(FS{}, true, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH));
     }

@@ -157,6 +157,18 @@ bool supported_geometry(int r, int c) {
         if (!done_) return fail(SGX_EINVAL, "unsupported board size%s");               \
     } while (0)
 
+// bytes of one game's compact observation record (SGX_STEP_COMPACT_OBS): 4-bit codes padded to 16 B, a 16-byte header, then room for
+// every entry that can be without a code (capture events + the four recent-move pairs) as {uint32 entry, float value}; whole 128-byte lines
+int compact_capacity(const sgx_env *h) { return h->max_events + 4; }
+int compact_obs_stride(const sgx_env *h) {
+    const int nib = ((h->cfg.rows * h->cfg.cols * OBS_CH + 1) / 2 + 15) & ~15;
+    return (nib + 16 + 8 * compact_capacity(h) + 127) & ~127;
+}
+int mask_words(const sgx_env *h) {
+    const int na = h->cfg.rows * h->cfg.cols * h->K;
+    return (((na + 31) / 32 + 1) + 3) & ~3;                          // Geo::MB_WORDS
+}
+
 KParams make_params(const sgx_env *h) {
     KParams p;
     memset(&p, 0, sizeof(p));
@@ -171,6 +183,7 @@ KParams make_params(const sgx_env *h) {
     p.max_events = h->max_events;
     for (int i = 0; i < 12; ++i)
         if (h->cfg.piece_counts[i] > EV_COUNT_MAX) p.multi_ev = 1;
+    p.compact_stride = compact_obs_stride(h);
     p.n_envs = h->n_envs;
     p.seed = h->seed;
     p.env_id_offset = h->env_id_offset;
@@ -580,7 +593,7 @@ static bool lane_eligible(const sgx_env *h, const KParams &p, bool full, bool or
     auto aligned = [](const void *ptr, uintptr_t a) { return (reinterpret_cast<uintptr_t>(ptr) & (a - 1)) == 0; };
     // -1 (auto): only where it is the faster kernel -- launches that emit no observation (2 x on Micro / Tiny)
     if (h->lane_mode < 0 && p.io.obs_dev) return false;
-    return h->lane_mode != 0 && !p.multi_ev && cells <= 16 && cells % 4 == 0 && !full && !original && h->map_mode == 0 &&
+    return h->lane_mode != 0 && !p.multi_ev && !(p.io.flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) && cells <= 16 && cells % 4 == 0 && !full && !original && h->map_mode == 0 &&
            !(p.io.flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) && !p.src_boards && !p.io.final_obs_dev && !p.io.final_fobs_dev &&
            (h->rec_bytes == 128 || h->rec_bytes == 256) && (p.env_first & 63) == 0 &&
            aligned(p.io.obs_dev, 16) && aligned(p.io.mask_dev, 16) && aligned(p.io.reward_dev, 8) && aligned(p.io.actions_dev, 16);
@@ -602,6 +615,13 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
     int32_t skew[8];                     // unequal XCD shares (sgx_layout.h: group_of_block)
     launch_shares(h, streaming, skew);
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
+    if (p.io.flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) {
+        // compact outputs: the 67-channel 'extended' observation as 4-bit codes / the mover's-perspective mask as bits, nothing else
+        if (full || original || p.io.final_obs_dev || p.src_boards || (p.io.flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)))
+            return fail(SGX_EINVAL, "compact outputs come with the 67-channel partial observation and the perspective mask only (no fobs / final_obs / original channels / state-coordinate masks)%s");
+        if ((reinterpret_cast<uintptr_t>(p.io.obs_dev) | reinterpret_cast<uintptr_t>(p.io.mask_dev)) & 15)
+            return fail(SGX_EINVAL, "compact outputs need 16-byte aligned obs_dev / mask_dev%s");
+    }
     if (lane_eligible(h, p, full, original)) {
         // boards of at most 16 cells: one game per lane, 64 games per wave (sgx_lane_kernel.h)
 #define CALL_LANE(R, C)                                                                                    \
@@ -660,7 +680,7 @@ SGX_API int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *ma
     p.mode = 1;
     p.io.obs_dev = obs_dev;
     p.io.fobs_dev = fobs_dev;
-    p.io.flags = flags & (SGX_STEP_RAW_OBS | SGX_STEP_ORIGINAL_CHANNELS | SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS);
+    p.io.flags = flags & (SGX_STEP_RAW_OBS | SGX_STEP_ORIGINAL_CHANNELS | SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS | SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK);
     p.io.mask_dev = mask_dev;
     p.io.player_dev = player_dev;
     return launch_step(h, p, stream);
@@ -956,7 +976,7 @@ SGX_API int sgx_step_sync(sgx_env *h, const sgx_step_io *io, void *stream) {
     if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
     if (!io->actions_dev) return fail(SGX_EINVAL, "actions_dev is NULL%s");
     const bool original = (io->flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
-    if (h->n_envs <= SGX_SINGLE_MAX_ENVS && !original && !(io->flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) && h->map_mode == 0 &&
+    if (h->n_envs <= SGX_SINGLE_MAX_ENVS && !original && !(io->flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS | SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) && h->map_mode == 0 &&
         !h->no_single) {
         SGX_ON_DEVICE(h->device);
         KParams p = make_params(h);
@@ -1058,6 +1078,43 @@ SGX_API int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int3
     return join_chains(h, chains, (hipStream_t)stream, rc);
 }
 
+SGX_API int64_t sgx_compact_obs_stride(const sgx_env *h) { return h ? compact_obs_stride(h) : 0; }
+SGX_API int64_t sgx_compact_mask_words(const sgx_env *h) { return h ? mask_words(h) : 0; }
+
+SGX_API int sgx_decode_obs(sgx_env *h, const uint8_t *compact_dev, float *obs_dev, void *stream) {
+    if (!h || !compact_dev || !obs_dev) return fail(SGX_EINVAL, "NULL argument%s");
+    if (reinterpret_cast<uintptr_t>(compact_dev) & 15) return fail(SGX_EINVAL, "sgx_decode_obs: compact_dev must be 16-byte aligned%s");
+    SGX_ON_DEVICE(h->device);
+    const int64_t obs_bytes = h->n_envs * (int64_t)h->cfg.rows * h->cfg.cols * OBS_CH * 4;
+    const int nt = h->nt_mode < 0 ? (obs_bytes > (int64_t)300 * 1000 * 1000 ? 1 : 0) : h->nt_mode;
+#define CALL_DECODE_OBS(R, C)                                                                                              \
+    do {                                                                                                                   \
+        using G_ = Geo<R, C>;                                                                                              \
+        const unsigned grid = (unsigned)((h->n_envs + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW));                       \
+        decode_obs_kernel<R, C><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(compact_dev, compact_obs_stride(h), compact_capacity(h), obs_dev, h->n_envs, nt); \
+    } while (0)
+    DISPATCH_GEOMETRY(h, CALL_DECODE_OBS);
+#undef CALL_DECODE_OBS
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}
+
+SGX_API int sgx_decode_mask(sgx_env *h, const uint32_t *bits_dev, uint8_t *mask_dev, void *stream) {
+    if (!h || !bits_dev || !mask_dev) return fail(SGX_EINVAL, "NULL argument%s");
+    if (reinterpret_cast<uintptr_t>(bits_dev) & 15) return fail(SGX_EINVAL, "sgx_decode_mask: bits_dev must be 16-byte aligned%s");
+    SGX_ON_DEVICE(h->device);
+#define CALL_DECODE_MASK(R, C)                                                                                             \
+    do {                                                                                                                   \
+        using G_ = Geo<R, C>;                                                                                              \
+        const unsigned grid = (unsigned)((h->n_envs + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW));                       \
+        decode_mask_kernel<R, C><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(bits_dev, mask_dev, h->n_envs);           \
+    } while (0)
+    DISPATCH_GEOMETRY(h, CALL_DECODE_MASK);
+#undef CALL_DECODE_MASK
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}
+
 SGX_API int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actions_dev, void *stream) {
     if (!h || !mask_dev || !actions_dev) return fail(SGX_EINVAL, "NULL argument%s");
     SGX_ON_DEVICE(h->device);
@@ -1123,6 +1180,7 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
                             const sgx_step_io *io, int64_t *state_out_dev, int8_t *player_out_dev, int32_t chains, void *stream) {
     if (!h || !state_in_dev || !io) return fail(SGX_EINVAL, "NULL argument%s");
     if (io->auto_reset || io->next_actions_dev) return fail(SGX_EINVAL, "sgx_step_states: no auto_reset, no sampled next actions%s");
+    if (io->flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) return fail(SGX_EINVAL, "sgx_step_states: no compact outputs%s");
     if (chains < 1 || chains > SGX_MAX_CHAINS) return fail(SGX_EINVAL, "chains out of range%s");
     SGX_ON_DEVICE(h->device);
     const int64_t unit = 64;

@@ -71,17 +71,25 @@ def _wrap_device(ptr, shape, dtype, device, owner):
 
 class VecStrategoEnv:
     def __init__(self, version='barrage', num_envs=1, device=0, seed=0, env_id_offset=0, human_inits=None,
-                 auto_reset=False, final_obs=False, full_obs=False, lib_path=None, obs_channel_mode='extended'):
+                 auto_reset=False, final_obs=False, full_obs=False, lib_path=None, obs_channel_mode='extended', compact_outputs=False):
         """human_inits: None = use the Gravon table when the variant has one (util.py:301-319), False = uniformly
         random back-row placement (util.py:33-53), True = require the table.
         obs_channel_mode: 'extended' (67 / 79 one-hot channels) or 'original' (the deprecated 32 / 33 value channels,
         maenv:67, 368-375)."""
         if obs_channel_mode not in ('extended', 'original'):
             raise ValueError("obs_channel_mode must be 'extended' or 'original'")
+        # compact_outputs=True (opt-in): `obs` is uint8 [N, compact_obs_stride] -- the 4-bit codes the float32 observation decodes from --
+        # and `mask` int32 [N, compact_mask_words] -- one bit per action: 1/8 of the bytes per step.  decode_obs() / decode_mask() give the
+        # contract tensors, byte-identical to a non-compact step (include/stratego_mi355x.h: SGX_STEP_COMPACT_OBS).
+        self.compact = bool(compact_outputs)
+        if self.compact and (final_obs or full_obs or obs_channel_mode != 'extended'):
+            raise ValueError("compact_outputs comes with the 67-channel partial observation only (no final_obs / full_obs / original channels)")
         self.obs_channel_mode = obs_channel_mode
         self._mode_flags = _lib.STEP_ORIGINAL_CHANNELS if obs_channel_mode == 'original' else 0
-        self.p_channels = PO_OBS_CHANNELS_ORIGINAL if self._mode_flags else PO_OBS_CHANNELS
-        self.f_channels = FO_OBS_CHANNELS_ORIGINAL if self._mode_flags else FO_OBS_CHANNELS
+        if compact_outputs:
+            self._mode_flags |= _lib.STEP_COMPACT_OBS | _lib.STEP_COMPACT_MASK
+        self.p_channels = PO_OBS_CHANNELS_ORIGINAL if obs_channel_mode == 'original' else PO_OBS_CHANNELS
+        self.f_channels = FO_OBS_CHANNELS_ORIGINAL if obs_channel_mode == 'original' else FO_OBS_CHANNELS
         if not torch.cuda.is_available():
             raise _lib.SgxError("VecStrategoEnv needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
         self.variant = get_variant(version)
@@ -107,8 +115,15 @@ class VecStrategoEnv:
             _lib.check(self._L.sgx_set_setup_table(self._h, table.ctypes.data_as(C.c_void_p), table.shape[0]), self._L)
         self.human_inits = bool(human_inits)
         N, R, Cc, K, dev = self.num_envs, self.R, self.Cc, self.K, self.device
-        self.obs = torch.empty((N, R, Cc, self.p_channels), dtype=torch.float32, device=dev)
-        self.mask = torch.empty((N, R, Cc, K), dtype=torch.uint8, device=dev)
+        if self.compact:
+            self.compact_obs_stride = int(self._L.sgx_compact_obs_stride(self._h))
+            self.compact_mask_words = int(self._L.sgx_compact_mask_words(self._h))
+            self.obs = torch.empty((N, self.compact_obs_stride), dtype=torch.uint8, device=dev)
+            self.mask = torch.empty((N, self.compact_mask_words), dtype=torch.int32, device=dev)
+            self._mask_bytes = None
+        else:
+            self.obs = torch.empty((N, R, Cc, self.p_channels), dtype=torch.float32, device=dev)
+            self.mask = torch.empty((N, R, Cc, K), dtype=torch.uint8, device=dev)
         self.reward = torch.zeros((N, 2), dtype=torch.float32, device=dev)
         self.done = torch.zeros((N,), dtype=torch.uint8, device=dev)
         self.player = torch.ones((N,), dtype=torch.int8, device=dev)
@@ -143,6 +158,24 @@ class VecStrategoEnv:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def decode_obs(self, out=None):
+        """compact_outputs only: the contract observation float32 [N,R,C,67] of the current compact `obs` (sgx_decode_obs)."""
+        assert self.compact
+        if out is None:
+            out = torch.empty((self.num_envs, self.R, self.Cc, self.p_channels), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_decode_obs(self._h, _ptr(self.obs), _ptr(out), self._stream()), self._L)
+        return out
+
+    def decode_mask(self, out=None):
+        """compact_outputs only: the contract mask uint8 [N,R,C,K] of the current bit mask (sgx_decode_mask)."""
+        assert self.compact
+        if out is None:
+            out = torch.empty((self.num_envs, self.R, self.Cc, self.K), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_decode_mask(self._h, _ptr(self.mask), _ptr(out), self._stream()), self._L)
+        return out
 
     def set_nt_stores(self, mode='auto'):
         """Store policy of the observation writes (sgx_set_nt_stores): 'auto' (by the launch's output size), False or True.
@@ -231,6 +264,8 @@ class VecStrategoEnv:
         few state-preserving sgx_observe launches on each and keeps the fastest; it never holds more than `max_extra_bytes`
         beyond the buffers it returns.  Call after reset().  Returns the per-candidate launch times in microseconds:
         {'obs': [...], ('fobs': [...])}; [0] is the plain first allocation."""
+        if self.compact:
+            raise ValueError("tune_placement: compact outputs (235 MB per 65,536 Barrage games) fit the Infinity Cache and have no placement classes")
         out = _lib.SgxOutputs()
         flags = self._mode_flags | (_lib.OUT_FULL_OBS if self.fobs is not None else 0)
         with torch.cuda.device(self.device):
@@ -273,7 +308,7 @@ class VecStrategoEnv:
         self._ring_owners = [getattr(self, '_outputs_owner', None)]
         reports = [None]
         for _ in range(1, n_sets):
-            if tune:
+            if tune and not self.compact:
                 out = _lib.SgxOutputs()
                 flags = self._mode_flags | (_lib.OUT_FULL_OBS if self.fobs is not None else 0)
                 with torch.cuda.device(self.device):
@@ -286,8 +321,7 @@ class VecStrategoEnv:
                 reports.append({'obs': [float(x) for x in out.trial_us[:out.n_trials]]})
                 self._ring_owners.append(owner)
             else:
-                obs = torch.empty((N, R, Cc, self.p_channels), dtype=torch.float32, device=dev)
-                mask = torch.empty((N, R, Cc, K), dtype=torch.uint8, device=dev)
+                obs, mask = torch.empty_like(self.obs), torch.empty_like(self.mask)       # (compact outputs: the same compact shapes)
                 fobs = torch.empty((N, R, Cc, self.f_channels), dtype=torch.float32, device=dev) if self.fobs is not None else None
                 reports.append(None)
                 self._ring_owners.append(None)
@@ -383,11 +417,16 @@ class VecStrategoEnv:
 
     def sample_valid_actions(self, mask=None, out=None):
         """Uniformly random valid action per env from `mask` (default: the current one) -- maenv:830-834."""
+        own = mask is None or mask is self.mask
         mask = self.mask if mask is None else mask
         out = self.next_actions if out is None else out
+        src = mask
+        if own and self.compact:                 # the standalone sampler reads mask BYTES: expand the bit mask first
+            self._mask_bytes = self.decode_mask(self._mask_bytes)
+            src = self._mask_bytes
         with torch.cuda.device(self.device):
-            _lib.check(self._L.sgx_sample_valid(self._h, _ptr(mask), _ptr(out), self._stream()), self._L)
-        if mask is self.mask and out is self.next_actions:
+            _lib.check(self._L.sgx_sample_valid(self._h, _ptr(src), _ptr(out), self._stream()), self._L)
+        if own and out is self.next_actions:
             self._next_actions_fresh = True
         return out
 
