@@ -181,6 +181,7 @@ struct KParams {
     // 8, so a ninth capture of one type on one cell opens ANOTHER event with the same (layer, cell) key.  Every reader of the list then
     // sums the events of a key (the first one speaks for all); 0 for every variant of the reference, whose lists never hold duplicates.
     int32_t multi_ev;
+    int32_t mask_nt;          // the mask's interior lines leave as non-temporal stores (sgx_mask.h: emit_mask)
     int32_t compact_stride;   // SGX_STEP_COMPACT_OBS: bytes of one game's compact observation record (sgx_compact_obs_stride)
     // functional-API instantiation only (sgx_expand): game i is read from record src_index[i] (i when NULL) of ANOTHER handle's
     // records and written to record i of this one, whether or not the move was valid

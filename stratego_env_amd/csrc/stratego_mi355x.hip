@@ -111,6 +111,7 @@ struct sgx_env {
     int nt_mode;                 // sgx_set_nt_stores: -1 = by the launch's output size, 0 = never, 1 = always
     int lane_mode;               // sgx_set_lane_kernel: 0 = never the lane-per-game kernel, otherwise wherever it is eligible
     int prio_mode;               // SGX_PRIO experiment (sgx_layout.h: stagger_priority)
+    int mask_nt_mode;            // SGX_MASK_NT experiment: 1 = non-temporal stores for the mask's interior lines (default off)
     hipStream_t chain_stream[SGX_MAX_CHAINS];   // sgx_rollout: created on first use
     hipEvent_t chain_fork, chain_join[SGX_MAX_CHAINS];
     // sgx_step_sync on a handful of games (single_kernel): a host-mapped word the kernel publishes its sequence number in, and the
@@ -388,6 +389,8 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     if (const char *e = getenv("SGX_GENERAL_STATES")) h->general_states = atoi(e);
     if (const char *e = getenv("SGX_LANE")) { if (!strcmp(e, "0")) h->lane_mode = 0; else if (!strcmp(e, "1")) h->lane_mode = 1; }   // SGX_LANE=0|1|auto
     if (const char *e = getenv("SGX_PRIO")) h->prio_mode = atoi(e);
+    h->mask_nt_mode = -1;
+    if (const char *e = getenv("SGX_MASK_NT")) { if (!strcmp(e, "0")) h->mask_nt_mode = 0; else if (!strcmp(e, "1")) h->mask_nt_mode = 1; }
     h->xcd_skew = -1;
     if (const char *e = getenv("SGX_XCD_SKEW")) { if (strcmp(e, "auto")) h->xcd_skew = atoi(e); }   // SGX_XCD_SKEW=<per mille>|auto
     if (h->xcd_skew > 900) h->xcd_skew = 900;
@@ -477,6 +480,7 @@ SGX_API int sgx_set_nt_stores(sgx_env *h, int32_t mode) {
 
 // experiment, not part of the ABI header's contract: wave priorities by SIMD slot (0 = off)
 SGX_API int sgx_debug_set_prio(sgx_env *h, int32_t mode) { if (h) h->prio_mode = mode; return SGX_OK; }
+SGX_API int sgx_debug_set_mask_nt(sgx_env *h, int32_t mode) { if (h) h->mask_nt_mode = mode; return SGX_OK; }
 
 SGX_API int sgx_set_general_states(sgx_env *h, int32_t mode) {
     if (!h || mode < 0 || mode > 1) return fail(SGX_EINVAL, "sgx_set_general_states: mode must be 0 or 1%s");
@@ -612,6 +616,9 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
     p.prio_mode = h->prio_mode;
     const bool streaming = launch_streams_past_cache(h, p, ring_sets);
     p.nt_stores = h->nt_mode < 0 ? (streaming ? 1 : 0) : h->nt_mode;
+    // the mask stays on plain stores: non-temporal ones measured no different in place and in a ring on every board size
+    // (tools/mask_nt_ab.py, profiles/r04_mask_nt_ab.log); SGX_MASK_NT=1 / sgx_debug_set_mask_nt force them for that A/B
+    p.mask_nt = h->mask_nt_mode > 0 ? 1 : 0;
     int32_t skew[8];                     // unequal XCD shares (sgx_layout.h: group_of_block)
     launch_shares(h, streaming, skew);
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
