@@ -1091,6 +1091,8 @@ SGX_API int64_t sgx_compact_mask_words(const sgx_env *h) { return h ? mask_words
 SGX_API int sgx_decode_obs(sgx_env *h, const uint8_t *compact_dev, float *obs_dev, void *stream) {
     if (!h || !compact_dev || !obs_dev) return fail(SGX_EINVAL, "NULL argument%s");
     if (reinterpret_cast<uintptr_t>(compact_dev) & 15) return fail(SGX_EINVAL, "sgx_decode_obs: compact_dev must be 16-byte aligned%s");
+    if ((reinterpret_cast<uintptr_t>(obs_dev) & 15) && (h->cfg.rows * h->cfg.cols) % 4 == 0)
+        return fail(SGX_EINVAL, "sgx_decode_obs: obs_dev must be 16-byte aligned%s");
     SGX_ON_DEVICE(h->device);
     const int64_t obs_bytes = h->n_envs * (int64_t)h->cfg.rows * h->cfg.cols * OBS_CH * 4;
     const int nt = h->nt_mode < 0 ? (obs_bytes > (int64_t)300 * 1000 * 1000 ? 1 : 0) : h->nt_mode;
