@@ -10,7 +10,12 @@ the strong-scaling leg (2,097,152 games in total split over the ranks: config.st
 65,536 games per GPU (config.weak_65536) so that the 1-GPU line has a like-for-like counterpart; --envs / --total-envs override.
 One "step" = one batched env.step() over all of the rank's games: action in, move/combat/capture applied, win/draw detection,
 next mover's valid-actions mask (uint8 [R,C,K]) and normalised partial observation (float32 [R,C,67]) written to HBM, plus the
-next random valid action.  Inputs are resident in HBM when the timed region starts.
+next random valid action.  Inputs are resident in HBM when the timed region starts.  On one GPU the K timed steps write their outputs
+round-robin into THREE output sets (sgx_step_ring: a trajectory buffer of the last three steps): what a learner that stores every step
+does, and the rate a policy that reads the outputs between steps sees (config.consumer_in_loop) -- nothing a launch writes can still be
+cached when its addresses are written again, so `value` and `roofline` are DRAM-side figures.  The in-place variant (one set of
+tensors rewritten every step: the headline of rounds 1-3, 8-10 % faster because rewriting the same 1-2 GB back to back is) follows as
+config.in_place.  --output-sets 1 makes it the headline again.
 
 Multi-GPU: one process per GPU.  Under a launcher (RANK / WORLD_SIZE set) this process is one rank; run directly with
 --gpus N > 1 it starts the N ranks itself as fresh child processes BEFORE anything touches the GPU (a process that has
@@ -21,18 +26,17 @@ of the timed region and one MAX / SUM all-reduce for reporting.
 Prints ONE JSON line (rank 0) with
   `roofline`      HBM.  `achieved` = B_min x games per launch / launch time (HIP events on the launch stream over the timed region),
                   B_min = the packed layout's own byte minimum per env step (record in + record out + action in + next action out +
-                  float32 observation + uint8 mask + results: 31,544 B for Barrage; DESIGN.md section 3.1) -- what the kernel cannot avoid
-                  moving; `frac` = achieved / 8 TB/s.  The headline writes ONE set of output tensors in place, so part of it (the 242 MB
-                  mask) can be absorbed by the 256 MiB Infinity Cache: `frac_dram` is the same arithmetic on the ROTATING-OUTPUTS leg
-                  (config.rotating_outputs: >= 3 output sets written round-robin, sgx_step_ring, so that no line written by launch k can
-                  still sit in that cache at launch k+1) -- the DRAM-side figure.  `traffic` = counter bytes per launch from the
-                  committed rocprofv3 --pmc passes (profiles/traffic.json; `traffic_source` says which binary they were measured on:
-                  "static" unless the build id matches); `frac_untuned` = `frac` on the process's plain first allocation;
+                  float32 observation + uint8 mask + results: 31,544 B for Barrage; DESIGN.md section 3.2) -- what the kernel cannot avoid
+                  moving; `frac` = achieved / 8 TB/s, and with the ring headline that is a DRAM fraction (`frac_dram` repeats it).
+                  `in_place_rate_over_spec_peak` = the same bytes over the in-place leg's launch time: a memory-side rate that can touch
+                  the spec peak, deliberately not called a fraction.  `traffic` = counter bytes per launch from the committed rocprofv3
+                  --pmc passes (profiles/traffic.json; `traffic_source` says which binary they were measured on: "static" unless the
+                  build id matches); `frac_untuned` = B_min over the observe launch of the process's plain first allocation;
                   `survey_8d` = SURVEY 8d's 33,848 B per step x games / launch time, a labelled comparison only (the kernel moves
                   fewer bytes than that formula assumes, so it is not a fraction of anything);
   `verified_envs` sampled envs of the very env object that was timed, checked after the timed region against the CPU oracle
                   replaying the same number of steps (outputs of the last step, turn and game counters);
-  `config.rotating_outputs`   the rotating-outputs leg; `config.consumer_in_loop`  sgx_step alternating with a device policy that READS
+  `config.in_place`   the in-place leg (+ `config.two_chains`); `config.consumer_in_loop`  sgx_step alternating with a device policy that READS
                   the observation and the mask (examples/batched_policy_loop.py), non-temporal against plain stores under that reader;
   `config.other_workloads`  BASELINE configs 3 and 4 and the reference's default BOTH_OBSERVATIONS mode (1-GPU run only);
   `cpu_baseline`  the CPU oracle (a port of the reference's algorithm) timed on this box's host cores on a bounded sample.
@@ -197,10 +201,13 @@ def parse_args(argv=None):
                     help='untimed, state-preserving sgx_observe launches directly before the timed bracket (gpu_settle); 0 = none')
     ap.add_argument('--wake-seconds', type=float, default=2.0,
                     help='untimed GPU wake-up before the warmup steps (a fresh box runs its first ~second at idle clocks)')
-    ap.add_argument('--rotate-outputs', type=int, default=0,
-                    help='R >= 2: the HEADLINE writes a ring of R output sets round-robin (sgx_step_ring) instead of one set in place -- for '
-                         'profiling the rotating-outputs workload under rocprofv3; 0 (default): headline in place, rotating leg after it')
-    ap.add_argument('--rotate-sets', type=int, default=3, help='output sets of the rotating-outputs leg after the headline (0 = skip the leg)')
+    ap.add_argument('--output-sets', type=int, default=None,
+                    help='output sets the HEADLINE writes round-robin (sgx_step_ring: a trajectory buffer of the last R steps).  Default: 3 on one '
+                         'GPU -- no line a launch writes can still be cached when it is written again, so value / roofline are DRAM-side '
+                         'figures, the rate a learner that stores every step, or a policy that reads the outputs, sees -- and 1 (in place) '
+                         'on several GPUs, whose 262,144 games per GPU stream past every cache anyway')
+    ap.add_argument('--no-in-place-leg', action='store_true',
+                    help='skip the in-place leg after a ring headline (the same K steps into ONE set of tensors, and its two-chains variant)')
     ap.add_argument('--no-consumer-leg', action='store_true', help='skip the consumer-in-the-loop leg (sgx_step alternating with a device policy)')
     ap.add_argument('--chains', type=int, default=1,
                     help='sgx_rollout: split the batch into this many ranges of games whose launches overlap on streams of their own '
@@ -222,6 +229,11 @@ def parse_args(argv=None):
         args.envs_defaulted = True
     else:
         args.envs_defaulted = False
+    if args.output_sets is None:
+        args.output_sets = 3 if (args.gpus == 1 and not args.unfused and args.chains == 1) else 1
+    if args.output_sets < 1:
+        ap.error("--output-sets must be >= 1")
+    args.rotate_sets = 3           # the ring of the Micro leg (other_workloads)
     if args.strong_total is None:
         args.strong_total = STRONG_TOTAL if (args.gpus > 1 and not args.total_envs and args.envs_defaulted) else 0
     return args
@@ -598,19 +610,24 @@ def place_outputs(env, args):
 
 
 def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, first_us=None, rec_bytes=None, build_id=None,
-             rotating=None):
+             rotating=None, ring_sets=1):
     """The roofline object of one workload.  Every `frac*` is B_min x games / time / 8 TB/s -- bytes the kernel cannot avoid moving
     (b_min), so none of them overstates the traffic; `frac_dram` comes from the rotating-outputs leg (`rotating` = its launch
     seconds), where the Infinity Cache cannot hold anything back from DRAM."""
     key = version + ('+full_obs' if full_obs else '')
+    if ring_sets > 1 and measured_traffic(key + '+rotating', n, build_id)[0]:
+        key += '+rotating'
     per_step = b_min(v, full_obs, rec_bytes)
     min_bytes = per_step * n
     traffic, source = (traffic_override, "--traffic-bytes") if traffic_override is not None else measured_traffic(key, n, build_id)
     ach = min_bytes / launch_s / 1e9
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
            "frac_basis": "B_min = %d B per env step (packed record in + out, action in, next action out, float32 observation%s, uint8 mask, "
-                         "results) x %d games per launch / launch time by HIP events; outputs written in place (one set of tensors): "
-                         "memory side including the 256 MiB Infinity Cache" % (per_step, "s" if full_obs else "", n),
+                         "results) x %d games per launch / launch time by HIP events; %s" % (
+                             per_step, "s" if full_obs else "", n,
+                             "outputs written round-robin into %d sets, so that no line a launch writes can still be cached when it is written "
+                             "again: DRAM side" % ring_sets if ring_sets > 1 else
+                             "outputs written in place (one set of tensors): memory side including the 256 MiB Infinity Cache where a set fits it"),
            "bytes_per_launch": min_bytes, "b_min_bytes_per_step": per_step,
            "kernel": "step_kernel<%d,%d,%d,false>" % (v.rows, v.columns, 1 if full_obs else 0), "launch_us": launch_s * 1e6,
            "frac_dram": None, "traffic": traffic, "traffic_source": source,
@@ -623,7 +640,7 @@ def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, fir
            "survey_8d": {"bytes_per_step": b_alg(v.rows, v.columns, full_obs), "gbps_if_those_bytes_moved": b_alg(v.rows, v.columns, full_obs) * n / launch_s / 1e9}}
     if rotating:
         out["frac_dram"] = min_bytes / rotating / 1e9 / HBM_PEAK_GBS
-        out["frac_dram_basis"] = "the same B_min bytes over the launch time of the rotating-outputs leg (config.rotating_outputs)"
+        out["frac_dram_basis"] = "B_min bytes over the launch time of a run that writes a ring of output sets (the headline itself, or the leg's rotating_outputs)"
     return out
 
 
@@ -906,32 +923,41 @@ def run_rank(args):
     env = make_env(args.version, n, first, rk.device_index, full_obs=args.full_obs)
     build_id, rec_bytes = env.build_id, env.record_bytes
     placement = place_outputs(env, args)
-    headline_ring = args.rotate_outputs >= 2
-    if headline_ring:      # profiling runs of the rotating-outputs workload: the headline itself writes the ring
+    headline_ring = args.output_sets >= 2 and not args.unfused and args.chains == 1
+    ring_report = None
+    if headline_ring:      # the headline writes a ring of output sets: each extra set from its own placement trial, like the first
         budget, _ = placement_budgets(args, max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if args.placement == 'trial' else 0)
-        env.alloc_output_ring(args.rotate_outputs, tune=budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6, max_extra_bytes=budget,
-                              trials=args.placement_trials)
+        reps = env.alloc_output_ring(args.output_sets, tune=budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6, max_extra_bytes=budget,
+                                     trials=args.placement_trials)
+        ring_report = [(round(r['obs'][0], 1), round(min(r['obs']), 1)) if (r and r.get('obs')) else None for r in reps[1:]]
     elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring)
     assert invalid == 0, "rollout produced invalid actions"
     # outside the timed region: the envs that were just timed against the CPU oracle, and the sharding-independent checksum
     checked = verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if args.verify_envs else 0
     verified_steps = env.bench_steps_played
     _, (checked, checksum) = rk.reduce([], [checked, outputs_checksum(env)])
-    two_chains = None
-    if rk.world == 1 and args.chains == 1 and not args.unfused and not args.no_two_chains and not headline_ring:
-        # The same K steps with the batch split into two ranges of games whose launches overlap (sgx_rollout, chains = 2): reported
-        # next to the headline, which stays one launch per step so that its per-launch figures can be checked against a kernel trace.
+    in_place, two_chains = None, None
+    per_step = b_min(v, args.full_obs, rec_bytes)
+    if rk.world == 1 and headline_ring and not args.no_in_place_leg:
+        # The same K / W on the same env object into ONE set of tensors (the set the ring wrote last), step after step: what rounds 1-3
+        # reported as the headline.  Rewriting the same 1-2 GB back to back is 8-10 % faster than anything that cannot reuse its lines
+        # (DESIGN.md section 3.2), so its rate is a memory-side figure that can touch the 8 TB/s spec peak: a ratio, not a DRAM fraction.
+        e1, d1, _, g1, inv1 = time_workload(rk, env, args.steps, args.warmup)
+        assert inv1 == 0
+        in_place = {"workload": "the same rollout writing one set of output tensors in place", "value": total * args.steps / e1,
+                    "unit": "env steps/s", "launch_us": d1 / args.steps * 1e3, "games_finished_in_timed_region": g1,
+                    "rate_over_spec_peak": per_step * n / (d1 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS,
+                    "rate_is": "memory side including the 256 MiB Infinity Cache and whatever else favours rewriting the same lines; not a DRAM fraction",
+                    "verified_envs": verify_against_oracle(env, args.version, min(args.verify_envs, 8), both=args.full_obs) if args.verify_envs else 0,
+                    "verified_steps": env.bench_steps_played}
+    if rk.world == 1 and args.chains == 1 and not args.unfused and not args.no_two_chains and not (headline_ring and args.no_in_place_leg):
+        # The same K steps (in place) with the batch split into two ranges of games whose launches overlap (sgx_rollout, chains = 2)
         e2, d2, _, _, inv2 = time_workload(rk, env, args.steps, args.warmup, False, 2)
         assert inv2 == 0
-        two_chains = {"chains": 2, "value": total * args.steps / e2, "us_per_step": d2 / args.steps * 1e3,
-                      "frac": b_min(v, args.full_obs, rec_bytes) * n / (d2 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS,
+        two_chains = {"chains": 2, "outputs": "in place", "value": total * args.steps / e2, "us_per_step": d2 / args.steps * 1e3,
+                      "rate_over_spec_peak": per_step * n / (d2 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS,
                       "verified_envs": verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if args.verify_envs else 0,
                       "verified_steps": env.bench_steps_played}
-    rotating, rot_s = None, None
-    if rk.world == 1 and args.rotate_sets >= 2 and not headline_ring and not args.unfused and args.chains == 1:
-        # the DRAM-side figure: the same env object, the same K / W, outputs written round-robin into rotate_sets sets
-        rotating, rot_s = rotating_leg(rk, env, args, args.version, v, args.steps, args.warmup, args.rotate_sets, full_obs=args.full_obs,
-                                       verify=min(args.verify_envs, 8))
 
     out = None
     if rk.rank == 0:
@@ -939,10 +965,8 @@ def run_rank(args):
         launch_s = dev_ms / 1e3 / args.steps                 # average device time per batched step (HIP events)
         rf = roofline(args.version, v, n, launch_s, args.traffic_bytes, full_obs=args.full_obs,
                       first_us=(placement or {}).get('fobs_plain_us' if args.full_obs else 'plain_us'), rec_bytes=rec_bytes, build_id=build_id,
-                      rotating=launch_s if headline_ring else rot_s)
-        if headline_ring:
-            rf["frac_basis"] = rf["frac_basis"].replace("outputs written in place (one set of tensors): memory side including the 256 MiB Infinity Cache",
-                                                        "outputs written round-robin into %d sets (--rotate-outputs): DRAM side" % args.rotate_outputs)
+                      rotating=launch_s if headline_ring else None, ring_sets=args.output_sets if headline_ring else 1)
+        rf["in_place_rate_over_spec_peak"] = in_place["rate_over_spec_peak"] if in_place else None
         out = {
             "metric": "env steps/sec", "value": total_steps / elapsed, "unit": "env steps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
@@ -953,13 +977,14 @@ def run_rank(args):
                                    "%s step+sample%s" % (n, args.version, v.rows, v.columns,
                                                          ", BOTH_OBSERVATIONS (67 + 79 channels)" if args.full_obs else "",
                                                          "separate" if args.unfused else "fused",
-                                                         ", outputs written round-robin into %d sets" % args.rotate_outputs if headline_ring else ""),
+                                                         ", outputs written round-robin into %d sets (a trajectory buffer of the last %d steps)" % (args.output_sets, args.output_sets) if headline_ring else ", outputs written in place"),
                        "games_per_gpu": n, "total_games": total, "version": args.version, "seed": BASE_SEED,
                        "arithmetic": "game logic on int8 / uint8 boards (dtype u8); outputs: float32 observation (85 % of the bytes), uint8 mask",
                        "games_finished_in_timed_region": games, "b_min_bytes_per_step": b_min(v, args.full_obs, rec_bytes),
                        "record_bytes": rec_bytes,
                        "untimed_before_bracket": "%d warm-up steps, then %.2f s of state-preserving sgx_observe launches (gpu_settle)" % (args.warmup, SETTLE_SECONDS),
-                       "concurrent_chains": args.chains, "two_chains": two_chains, "rotating_outputs": rotating,
+                       "output_sets": args.output_sets if headline_ring else 1, "ring_placement_plain_and_kept_us_per_extra_set": ring_report,
+                       "concurrent_chains": args.chains, "in_place": in_place, "two_chains": two_chains,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),
                        "reduction_backend": backend if rk.world > 1 else None, "devices": args.devices,
                        # the slowest / fastest rank's own K steps (no waiting for the others): weak scaling without a data-path

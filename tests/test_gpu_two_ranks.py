@@ -38,13 +38,16 @@ def test_two_ranks_on_one_gpu_equal_one_rank_and_the_oracle(version, per_rank):
     assert two['config']['games_per_gpu'] == per_rank and two['scaling'] == 'weak'
     assert two['verified_envs'] >= 32 and one['verified_envs'] >= 16          # both ranks checked their sample against the oracle
     assert two['verified_steps'] == one['verified_steps'] == 30
-    assert one['config']['two_chains']['verified_steps'] == 60 and one['config']['two_chains']['verified_envs'] >= 16
+    # one GPU: the headline writes a ring of three output sets (DRAM-side figures); several GPUs: in place.  Same games either way.
+    assert one['config']['output_sets'] == 3 and two['config']['output_sets'] == 1
     assert two['config']['outputs_checksum'] == one['config']['outputs_checksum']
     assert two['value'] > 0 and two['config']['per_gpu_value_min'] <= two['config']['per_gpu_value_max']
-    # the 1-rank run also played the rotating-outputs leg on the same env object, verified against the oracle again
-    rot = one['config']['rotating_outputs']
-    assert rot['output_sets'] == 3 and rot['verified_steps'] == 90 and rot['verified_envs'] >= 8 and rot['frac_dram'] > 0
-    assert one['roofline']['frac_dram'] == rot['frac_dram'] and len(one['build_id']) == 16
+    # the 1-rank run then played the in-place leg and its two-chains variant on the same env object, each verified against the oracle
+    inp = one['config']['in_place']
+    assert inp['verified_steps'] == 60 and inp['verified_envs'] >= 8 and inp['rate_over_spec_peak'] > 0
+    assert one['config']['two_chains']['verified_steps'] == 90 and one['config']['two_chains']['verified_envs'] >= 16
+    assert one['roofline']['frac_dram'] == one['roofline']['frac'] and one['roofline']['in_place_rate_over_spec_peak'] == inp['rate_over_spec_peak']
+    assert two['roofline']['frac_dram'] is None and len(one['build_id']) == 16
 
 
 def test_eight_ranks_on_one_gpu_equal_one_rank_and_the_oracle():
@@ -52,8 +55,8 @@ def test_eight_ranks_on_one_gpu_equal_one_rank_and_the_oracle():
     VecStrategoEnv on its range of global env ids, gloo for the reporting reductions; the checksum of checksums over all 65,536 games
     equals the 1-rank run's and every rank verified its sample against the CPU oracle."""
     eight = _run(['--gpus', '8', '--devices', '0,0,0,0,0,0,0,0', '--backend', 'gloo', '--envs', '8192', '--version', 'barrage',
-                  '--rotate-sets', '0'] + COMMON, timeout=1500)
-    one = _run(['--gpus', '1', '--envs', '65536', '--version', 'barrage', '--no-two-chains', '--rotate-sets', '0'] + COMMON, timeout=900)
+                  '--output-sets', '1'] + COMMON, timeout=1500)
+    one = _run(['--gpus', '1', '--envs', '65536', '--version', 'barrage', '--no-two-chains', '--output-sets', '1'] + COMMON, timeout=900)
     assert eight['n_gpus'] == 8 and eight['config']['launched_by'] == 'bench.py' and eight['config']['reduction_backend'] == 'gloo'
     assert eight['config']['total_games'] == one['config']['total_games'] == 65536 and eight['config']['games_per_gpu'] == 8192
     assert eight['verified_envs'] >= 8 * 16 and eight['verified_steps'] == 30

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel stats + PMC passes of bench.py, results under gpurun_out/prof_<tag>/.
 # (bench.py runs with --placement plain here to keep the profiled runs short; sgx_observe launches -- placement trials, reset() --
-# have their own kernel symbol, observe_kernel, and do not mix into step_kernel's statistics.  --rotate-sets 0 / --no-consumer-leg /
-# --no-two-chains keep every step_kernel launch of a run to ONE launch shape: the headline's.)
+# have their own kernel symbol, observe_kernel, and do not mix into step_kernel's statistics.  --no-in-place-leg / --no-two-chains keep every
+# step_kernel launch of a run to ONE launch shape: the headline's -- a ring of three output sets by default, `--output-sets 1` = in place.)
 # usage: tools/gpu_profile.sh <tag> <traffic key or -> <games per launch> [extra bench args]
-#   a traffic key (e.g. barrage, barrage+rotating) merges the pass' counter bytes into gpurun_out/prof_<tag>/traffic_entry.json
+#   a traffic key (e.g. barrage+rotating for the default ring headline, barrage with --output-sets 1) merges the pass' counter bytes into gpurun_out/prof_<tag>/traffic_entry.json
 TAG=$1; KEY=$2; GAMES=$3; shift 3
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -13,7 +13,7 @@ mkdir -p $OUT
 cd /tmp
 python3 -c "import torch,time; x=torch.empty(1<<28,device='cuda'); t=time.time()
 while time.time()-t<3: x.fill_(1.0); torch.cuda.synchronize()"
-COMMON="--no-cpu-baseline --no-other-workloads --no-two-chains --rotate-sets 0 --placement plain"
+COMMON="--no-cpu-baseline --no-other-workloads --no-two-chains --no-in-place-leg --placement plain"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 64 --warmup 8 $COMMON "$@" > $OUT/stats.log 2>&1
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum" \
