@@ -73,16 +73,20 @@ def state_from_player_perspective(state, player):
 def load_curriculum_start_states(path):
     """Curriculum start states (util.py:322-387): datasets 'state' [n,34,R,C] and 'winner' [n] (the likely winner, +1/-1).
 
-    `.npz` / `.npy`-archive files are read with numpy; anything else is opened as HDF5 like the reference does, which needs
-    `h5py` (absent from the MI355X image: convert with `np.savez(path, state=..., winner=...)`).  The reference re-opens the
-    file on every reset; the table is loaded once here (same draws from `np.random`)."""
+    `.npz` files are read with numpy; anything else is opened as HDF5 like the reference does (`h5py.File`, util.py:327) -- with h5py
+    where it is installed, else with the package's own small reader (stratego_env_amd/hdf5_lite.py: the MI355X image has no h5py; it
+    reads what h5py writes for plain numeric datasets -- contiguous or chunked, gzip / shuffle / fletcher32, old and new file
+    format -- and is tested against files written by the real h5py and against what the reference reads from them,
+    tests/test_hdf5_lite.py).  The reference re-opens the file on every reset; the table is loaded once here (same draws from `np.random`)."""
     if str(path).endswith('.npz'):
         with np.load(path) as z:
             return np.asarray(z['state']), np.asarray(z['winner'])
     try:
         import h5py
-    except ImportError as e:
-        raise ImportError("curriculum_start_states_path %r is not an .npz file and h5py is not installed" % (path,)) from e
+    except ImportError:
+        from . import hdf5_lite
+        with hdf5_lite.File(path) as f:
+            return np.asarray(f['state']), np.asarray(f['winner'])
     with h5py.File(path, 'r') as f:
         return np.asarray(f['state']), np.asarray(f['winner'])
 

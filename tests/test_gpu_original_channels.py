@@ -163,7 +163,9 @@ def test_operator_debugging_aids_match_reference_goldens(capsys):
             assert capsys.readouterr().out == r['print_po%d_hide%d' % (po_flag, hide)]
 
 
-def test_facade_curriculum_start_states_replay_reference_goldens():
+@pytest.mark.parametrize('table', ['curriculum_barrage.npz', 'curriculum_barrage_contiguous.h5', 'curriculum_barrage_chunked_gzip.h5',
+                                   'curriculum_barrage_latest.h5'])
+def test_facade_curriculum_start_states_replay_reference_goldens(table):
     """curriculum_start_states_path (maenv:341-346, 519-527; util.py:372-387): same np.random consumption, start state,
     first mover, player relabelling and per-step outputs as recorded from the reference."""
     import hashlib
@@ -183,7 +185,7 @@ def test_facade_curriculum_start_states_replay_reference_goldens():
 
     with open(os.path.join(GOLDEN, 'curriculum.json')) as f:
         cases = json.load(f)
-    path = os.path.join(GOLDEN, 'curriculum_barrage.npz')
+    path = os.path.join(GOLDEN, table)       # (.h5: real HDF5 files written by h5py, read by the package's own reader here: no h5py in the image)
     for case in cases:
         np.random.seed(case['seed'])
         random.seed(case['seed'])

@@ -1,0 +1,74 @@
+"""stratego_env_amd/hdf5_lite.py -- the package's own reader for the reference's HDF5 curriculum files (game/util.py:322-387), for
+boxes without h5py.  The fixtures are REAL HDF5 files written with h5py 3.3.0 in the build container
+(tools/oracle/gen_golden_curriculum_h5.py, run with the image's /opt/conda python3.9): contiguous int64 / int64; resizable chunked
+gzip + shuffle int64 with a fletcher32 float64 'winner'; libver='latest' int16 / int32.  tests/golden/curriculum_h5.json holds what the
+REFERENCE's load_h5 / get_random_curriculum_init_fn read from those files with the real h5py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from stratego_env_amd import hdf5_lite, util
+from stratego_env_amd.multiagent_env import load_curriculum_start_states
+from tests.helpers import GOLDEN
+
+import hashlib
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+@pytest.fixture(scope='module')
+def recorded():
+    with open(os.path.join(GOLDEN, 'curriculum_h5.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('kind', ['contiguous', 'chunked_gzip', 'latest'])
+def test_reader_returns_what_the_reference_read_with_h5py(recorded, kind):
+    rec = recorded['files'][kind]
+    path = os.path.join(GOLDEN, rec['file'])
+    with np.load(os.path.join(GOLDEN, 'curriculum_barrage.npz')) as z:
+        want_state, want_winner = np.asarray(z['state']), np.asarray(z['winner'])
+    with hdf5_lite.File(path) as f:
+        assert sorted(f.keys()) == ['state', 'winner'] and 'state' in f and 'nothing' not in f
+        state, winner = f['state'], f['winner']
+        with pytest.raises(KeyError):
+            f['nothing']
+    assert str(state.dtype) == rec['state_dtype'] and str(winner.dtype) == rec['winner_dtype']       # the file's own dtypes, like h5py
+    assert state.shape == want_state.shape and np.array_equal(state.astype(np.int64), want_state)
+    assert sha(state.astype(np.int64)) == rec['state_sha_as_int64'] == recorded['state_sha']
+    assert [int(x) for x in winner] == rec['winner_as_int'] == [int(x) for x in want_winner]
+    # the loader the facade uses (h5py if there is one, this reader otherwise)
+    s2, w2 = load_curriculum_start_states(path)
+    assert np.array_equal(np.asarray(s2).astype(np.int64), want_state) and [int(x) for x in w2] == rec['winner_as_int']
+
+
+@pytest.mark.parametrize('kind', ['contiguous', 'chunked_gzip', 'latest'])
+def test_curriculum_draws_from_real_hdf5_files_equal_the_references(recorded, kind):
+    """util.get_random_curriculum_init_fn on an .h5 path: after np.random.seed(s) the same table row, winner, cleared turn count and
+    patched max_turns as the reference's own function drew from the same file with the real h5py."""
+    rec = recorded['files'][kind]
+    fn = util.get_random_curriculum_init_fn(os.path.join(GOLDEN, rec['file']), 1000)
+    for d in rec['draws']:
+        np.random.seed(d['seed'])
+        state, winner = fn()
+        assert winner == d['winner'] and sha(np.asarray(state).astype(np.int64)) == d['state_sha_as_int64']
+        assert int(state[5, 1, 0]) == d['max_turns'] == 1000 and int(state[5, 0, 0]) == d['turn'] == 0
+    assert recorded['env_episodes_rechecked_from_the_real_file'] >= 60      # the stand-in File object of the older goldens changed nothing
+
+
+def test_unsupported_and_foreign_files_fail_loudly(tmp_path):
+    p = tmp_path / 'not_hdf5.h5'
+    p.write_bytes(b'PK\x03\x04' + b'\0' * 4096)
+    with pytest.raises(hdf5_lite.Hdf5LiteError, match='not an HDF5 file'):
+        hdf5_lite.File(str(p))
+    # a real file whose superblock version byte is from the future
+    data = bytearray(open(os.path.join(GOLDEN, 'curriculum_barrage_contiguous.h5'), 'rb').read())
+    data[8] = 9
+    q = tmp_path / 'future.h5'
+    q.write_bytes(bytes(data))
+    with pytest.raises(hdf5_lite.Hdf5LiteError, match='install h5py'):
+        hdf5_lite.File(str(q))
