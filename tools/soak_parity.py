@@ -46,6 +46,11 @@ def main():
             if time.time() - t0 > budget:
                 break
         F.check_both_obs_vs_oracle(('barrage', 'tiny', 'micro', 'fives')[salt % 4], 16 + salt % 7, 150, ('extended', 'original')[salt % 2])
+        # the lane-per-game kernel (forced; it is the default only for launches without an observation) on the boards it plays
+        for name, n, t, g in (('micro', 131, 150, 0.2), ('tiny', 77, 200, 0.2)):
+            T.test_step_bit_exact_vs_oracle(name, n + salt % 64, t, g, seed_salt=salt, final_obs=False, lane_kernel=True)
+            runs += 1
+            steps += (n + salt % 64) * t
         salt += 1
     print("soak ok: %d runs, %d env steps compared output by output against the oracle in %.0f s" % (runs, steps, time.time() - t0))
 
