@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 11
+#define SGX_ABI_VERSION 12
 #define SGX_MAX_CELLS 1024       /* rows*cols <= 1024 (largest reference variant: 15x15 = 225; the reference's StrategoProceduralEnv
                                     takes any size, penv:27-36: boards of more than 256 cells use 10-bit cell indices in the record) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
@@ -261,6 +261,10 @@ typedef struct sgx_outputs {
     int32_t reserved_;
 } sgx_outputs;
 int sgx_alloc_outputs(sgx_env *h, int32_t flags, int64_t max_extra_bytes, int32_t max_trials, void *stream, sgx_outputs *out);
+/* A target for the searches that follow: with target_us > 0 sgx_alloc_outputs keeps trying candidates (inside its budget) until one is
+ * within 3 % of the target instead of applying its own stop rules -- for a RING of output sets (sgx_step_ring), whose every set should
+ * be as fast as the first one (target = the observe-launch time the first search kept); 0 (default) = the stop rules above. */
+int sgx_set_placement_target(sgx_env *h, float target_us);
 /* Frees the buffers of `out` (h may be NULL, also after sgx_destroy of the handle that allocated them: the buffers belong to
  * whoever holds the sgx_outputs -- the Python binding ties them to the tensors that view them). */
 int sgx_free_outputs(sgx_env *h, sgx_outputs *out);

@@ -134,6 +134,17 @@ __device__ __forceinline__ GameInput load_game(const KParams &P, const int64_t e
     return load_game_from<G>(P, reinterpret_cast<const int4 *>(rec_src), env, lane);
 }
 
+// The compact observation of one game (SGX_STEP_COMPACT_OBS): build the code buffer exactly as render() does, then store it as it is.
+// One call site (env_step), outside render(): see there.
+template <class G, class Spec, int NB>
+__device__ __forceinline__ void compact_obs(const KParams &P, Lds<G, NB> &L, const uint8_t *shared, const uint8_t *codetab, const float *glut, bool raw, int qi,
+                                         int n_events, int rp0, int rp1, int64_t env, int lane) {
+    const uint8_t *tmpl = shared;
+    if constexpr (G::WIDE) tmpl = P.tab->tmpl[raw ? 2 : 0];
+    const int n_unc = build_codes<G, Spec>(L, tmpl, codetab, glut, qi, n_events, rp0, rp1, lane, P.piece_counts, raw, P.multi_ev != 0);
+    store_compact<G, Spec>(L, reinterpret_cast<uint8_t *>(P.io.obs_dev) + env * (int64_t)P.compact_stride, n_unc, lane);
+}
+
 // What the emission of the next mover's mask and observations needs from the step (SPLIT instantiation: single_kernel)
 struct StepOut {
     int qi, n_events, rp0, rp1, n_unc;
@@ -149,7 +160,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     using G = Geo<R_, C_, VAR>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
-    constexpr bool ORIG = ObsKind<KIND>::ORIG, FULL = ObsKind<KIND>::FULL;
+    constexpr bool ORIG = ObsKind<KIND>::ORIG, FULL = ObsKind<KIND>::FULL, COMPACT = (KIND & 4) != 0;
     const uint8_t *combat_s = obst_s + G::OBST_BYTES;           // the combat table follows the obstacle map in the shared LDS
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     STAMP(0);
@@ -411,10 +422,6 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
             if constexpr (G::WIDE) tmpl = P.tab->tmpl[(raw ? 2 : 0) + (full ? 1 : 0)];           // (global memory, L2-resident)
             const int n_unc = build_codes<G, Spec>(L, tmpl, codetab, full ? glut_f : glut_p, q,
                                                    n_events, rp0, rp1, lane, P.piece_counts, raw, P.multi_ev != 0);
-            if (!full && (P.io.flags & SGX_STEP_COMPACT_OBS)) {      // the codes themselves: 1/8 of the bytes (sgx_decode_obs expands them)
-                store_compact<G, Spec>(L, reinterpret_cast<uint8_t *>(dst), n_unc, lane);
-                return 0;
-            }
             if constexpr (RC % 4 == 0) {
                 if (n_unc == 0) {
                     if (P.nt_stores) emit_codes<G, Spec, false, true>(L, dst, lane);
@@ -479,7 +486,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
         // 16 index computations per lane cost 30 VGPRs)
         if (MAPPED && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
         else if (MAPPED && qi) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
-        else if (P.io.flags & SGX_STEP_COMPACT_MASK) {               // the mask as bits: uint32 [MB_WORDS] per game, bit a = action a
+        else if (COMPACT && (P.io.flags & SGX_STEP_COMPACT_MASK)) {   // the mask as bits: uint32 [MB_WORDS] per game, bit a = action a
             int4 *mdst = reinterpret_cast<int4 *>(reinterpret_cast<uint32_t *>(P.io.mask_dev) + env * (int64_t)G::MB_WORDS);
             for (int i = lane; i < G::MB_WORDS / 4; i += G::LPG) mdst[i] = reinterpret_cast<const int4 *>(L.mbits)[i];
         }
@@ -488,9 +495,16 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     STAMP(5);   // mask stores issued
     // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
     if (P.io.obs_dev) {
-        float *odst = (P.io.flags & SGX_STEP_COMPACT_OBS) ? reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(P.io.obs_dev) + env * (int64_t)P.compact_stride)
-                                                          : P.io.obs_dev + env * (int64_t)(RC * PS::NCH);
-        render(PS{}, false, qi, odst);
+        // compact output (opt-in, KIND bit 2): the codes themselves, 1/8 of the bytes; sgx_decode_obs expands them.  An instantiation of
+        // its own: as a run-time branch it took the 8x8 hot kernel from 35 to 64 VGPRs + scratch
+        bool done_compact = false;
+        if constexpr (COMPACT) {
+            if (P.io.flags & SGX_STEP_COMPACT_OBS) {
+                compact_obs<G, PS>(P, L, shared, codetab, glut_p, raw, qi, n_events, rp0, rp1, env, lane);
+                done_compact = true;
+            }
+        }
+        if (!done_compact) render(PS{}, false, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH));
     }
     if constexpr (FULL)
         if (P.io.fobs_dev) render(FS{}, true, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH));
@@ -516,7 +530,8 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
 }
 
 // KIND bit 0: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492);
-// KIND bit 1: obs_channel_mode 'original' (32/33 value channels) instead of 'extended' (67/79 one-hot channels)
+// KIND bit 1: obs_channel_mode 'original' (32/33 value channels) instead of 'extended' (67/79 one-hot channels);
+// KIND bit 2 (alone: KIND 4): compact outputs -- the partial 'extended' kind whose observation / mask may leave as codes / bits
 template <int R_, int C_, int KIND, bool MAPPED>
 __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     using G = Geo<R_, C_>;

@@ -111,6 +111,7 @@ struct sgx_env {
     int nt_mode;                 // sgx_set_nt_stores: -1 = by the launch's output size, 0 = never, 1 = always
     int lane_mode;               // sgx_set_lane_kernel: 0 = never the lane-per-game kernel, otherwise wherever it is eligible
     int prio_mode;               // SGX_PRIO experiment (sgx_layout.h: stagger_priority)
+    float placement_target_us;   // sgx_set_placement_target: sgx_alloc_outputs searches on until a candidate is within 3 % of it (0 = its own stop rules)
     int mask_nt_mode;            // SGX_MASK_NT experiment: 1 = non-temporal stores for the mask's interior lines (default off)
     hipStream_t chain_stream[SGX_MAX_CHAINS];   // sgx_rollout: created on first use
     hipEvent_t chain_fork, chain_join[SGX_MAX_CHAINS];
@@ -482,6 +483,12 @@ SGX_API int sgx_set_nt_stores(sgx_env *h, int32_t mode) {
 SGX_API int sgx_debug_set_prio(sgx_env *h, int32_t mode) { if (h) h->prio_mode = mode; return SGX_OK; }
 SGX_API int sgx_debug_set_mask_nt(sgx_env *h, int32_t mode) { if (h) h->mask_nt_mode = mode; return SGX_OK; }
 
+SGX_API int sgx_set_placement_target(sgx_env *h, float target_us) {
+    if (!h || !(target_us >= 0.f)) return fail(SGX_EINVAL, "sgx_set_placement_target: target_us must be >= 0%s");
+    h->placement_target_us = target_us;
+    return SGX_OK;
+}
+
 SGX_API int sgx_set_general_states(sgx_env *h, int32_t mode) {
     if (!h || mode < 0 || mode > 1) return fail(SGX_EINVAL, "sgx_set_general_states: mode must be 0 or 1%s");
     h->general_states = mode;
@@ -653,6 +660,7 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
         else step_kernel<R, C, KIND><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);           \
     } while (0)
 #define CALL_STEP0(R, C) CALL_STEP_KIND(R, C, 0)
+#define CALL_STEP4(R, C) CALL_STEP_KIND(R, C, 4)
 #define CALL_STEP1(R, C) CALL_STEP_KIND(R, C, 1)
 #define CALL_STEP2(R, C) CALL_STEP_KIND(R, C, 2)
 #define CALL_STEP3(R, C) CALL_STEP_KIND(R, C, 3)
@@ -667,11 +675,13 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
     } while (0)
         DISPATCH_GEOMETRY(h, CALL_STEP_MAPPED);
 #undef CALL_STEP_MAPPED
-    } else if (!original && !full) DISPATCH_GEOMETRY(h, CALL_STEP0);
+    } else if (p.io.flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) DISPATCH_GEOMETRY(h, CALL_STEP4);
+    else if (!original && !full) DISPATCH_GEOMETRY(h, CALL_STEP0);
     else if (!original) DISPATCH_GEOMETRY(h, CALL_STEP1);
     else if (!full) DISPATCH_GEOMETRY(h, CALL_STEP2);
     else DISPATCH_GEOMETRY(h, CALL_STEP3);
 #undef CALL_STEP0
+#undef CALL_STEP4
 #undef CALL_STEP1
 #undef CALL_STEP2
 #undef CALL_STEP3
@@ -792,6 +802,8 @@ int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t 
     if (rc != SGX_OK) return rc;
     trial_us[0] = best_us;
     *n_trials = 1;
+    const float target = which == 0 ? c.h->placement_target_us : 0.f;      // (the target is a partial-observation launch time)
+    if (target > 0.f && best_us <= 1.03f * target) return SGX_OK;
     const size_t room = (size_t)max_extra - bytes;                        // what the padding may take
     size_t step = bytes / 8;                                              // (a big buffer leaves little room: smaller steps then)
     if (step * 12 > room) step = room / 12;
@@ -824,6 +836,10 @@ int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t 
         // Two steps: the classes are ~255-265 / 300-310 / 320-330 / ~345 us (65,536 Barrage games): a candidate 9 % below the slowest may
         // be the middle class only, so the search goes on for up to eight more candidates and stops at once at 17 % (fast class: 272-277 us after 335-340 us;
         // 282 us, 16 %, is not the best a box has).
+        if (target > 0.f) {                           // a ring of output sets: every set as fast as the first one (sgx_set_placement_target)
+            if (best_us <= 1.03f * target) break;
+            continue;
+        }
         float worst = 0.f;
         for (int j = 0; j <= k; ++j) worst = trial_us[j] > worst ? trial_us[j] : worst;
         if (k >= 2 && best_us < 0.83f * worst) break;

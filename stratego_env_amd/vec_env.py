@@ -303,6 +303,12 @@ class VecStrategoEnv:
         n_sets = int(n_sets)
         if n_sets < 1:
             raise ValueError("n_sets must be >= 1")
+        # every extra set should be as fast as the env's own: the searches go on until a candidate is within 3 % of what the first
+        # search kept (sgx_set_placement_target), inside the same budget
+        target = 0.0
+        if tune and not self.compact and getattr(self, '_outputs', None) is not None and self._outputs.n_trials > 0:
+            target = min(float(x) for x in self._outputs.trial_us[:self._outputs.n_trials])
+        _lib.check(self._L.sgx_set_placement_target(self._h, C.c_float(target)), self._L)
         N, R, Cc, K, dev = self.num_envs, self.R, self.Cc, self.K, self.device
         self._ring = [(self.obs, self.mask, self.fobs)]
         self._ring_owners = [getattr(self, '_outputs_owner', None)]
@@ -326,6 +332,7 @@ class VecStrategoEnv:
                 reports.append(None)
                 self._ring_owners.append(None)
             self._ring.append((obs, mask, fobs))
+        _lib.check(self._L.sgx_set_placement_target(self._h, C.c_float(0.0)), self._L)
         self._ring_pos = 1 % n_sets          # set 0 holds the current position's outputs: the next step writes set 1
         self._ring_ios = (_lib.SgxStepIO * n_sets)()
         return reports

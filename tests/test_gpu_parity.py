@@ -357,6 +357,33 @@ def test_standard_full_size_properties_and_oracle_digests():
     env.close()
 
 
+def test_placement_target_for_ring_sets():
+    """sgx_set_placement_target: a search with a target goes on (inside its budget) until a candidate is within 3 % of it -- the
+    sets of a ring should all be as fast as the first one -- and stops at the first candidate that is."""
+    import ctypes as C
+    from stratego_env_amd import _lib
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    env = VecStrategoEnv('barrage', 4096, seed=5, auto_reset=True)
+    env.reset()
+    L = env._L
+    assert L.sgx_set_placement_target(env._h, C.c_float(-1.0)) == -1           # SGX_EINVAL
+    _lib.check(L.sgx_set_placement_target(env._h, C.c_float(1e9)), L)               # anything meets it: the plain allocation is kept
+    assert len(env.tune_placement_once(trials=6)['obs']) == 1
+    _lib.check(L.sgx_set_placement_target(env._h, C.c_float(1e-3)), L)              # nothing meets it: every candidate is tried
+    assert len(env.tune_placement_once(trials=6)['obs']) == 6
+    _lib.check(L.sgx_set_placement_target(env._h, C.c_float(0.0)), L)
+    twin = VecStrategoEnv('barrage', 4096, seed=5, auto_reset=True)
+    twin.reset()
+    reps = env.alloc_output_ring(3, tune=True, trials=4)                            # target = what the env's own search kept
+    assert reps[0] is None and all(1 <= len(r['obs']) <= 4 for r in reps[1:])
+    env.rollout_steps(6, ring=True)
+    twin.rollout_steps(6)
+    import torch
+    assert torch.equal(env.obs, twin.obs) and torch.equal(env.mask, twin.mask)
+    env.close()
+    twin.close()
+
+
 def test_tune_placement_keeps_outputs():
     """Placement trials only swap which allocation the outputs live in."""
     from stratego_env_amd.vec_env import VecStrategoEnv
