@@ -307,7 +307,10 @@ int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, int32_t fi
  * stream of its own: games never interact, so the ranges' launches may overlap, and the ramp-up / drain of one range's step is filled
  * by the other's (a launch that lasts tens of microseconds spends a third of its time with the chip half empty).  The caller's
  * stream waits for all chains; results are identical to sgx_step_n.  Measured with chains = 2 on 65,536 games: Micro 41.3 -> 37.2 us per
- * step of all games, 5x5 107.6 -> 96.0 us, 8x8 198 -> 183 us, Barrage 322 -> 304 us.  No reference counterpart. */
+ * step of all games, 5x5 107.6 -> 96.0 us, 8x8 198 -> 183 us, Barrage 322 -> 304 us.  chains = 0 lets the
+ * library choose by the rule measured on the current kernels (2 for boards of up to 36 cells and for boards whose cell count is no
+ * multiple of 4, else 1: 8x8 and 10x10 launches already stream at the memory rate and lose 2-5 % to a second chain).  No reference
+ * counterpart. */
 #define SGX_MAX_CHAINS 4
 int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int32_t chains, void *stream);
 

@@ -67,7 +67,6 @@ __global__ __launch_bounds__(64) void lane_kernel(const KParams P) {
     const int64_t grp = group_of_block(P);
     const int64_t env0 = P.env_first + grp * 64;
     if (env0 >= P.n_envs) return;
-    stagger_priority(P.prio_mode);
     const int n_act = (int)((P.n_envs - env0) < 64 ? (P.n_envs - env0) : 64);
     const int64_t env = env0 + lane;
     const bool act = lane < n_act;

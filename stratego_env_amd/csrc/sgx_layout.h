@@ -176,12 +176,10 @@ struct KParams {
     int32_t map_mode, map_arg;   // experiment only: see group_of_block
     int32_t xcd_first[8], xcd_count[8];   // workgroup-groups of this launch played by XCD x: [xcd_first[x], + xcd_count[x]) (group_of_block)
     int32_t nt_stores;  // the launch's observations do not fit the Infinity Cache: whole lines leave as non-temporal stores (sgx_obs.h)
-    int32_t prio_mode;  // experiment (SGX_PRIO): wave priorities by the wave's slot on its SIMD, see stagger_priority
     // A variant with more than 8 pieces of one type (the reference's piece_amounts is unbounded, config.py:3-23): a capture event counts to
     // 8, so a ninth capture of one type on one cell opens ANOTHER event with the same (layer, cell) key.  Every reader of the list then
     // sums the events of a key (the first one speaks for all); 0 for every variant of the reference, whose lists never hold duplicates.
     int32_t multi_ev;
-    int32_t mask_nt;          // the mask's interior lines leave as non-temporal stores (sgx_mask.h: emit_mask)
     int32_t compact_stride;   // SGX_STEP_COMPACT_OBS: bytes of one game's compact observation record (sgx_compact_obs_stride)
     // functional-API instantiation only (sgx_expand): game i is read from record src_index[i] (i when NULL) of ANOTHER handle's
     // records and written to record i of this one, whether or not the move was valid
@@ -326,20 +324,6 @@ __device__ inline int64_t group_of_block(const KParams &P) {
     if (P.map_mode == 5) return x * per + ((x & 1) ? per - 1 - i : i);                   // neighbouring XCDs walk towards each other
     if (P.map_mode == 6) { const int64_t f = map_arg, sub = per / f; return x * per + (i % f) * sub + (i / f); }   // f sub-fronts per XCD (f divides nb / 8)
     return x * per + i;
-}
-
-// Experiment (SGX_PRIO=1|2).  All waves of a SIMD start their game logic together and share the issue slots, so the FIRST store of the
-// launch leaves only when the whole cohort is through its logic (Micro: ~11 us of a 41 us launch with nothing on the memory pipes).
-// With priorities by slot (s_setprio: 3 for the waves in slots 0-1, 2 for slots 2-3, ...) the cohort runs staggered: the first pair reaches
-// its stores after a quarter of that time and the later pairs' logic overlaps the earlier pairs' emission.
-__device__ inline void stagger_priority(int mode) {
-    if (mode == 0) return;
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;       // HW_REG_HW_ID[3:0] = wave slot on its SIMD
-    const unsigned level = mode == 1 ? (slot >> 1) : (slot & 3u);
-    if (level == 0) __builtin_amdgcn_s_setprio(3);
-    else if (level == 1) __builtin_amdgcn_s_setprio(2);
-    else if (level == 2) __builtin_amdgcn_s_setprio(1);
-    else __builtin_amdgcn_s_setprio(0);
 }
 
 // Orders the LDS phases of ONE wave (each wave owns its game's LDS region; waves of a workgroup never exchange

@@ -114,16 +114,14 @@ __device__ inline uint32_t mask_bits(const Lds<G, NB> &L, int p, int n) {
 // (3700 = 4 mod 16), byte aligned when NA is odd (5x5, 15x15); lanes own 16-byte-aligned chunks of the global range, so
 // whole chunks leave as one 16-byte store per lane and only the partial first / last chunks go out as dwords (bytes when
 // the base is not 4-byte aligned).
-// nt (KParams::mask_nt, experiment, default off): the mask's interior lines as non-temporal stores; the first and the last 128-byte line
-// are shared with the neighbouring games and always go through L2.  Measured no different from plain stores in place and in a ring of
-// three output sets on 10x10, 8x8 and 3x4 (profiles/r04_mask_nt_ab.log).
+// (Non-temporal stores for the mask measured no different from plain ones, in place and in a ring of output sets, on 10x10, 8x8 and
+// 3x4: profiles/r04_mask_nt_ab.log; the experiment was removed.)
 template <class G, int STRIDE = G::LPG, int NB>
-__device__ void emit_mask(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int lane, bool nt = false) {
+__device__ void emit_mask(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int lane) {
     const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
     const int nchunks = (A + G::NA + 15) >> 4;
     uint8_t *gbase = dst - A;                       // 16-byte aligned
     const int shift = (int)((reinterpret_cast<uintptr_t>(gbase) >> 4) & (G::LPG - 1));   // start the sweep on a 1 KiB boundary
-    const int l0 = (int)((reinterpret_cast<uintptr_t>(gbase) >> 4) & 7), last_line = (nchunks - 1 + l0) >> 3;
     for (int c0 = -shift; c0 < nchunks; c0 += STRIDE) {
         const int c = c0 + lane;
         if (c < 0 || c >= nchunks) continue;
@@ -131,9 +129,7 @@ __device__ void emit_mask(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int la
         if (lo >= 0 && lo + 16 <= G::NA) {
             const uint32_t b16 = mask_bits(L, lo, 16);
             i32x4 q4 = {(int)expand4(b16 & 15), (int)expand4((b16 >> 4) & 15), (int)expand4((b16 >> 8) & 15), (int)expand4(b16 >> 12)};
-            const int line = (c + l0) >> 3;
-            if (nt && line != 0 && line != last_line) __builtin_nontemporal_store(q4, &reinterpret_cast<i32x4 *>(gbase)[c]);
-            else reinterpret_cast<i32x4 *>(gbase)[c] = q4;
+            reinterpret_cast<i32x4 *>(gbase)[c] = q4;
         } else if constexpr (G::NA % 4 == 0) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) {

@@ -490,7 +490,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
             int4 *mdst = reinterpret_cast<int4 *>(reinterpret_cast<uint32_t *>(P.io.mask_dev) + env * (int64_t)G::MB_WORDS);
             for (int i = lane; i < G::MB_WORDS / 4; i += G::LPG) mdst[i] = reinterpret_cast<const int4 *>(L.mbits)[i];
         }
-        else emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane, P.mask_nt != 0);
+        else emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
     }
     STAMP(5);   // mask stores issued
     // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
@@ -543,7 +543,6 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     __shared__ alignas(16) uint8_t obst_s[G::OBST_BYTES + COMBAT_BYTES];    // obstacle map, then the combat outcome table
     const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;     // lane inside the game, game inside the workgroup
     const int64_t env = P.env_first + group_of_block(P) * (G::WPB * G::GPW) + slot;
-    stagger_priority(P.prio_mode);
     // The game's record and action are requested FIRST: the reads fly while the workgroup stages its shared tables (another
     // global round trip) and waits at the barrier -- the two round trips used to follow each other.
     const GameInput in = load_game<G, MAPPED>(P, env, lane);

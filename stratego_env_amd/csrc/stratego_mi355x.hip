@@ -110,9 +110,7 @@ struct sgx_env {
     int32_t xcd_w[8];            // shares of the eight XCDs, per mille of the mean share (sum 8000)
     int nt_mode;                 // sgx_set_nt_stores: -1 = by the launch's output size, 0 = never, 1 = always
     int lane_mode;               // sgx_set_lane_kernel: 0 = never the lane-per-game kernel, otherwise wherever it is eligible
-    int prio_mode;               // SGX_PRIO experiment (sgx_layout.h: stagger_priority)
     float placement_target_us;   // sgx_set_placement_target: sgx_alloc_outputs searches on until a candidate is within 3 % of it (0 = its own stop rules)
-    int mask_nt_mode;            // SGX_MASK_NT experiment: 1 = non-temporal stores for the mask's interior lines (default off)
     hipStream_t chain_stream[SGX_MAX_CHAINS];   // sgx_rollout: created on first use
     hipEvent_t chain_fork, chain_join[SGX_MAX_CHAINS];
     // sgx_step_sync on a handful of games (single_kernel): a host-mapped word the kernel publishes its sequence number in, and the
@@ -389,9 +387,6 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     h->general_states = 1;
     if (const char *e = getenv("SGX_GENERAL_STATES")) h->general_states = atoi(e);
     if (const char *e = getenv("SGX_LANE")) { if (!strcmp(e, "0")) h->lane_mode = 0; else if (!strcmp(e, "1")) h->lane_mode = 1; }   // SGX_LANE=0|1|auto
-    if (const char *e = getenv("SGX_PRIO")) h->prio_mode = atoi(e);
-    h->mask_nt_mode = -1;
-    if (const char *e = getenv("SGX_MASK_NT")) { if (!strcmp(e, "0")) h->mask_nt_mode = 0; else if (!strcmp(e, "1")) h->mask_nt_mode = 1; }
     h->xcd_skew = -1;
     if (const char *e = getenv("SGX_XCD_SKEW")) { if (strcmp(e, "auto")) h->xcd_skew = atoi(e); }   // SGX_XCD_SKEW=<per mille>|auto
     if (h->xcd_skew > 900) h->xcd_skew = 900;
@@ -478,10 +473,6 @@ SGX_API int sgx_set_nt_stores(sgx_env *h, int32_t mode) {
     h->nt_mode = mode;
     return SGX_OK;
 }
-
-// experiment, not part of the ABI header's contract: wave priorities by SIMD slot (0 = off)
-SGX_API int sgx_debug_set_prio(sgx_env *h, int32_t mode) { if (h) h->prio_mode = mode; return SGX_OK; }
-SGX_API int sgx_debug_set_mask_nt(sgx_env *h, int32_t mode) { if (h) h->mask_nt_mode = mode; return SGX_OK; }
 
 SGX_API int sgx_set_placement_target(sgx_env *h, float target_us) {
     if (!h || !(target_us >= 0.f)) return fail(SGX_EINVAL, "sgx_set_placement_target: target_us must be >= 0%s");
@@ -620,12 +611,8 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
     if (p.mode == 0 && p.io.auto_reset)
         if (int rc = check_random_setups(h)) return rc;
     p.map_mode = h->map_mode; p.map_arg = h->map_arg;
-    p.prio_mode = h->prio_mode;
     const bool streaming = launch_streams_past_cache(h, p, ring_sets);
     p.nt_stores = h->nt_mode < 0 ? (streaming ? 1 : 0) : h->nt_mode;
-    // the mask stays on plain stores: non-temporal ones measured no different in place and in a ring on every board size
-    // (tools/mask_nt_ab.py, profiles/r04_mask_nt_ab.log); SGX_MASK_NT=1 / sgx_debug_set_mask_nt force them for that A/B
-    p.mask_nt = h->mask_nt_mode > 0 ? 1 : 0;
     int32_t skew[8];                     // unequal XCD shares (sgx_layout.h: group_of_block)
     launch_shares(h, streaming, skew);
     const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
@@ -1067,9 +1054,13 @@ SGX_API int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int3
     if (!h || !io) return fail(SGX_EINVAL, "handle or io is NULL%s");
     if (!io->actions_dev || io->next_actions_dev != io->actions_dev)
         return fail(SGX_EINVAL, "sgx_rollout needs next_actions_dev == actions_dev (each step plays the action the previous one drew)%s");
-    if (n_steps < 0 || chains < 1 || chains > SGX_MAX_CHAINS) return fail(SGX_EINVAL, "n_steps or chains out of range%s");
+    if (n_steps < 0 || chains < 0 || chains > SGX_MAX_CHAINS) return fail(SGX_EINVAL, "n_steps or chains out of range%s");
     // games per chain: a multiple of what eight workgroups play, so that every chain keeps the XCD-aware map
     const int cells = h->cfg.rows * h->cfg.cols;
+    // chains = 0: the measured rule (profiles/r04_variant_bench.log, 65,536 games in place): two chains gain where one launch leaves
+    // the chip part empty -- boards of up to 36 cells (Micro +19 %, Tiny +4 %, 5x5 +3 %, 6x6 +5 %) and boards whose cell count is no
+    // multiple of 4 (15x15 +4 %) -- and lose 2-5 % on 8x8 / 10x10, whose single launch already streams at the memory rate
+    if (chains == 0) chains = (cells <= 36 || cells % 4 != 0) ? 2 : 1;
     const int64_t unit = 8 * 8 * (cells <= 16 ? 4 : (cells <= 32 ? 2 : 1));     // 8 workgroups x SGX_WPB waves x Geo::GPW games
     int64_t per = (h->n_envs / chains) / unit * unit;
     if (chains == 1 || per == 0 || n_steps == 0) return sgx_step_n(h, io, n_steps, stream);

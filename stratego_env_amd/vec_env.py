@@ -396,7 +396,8 @@ class VecStrategoEnv:
     def rollout_steps(self, n_steps, chains=1, ring=False):
         """`n_steps` rollout steps enqueued by one library call (sgx_step_n): same results as calling rollout_step()
         n_steps times, without a Python round trip per step (toy boards are launch-bound otherwise).  chains > 1 (sgx_rollout):
-        the batch is split into that many contiguous ranges of games whose launches overlap on streams of their own.
+        the batch is split into that many contiguous ranges of games whose launches overlap on streams of their own; chains = 0 /
+        'auto': as many as the library's measured rule says (2 on boards of up to 36 cells and on odd boards, else 1).
         ring=True (after alloc_output_ring): the steps write the ring's output sets in turn (sgx_step_ring); self.obs / self.mask /
         self.fobs are the set the LAST step wrote afterwards."""
         if not self._next_actions_fresh:
@@ -416,8 +417,8 @@ class VecStrategoEnv:
             return self.obs, self.mask, self.reward, self.done, self.player
         io = self._fill_io(self.next_actions, True, True, True, 0)
         with torch.cuda.device(self.device):
-            if chains > 1:
-                _lib.check(self._L.sgx_rollout(self._h, C.byref(io), int(n_steps), int(chains), self._stream()), self._L)
+            if chains in (0, 'auto') or chains > 1:        # 0 / 'auto': the library's measured rule (2 chains on small and odd boards)
+                _lib.check(self._L.sgx_rollout(self._h, C.byref(io), int(n_steps), 0 if chains == 'auto' else int(chains), self._stream()), self._L)
             else:
                 _lib.check(self._L.sgx_step_n(self._h, C.byref(io), int(n_steps), self._stream()), self._L)
         return self.obs, self.mask, self.reward, self.done, self.player

@@ -749,7 +749,7 @@ def test_rollout_chains_equal_a_single_chain(name, n):
     ref.reset()
     ref.rollout_steps(41)
     want_state, want_player = ref.export_state()
-    for chains in (2, 3, 4):
+    for chains in (2, 3, 4, 0, 'auto'):
         env = VecStrategoEnv(name, n, seed=77, auto_reset=True)
         env.reset()
         env.rollout_steps(20, chains=chains)

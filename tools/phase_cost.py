@@ -23,7 +23,7 @@ def main():
     for _ in range(40):
         env.rollout_step()
 
-    def timed(obs, mask, fused, steps=64):
+    def timed(obs, mask, fused, steps=64):        # (`env` is looked up at call time: the compact env below is timed by the same code)
         def one():
             env.step(env.next_actions, want_next_actions=fused, emit_obs=obs, emit_mask=mask)
             if not fused:
@@ -43,6 +43,18 @@ def main():
     print("  without the observation        %.1f us  (observation: %.1f us)" % (timed(False, True, True), full - timed(False, True, True)))
     print("  without the mask bytes         %.1f us" % timed(True, False, True))
     print("  without observation and mask   %.1f us" % timed(False, False, True))
+    env.close()
+    try:
+        env = VecStrategoEnv(version, n, seed=3, auto_reset=True, compact_outputs=True)
+    except Exception as e:                      # boards / modes without compact outputs
+        print("  (no compact outputs: %s)" % e)
+        return
+    env.reset()
+    env.sample_valid_actions()
+    for _ in range(40):
+        env.rollout_step()
+    print("  compact outputs: full step %.1f us   codes only %.1f us   mask bits only %.1f us   neither %.1f us"
+          % (timed(True, True, True), timed(True, False, True), timed(False, True, True), timed(False, False, True)))
     env.close()
 
 
