@@ -28,6 +28,27 @@ class Hdf5LiteError(ValueError):
     pass
 
 
+_MAX_NODES = 1 << 20              # object header blocks / B-tree nodes one call may visit
+_MAX_DATASET_BYTES = 1 << 31      # a dataset is read whole
+
+
+def _malformed(what):
+    raise Hdf5LiteError("malformed HDF5 file: %s" % what)
+
+
+def _guarded(fn):
+    """Entry points raise Hdf5LiteError (a ValueError) on anything a corrupt file can provoke -- never an IndexError from the parser."""
+    def wrapper(self, *a, **k):
+        try:
+            return fn(self, *a, **k)
+        except (Hdf5LiteError, KeyError, OSError):
+            raise
+        except (IndexError, TypeError, ValueError, OverflowError, RecursionError, MemoryError, UnicodeDecodeError, zlib.error) as e:
+            raise Hdf5LiteError("malformed HDF5 file (%s: %s)" % (type(e).__name__, e)) from e
+    wrapper.__doc__ = fn.__doc__
+    return wrapper
+
+
 def _unsupported(what):
     raise Hdf5LiteError("hdf5_lite cannot read this file (%s): install h5py, or convert the table with "
                         "np.savez(path, state=..., winner=...)" % what)
@@ -53,10 +74,12 @@ class _Reader:
 class File:
     """`File(path)['state']` -> numpy array (the whole dataset; these tables are small)."""
 
+    @_guarded
     def __init__(self, path):
         with open(path, 'rb') as fh:
             data = fh.read()
         r = self.r = _Reader(data)
+        self._nodes = 0
         at = 0
         while data[at:at + 8] != SIGNATURE:                  # the superblock may sit at 0, 512, 1024, ... (III.A)
             at = 512 if at == 0 else at * 2
@@ -76,6 +99,8 @@ class File:
             root_header = r.off(p + 3 * r.O)                 # base, superblock extension, end of file, root object header
         else:
             _unsupported("superblock version %d" % ver)
+        if r.O not in (2, 4, 8) or r.L not in (2, 4, 8) or root_header is None:
+            _malformed("superblock")
         self._links = self._group_links(root_header)
 
     # ---- object headers (IV.A.1) ---------------------------------------------------------------------------------
@@ -95,7 +120,11 @@ class File:
             p += n
             blocks = [(p, p + size)]
             order = bool(flags & 0x04)
+            seen = 0
             while blocks:
+                seen += 1
+                if seen > _MAX_NODES:
+                    _malformed("object header continuation blocks do not end")
                 p, end = blocks.pop(0)
                 while p + 4 <= end:
                     mtype, msize, mflags = d[p], r.u(p + 1, 2), d[p + 3]
@@ -103,6 +132,8 @@ class File:
                     body = d[p:p + msize]
                     if mtype == 0x10:                        # continuation: offset, length -> an 'OCHK' block, checksum at its end
                         caddr, clen = r.off(p), r.ln(p + r.O)
+                        if caddr is None:
+                            _malformed("undefined continuation address")
                         blocks.append((caddr + 4, caddr + clen - 4))
                     elif mtype != 0:
                         out.append((mtype, mflags, body))
@@ -112,13 +143,19 @@ class File:
                 _unsupported("object header version %d" % d[addr])
             nmsg, size = r.u(addr + 2, 2), r.u(addr + 8, 4)
             blocks = [(addr + 16, addr + 16 + size)]
+            seen = 0
             while blocks and len(out) < nmsg + 64:
+                seen += 1
+                if seen > _MAX_NODES:
+                    _malformed("object header continuation blocks do not end")
                 p, end = blocks.pop(0)
                 while p + 8 <= end:
                     mtype, msize, mflags = r.u(p, 2), r.u(p + 2, 2), d[p + 4]
                     p += 8
                     body = d[p:p + msize]
                     if mtype == 0x10:
+                        if r.off(p) is None:
+                            _malformed("undefined continuation address")
                         blocks.append((r.off(p), r.off(p) + r.ln(p + r.O)))
                     elif mtype != 0:
                         out.append((mtype, mflags, body))
@@ -158,6 +195,12 @@ class File:
                     _unsupported("a group with dense link storage")
         return links
 
+    def _visit(self, addr, depth):
+        """Bounds a B-tree walk: a corrupt file may link a node to itself."""
+        self._nodes += 1
+        if addr is None or depth > 64 or self._nodes > _MAX_NODES:
+            _malformed("B-tree does not end")
+
     def _off_in(self, body, p):
         v = int.from_bytes(body[p:p + self.r.O], 'little')
         return None if v == (1 << (8 * self.r.O)) - 1 else v + self.r.base
@@ -165,17 +208,19 @@ class File:
     def _off_abs(self, at):
         return self.r.off(at)
 
-    def _walk_group_btree(self, addr, heap_data, links):
+    def _walk_group_btree(self, addr, heap_data, links, depth=0):
         r, d = self.r, self.r.d
+        self._visit(addr, depth)
         if d[addr:addr + 4] != b'TREE' or d[addr + 4] != 0:
             _unsupported("group B-tree node")
         level, used = d[addr + 5], r.u(addr + 6, 2)
+        self._nodes += used
         p = addr + 8 + 2 * r.O
         for i in range(used):
             child = r.off(p + r.L)                           # key (length), child (offset), key, child, ..., key
             p += r.L + r.O
             if level > 0:
-                self._walk_group_btree(child, heap_data, links)
+                self._walk_group_btree(child, heap_data, links, depth + 1)
                 continue
             if d[child:child + 4] != b'SNOD':
                 _unsupported("symbol table node")
@@ -194,10 +239,12 @@ class File:
         return name in self._links
 
     # ---- datasets -------------------------------------------------------------------------------------------------
+    @_guarded
     def __getitem__(self, name):
         if name not in self._links:
             raise KeyError(name)
         r, d = self.r, self.r.d
+        self._nodes = 0
         shape = dtype = layout = None
         filters = []
         for mtype, _, body in self._messages(self._links[name]):
@@ -232,7 +279,11 @@ class File:
                     filters.append((fid, cv))
         if shape is None or dtype is None or layout is None:
             _unsupported("dataset %r without dataspace / datatype / layout" % name)
-        n = int(np.prod(shape)) if shape else 1
+        n = 1
+        for extent in shape:
+            n *= int(extent)
+        if n * dtype.itemsize > _MAX_DATASET_BYTES:
+            _unsupported("dataset %r of %d bytes (curriculum tables are small; this reader holds a dataset in memory)" % (name, n * dtype.itemsize))
         lver = layout[0]
         if lver in (1, 2):                                   # (HDF5 1.6 and older) version, dimensionality, class, 5 reserved, address, sizes
             ndim, lcls = layout[1], layout[2]
@@ -284,11 +335,13 @@ class File:
             self._place_chunk(d[addr:addr + size], mask, (0,) * rank, cdims, dtype, filters, out)
         return out
 
-    def _walk_chunk_btree(self, addr, rank, cdims, dtype, filters, out):
+    def _walk_chunk_btree(self, addr, rank, cdims, dtype, filters, out, depth=0):
         r, d = self.r, self.r.d
+        self._visit(addr, depth)
         if d[addr:addr + 4] != b'TREE' or d[addr + 4] != 1:
             _unsupported("chunk B-tree node")
         level, used = d[addr + 5], r.u(addr + 6, 2)
+        self._nodes += used
         p = addr + 8 + 2 * r.O
         key = 8 + 8 * (rank + 1)                             # chunk size, filter mask, offsets (one more for the element size)
         for i in range(used):
@@ -297,7 +350,7 @@ class File:
             child = r.off(p + key)
             p += key + r.O
             if level > 0:
-                self._walk_chunk_btree(child, rank, cdims, dtype, filters, out)
+                self._walk_chunk_btree(child, rank, cdims, dtype, filters, out, depth + 1)
             else:
                 self._place_chunk(d[child:child + size], mask, offs, cdims, dtype, filters, out)
 
@@ -308,8 +361,17 @@ class File:
             fid, cv = filters[i]
             if mask & (1 << i):
                 continue
-            if fid == 1:
-                raw = zlib.decompress(raw)
+            if fid == 1:                                     # deflate, bounded by what a chunk can hold (+ its checksum)
+                limit = 1
+                for c in cdims:
+                    limit *= int(c)
+                limit = limit * dtype.itemsize + 4
+                if limit > _MAX_DATASET_BYTES:
+                    _malformed("chunk of %d bytes" % limit)
+                z = zlib.decompressobj()
+                raw = z.decompress(raw, limit + 1)
+                if len(raw) > limit:
+                    _malformed("a chunk inflates beyond its dimensions")
             elif fid == 2:                                   # shuffle: byte k of every element was stored together
                 es = cv[0] if cv else dtype.itemsize
                 a = np.frombuffer(raw, dtype=np.uint8)

@@ -72,3 +72,46 @@ def test_unsupported_and_foreign_files_fail_loudly(tmp_path):
     q.write_bytes(bytes(data))
     with pytest.raises(hdf5_lite.Hdf5LiteError, match='install h5py'):
         hdf5_lite.File(str(q))
+
+
+def test_corrupt_files_raise_hdf5_lite_error_only(tmp_path):
+    """Byte flips, truncations and zeroed ranges of the real fixtures: the reader either still returns arrays or raises
+    Hdf5LiteError (a ValueError that names the file format) -- never an IndexError / TypeError / RecursionError from the parser, never a
+    hang (self-referencing B-tree nodes and continuation blocks are bounded), never an unbounded allocation."""
+    import random
+    import time
+    from stratego_env_amd import hdf5_lite
+    rng = random.Random(1234)
+    t0 = time.time()
+    outcomes = {'ok': 0, 'refused': 0}
+    for name in ('curriculum_barrage_contiguous.h5', 'curriculum_barrage_chunked_gzip.h5', 'curriculum_barrage_latest.h5'):
+        good = open(os.path.join(GOLDEN, name), 'rb').read()
+        for trial in range(250):
+            b = bytearray(good)
+            kind = trial % 5
+            if kind == 0:                                   # a few random byte flips anywhere
+                for _ in range(rng.randint(1, 8)):
+                    b[rng.randrange(len(b))] = rng.randrange(256)
+            elif kind == 1:                                 # flips in the metadata at the front of the file
+                for _ in range(rng.randint(1, 6)):
+                    b[rng.randrange(min(len(b), 4096))] = rng.randrange(256)
+            elif kind == 2:                                 # truncation
+                b = b[:rng.randrange(8, len(b))]
+            elif kind == 3:                                 # a zeroed range
+                at = rng.randrange(len(b))
+                b[at:at + rng.randint(1, 512)] = bytes(min(rng.randint(1, 512), len(b) - at))
+            else:                                           # 0xFF range (undefined addresses, huge sizes)
+                at = rng.randrange(min(len(b), 8192))
+                n = rng.randint(1, 16)
+                b[at:at + n] = b'\xff' * len(b[at:at + n])
+            path = tmp_path / 'mutant.h5'
+            path.write_bytes(bytes(b))
+            try:
+                with hdf5_lite.File(str(path)) as f:
+                    for key in f.keys():
+                        f[key]
+                outcomes['ok'] += 1
+            except hdf5_lite.Hdf5LiteError:
+                outcomes['refused'] += 1
+    assert outcomes['ok'] > 50 and outcomes['refused'] > 50, outcomes          # both outcomes are exercised
+    assert time.time() - t0 < 120
