@@ -194,6 +194,34 @@ def main():
         total += play_game(ref, name, cfg, rng, garbage_rate=0.15, check_fns=False, mode='both_observations',
                            channel_mode='original')
         print("%-16s %d games (+1 original-channel game), %d steps: OK" % (name, games, total), flush=True)
+    # Variants the reference has no name for: MORE THAN 8 PIECES OF ONE TYPE (the reference's piece_amounts is unbounded; the
+    # normalisation of the captured-count channels then divides by the amount, maenv:288-298) -- the piece sets of
+    # tests/test_gpu_many_pieces.py.  The reference resolves a version through VERSION_CONFIGS, so its TINY entry is replaced for the
+    # duration of the games (this tool's own process only).
+    GV = ref.enums.GameVersions
+    SPn = ref.impl.SP
+    many = {
+        'many66': {'rows': 6, 'columns': 6, 'max_turns': 120, 'obstacle_locations': [],
+                   'piece_amounts': {SPn(t): n for t, n in zip(range(1, 13), (0, 9, 1, 0, 0, 0, 0, 0, 0, 0, 1, 1)) if n},
+                   'initial_state_usable_rows': 2},
+        'many88': {'rows': 8, 'columns': 8, 'max_turns': 160, 'obstacle_locations': [(3, 2), (4, 5)],
+                   'piece_amounts': {SPn(t): n for t, n in zip(range(1, 13), (1, 12, 2, 0, 0, 0, 0, 0, 0, 1, 1, 3)) if n},
+                   'initial_state_usable_rows': 3},
+    }
+    saved = ref.maenv.VERSION_CONFIGS[GV.TINY]
+    try:
+        for name, cfg in many.items():
+            cfg = dict(cfg)
+            cfg['piece_amounts'] = {SPn(t): cfg['piece_amounts'].get(SPn(t), 0) for t in range(1, 13)}
+            ref.maenv.VERSION_CONFIGS[GV.TINY] = cfg
+            total = 0
+            for g in range(max(3, args.games)):
+                mode = ('partially_observable', 'both_observations', 'fully_observable')[g % 3]
+                total += play_game(ref, 'tiny', cfg, rng, garbage_rate=0.1, check_fns=(g == 0), mode=mode)
+            total += play_game(ref, 'tiny', cfg, rng, garbage_rate=0.1, check_fns=False, mode='both_observations', channel_mode='original')
+            print("%-16s (TINY's config entry replaced: up to %d pieces of one type) %d steps: OK" % (name, max(cfg['piece_amounts'].values()), total), flush=True)
+    finally:
+        ref.maenv.VERSION_CONFIGS[GV.TINY] = saved
     print("oracle == reference on all checks")
 
 
