@@ -650,9 +650,9 @@ def rotating_leg(rk, env, args, version, v, steps, warmup, n_sets, full_obs=Fals
     the 256 MiB Infinity Cache when the same addresses are written again, three launches later: this leg's launch time is DRAM's."""
     import torch
     budget = max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if (args.placement == 'trial' and args.placement_gb > 0) else 0
-    budget, _ = placement_budgets(args, budget)
+    budget, wide = placement_budgets(args, budget)
     tune = budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6
-    reports = env.alloc_output_ring(n_sets, tune=tune, max_extra_bytes=budget, trials=args.placement_trials)
+    reports = env.alloc_output_ring(n_sets, tune=tune, max_extra_bytes=budget, trials=args.placement_trials, wide_extra_bytes=wide)
     elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, warmup, ring=True)
     assert invalid == 0
     checked = verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
@@ -926,9 +926,9 @@ def run_rank(args):
     headline_ring = args.output_sets >= 2 and not args.unfused and args.chains == 1
     ring_report = None
     if headline_ring:      # the headline writes a ring of output sets: each extra set from its own placement trial, like the first
-        budget, _ = placement_budgets(args, max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if args.placement == 'trial' else 0)
+        budget, wide = placement_budgets(args, max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if args.placement == 'trial' else 0)
         reps = env.alloc_output_ring(args.output_sets, tune=budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6, max_extra_bytes=budget,
-                                     trials=args.placement_trials)
+                                     trials=args.placement_trials, wide_extra_bytes=wide)
         ring_report = [(round(r['obs'][0], 1), round(min(r['obs']), 1)) if (r and r.get('obs')) else None for r in reps[1:]]
     elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring)
     assert invalid == 0, "rollout produced invalid actions"

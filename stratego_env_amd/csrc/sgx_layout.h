@@ -387,11 +387,14 @@ struct OrigFullObs {
     }
     __device__ static inline int bias(int ch) { return (ch == 3 || ch == 4) ? 3 : 0; }
 };
-// step-kernel observation kind: bit 0 = also render the fully-observable observation, bit 1 = 'original' channels
+// step-kernel observation kind: bit 0 = also render the fully-observable observation, bit 1 = 'original' channels, bit 2 (KIND 4) =
+// compact outputs, bit 3 (KIND 8) = NO observation at all (launches without any observation pointer: search expansions, mask-only
+// steps): no code buffer and no observation tables in LDS, so the instantiation runs at the full 8 waves per SIMD instead of 6 at 10x10
 template <int KIND>
 struct ObsKind {
-    static constexpr bool FULL = (KIND & 1) != 0, ORIG = (KIND & 2) != 0;
-    static constexpr int NIB_CH = ORIG ? 0 : (FULL ? FOBS_CH : OBS_CH);     // code buffer of the game's Lds
+    static constexpr bool FULL = (KIND & 1) != 0, ORIG = (KIND & 2) != 0, NOOBS = (KIND & 8) != 0;
+    static_assert(!NOOBS || KIND == 8, "the no-observation kind stands alone");
+    static constexpr int NIB_CH = (ORIG || NOOBS) ? 0 : (FULL ? FOBS_CH : OBS_CH);     // code buffer of the game's Lds
     using P = std::conditional_t<ORIG, OrigPartialObs, PartialObs>;
     using F = std::conditional_t<ORIG, OrigFullObs, FullObs>;
 };

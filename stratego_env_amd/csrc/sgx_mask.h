@@ -147,7 +147,7 @@ __device__ void emit_mask(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int la
 // perspective: the 1-D encoding (impl:520-642) and the spatial encoding for player -1 (impl:399-517 on an unflipped state).
 // 16-byte chunks of the address range like emit_mask; the source index is computed per byte (a handful of integer ops).
 template <class G, int NB, class F>
-__device__ void emit_mask_mapped(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int n_bytes, F src, int lane) {
+__device__ __forceinline__ void emit_mask_mapped_inl(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int n_bytes, F src, int lane) {
     const int A = (int)(reinterpret_cast<uintptr_t>(dst) & 15);
     const int nchunks = (A + n_bytes + 15) >> 4;
     uint8_t *gbase = dst - A;
@@ -171,6 +171,13 @@ __device__ void emit_mask_mapped(const Lds<G, NB> &L, uint8_t *__restrict__ dst,
                 if (lo + j >= 0 && lo + j < n_bytes) dst[lo + j] = (uint8_t)((w[j >> 2] >> (8 * (j & 3))) & 1u);
         }
     }
+}
+
+// The same, inlining left to the compiler: in the observing MAPPED kernel the forced inline costs 352 B of scratch; in the small
+// no-observation kind the compiler otherwise keeps it as a call with a stack frame (env_step picks).
+template <class G, int NB, class F>
+__device__ void emit_mask_mapped(const Lds<G, NB> &L, uint8_t *__restrict__ dst, int n_bytes, F src, int lane) {
+    emit_mask_mapped_inl(L, dst, n_bytes, src, lane);
 }
 
 // perspective channel of the straight move (sr,sc)->(er,ec) given in the mover's perspective (impl:280-311)

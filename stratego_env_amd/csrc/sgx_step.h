@@ -17,18 +17,21 @@ constexpr int tmpl_lds_bytes(bool full) { return G::WIDE ? 0 : tmpl_bytes<G, KIN
 template <class G, int KIND>
 constexpr int shared_table_bytes() {
     constexpr bool FULL = (KIND & 1) != 0, ORIG = (KIND & 2) != 0;
+    if (ObsKind<KIND>::NOOBS) return 16;                       // no observation: no templates, no LUTs
     if (ORIG) return 4 * (OBS_TAB_DWORDS + (FULL ? FOBS_TAB_DWORDS : 0));
     return tmpl_lds_bytes<G, KIND>(false) + (FULL ? tmpl_lds_bytes<G, KIND>(true) : 0) + CODETAB_BYTES;
 }
 
 // waves per SIMD this geometry can reach: LDS per workgroup = WPB game regions + the shared LUT, 160 KiB per CU
-template <class G, int KIND>
+template <class G, int KIND, bool MAPPED = false>
 constexpr int waves_per_simd() {
     constexpr int per_wg = G::WPB * G::GPW * (int)sizeof(Lds<G, ObsKind<KIND>::NIB_CH>) + shared_table_bytes<G, KIND>() + G::OBST_BYTES + COMBAT_BYTES;
     constexpr int wgs = (160 * 1024) / per_wg;
     constexpr int w = wgs * G::WPB / 4;
     // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
-    constexpr int want = G::RC <= 64 ? 8 : SGX_MIN_WAVES;
+    // (the MAPPED instantiation's index computations take ~70 VGPRs: with the no-observation kind's small LDS footprint a promise of 8
+    //  waves would cap it at 64 and spill; 6 leaves it 80)
+    constexpr int want = (MAPPED && ObsKind<KIND>::NOOBS) ? 6 : (G::RC <= 64 ? 8 : SGX_MIN_WAVES);
     return w > want ? want : (w < 1 ? 1 : w);
 }
 
@@ -160,7 +163,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     using G = Geo<R_, C_, VAR>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
-    constexpr bool ORIG = ObsKind<KIND>::ORIG, FULL = ObsKind<KIND>::FULL, COMPACT = (KIND & 4) != 0;
+    constexpr bool ORIG = ObsKind<KIND>::ORIG, FULL = ObsKind<KIND>::FULL, COMPACT = (KIND & 4) != 0, NOOBS = ObsKind<KIND>::NOOBS;
     const uint8_t *combat_s = obst_s + G::OBST_BYTES;           // the combat table follows the obstacle map in the shared LDS
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     STAMP(0);
@@ -452,6 +455,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     };
 
     // ---- terminal observations of both players (maenv:772-773)
+    if constexpr (!NOOBS)
     if (P.mode == 0 && ended_now && P.io.final_obs_dev) {
         float *fo = P.io.final_obs_dev + env * (int64_t)(2 * RC * PS::NCH);
         render(PS{}, false, 0, fo);
@@ -484,7 +488,9 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     if (P.io.mask_dev) {
         // MAPPED: the separate instantiation behind SGX_STEP_MASK_1D / SGX_STEP_MASK_STATE_COORDS (kept out of the hot kernel: its
         // 16 index computations per lane cost 30 VGPRs)
-        if (MAPPED && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
+        if (MAPPED && NOOBS && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped_inl(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
+        else if (MAPPED && NOOBS && qi) emit_mask_mapped_inl(L, P.io.mask_dev + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
+        else if (MAPPED && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
         else if (MAPPED && qi) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
         else if (COMPACT && (P.io.flags & SGX_STEP_COMPACT_MASK)) {   // the mask as bits: uint32 [MB_WORDS] per game, bit a = action a
             int4 *mdst = reinterpret_cast<int4 *>(reinterpret_cast<uint32_t *>(P.io.mask_dev) + env * (int64_t)G::MB_WORDS);
@@ -494,6 +500,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     }
     STAMP(5);   // mask stores issued
     // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
+    if constexpr (!NOOBS)
     if (P.io.obs_dev) {
         // compact output (opt-in, KIND bit 2): the codes themselves, 1/8 of the bytes; sgx_decode_obs expands them.  An instantiation of
         // its own: as a run-time branch it took the 8x8 hot kernel from 35 to 64 VGPRs + scratch
@@ -548,7 +555,9 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     const GameInput in = load_game<G, MAPPED>(P, env, lane);
     // ---- the workgroup's shared tables (L2-resident sources)
     const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
-    if constexpr (ORIG) {
+    if constexpr (ObsKind<KIND>::NOOBS) {
+        // nothing to render: only the obstacle map and the combat table below
+    } else if constexpr (ORIG) {
         float *lut_s = reinterpret_cast<float *>(shared);
         const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[4 + (raw ? 2 : 0)]);
         for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * G::WPB) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
@@ -580,11 +589,11 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
 // step kernel's schedule and cost 3.7 % on Barrage); two kernel symbols, so that a kernel trace keeps the env.step() launches
 // apart from the state-preserving observe launches (placement trials, reset())
 template <int R_, int C_, int KIND, bool MAPPED = false>
-__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND>())) void step_kernel(const KParams P) {
+__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND, MAPPED>())) void step_kernel(const KParams P) {
     game_kernel_body<R_, C_, KIND, MAPPED>(P);
 }
 template <int R_, int C_, int KIND, bool MAPPED = false>
-__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND>())) void observe_kernel(const KParams P) {
+__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND, MAPPED>())) void observe_kernel(const KParams P) {
     game_kernel_body<R_, C_, KIND, MAPPED>(P);
 }
 

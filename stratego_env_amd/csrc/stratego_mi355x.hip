@@ -651,8 +651,19 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
 #define CALL_STEP1(R, C) CALL_STEP_KIND(R, C, 1)
 #define CALL_STEP2(R, C) CALL_STEP_KIND(R, C, 2)
 #define CALL_STEP3(R, C) CALL_STEP_KIND(R, C, 3)
+#define CALL_STEP8(R, C) CALL_STEP_KIND(R, C, 8)
+    // no observation pointer at all (search expansions, mask-only steps, logic-only rollouts): the kind without observation tables
+    const bool no_obs = !p.io.obs_dev && !p.io.fobs_dev && !p.io.final_obs_dev && !p.io.final_fobs_dev &&
+                        !(p.io.flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK));
     if ((p.io.flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) || p.src_boards) {
-        if (full || original) return fail(SGX_EINVAL, "state-coordinate masks and sgx_expand come with the 67-channel partial observation only%s");
+        if (full || (original && !no_obs)) return fail(SGX_EINVAL, "state-coordinate masks and sgx_expand come with the 67-channel partial observation only%s");
+#define CALL_STEP_MAPPED8(R, C)                                                                    \
+    do {                                                                                           \
+        using G_ = Geo<R, C>;                                                                      \
+        const unsigned grid = shares_for(p, (p.n_envs - p.env_first + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW), skew); \
+        if (p.mode) observe_kernel<R, C, 8, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);  \
+        else step_kernel<R, C, 8, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);        \
+    } while (0)
 #define CALL_STEP_MAPPED(R, C)                                                                     \
     do {                                                                                           \
         using G_ = Geo<R, C>;                                                                      \
@@ -660,9 +671,12 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
         if (p.mode) observe_kernel<R, C, 0, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);  \
         else step_kernel<R, C, 0, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);        \
     } while (0)
-        DISPATCH_GEOMETRY(h, CALL_STEP_MAPPED);
+        if (no_obs) DISPATCH_GEOMETRY(h, CALL_STEP_MAPPED8);
+        else DISPATCH_GEOMETRY(h, CALL_STEP_MAPPED);
 #undef CALL_STEP_MAPPED
+#undef CALL_STEP_MAPPED8
     } else if (p.io.flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) DISPATCH_GEOMETRY(h, CALL_STEP4);
+    else if (no_obs) DISPATCH_GEOMETRY(h, CALL_STEP8);
     else if (!original && !full) DISPATCH_GEOMETRY(h, CALL_STEP0);
     else if (!original) DISPATCH_GEOMETRY(h, CALL_STEP1);
     else if (!full) DISPATCH_GEOMETRY(h, CALL_STEP2);
@@ -672,6 +686,7 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
 #undef CALL_STEP1
 #undef CALL_STEP2
 #undef CALL_STEP3
+#undef CALL_STEP8
 #undef CALL_STEP_KIND
     HIP_TRY(hipGetLastError());
     return SGX_OK;

@@ -1,0 +1,72 @@
+"""Launches without any observation pointer run an instantiation of their own (KIND 8: no code buffer, no observation tables in LDS,
+8 waves per SIMD).  Its game logic, mask and sampler are the same source as the observing kernels'; this file pins that the RESULTS are
+too: a twin env that emits observations (the kernels the parity suites compare with the oracle) must see the same masks, rewards,
+flags, sampled actions and int64 states step by step."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [('barrage', 512), ('standard', 256), ('octa_barrage', 512), ('medium', 512), ('fives', 777), ('tiny', 1000), ('micro', 1000),
+            ('standard2', 96)]
+
+
+@pytest.mark.parametrize('name,n', VARIANTS)
+@pytest.mark.parametrize('emit_mask', [True, False])
+def test_steps_without_observation_equal_steps_with_one(name, n, emit_mask):
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    a = VecStrategoEnv(name, n, seed=11, auto_reset=True)
+    b = VecStrategoEnv(name, n, seed=11, auto_reset=True)
+    b.set_lane_kernel(0)                     # toy boards: the wave-per-game no-observation kind, not the lane kernel (tested on its own)
+    a.reset()
+    b.reset()
+    a.sample_valid_actions()
+    b.sample_valid_actions()
+    for t in range(70):
+        assert torch.equal(a.next_actions, b.next_actions), (name, t)
+        a.step(a.next_actions, want_next_actions=True)
+        b.step(b.next_actions, want_next_actions=True, emit_obs=False, emit_mask=emit_mask)
+        for x, y, what in ((a.reward, b.reward, 'reward'), (a.done, b.done, 'done'), (a.player, b.player, 'player'),
+                           (a.invalid_action, b.invalid_action, 'invalid')):
+            assert torch.equal(x, y), (name, t, what)
+        if emit_mask:
+            assert torch.equal(a.mask, b.mask), (name, t)
+    sa, pa = a.export_state()
+    sb, pb = b.export_state()
+    assert torch.equal(sa, sb) and torch.equal(pa, pb)
+    # the state-preserving observe launch without an observation: the same mask
+    b.observe(emit_obs=False)
+    a.observe()
+    assert torch.equal(a.mask, b.mask)
+    assert int(a.done.sum()) >= 0 and int(a.invalid_action.sum()) == 0
+    a.close()
+    b.close()
+
+
+def test_garbage_actions_without_observation():
+    """Injected garbage (out-of-range indices, the no-op channel, other cells' moves): accept / reject decisions and what a rejected
+    action leaves behind are the same with and without an observation."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    n = 2048
+    a = VecStrategoEnv('barrage', n, seed=5, auto_reset=True)
+    b = VecStrategoEnv('barrage', n, seed=5, auto_reset=True)
+    a.reset()
+    b.reset()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    for t in range(40):
+        a.sample_valid_actions()
+        acts = a.next_actions.clone()
+        junk = torch.randint(-50, 3700 + 50, (n,), generator=g, dtype=torch.int32).to(acts.device)
+        use = (torch.rand(n, generator=g) < 0.3).to(acts.device)
+        acts = torch.where(use, junk, acts)
+        a.step(acts)
+        b.step(acts, emit_obs=False)
+        assert torch.equal(a.invalid_action, b.invalid_action) and torch.equal(a.mask, b.mask) and torch.equal(a.reward, b.reward)
+        assert torch.equal(a.done, b.done) and torch.equal(a.player, b.player)
+    assert int(a.invalid_action.sum()) > 0
+    sa, _ = a.export_state()
+    sb, _ = b.export_state()
+    assert torch.equal(sa, sb)
+    a.close()
+    b.close()

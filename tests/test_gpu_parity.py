@@ -380,6 +380,16 @@ def test_placement_target_for_ring_sets():
     twin.rollout_steps(6)
     import torch
     assert torch.equal(env.obs, twin.obs) and torch.equal(env.mask, twin.mask)
+    # a set whose search ends above the target is searched once more over the wide budget and the faster of the two is kept: pretend
+    # the env's own set was impossibly fast, so that every extra set takes that path
+    env._outputs.trial_us[0] = 1e-3
+    env._outputs.n_trials = 1
+    reps = env.alloc_output_ring(3, tune=True, trials=3, max_extra_bytes=256 << 20, wide_extra_bytes=1 << 30)
+    for r in reps[1:]:
+        assert len(r['obs']) >= 3 and len(r['wide']['obs']) == 3 and r['wide']['used'] == (min(r['wide']['obs']) < min(r['obs'][:3]))
+    env.rollout_steps(7, ring=True)
+    twin.rollout_steps(7)
+    assert torch.equal(env.obs, twin.obs) and torch.equal(env.mask, twin.mask) and torch.equal(env.reward, twin.reward)
     env.close()
     twin.close()
 
