@@ -33,9 +33,12 @@ def _oracle_batch(name, seed, g0, n):
     ('medium', 32, 300, 0.1), ('fives', 32, 200, 0.1), ('tiny', 64, 200, 0.1), ('micro', 64, 120, 0.1),
     ('short_barrage', 32, 250, 0.1), ('standard2', 4, 150, 0.05),
 ])
-def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0, require_endings=True, final_obs=True, lane_kernel='auto'):
+def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0, require_endings=True, final_obs=True, lane_kernel='auto', emit_obs=True):
     """Random-valid-action rollouts with auto-reset (+ injected garbage actions): every output of every step.
-    (tools/soak_parity.py re-runs this with other seeds, batch sizes and garbage rates for minutes.)"""
+    (tools/soak_parity.py re-runs this with other seeds, batch sizes and garbage rates for minutes.)
+    emit_obs=False (with final_obs=False): the steps pass no observation pointer -- the no-observation kernel kind -- and everything
+    else (mask, rewards, flags, sampled action, exported state) is compared as before."""
+    assert emit_obs or not final_obs
     import torch
     from stratego_env_amd.vec_env import VecStrategoEnv
     v = VARIANTS[name]
@@ -66,7 +69,7 @@ def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0, r
                 a = int(rs.choice([rs.randint(NA), rs.randint(v.cells) * v.spatial_channels + v.spatial_channels - 1,
                                    -1, NA, NA + 3, (v.cells - 1) * v.spatial_channels + rs.randint(v.spatial_channels)]))
             acts[e] = a
-        env.step(torch.from_numpy(acts), want_next_actions=True)
+        env.step(torch.from_numpy(acts), want_next_actions=True, emit_obs=emit_obs)
         obs_h, mask_h = env.obs.cpu().numpy(), env.mask.cpu().numpy()
         rew_h, done_h, player_h = env.reward.cpu().numpy(), env.done.cpu().numpy(), env.player.cpu().numpy()
         inv_h, einv_h = env.invalid_action.cpu().numpy(), env.ending_invalid.cpu().numpy()
@@ -78,7 +81,7 @@ def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0, r
             except ValueError:
                 assert inv_h[e] == 1, (name, t, e, acts[e], 'oracle raised, GPU accepted')
                 assert not done_h[e]
-                assert np.array_equal(cur[e][MASK], mask_h[e]) and cur[e][POBS].tobytes() == obs_h[e].tobytes()
+                assert np.array_equal(cur[e][MASK], mask_h[e]) and (not emit_obs or cur[e][POBS].tobytes() == obs_h[e].tobytes())
                 assert player_h[e] == oe.player
                 continue
             assert inv_h[e] == 0, (name, t, e, acts[e], 'GPU flagged a move the oracle accepts')
@@ -97,7 +100,7 @@ def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0, r
             p = oe.player
             assert player_h[e] == p, (name, t, e)
             assert np.array_equal(o[p][MASK], mask_h[e]), (name, t, e, 'mask')
-            assert o[p][POBS].tobytes() == obs_h[e].tobytes(), (name, t, e, 'obs')
+            assert not emit_obs or o[p][POBS].tobytes() == obs_h[e].tobytes(), (name, t, e, 'obs')
             cur[e] = o[p]
         if t % 50 == 49:
             st, pl = env.export_state()
@@ -105,6 +108,15 @@ def test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=0, r
             assert np.array_equal(pl.cpu().numpy(), np.asarray([oe.player for oe in oenvs], dtype=np.int8))
     assert games_done > 0 or not require_endings or name in ('standard', 'standard2', 'medium_standard', 'short_standard', 'c12x12', 'c20x20', 'c17x16', 'c32x32')
     env.close()
+
+
+@pytest.mark.parametrize('name,n_envs,n_steps,garbage', [('barrage', 40, 500, 0.1), ('standard', 12, 400, 0.05), ('octa_barrage', 24, 300, 0.1),
+                                                        ('medium', 24, 250, 0.1), ('fives', 24, 200, 0.1), ('standard2', 3, 150, 0.05)])
+def test_step_without_observation_bit_exact_vs_oracle(name, n_envs, n_steps, garbage):
+    """The no-observation kernel kind (steps that pass no observation pointer: mask-only rollouts, search expansions) against the
+    oracle, step by step: masks, rewards, flags, sampled actions, exported states.  (Toy boards: the lane kernel plays such launches,
+    tests/test_gpu_lane_kernel.py; tests/test_gpu_no_obs_kind.py forces the wave-per-game kind there.)"""
+    test_step_bit_exact_vs_oracle(name, n_envs, n_steps, garbage, seed_salt=3, final_obs=False, emit_obs=False)
 
 
 def test_config2_256_heldout_seeds_to_termination():

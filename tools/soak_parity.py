@@ -51,6 +51,11 @@ def main():
             T.test_step_bit_exact_vs_oracle(name, n + salt % 64, t, g, seed_salt=salt, final_obs=False, lane_kernel=True)
             runs += 1
             steps += (n + salt % 64) * t
+        # the no-observation kernel kind (steps without an observation pointer) on the boards with one game per wave
+        for name, n, t, g in (('barrage', 37, 300, 0.1), ('octa_barrage', 29, 200, 0.1), ('standard', 9, 250, 0.05)):
+            T.test_step_bit_exact_vs_oracle(name, n + salt % 5, t, g, seed_salt=salt, final_obs=False, emit_obs=False)
+            runs += 1
+            steps += (n + salt % 5) * t
         salt += 1
     print("soak ok: %d runs, %d env steps compared output by output against the oracle in %.0f s" % (runs, steps, time.time() - t0))
 

@@ -27,6 +27,7 @@ def main():
     for env, _ in envs.values():
         env.reset()
     rng = np.random.RandomState(99)
+    pools = {}
     while time.time() - t0 < budget:
         for name, n in PLAN:
             env, penv = envs[name]
@@ -42,6 +43,20 @@ def main():
                                for i in range(n)], dtype=np.int64)
             ns, npl, ok = penv.get_next_state(states_t, players_t, acts, allow_piece_oscillation=osc)
             ns, npl, ok = ns.cpu().numpy(), npl.cpu().numpy(), ok.cpu().numpy()
+            # the same transitions pool to pool on packed records (sgx_expand: the no-observation kernel kind), successors' 1-D masks
+            # in the same launch, through a shuffled parent index
+            perm = rng.permutation(n).astype(np.int32)
+            nodes = penv.pack(states_t, players_t)
+            kids = pools.setdefault(name, penv.new_packed())
+            m1_kids = torch.empty((n, ru.action_size), dtype=torch.uint8, device=states_t.device)
+            ok_p, pl_p = kids.expand(nodes, acts[perm], parent_index=torch.as_tensor(perm), allow_piece_oscillation=osc, mask_1d_out=m1_kids)
+            ns_p, npl_p = kids.unpack()
+            ns_p, npl_p, ok_p, m1_kids = ns_p.cpu().numpy(), npl_p.cpu().numpy(), ok_p.cpu().numpy(), m1_kids.cpu().numpy()
+            assert np.array_equal(ns_p, ns[perm]) and np.array_equal(ok_p, ok[perm]) and np.array_equal(npl_p, pl_p.cpu().numpy()), (name, 'expand')
+            assert np.array_equal(npl_p[ok_p], npl[perm][ok_p]), (name, 'expand players')
+            for i in rng.choice(n, size=min(n, 12), replace=False):
+                assert np.array_equal(m1_kids[i], ru.get_valid_moves_as_1d_mask(ns_p[i], int(npl_p[i]))), (name, i, 'expand mask')
+            nodes.close()
             obs = [fn(states_t, players_t).cpu().numpy() for fn in (
                 penv.get_partially_observable_observation_extended_channels, penv.get_fully_observable_observation_extended_channels,
                 penv.get_partially_observable_observation, penv.get_fully_observable_observation)]
