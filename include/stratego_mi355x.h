@@ -342,11 +342,13 @@ int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_t *playe
                     const sgx_step_io *io, int64_t *state_out_dev, int8_t *player_out_dev, int32_t chains, void *stream);
 
 /* General states in sgx_step_states.  The reference's pure functions accept ANY int64 [34,R,C] (penv:74-155); the packed record carries what
- * play can produce.  On boards of 33 .. 256 cells with the 67-channel observation kind (the one-launch path above) sgx_step_states runs a
- * second pass over the states its import had to alter: they are redone from the caller's int64 input on a general-state variant of the
- * kernels -- dense recent-move layers, a capture event for every (layer, cell) pair, counts up to 32,768, captured-count channels beyond the
- * 16-entry table normalised by the reference's own float32 arithmetic (maenv:506-508) -- so that get_next_state, is_move_valid_*, the
- * masks and the partial observation of such states equal the reference's; sanitised_dev then reports only what still had to be altered
+ * play can produce.  On boards of up to 256 cells sgx_step_states runs a second pass over the states its import had to alter (behind the
+ * one-launch path above, or behind the three launches of the other paths: boards of up to 32 cells, the 79-channel and 'original'
+ * observation kinds): they are redone from the caller's int64 input on a general-state variant of the kernels -- dense recent-move
+ * layers, a capture event for every (layer, cell) pair, counts up to 32,768, captured-count channels beyond the 16-entry table
+ * normalised by the reference's own float32 arithmetic (maenv:506-508) -- so that get_next_state, is_move_valid_*, the masks and every
+ * observation kind of such states equal the reference's (not covered: boards of more than 256 cells; state-coordinate masks requested
+ * together with a 79-channel or 'original' observation); sanitised_dev then reports only what still had to be altered
  * (values outside their layer's range, an obstacle layer that differs from the variant's, a player that is not +1 / -1).  mode 1 (default):
  * on; 0: off (flagged states keep the first pass' sanitised results).  SGX_GENERAL_STATES=0|1 sets the default of handles created
  * afterwards.  Costs one launch of early-exit blocks (~2 % of a get_next_state call) when no state is flagged. */

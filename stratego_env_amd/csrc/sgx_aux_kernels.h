@@ -394,21 +394,54 @@ __global__ __launch_bounds__(256) void import_kernel(const KParams P, const int6
 // Threads per state: 128 / 192 / 256 measured 654 / 628 / 636 us per 65,536 Barrage states in one process (tools/states_ab.py).
 // (get_next_state / is_move_valid_*: three waves per state; the variants whose ONE stepping wave also emits a mask or an observation
 // want more blocks per CU instead: 1-D masks 463 us with 128 threads, 592 us with 192)
+// The workgroup-shared observation tables of a step of kind KIND (the staging of game_kernel_body, sgx_step.h, for a block of `nthreads`)
+template <class G, int KIND>
+__device__ inline void stage_kind_tables(const KParams &P, uint8_t *shared, int tid, int nthreads) {
+    using PS = typename ObsKind<KIND>::P;
+    using FS = typename ObsKind<KIND>::F;
+    constexpr bool FULL = ObsKind<KIND>::FULL, ORIG = ObsKind<KIND>::ORIG;
+    const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
+    if constexpr (ORIG) {
+        float *lut_s = reinterpret_cast<float *>(shared);
+        const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[4 + (raw ? 2 : 0)]);
+        for (int i = tid; i < LUT_DWORDS / 4; i += nthreads) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
+        build_quad_table<G, PS>(reinterpret_cast<uint32_t *>(lut_s + LUT_DWORDS), tid, nthreads);
+        if constexpr (FULL) {
+            const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[4 + (raw ? 2 : 0) + 1]);
+            for (int i = tid; i < LUT_DWORDS / 4; i += nthreads) reinterpret_cast<f32x4 *>(lut_s + OBS_TAB_DWORDS)[i] = fsrc[i];
+            build_quad_table<G, FS>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), tid, nthreads);
+        }
+    } else {
+        constexpr int NP = tmpl_lds_bytes<G, KIND>(false), NF = FULL ? tmpl_lds_bytes<G, KIND>(true) : 0;
+        const int4 *tp = reinterpret_cast<const int4 *>(P.tab->tmpl[raw ? 2 : 0]);
+        for (int i = tid; i < NP / 16; i += nthreads) reinterpret_cast<int4 *>(shared)[i] = tp[i];
+        if constexpr (FULL) {
+            const int4 *tf = reinterpret_cast<const int4 *>(P.tab->tmpl[(raw ? 2 : 0) + 1]);
+            for (int i = tid; i < NF / 16; i += nthreads) reinterpret_cast<int4 *>(shared + NP)[i] = tf[i];
+        }
+        const int4 *ct = reinterpret_cast<const int4 *>(P.tab->codetab[raw ? 1 : 0]);
+        for (int i = tid; i < CODETAB_BYTES / 16; i += nthreads) reinterpret_cast<int4 *>(shared + NP + NF)[i] = ct[i];
+    }
+}
+
 template <bool MAPPED, bool OBS>
 constexpr int states_threads() { return (!MAPPED && !OBS) ? 192 : 128; }
 // VAR = 1: the second pass of sgx_step_states over the states the first pass had to alter (sanitised[env] != 0; every other block leaves at
 // once): the same import -> env_step -> export on the general-state variant of the geometry (Geo<R, C, 1>: dense recent-move boards, an
 // event for every (layer, cell) pair, counts to 32,768), whose record image exists only here in LDS; the outputs of the first pass are
 // overwritten and the flag is cleared unless the state holds values outside its layers' ranges.
-template <int R_, int C_, bool MAPPED, bool OBS, int VAR = 0>
+// KINDX >= 0 (general-state pass only): the observation kind of the step (sgx_layout.h: ObsKind; 1 = also the 79-channel observation, 2 / 3 =
+// 'original' channels) instead of the partial 'extended' one -- the first pass of those kinds is the three-launch path on packed records.
+template <int R_, int C_, bool MAPPED, bool OBS, int VAR = 0, int KINDX = -1>
 __global__ __launch_bounds__((states_threads<MAPPED, OBS>())) void states_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in,
                                                      uint8_t *__restrict__ sanitised, int64_t *__restrict__ out, int8_t *__restrict__ player_out, const int nt) {
     using G = Geo<R_, C_, VAR>;
     static_assert(G::LPG == 64, "one game per wave");
-    constexpr int NT = states_threads<MAPPED, OBS>(), KIND = OBS ? 0 : 2;
+    static_assert(KINDX < 0 || (VAR == 1 && OBS && !MAPPED && KINDX >= 1 && KINDX <= 3), "other kinds: general-state pass, observing, unmapped");
+    constexpr int NT = states_threads<MAPPED, OBS>(), KIND = KINDX >= 0 ? KINDX : (OBS ? 0 : 2);
     __shared__ StateLds<G, NT> W;
     __shared__ Lds<G, ObsKind<KIND>::NIB_CH> L;
-    __shared__ alignas(16) uint8_t shared[OBS ? shared_table_bytes<G, 0>() : 16];
+    __shared__ alignas(16) uint8_t shared[OBS ? shared_table_bytes<G, KIND>() : 16];
     __shared__ alignas(16) uint8_t obst_s[G::OBST_BYTES + COMBAT_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t env = P.env_first + group_of_block(P);
@@ -416,7 +449,9 @@ __global__ __launch_bounds__((states_threads<MAPPED, OBS>())) void states_kernel
     if constexpr (G::BIG)
         if (sanitised[env] == 0) return;                                     // (block-uniform) nothing to redo for this state
     {   // the step's workgroup-shared tables (game_kernel_body): default-code templates, code table, obstacle map, combat outcomes
-        if constexpr (OBS) {
+        if constexpr (KINDX >= 0) {
+            stage_kind_tables<G, KIND>(P, shared, tid, NT);
+        } else if constexpr (OBS) {
             const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
             constexpr int NP = tmpl_lds_bytes<G, 0>(false);
             const int4 *tp = reinterpret_cast<const int4 *>(P.tab->tmpl[raw ? 2 : 0]);

@@ -123,7 +123,8 @@ struct Geo {
     // at the VALU issue limit with 80 % of the lanes idle).  Everything below that says `lane` means the lane inside the game.
     // (twice the games per wave -- 8 / 16 / 32 lanes per game, two cells per lane up to 8x8 -- is bit-exact too but 3-5 % slower on
     // every board size: the cell loops double)
-    static constexpr int LPG = RC <= 16 ? 16 : (RC <= 32 ? 32 : 64);
+    // (The general-state variant is one game per wave on every board: it only runs in the fused states_kernel, one state per block.)
+    static constexpr int LPG = (RC > 32 || BIG) ? 64 : (RC <= 16 ? 16 : 32);
     static constexpr int GPW = 64 / LPG;              // games per wave
     // a wave may play several games in turn with the next game's reads in flight (13 more VGPRs: one-game-per-wave boards only)
     static constexpr bool PIPELINED = LPG == 64;      // observation lines written whole leave as non-temporal stores (sgx_obs.h)

@@ -1263,10 +1263,58 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
 #undef CALL_STATES_K
         return SGX_OK;
     }
+    // What the fused path above does not cover takes the three-launch path on packed records -- boards of up to 32 cells (several games per
+    // wave) and the other observation kinds (79-channel, 'original' channels).  States the packed records cannot carry are then redone,
+    // like above, by the general-state variant of the fused kernel, which is one game per wave on every board and takes the observation
+    // kind as a parameter.  (Not: boards of more than 256 cells; state-coordinate masks together with another observation kind.)
+    const int cells_ = h->cfg.rows * h->cfg.cols;
+    const bool mapped_ = (io->flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) != 0;
+    const bool general_small = h->general_states != 0 && cells_ <= 256 && (kind0 ? cells_ <= 32 : !mapped_);
+    uint8_t *flags_small = sanitised_dev;
+    if (general_small && !flags_small) {
+        if (!h->san_flags) HIP_TRY(hipMalloc((void **)&h->san_flags, (size_t)h->n_envs));
+        flags_small = h->san_flags;
+    }
+    auto second_pass_small = [&]() -> int {
+        if (!general_small) return SGX_OK;
+        if (int rc = check_step_io(h, p)) return rc;
+        KParams q = p;
+        q.env_first = 0;
+        q.n_envs = h->n_envs;
+        const int nt = h->nt_mode < 0 ? states_stream_past_cache(h) : h->nt_mode;
+        const unsigned grid = state_grid(h, q);
+        q.nt_stores = h->nt_mode < 0 ? (launch_streams_past_cache(h, q) ? 1 : 0) : h->nt_mode;
+        const bool obs = io->obs_dev || io->final_obs_dev;
+        const int kindx = ((io->fobs_dev || io->final_fobs_dev) ? 1 : 0) | ((io->flags & SGX_STEP_ORIGINAL_CHANNELS) ? 2 : 0);
+#define CALL_STATES_SMALL_K(R, C, M, O) states_kernel<R, C, M, O, 1><<<grid, states_threads<M, O>(), 0, (hipStream_t)stream>>>(q, state_in_dev, player_in_dev, flags_small, state_out_dev, player_out_dev, nt)
+#define CALL_STATES_KIND_K(R, C, KX) states_kernel<R, C, false, true, 1, KX><<<grid, states_threads<false, true>(), 0, (hipStream_t)stream>>>(q, state_in_dev, player_in_dev, flags_small, state_out_dev, player_out_dev, nt)
+#define CALL_STATES_SMALL(R, C)                                                                                             \
+    do {                                                                                                                    \
+        if constexpr (!Geo<R, C>::WIDE) {                                                                                   \
+            if (kindx == 1) CALL_STATES_KIND_K(R, C, 1);                                                                    \
+            else if (kindx == 2) CALL_STATES_KIND_K(R, C, 2);                                                               \
+            else if (kindx == 3) CALL_STATES_KIND_K(R, C, 3);                                                               \
+            else if constexpr (Geo<R, C>::LPG != 64) {                                                                      \
+                if (mapped_ && obs) CALL_STATES_SMALL_K(R, C, true, true);                                                  \
+                else if (mapped_) CALL_STATES_SMALL_K(R, C, true, false);                                                   \
+                else if (obs) CALL_STATES_SMALL_K(R, C, false, true);                                                       \
+                else CALL_STATES_SMALL_K(R, C, false, false);                                                               \
+            }                                                                                                               \
+        }                                                                                                                   \
+    } while (0)
+        DISPATCH_GEOMETRY(h, CALL_STATES_SMALL);
+#undef CALL_STATES_SMALL
+#undef CALL_STATES_SMALL_K
+#undef CALL_STATES_KIND_K
+        HIP_TRY(hipGetLastError());
+        return SGX_OK;
+    };
     if (chains == 1) {
-        if (int rc = launch_import(h, p, state_in_dev, player_in_dev, sanitised_dev, (hipStream_t)stream)) return rc;
+        if (int rc = launch_import(h, p, state_in_dev, player_in_dev, flags_small, (hipStream_t)stream)) return rc;
         if (int rc = launch_step(h, p, stream)) return rc;
-        return state_out_dev ? launch_export(h, p, state_out_dev, player_out_dev, (hipStream_t)stream) : SGX_OK;
+        if (state_out_dev)
+            if (int rc = launch_export(h, p, state_out_dev, player_out_dev, (hipStream_t)stream)) return rc;
+        return second_pass_small();
     }
     if (!h->chain_fork) HIP_TRY(hipEventCreateWithFlags(&h->chain_fork, hipEventDisableTiming));
     for (int c = 0; c < chains; ++c) {
@@ -1280,11 +1328,12 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
         KParams pc = p;
         pc.env_first = c * per;
         pc.n_envs = c == chains - 1 ? h->n_envs : (c + 1) * per;
-        rc = launch_import(h, pc, state_in_dev, player_in_dev, sanitised_dev, h->chain_stream[c]);
+        rc = launch_import(h, pc, state_in_dev, player_in_dev, flags_small, h->chain_stream[c]);
         if (rc == SGX_OK) rc = launch_step(h, pc, (void *)h->chain_stream[c]);
         if (rc == SGX_OK && state_out_dev) rc = launch_export(h, pc, state_out_dev, player_out_dev, h->chain_stream[c]);
     }
-    return join_chains(h, chains, (hipStream_t)stream, rc);     // (also after a failed launch: see sgx_rollout)
+    rc = join_chains(h, chains, (hipStream_t)stream, rc);     // (also after a failed launch: see sgx_rollout)
+    return rc != SGX_OK ? rc : second_pass_small();
 }
 
 SGX_API int sgx_import_state(sgx_env *h, const int64_t *state_dev, const int8_t *player_dev, void *stream) {

@@ -99,7 +99,7 @@ class BatchedStrategoProceduralEnv:
     def _in_loaded_scope(self, states, players):
         return self._held is not None and self._scratch_is_held and states is self._held[0] and players is self._held[1]
 
-    def _step_states(self, states, players, actions, flags, export=False, mask_out=None, positions=False, out=None, obs_out=None):
+    def _step_states(self, states, players, actions, flags, export=False, mask_out=None, positions=False, out=None, obs_out=None, fobs_out=None):
         """sgx_step_states: import -> step (actions given) or observe (actions None) -> optional export, one library call (one
         launch on boards of more than 32 cells).  -> (new_states, new_players) or None."""
         st = torch.as_tensor(states).to(device=self.device, dtype=torch.int64).contiguous()
@@ -118,6 +118,7 @@ class BatchedStrategoProceduralEnv:
             io.actions_dev = None
         io.mask_dev = mask_out.data_ptr() if mask_out is not None else None
         io.obs_dev = obs_out.data_ptr() if obs_out is not None else None
+        io.fobs_dev = fobs_out.data_ptr() if fobs_out is not None else None
         with torch.cuda.device(self.device):
             _lib.check(vec._L.sgx_step_states(vec._h, st.data_ptr(), pl.data_ptr(), self.last_sanitised.data_ptr(), io,
                                               _ptr_or_none(new_states), _ptr_or_none(new_players), 2, vec._stream()), vec._L)
@@ -261,18 +262,17 @@ class BatchedStrategoProceduralEnv:
     def _observe_raw(self, states, players, full, original):
         """One raw (un-normalised) observation kind into a fresh tensor; nothing else is rendered."""
         vec = self._vec
-        if not full and not original and not self._in_loaded_scope(states, players):
-            # the 67-channel kind goes through sgx_step_states (observe): states the packed record cannot carry are redone exactly
-            out = torch.empty((self.batch_size, self.rows, self.columns, _lib.PO_OBS_CHANNELS), dtype=torch.float32, device=self.device)
-            self._step_states(states, players, None, _lib.STEP_RAW_OBS, obs_out=out)
-            return out
-        self._load(states, players)
         if original:
             ch = _lib.FO_OBS_CHANNELS_ORIGINAL if full else _lib.PO_OBS_CHANNELS_ORIGINAL
         else:
             ch = _lib.FO_OBS_CHANNELS if full else _lib.PO_OBS_CHANNELS
         out = torch.empty((self.batch_size, self.rows, self.columns, ch), dtype=torch.float32, device=self.device)
         flags = _lib.STEP_RAW_OBS | (_lib.STEP_ORIGINAL_CHANNELS if original else 0)
+        if not self._in_loaded_scope(states, players):
+            # through sgx_step_states (observe): states the packed record cannot carry are redone exactly (every kind, boards <= 256 cells)
+            self._step_states(states, players, None, flags, obs_out=None if full else out, fobs_out=out if full else None)
+            return out
+        self._load(states, players)
         with torch.cuda.device(self.device):
             _lib.check(vec._L.sgx_observe(vec._h, None if full else out.data_ptr(), out.data_ptr() if full else None, None, None,
                                           flags, vec._stream()), vec._L)

@@ -50,8 +50,16 @@ def test_functional_api_matches_oracle(name):
         fo = pe.get_fully_observable_observation_extended_channels(states, pl_all).cpu().numpy()
         ge = pe.get_game_ended(states, pl_all).cpu().numpy()
         gi = pe.get_game_result_is_invalid(states).cpu().numpy()
+        # the other observation kinds (79-channel, 'original' channels): three launches on packed records first, then the same second pass
+        others = []
+        for fn_name in ('get_fully_observable_observation_extended_channels', 'get_partially_observable_observation',
+                        'get_fully_observable_observation'):
+            others.append((fn_name, getattr(pe, fn_name)(states, pl_all).cpu().numpy()))
+            assert int(pe.last_sanitised.sum()) == 0, (name, fn_name)
         for e in range(n):
             p = int(pl_all[e])
+            for fn_name, got in others:
+                assert got[e].tobytes() == getattr(ru, fn_name)(states[e], p).tobytes(), (name, e, fn_name)
             assert np.array_equal(m1[e], ru.get_valid_moves_as_1d_mask(states[e], p)), (name, e, '1d mask')
             assert np.array_equal(ms[e], ru.get_valid_moves_as_spatial_mask(states[e], p)), (name, e, 'spatial mask')
             assert np.array_equal(pp[e], ru.get_state_from_player_perspective(states[e], p))
@@ -366,7 +374,7 @@ def test_heuristic_rewards_match_reference_golden():
     penv.close()
 
 
-@pytest.mark.parametrize('name', ['barrage', 'medium', 'octa_barrage', 'standard2'])
+@pytest.mark.parametrize('name', ['barrage', 'medium', 'octa_barrage', 'standard2', 'fives', 'tiny', 'micro'])
 def test_general_states_are_reproduced_not_sanitised(name):
     """penv's pure functions accept ANY int64 [34,R,C] (penv:74-155).  States the packed record cannot carry are redone by
     sgx_step_states' second pass on the general-state variant of the kernels: next state, validity, both mask encodings and the raw
@@ -389,8 +397,16 @@ def test_general_states_are_reproduced_not_sanitised(name):
         assert int(pe.last_sanitised.sum()) == 0
         po = pe.get_partially_observable_observation_extended_channels(states, pl_all).cpu().numpy()
         assert int(pe.last_sanitised.sum()) == 0
+        # the other observation kinds (79-channel, 'original' channels): three launches on packed records first, then the same second pass
+        others = []
+        for fn_name in ('get_fully_observable_observation_extended_channels', 'get_partially_observable_observation',
+                        'get_fully_observable_observation'):
+            others.append((fn_name, getattr(pe, fn_name)(states, pl_all).cpu().numpy()))
+            assert int(pe.last_sanitised.sum()) == 0, (name, fn_name)
         for e in range(n):
             p = int(pl_all[e])
+            for fn_name, got in others:
+                assert got[e].tobytes() == getattr(ru, fn_name)(states[e], p).tobytes(), (name, e, fn_name)
             assert np.array_equal(m1[e], ru.get_valid_moves_as_1d_mask(states[e], p)), (name, e, '1d mask')
             assert np.array_equal(ms[e], ru.get_valid_moves_as_spatial_mask(states[e], p)), (name, e, 'spatial mask')
             assert po[e].tobytes() == ru.get_partially_observable_observation_extended_channels(states[e], p).tobytes(), (name, e, 'obs')

@@ -3,7 +3,7 @@ layer's legal range but that play cannot produce (tests.helpers.general_states: 
 capture cells everywhere, stale flags): the reference's pure functions accept them (penv:74-155), the GPU's general-state pass
 (sgx_step_states) reproduces them, and this check pins the oracle -- which the GPU test compares against -- to the
 reference on exactly that kind of input: masks (both encodings), validity and next state for valid and garbage 1-D actions with and
-without allow_piece_oscillation, validity by position, the raw partial observation."""
+without allow_piece_oscillation, validity by position, the four raw observation kinds."""
 import os
 import sys
 
@@ -19,7 +19,7 @@ from tests.helpers import general_states  # noqa: E402
 def main():
     ref = import_reference()
     total = 0
-    for name, n in (('barrage', 24), ('medium', 48), ('octa_barrage', 32), ('standard2', 6), ('tiny', 48)):
+    for name, n in (('barrage', 24), ('medium', 48), ('octa_barrage', 32), ('standard2', 6), ('tiny', 48), ('micro', 48), ('fives', 48)):
         v = VARIANTS[name]
         rs = np.random.RandomState(23)
         states, players = general_states(name, n, rs)
@@ -30,8 +30,9 @@ def main():
                 want_mask = pe.get_valid_moves_as_1d_mask(st, pl)
                 assert np.array_equal(want_mask, ru.get_valid_moves_as_1d_mask(st, pl)), (name, e, pl, '1d mask')
                 assert np.array_equal(pe.get_valid_moves_as_spatial_mask(st, pl), ru.get_valid_moves_as_spatial_mask(st, pl)), (name, e, pl)
-                assert pe.get_partially_observable_observation_extended_channels(st, pl).tobytes() == \
-                    ru.get_partially_observable_observation_extended_channels(st, pl).tobytes(), (name, e, pl, 'obs')
+                for fn in ('get_partially_observable_observation_extended_channels', 'get_fully_observable_observation_extended_channels',
+                           'get_partially_observable_observation', 'get_fully_observable_observation'):     # all four kinds (penv:157-173)
+                    assert getattr(pe, fn)(st, pl).tobytes() == getattr(ru, fn)(st, pl).tobytes(), (name, e, pl, fn)
                 valid = np.flatnonzero(want_mask)
                 acts = [int(valid[rs.randint(len(valid))]) for _ in range(3)] + [int(rs.randint(-3, ru.action_size + 3)) for _ in range(2)]
                 for a in acts:
