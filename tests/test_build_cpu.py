@@ -69,6 +69,16 @@ def test_built_library_carries_the_hash_of_its_sources():
     assert L.sgx_build_id().decode() == B.source_hash() == L.build_id
 
 
+def test_prebuilt_geometry_libraries_are_current():
+    """The libraries of board sizes outside the reference's variants (build_geometry) travel to the GPU box prebuilt; one left over from
+    older sources would be rebuilt there on first use (half a minute of hipcc inside a GPU test).  __graft_entry__.build() refreshes
+    them all: whatever is in the tree must carry the hash of the sources next to it."""
+    import glob
+    B.build()
+    stale = [os.path.basename(f) for f in glob.glob(os.path.join(B.OUT_DIR, 'libstratego_mi355x_*x*.so')) if B.read_build_id(f) != B.source_hash()]
+    assert not stale, "stale geometry libraries (run `python -c 'import __graft_entry__ as g; g.build()'`): %s" % stale
+
+
 def test_stale_library_fails_loudly(tmp_path, monkeypatch):
     """The same binary under another build id -- what a library left over from older sources looks like -- must not load."""
     path = B.build()
