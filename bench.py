@@ -930,6 +930,13 @@ def run_rank(args):
         reps = env.alloc_output_ring(args.output_sets, tune=budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6, max_extra_bytes=budget,
                                      trials=args.placement_trials, wide_extra_bytes=wide)
         ring_report = [(round(r['obs'][0], 1), round(min(r['obs']), 1)) if (r and r.get('obs')) else None for r in reps[1:]]
+        if reps[0]:            # the env's own set was slower than the extra ones and was searched again against them (alloc_output_ring)
+            placement = dict(placement or {})
+            placement["first_set_searched_again"] = {"before_us": round(reps[0]['before_us'], 1), "target_us": round(reps[0]['target_us'], 1),
+                                                     "candidates": len(reps[0]['obs']), "kept_us": round(min(reps[0]['obs']), 1) if reps[0]['obs'] else None,
+                                                     "used": reps[0]['used']}
+            if reps[0]['used']:
+                placement["kept_us"] = round(min(reps[0]['obs']), 1)
     elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring)
     assert invalid == 0, "rollout produced invalid actions"
     # outside the timed region: the envs that were just timed against the CPU oracle, and the sharding-independent checksum

@@ -300,7 +300,9 @@ class VecStrategoEnv:
         rollout into a trajectory buffer that keeps the last n_sets steps (sgx_step_ring).  Set 0 is the env's current set; the others
         are torch.empty tensors or, with tune=True, library-owned buffers from the placement trial (one sgx_alloc_outputs each; a set
         whose search ends more than 3 % above the env's own set is searched once more over `wide_extra_bytes`, like tune_placement's
-        wide pass, and the faster of the two is kept).  Returns the per-set trial reports (None for set 0 and for untuned sets)."""
+        wide pass, and the faster of the two is kept; if the extra sets turn out more than 3 % faster than the env's own set, that one
+        is searched once more against them).  Returns the per-set trial reports (None for untuned sets and for set 0 unless it was
+        searched again: {'obs', 'used', 'target_us', 'before_us'} then)."""
         n_sets = int(n_sets)
         if n_sets < 1:
             raise ValueError("n_sets must be >= 1")
@@ -347,6 +349,21 @@ class VecStrategoEnv:
                 reports.append(None)
                 self._ring_owners.append(None)
             self._ring.append((obs, mask, fobs))
+        # The other way round: the env's OWN set may be the slow one (its search ran first, with no target -- one box: 298.5 us after 82
+        # candidates, then 274-281 us for the extra sets).  It is searched once more, against the best of the others, and replaced if
+        # that finds something faster; reports[0] = {'obs': [...], 'used': bool} then.
+        best_extra = min([min(r['obs']) for r in reports[1:] if r and r.get('obs')] or [0.0])
+        if target > 0 and 0 < best_extra < 0.97 * target and self.fobs is None:
+            _lib.check(self._L.sgx_set_placement_target(self._h, C.c_float(best_extra)), self._L)
+            first = (self.obs, self.mask, self._outputs_owner, self._outputs, self.placement_peak_extra_bytes)
+            rep0 = self.tune_placement_once(trials, max(int(max_extra_bytes), int(wide_extra_bytes)))
+            used = bool(rep0.get('obs')) and min(rep0['obs']) < target
+            if not used:
+                self.obs, self.mask, self._outputs_owner, self._outputs, self.placement_peak_extra_bytes = first
+                self.observe()
+            self._ring[0] = (self.obs, self.mask, self.fobs)
+            self._ring_owners[0] = self._outputs_owner
+            reports[0] = {'obs': rep0.get('obs') or [], 'used': used, 'target_us': best_extra, 'before_us': target}
         _lib.check(self._L.sgx_set_placement_target(self._h, C.c_float(0.0)), self._L)
         self._ring_pos = 1 % n_sets          # set 0 holds the current position's outputs: the next step writes set 1
         self._ring_ios = (_lib.SgxStepIO * n_sets)()

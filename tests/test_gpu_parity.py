@@ -402,6 +402,17 @@ def test_placement_target_for_ring_sets():
     env.rollout_steps(7, ring=True)
     twin.rollout_steps(7)
     assert torch.equal(env.obs, twin.obs) and torch.equal(env.mask, twin.mask) and torch.equal(env.reward, twin.reward)
+    # the other way round: the env's own set looks 10 x slower than anything the extra sets find -> it is searched again against them,
+    # replaced if that is faster, and the ring goes on with the right buffers and the current outputs
+    env._outputs.trial_us[0] = 1e6
+    env._outputs.n_trials = 1
+    reps = env.alloc_output_ring(3, tune=True, trials=3, max_extra_bytes=256 << 20)
+    assert reps[0] is not None and reps[0]['used'] and reps[0]['before_us'] == 1e6 and len(reps[0]['obs']) >= 1
+    assert env._ring[0][0].data_ptr() == env.obs.data_ptr() == env._outputs.obs_dev
+    assert torch.equal(env.obs, twin.obs) and torch.equal(env.mask, twin.mask)
+    env.rollout_steps(5, ring=True)
+    twin.rollout_steps(5)
+    assert torch.equal(env.obs, twin.obs) and torch.equal(env.mask, twin.mask) and torch.equal(env.reward, twin.reward)
     env.close()
     twin.close()
 
