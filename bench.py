@@ -328,6 +328,7 @@ class Rank:
             self.device_index = dmap[self.local_rank]
         self.use_cuda = use_cuda
         self.dist = None
+        self.backend, self.backend_note = backend, None
         if use_cuda:
             torch.cuda.set_device(self.device_index)
         # reductions run on the GPU over RCCL, or on the host over gloo (dry run; ranks that share one GPU, which RCCL refuses)
@@ -341,9 +342,38 @@ class Rank:
             sys.stdout.flush()
             saved = os.dup(1)
             os.dup2(2, 1)
+            self.backend, self.backend_note = backend, None
             try:
-                dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
-                if backend == 'gloo':
+                if backend == 'nccl':
+                    # RCCL carries nothing but two tiny reporting reductions and the barriers here (the games never interact): if it cannot
+                    # come up on this node -- the one thing the builder's 1-GPU boxes could never exercise -- the run falls back to gloo on
+                    # the host for them instead of dying, and says so in the line (config.reduction_backend).
+                    import datetime
+                    try:
+                        if not use_cuda:
+                            raise RuntimeError("nccl needs a GPU per rank (dry run)")
+                        dist.init_process_group('nccl', rank=self.rank, world_size=self.world, timeout=datetime.timedelta(seconds=300), **kw)
+                        probe = torch.ones(1, device='cuda')
+                        dist.all_reduce(probe)
+                        torch.cuda.synchronize()
+                        if int(probe.item()) != self.world:
+                            raise RuntimeError("all_reduce of ones over %d ranks gave %r" % (self.world, probe.item()))
+                    except Exception as e:          # noqa: BLE001 -- whatever RCCL / the rendezvous raises
+                        self.backend_note = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else '')
+                        print("bench.py rank %d: nccl (RCCL) process group failed (%s); reporting reductions fall back to gloo" % (self.rank, self.backend_note),
+                              file=sys.stderr, flush=True)
+                        try:
+                            if dist.is_initialized():
+                                dist.destroy_process_group()
+                        except Exception:           # noqa: BLE001
+                            pass
+                        os.environ['MASTER_PORT'] = str(int(os.environ['MASTER_PORT']) + 1)        # a fresh store for the second group
+                        backend = self.backend = 'gloo'
+                        self.reduce_device = 'cpu'
+                        dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
+                        dist.barrier()
+                else:
+                    dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
                     dist.barrier()
             finally:
                 sys.stdout.flush()
@@ -884,8 +914,9 @@ def run_rank(args):
         import torch
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    backend = 'gloo' if dry else (args.backend or 'nccl')
+    backend = args.backend or ('gloo' if dry else 'nccl')
     rk = Rank(args.gpus, backend, use_cuda=not dry, devices=args.devices)
+    backend = rk.backend if not rk.backend_note else "%s (nccl failed: %s)" % (rk.backend, rk.backend_note)
     first, n, total = shard_of(rk, args.envs, args.total_envs)
     if n <= 0:
         raise SystemExit("bench.py: rank %d got no games (%d games over %d ranks)" % (rk.rank, total, rk.world))
@@ -903,6 +934,7 @@ def run_rank(args):
                               "scaling": "strong" if args.total_envs else "weak",
                               "config": {"total_games": total, "games_covered_by_ranks": covered, "games_per_gpu": n,
                                          "strong_leg_total_games": args.strong_total,
+                                         "reduction_backend": backend if rk.world > 1 else None,
                                          "stub_steps_x_games": steps_x_games}}), flush=True)
         rk.close()
         return

@@ -41,6 +41,19 @@ def test_self_launch_two_ranks():
     assert d['config']['stub_steps_x_games'] == 5 * 2000      # the SUM all-reduce saw both ranks' timed steps
 
 
+def test_nccl_that_cannot_come_up_falls_back_to_gloo_and_says_so():
+    """RCCL carries only the reporting reductions (the games never interact).  If the nccl process group cannot come up -- here: no GPU at
+    all -- every rank falls back to gloo on a fresh store, the run completes, and the line names what happened."""
+    p = _run(['--gpus', '2', '--dry-run', '--backend', 'nccl', '--steps', '4', '--warmup', '1', '--envs', '500'])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1
+    d = lines[0]
+    assert d['n_gpus'] == 2 and d['config']['stub_steps_x_games'] == 4 * 1000
+    assert d['config']['reduction_backend'].startswith('gloo (nccl failed: '), d['config']['reduction_backend']
+    assert 'fall back to gloo' in p.stderr
+
+
 def test_self_launch_eight_ranks_with_the_config5_defaults():
     """BASELINE config 5 as the driver will launch it: --gpus 8 with no size argument = 262,144 games per GPU (2,097,152 in total,
     weak) plus the strong leg of 2,097,152 games; all eight ranks rendezvous, shard and reduce."""

@@ -50,6 +50,16 @@ def test_two_ranks_on_one_gpu_equal_one_rank_and_the_oracle(version, per_rank):
     assert two['roofline']['frac_dram'] is None and len(one['build_id']) == 16
 
 
+def test_rccl_refusing_the_job_falls_back_to_gloo():
+    """The default backend of the reporting reductions is nccl (= RCCL).  Two ranks on ONE GPU are something RCCL refuses ("invalid usage"):
+    the real failure path -- every rank falls back to gloo on the host, the run completes with the same games, and the line says what
+    happened.  (On a node with a GPU per rank the same code comes up on RCCL; that is the driver's to run.)"""
+    two = _run(['--gpus', '2', '--devices', '0,0', '--envs', '4096'] + COMMON)
+    ref = _run(['--gpus', '2', '--devices', '0,0', '--backend', 'gloo', '--envs', '4096'] + COMMON)
+    assert two['n_gpus'] == 2 and two['config']['reduction_backend'].startswith('gloo (nccl failed: ')
+    assert two['config']['outputs_checksum'] == ref['config']['outputs_checksum'] and two['verified_envs'] >= 32 and two['value'] > 0
+
+
 def test_eight_ranks_on_one_gpu_equal_one_rank_and_the_oracle():
     """World size 8 -- BASELINE config 5's layout -- on the one GPU of the test box: 8 x 8,192 Barrage games, every rank its own
     VecStrategoEnv on its range of global env ids, gloo for the reporting reductions; the checksum of checksums over all 65,536 games
