@@ -3,11 +3,14 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload.  N = 1 (BASELINE.json configs[1]): 65,536 concurrent Barrage games, synthetic random-valid-action
-rollout with auto-reset, setups from the Gravon table, everything keyed by the counter RNG on (seed, global env id, game, turn).
-N > 1 (configs[4]): 262,144 games PER GPU (2,097,152 on 8 GPUs; "scaling": "weak"), plus, in the same line,
-the strong-scaling leg (2,097,152 games in total split over the ranks: config.strong_scaling) and the N = 1 workload's
-65,536 games per GPU (config.weak_65536) so that the 1-GPU line has a like-for-like counterpart; --envs / --total-envs override.
+Workload.  BASELINE.json configs[1] on EVERY GPU: 65,536 concurrent Barrage games per GPU, synthetic
+random-valid-action rollout with auto-reset, setups from the Gravon table, everything keyed by the counter RNG on (seed, global env id,
+game, turn) -- so `value` over --gpus 1 / 2 / 4 / 8 is the weak-scaling curve of ONE workload ("scaling": "weak": per-GPU work fixed).
+Every multi-GPU line is self-anchoring: before the ranks run a workload side by side, rank 0 times the same per-GPU workload ALONE (the
+other ranks parked at a host-side barrier; same process, env object and buffers), and the line reports config.solo, config.scaling_x =
+value / solo value and config.per_gpu_value_min_over_solo.  BASELINE configs[4] (262,144 games per GPU, 2,097,152 on
+8 GPUs) is config.scaling_legs[0] of every multi-GPU line (with its own solo anchor and scaling_x; the strong split of 2,097,152 games
+follows where it is a different size) and config.other_workloads[3] of the 1-GPU line; --envs / --total-envs override.
 One "step" = one batched env.step() over all of the rank's games: action in, move/combat/capture applied, win/draw detection,
 next mover's valid-actions mask (uint8 [R,C,K]) and normalised partial observation (float32 [R,C,67]) written to HBM, plus the
 next random valid action.  Inputs are resident in HBM when the timed region starts.  On one GPU the K timed steps write their outputs
@@ -15,13 +18,15 @@ round-robin into THREE output sets (sgx_step_ring: a trajectory buffer of the la
 does, and the rate a policy that reads the outputs between steps sees (config.consumer_in_loop) -- nothing a launch writes can still be
 cached when its addresses are written again, so `value` and `roofline` are DRAM-side figures.  The in-place variant (one set of
 tensors rewritten every step: the headline of rounds 1-3, 8-10 % faster because rewriting the same 1-2 GB back to back is) follows as
-config.in_place.  --output-sets 1 makes it the headline again.
+config.in_place; config.no_settle is the headline's K steps once more without the untimed gpu_settle launches.  --output-sets 1 makes
+in place the headline again.
 
 Multi-GPU: one process per GPU.  Under a launcher (RANK / WORLD_SIZE set) this process is one rank; run directly with
 --gpus N > 1 it starts the N ranks itself as fresh child processes BEFORE anything touches the GPU (a process that has
 initialised HIP is never re-executed; the parent does not even import torch) and relays rank 0's line.  Global env ids are sharded
 contiguously across the ranks (stratego_env_amd.sharding.shard_range), no collective on the data path: one barrier on each side
-of the timed region and one MAX / SUM all-reduce for reporting.
+of the timed region (host-side, gloo) and one MAX / SUM all-reduce for reporting (RCCL when EVERY rank brought it up, else gloo for all:
+class Rank).
 
 Prints ONE JSON line (rank 0) with
   `roofline`      HBM.  `achieved` = B_min x games per launch / launch time (HIP events on the launch stream over the timed region),
@@ -169,13 +174,16 @@ def parse_args(argv=None):
     ap.add_argument('--steps', type=int, default=512)
     ap.add_argument('--warmup', type=int, default=64)
     ap.add_argument('--envs', type=int, default=None,
-                    help='games per GPU (weak scaling: fixed as --gpus grows); default 65,536 on one GPU (BASELINE config 2), '
-                         '262,144 per GPU on several (config 5)')
+                    help='games per GPU (weak scaling: fixed as --gpus grows); default 65,536 (BASELINE config 2) on ANY number of GPUs, so '
+                         'that `value` over --gpus 1 / 2 / 4 / 8 is a curve of one workload; config 5 (262,144 per GPU) is a leg of every line')
     ap.add_argument('--total-envs', type=int, default=0,
                     help='strong scaling instead (SURVEY 8d config 5): this many games in total, split over the ranks')
     ap.add_argument('--strong-total', type=int, default=None,
                     help='games of the strong-scaling LEG reported next to the weak headline (default 2,097,152 when --gpus > 1, '
                          '0 = skip; pass it explicitly to get the leg on one GPU)')
+    ap.add_argument('--leg-envs', type=int, default=None,
+                    help="games per GPU of the multi-GPU line's first scaling leg (default 262,144 = BASELINE config 5 when --envs is "
+                         "defaulted, else no leg; 0 = skip)")
     ap.add_argument('--version', default='barrage')
     ap.add_argument('--unfused', action='store_true', help='sample actions with the standalone sampler kernel')
     ap.add_argument('--full-obs', action='store_true',
@@ -202,13 +210,14 @@ def parse_args(argv=None):
     ap.add_argument('--wake-seconds', type=float, default=2.0,
                     help='untimed GPU wake-up before the warmup steps (a fresh box runs its first ~second at idle clocks)')
     ap.add_argument('--output-sets', type=int, default=None,
-                    help='output sets the HEADLINE writes round-robin (sgx_step_ring: a trajectory buffer of the last R steps).  Default: 3 on one '
-                         'GPU -- no line a launch writes can still be cached when it is written again, so value / roofline are DRAM-side '
-                         'figures, the rate a learner that stores every step, or a policy that reads the outputs, sees -- and 1 (in place) '
-                         'on several GPUs, whose 262,144 games per GPU stream past every cache anyway')
+                    help='output sets the HEADLINE writes round-robin (sgx_step_ring: a trajectory buffer of the last R steps).  Default: 3 '
+                         '-- no line a launch writes can still be cached when it is written again, so value / roofline are DRAM-side '
+                         'figures, the rate a learner that stores every step, or a policy that reads the outputs, sees; 1 = in place')
     ap.add_argument('--no-in-place-leg', action='store_true',
                     help='skip the in-place leg after a ring headline (the same K steps into ONE set of tensors, and its two-chains variant)')
     ap.add_argument('--no-consumer-leg', action='store_true', help='skip the consumer-in-the-loop leg (sgx_step alternating with a device policy)')
+    ap.add_argument('--no-scaling-legs', action='store_true', help="skip config.scaling_legs (a multi-GPU line's other games-per-GPU sizes)")
+    ap.add_argument('--no-settle-leg', action='store_true', help='skip config.no_settle (the headline steps once more without gpu_settle)')
     ap.add_argument('--chains', type=int, default=1,
                     help='sgx_rollout: split the batch into this many ranges of games whose launches overlap on streams of their own '
                          '(1 = sgx_step_n, one launch per step: what the headline uses, so that the per-launch figures are per step)')
@@ -225,15 +234,20 @@ def parse_args(argv=None):
                     help="launcher self-test on CPU: gloo, stub env, no measurement (value is null)")
     args = ap.parse_args(argv)
     if args.envs is None:
-        args.envs = GAMES_1GPU if args.gpus == 1 else GAMES_PER_GPU_MULTI
+        # the SAME per-GPU workload on any number of GPUs (BASELINE config 2 on every GPU): `value` over --gpus 1 / 2 / 4 / 8 is a weak-scaling
+        # curve of one workload.  BASELINE config 5 (262,144 games per GPU, 2,097,152 on 8) is config.scaling_legs[0] of every multi-GPU
+        # line and config.other_workloads[3] of the 1-GPU line, each with its own anchor.
+        args.envs = GAMES_1GPU
         args.envs_defaulted = True
     else:
         args.envs_defaulted = False
     if args.output_sets is None:
-        args.output_sets = 3 if (args.gpus == 1 and not args.unfused and args.chains == 1) else 1
+        args.output_sets = 3 if (not args.unfused and args.chains == 1) else 1
     if args.output_sets < 1:
         ap.error("--output-sets must be >= 1")
     args.rotate_sets = 3           # the ring of the Micro leg (other_workloads)
+    if args.leg_envs is None:
+        args.leg_envs = GAMES_PER_GPU_MULTI if (args.gpus > 1 and not args.total_envs and args.envs_defaulted) else 0
     if args.strong_total is None:
         args.strong_total = STRONG_TOTAL if (args.gpus > 1 and not args.total_envs and args.envs_defaulted) else 0
     return args
@@ -309,7 +323,16 @@ def launch_ranks(args, argv):
 # ---------------------------------------------------------------------------------------------------------------
 class Rank:
     """This process's place in the job, from the launcher's environment.  world must equal --gpus: a launcher that
-    silently started fewer ranks is an error, not a smaller run."""
+    silently started fewer ranks is an error, not a smaller run.
+
+    Process groups.  The DEFAULT group is always gloo on the host: it carries the barriers of the timed bracket (ranks parked at a
+    gloo barrier do no GPU work: the solo anchors of the scaling legs need that) and the agreement below.  The reporting reductions
+    (one MAX, one SUM) run over RCCL (backend nccl, a second group on the same store: no second port) when -- and only when -- EVERY
+    rank brought it up: (1) each rank checks what it can check alone (a GPU of its own; SGX_BENCH_FAIL_NCCL_RANKS simulates a failure)
+    and the ranks all-gather the verdicts over gloo; (2) only if all passed do they create the nccl group and probe it with one
+    all-reduce, and all-gather the outcome again.  One rank failing at either stage moves ALL ranks to gloo for the reductions, and
+    the line says which rank and why (config.reduction_backend).  Nothing on the data path depends on any of this: the games never
+    interact."""
 
     def __init__(self, gpus, backend, use_cuda, devices=None):
         import torch
@@ -321,6 +344,7 @@ class Rank:
         if not 0 <= self.rank < self.world:
             raise SystemExit("bench.py: RANK=%d outside WORLD_SIZE=%d" % (self.rank, self.world))
         self.device_index = self.local_rank
+        dmap = None
         if devices:
             dmap = [int(x) for x in devices.split(',')]
             if self.local_rank >= len(dmap):
@@ -328,60 +352,90 @@ class Rank:
             self.device_index = dmap[self.local_rank]
         self.use_cuda = use_cuda
         self.dist = None
-        self.backend, self.backend_note = backend, None
+        self.red_group = None                  # None = the default (gloo) group
+        self.backend, self.backend_note = ('gloo' if self.world > 1 else backend), None
+        self.reduce_device = 'cpu'
         if use_cuda:
             torch.cuda.set_device(self.device_index)
-        # reductions run on the GPU over RCCL, or on the host over gloo (dry run; ranks that share one GPU, which RCCL refuses)
-        self.reduce_device = 'cuda' if (use_cuda and backend == 'nccl') else 'cpu'
         if self.world > 1:
+            import datetime
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
-            kw = {'device_id': torch.device('cuda', self.device_index)} if self.reduce_device == 'cuda' else {}
             # (gloo announces its connections on stdout, which has to stay ONE JSON line: send that to stderr)
             sys.stdout.flush()
             saved = os.dup(1)
             os.dup2(2, 1)
-            self.backend, self.backend_note = backend, None
             try:
+                dist.init_process_group('gloo', rank=self.rank, world_size=self.world, timeout=datetime.timedelta(seconds=600))
+                dist.barrier()
+                if dist.get_world_size() != gpus:
+                    raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), gpus))
+                self.dist = dist
                 if backend == 'nccl':
-                    # RCCL carries nothing but two tiny reporting reductions and the barriers here (the games never interact): if it cannot
-                    # come up on this node -- the one thing the builder's 1-GPU boxes could never exercise -- the run falls back to gloo on
-                    # the host for them instead of dying, and says so in the line (config.reduction_backend).
-                    import datetime
-                    try:
-                        if not use_cuda:
-                            raise RuntimeError("nccl needs a GPU per rank (dry run)")
-                        dist.init_process_group('nccl', rank=self.rank, world_size=self.world, timeout=datetime.timedelta(seconds=300), **kw)
-                        probe = torch.ones(1, device='cuda')
-                        dist.all_reduce(probe)
-                        torch.cuda.synchronize()
-                        if int(probe.item()) != self.world:
-                            raise RuntimeError("all_reduce of ones over %d ranks gave %r" % (self.world, probe.item()))
-                    except Exception as e:          # noqa: BLE001 -- whatever RCCL / the rendezvous raises
-                        self.backend_note = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else '')
-                        print("bench.py rank %d: nccl (RCCL) process group failed (%s); reporting reductions fall back to gloo" % (self.rank, self.backend_note),
-                              file=sys.stderr, flush=True)
-                        try:
-                            if dist.is_initialized():
-                                dist.destroy_process_group()
-                        except Exception:           # noqa: BLE001
-                            pass
-                        os.environ['MASTER_PORT'] = str(int(os.environ['MASTER_PORT']) + 1)        # a fresh store for the second group
-                        backend = self.backend = 'gloo'
-                        self.reduce_device = 'cpu'
-                        dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
-                        dist.barrier()
-                else:
-                    dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
-                    dist.barrier()
+                    self._bring_up_rccl(torch, dist, dmap, datetime.timedelta(seconds=int(os.environ.get('SGX_BENCH_NCCL_TIMEOUT', '120'))))
             finally:
                 sys.stdout.flush()
                 os.dup2(saved, 1)
                 os.close(saved)
-            if dist.get_world_size() != gpus:
-                raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), gpus))
-            self.dist = dist
+
+    def _agree(self, dist, ok, note):
+        """All ranks learn every rank's verdict (over gloo) -> (everybody ok, [(rank, note) of the ranks that failed])."""
+        verdicts = [None] * self.world
+        dist.all_gather_object(verdicts, (bool(ok), note))
+        failed = [(r, v[1]) for r, v in enumerate(verdicts) if not v[0]]
+        return not failed, failed
+
+    def _bring_up_rccl(self, torch, dist, dmap, timeout):
+        fake = os.environ.get('SGX_BENCH_FAKE_NCCL') == '1'      # CPU tests: a second gloo group stands in for RCCL
+        fail_ranks = [int(x) for x in os.environ.get('SGX_BENCH_FAIL_NCCL_RANKS', '').split(',') if x.strip() != '']
+        # ---- stage 1: what a rank can check on its own
+        ok, note = True, None
+        try:
+            if self.rank in fail_ranks:
+                raise RuntimeError("simulated failure (SGX_BENCH_FAIL_NCCL_RANKS)")
+            if not fake:
+                if not self.use_cuda:
+                    raise RuntimeError("nccl needs a GPU per rank (dry run)")
+                if dmap is not None and dmap.count(self.device_index) > 1 and os.environ.get('SGX_BENCH_SKIP_DEVICE_CHECK') != '1':
+                    raise RuntimeError("device %d is shared by %d ranks (RCCL refuses that: invalid usage)" % (self.device_index, dmap.count(self.device_index)))
+        except Exception as e:              # noqa: BLE001
+            ok, note = False, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else '')
+        all_ok, failed = self._agree(dist, ok, note)
+        group = None
+        if all_ok:
+            # ---- stage 2: the collective bring-up, probed with one all-reduce
+            try:
+                if self.rank in [int(x) for x in os.environ.get('SGX_BENCH_FAIL_NCCL_STAGE2_RANKS', '').split(',') if x.strip() != '']:
+                    raise RuntimeError("simulated failure inside the collective bring-up (SGX_BENCH_FAIL_NCCL_STAGE2_RANKS)")
+                if fake:
+                    group = dist.new_group(backend='gloo', timeout=timeout)
+                    probe = torch.ones(1)
+                else:
+                    group = dist.new_group(backend='nccl', timeout=timeout)
+                    probe = torch.ones(1, device='cuda')
+                dist.all_reduce(probe, group=group)
+                if not fake:
+                    torch.cuda.synchronize()
+                if int(probe.item()) != self.world:
+                    raise RuntimeError("all_reduce of ones over %d ranks gave %r" % (self.world, probe.item()))
+            except Exception as e:          # noqa: BLE001 -- whatever RCCL / the rendezvous raises
+                ok, note = False, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else '')
+            all_ok, failed = self._agree(dist, ok, note)
+        if all_ok:
+            self.red_group = group
+            self.backend = 'nccl (simulated by a second gloo group)' if fake else 'nccl'
+            self.reduce_device = 'cpu' if fake else 'cuda'
+            return
+        self.backend_note = "; ".join("rank %d: %s" % (r, n) for r, n in failed[:4]) + (" (+%d more)" % (len(failed) - 4) if len(failed) > 4 else "")
+        print("bench.py rank %d: nccl (RCCL) group not usable by every rank (%s); ALL ranks use gloo for the reporting reductions"
+              % (self.rank, self.backend_note), file=sys.stderr, flush=True)
+        if group is not None:
+            try:
+                dist.destroy_process_group(group)
+            except Exception:               # noqa: BLE001
+                pass
+        self.backend, self.reduce_device, self.red_group = 'gloo', 'cpu', None
 
     def sync(self):
         if self.use_cuda:
@@ -389,7 +443,8 @@ class Rank:
             torch.cuda.synchronize()
 
     def barrier(self):
-        """barrier + device synchronize on both sides (the bench contract's bracket of the timed region)."""
+        """barrier + device synchronize on both sides (the bench contract's bracket of the timed region).  The barrier is the host-side
+        gloo one: a rank waiting in it puts no work on its GPU."""
         self.sync()
         if self.dist:
             self.dist.barrier()
@@ -401,14 +456,33 @@ class Rank:
             return list(maxes), list(sums)
         import torch
         t = torch.tensor(list(maxes), dtype=torch.float64, device=self.reduce_device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        if len(maxes):
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.red_group)
         c = torch.tensor(list(sums), dtype=torch.int64, device=self.reduce_device)
-        self.dist.all_reduce(c, op=self.dist.ReduceOp.SUM)
+        if len(sums):
+            self.dist.all_reduce(c, op=self.dist.ReduceOp.SUM, group=self.red_group)
         return [float(x) for x in t], [int(x) for x in c]
+
+    def solo(self):
+        """This rank on its own: same device, no process group -- what times a leg's per-GPU workload ALONE (the other ranks parked at
+        the gloo barrier) before the ranks run it side by side."""
+        return _SoloRank(self)
 
     def close(self):
         if self.dist:
             self.dist.destroy_process_group()
+
+
+class _SoloRank:
+    def __init__(self, rk):
+        self.rank, self.world, self.local_rank, self.device_index, self.use_cuda, self.dist = rk.rank, 1, rk.local_rank, rk.device_index, rk.use_cuda, None
+        self.sync = rk.sync
+
+    def barrier(self):
+        self.sync()
+
+    def reduce(self, maxes, sums):
+        return list(maxes), list(sums)
 
 
 def shard_of(rk, per_gpu, total_envs):
@@ -451,21 +525,51 @@ def timed_steps(rk, run_warmup, run_timed, counters, settle=None):
 
 
 class _StubEnv:
-    """--dry-run only: stands in for VecStrategoEnv so that the launcher, rendezvous, sharding and reductions can be
-    exercised without a GPU.  It plays no game; the run reports value null."""
+    """--dry-run only: stands in for VecStrategoEnv so that the launcher, rendezvous, sharding, reductions, solo anchors and the leg
+    structure of a multi-GPU run can be exercised without a GPU (tests/test_bench_launcher_cpu.py).  It plays no game; the run reports
+    value null."""
+
+    class _Zero:
+        @staticmethod
+        def sum():
+            return 0
 
     def __init__(self, first, n):
-        self.first, self.n, self.steps_done = first, n, 0
+        self.first, self.num_envs, self.steps_done, self.bench_steps_played = first, n, 0, 0
+        self.invalid_action, self.ring_sets = self._Zero(), 1
+        self.build_id, self.record_bytes = 'dry-run', 0
 
-    def rollout_steps(self, k):
-        time.sleep(0.002 * k)
+    def sample_valid_actions(self):
+        pass
+
+    def rollout_steps(self, k, chains=1, ring=False):
+        time.sleep(0.0005 * k)
         self.steps_done += k
 
+    def rollout_step(self):
+        self.rollout_steps(1)
+
     def counters(self):
-        return [self.steps_done * self.n, 0]
+        return [self.steps_done * self.num_envs, 0]
+
+    def snapshot(self):
+        snap = _StubEnv(self.first, self.num_envs)
+        snap.steps_done = self.steps_done
+        return snap
+
+    def restore(self, snap):
+        self.steps_done = snap.steps_done
+
+    def close(self):
+        pass
+
+
+DRY_RUN = False
 
 
 def make_env(version, n, first, device_index, full_obs=False, compact=False):
+    if DRY_RUN:
+        return _StubEnv(first, n)
     from stratego_env_amd.vec_env import VecStrategoEnv
     env = VecStrategoEnv(version, n, device=device_index, seed=BASE_SEED, env_id_offset=first, auto_reset=True, full_obs=full_obs,
                          compact_outputs=compact)
@@ -495,9 +599,10 @@ def gpu_settle(env, seconds):
         torch.cuda.synchronize()
 
 
-def time_workload(rk, env, steps, warmup, unfused=False, chains=1, ring=False):
+def time_workload(rk, env, steps, warmup, unfused=False, chains=1, ring=False, settle=True):     # noqa: C901
     """(elapsed s, device ms, (min, max) of the ranks' own seconds, games finished, invalid actions) of `steps` batched steps on
-    `env`, MAX / SUM over ranks.  ring: the steps write the env's ring of output sets in turn (env.alloc_output_ring)."""
+    `env`, MAX / SUM over ranks.  ring: the steps write the env's ring of output sets in turn (env.alloc_output_ring).
+    settle=False: no gpu_settle between the warm-up steps and the bracket (config.no_settle)."""
     import torch
 
     def one_step():
@@ -525,9 +630,12 @@ def time_workload(rk, env, steps, warmup, unfused=False, chains=1, ring=False):
             env.rollout_steps(steps, chains=chains, ring=ring)    # the same K batched steps, enqueued by one C-ABI call (sgx_step_n / sgx_rollout / sgx_step_ring)
 
     def counters():
+        if DRY_RUN:
+            return env.counters()
         return [int(env.env_info()[:, 1].to(torch.int64).sum()), 0]
 
-    elapsed, dev_ms, own, (games, _) = timed_steps(rk, run_warmup, run_timed, counters, settle=lambda: gpu_settle(env, SETTLE_SECONDS))
+    elapsed, dev_ms, own, (games, _) = timed_steps(rk, run_warmup, run_timed, counters,
+                                                   settle=(lambda: gpu_settle(env, SETTLE_SECONDS)) if (settle and SETTLE_SECONDS > 0 and not DRY_RUN) else None)
     env.bench_steps_played += warmup + steps
     _, (invalid,) = rk.reduce([], [int(env.invalid_action.sum())])
     return elapsed, dev_ms, own, games, invalid
@@ -698,12 +806,14 @@ def rotating_leg(rk, env, args, version, v, steps, warmup, n_sets, full_obs=Fals
 
 
 def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_round=16, n_check=8):
-    """A consumer in the loop (examples/basic_game_loop.py:6-31, 48-63 for a batch): every step is `choose_actions` of
-    stratego_env_amd/examples/batched_policy_loop.py -- logits from the observation, invalid actions masked out, softmax, one sample
-    per game: the observation and the mask are READ on the device -- followed by sgx_step with the chosen actions.  In-process A/B of
-    the observation store policy under that reader: rounds of `steps_per_round` steps alternate between sgx_set_nt_stores(1)
-    (non-temporal interior lines: the default at this size) and (0) (plain stores) on the same env object and buffers; reported per
-    policy: whole-loop env steps/s and the step kernel's own time inside the loop (HIP events around every sgx_step).  The actions of
+    """A consumer in the loop (examples/basic_game_loop.py:6-31, 48-63 for a batch): every step is the policy of
+    stratego_env_amd/examples/batched_policy_loop.py -- logits from the observation (mean over the board, a fixed linear read-out: the
+    stand-in for a network) -- then the library's chooser sgx_choose_actions (invalid actions masked out, softmax, one sample per game
+    with the env's counter RNG: the logits and the mask the step wrote are READ on the device), then sgx_step with the chosen actions.
+    In-process A/B of the observation store policy under that reader: rounds of `steps_per_round` steps alternate between
+    sgx_set_nt_stores(1) (non-temporal interior lines: the default at this size) and (0) (plain stores) on the same env object and
+    buffers; reported per policy: whole-loop env steps/s, the step kernel's and the chooser's own time inside the loop (HIP events).
+    One more round runs the round-4 chooser composed from torch ops (masked_fill, softmax, multinomial) for comparison.  The actions of
     `n_check` sampled envs are logged on the device and replayed on the CPU oracle afterwards (same setups by the counter RNG,
     auto-reset included): the last step's mask / observation / rewards / flags must match bit for bit."""
     import numpy as np
@@ -718,18 +828,26 @@ def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_
         g = torch.Generator(device=dev)
         g.manual_seed(1234)
         readout = torch.randn(env.obs.shape[-1], env.mask[0].numel(), device=dev, generator=g) * 0.5
+        logits_buf = torch.empty((n, env.mask[0].numel()), dtype=torch.float32, device=dev)
+        chosen = torch.empty((n,), dtype=torch.int32, device=dev)
         ids = np.unique(np.linspace(0, n - 1, n_check).astype(np.int64))
         idx = torch.from_numpy(ids).to(dev)
-        total_steps = 2 * rounds * steps_per_round + 4
+        total_steps = 2 * rounds * steps_per_round + steps_per_round + 4
         act_log = torch.zeros((total_steps, len(ids)), dtype=torch.int32, device=dev)
         done_log = torch.zeros((total_steps, len(ids)), dtype=torch.uint8, device=dev)
         obs, mask = env.obs, env.mask
         played = 0
 
-        def loop(k, events=None):
+        def loop(k, events=None, fused=True):
             nonlocal played, obs, mask
             for i in range(k):
-                a = choose_actions(obs, mask, readout, g)
+                if fused:
+                    logits = torch.matmul(obs.mean(dim=(1, 2)), readout, out=logits_buf)
+                    if events is not None:
+                        events[i][2].record()
+                    a = env.choose_actions(logits, 1.0, out=chosen)
+                else:
+                    a = choose_actions(obs, mask, readout, g)
                 act_log[played] = a[idx]
                 if events is not None:
                     events[i][0].record()
@@ -740,17 +858,19 @@ def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_
                 played += 1
 
         loop(4)                                             # untimed: allocator warm-up of the policy's temporaries
-        res = {1: {"s": 0.0, "kernel_ms": 0.0, "steps": 0}, 0: {"s": 0.0, "kernel_ms": 0.0, "steps": 0}}
-        for _ in range(rounds):
-            for mode in (1, 0):
-                env.set_nt_stores(bool(mode))
-                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps_per_round)]
+        res = {m: {"s": 0.0, "kernel_ms": 0.0, "chooser_ms": 0.0, "steps": 0} for m in (1, 0, 'torch')}
+        for rnd in range(rounds + 1):
+            for mode in ((1, 0) if rnd < rounds else ('torch',)):
+                env.set_nt_stores('auto' if mode == 'torch' else bool(mode))
+                ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(steps_per_round)]
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                loop(steps_per_round, ev)
+                loop(steps_per_round, ev, fused=mode != 'torch')
                 torch.cuda.synchronize()
                 res[mode]["s"] += time.perf_counter() - t0
-                res[mode]["kernel_ms"] += sum(a.elapsed_time(b) for a, b in ev)
+                res[mode]["kernel_ms"] += sum(e[0].elapsed_time(e[1]) for e in ev)
+                if mode != 'torch':
+                    res[mode]["chooser_ms"] += sum(e[2].elapsed_time(e[0]) for e in ev)      # (includes the copy of 8 logged actions)
                 res[mode]["steps"] += steps_per_round
         env.set_nt_stores('auto')
         assert int(env.invalid_action.sum()) == 0
@@ -788,12 +908,20 @@ def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_
 
         def rep(m):
             r = res[m]
-            return {"value": n * r["steps"] / r["s"], "unit": "env steps/s", "ms_per_loop_step": r["s"] / r["steps"] * 1e3,
-                    "step_kernel_us_in_loop": r["kernel_ms"] / r["steps"] * 1e3, "steps": r["steps"]}
+            out = {"value": n * r["steps"] / r["s"], "unit": "env steps/s", "ms_per_loop_step": r["s"] / r["steps"] * 1e3,
+                   "step_kernel_us_in_loop": r["kernel_ms"] / r["steps"] * 1e3, "steps": r["steps"]}
+            if m != 'torch':
+                out["chooser_us_in_loop"] = r["chooser_ms"] / r["steps"] * 1e3
+            return out
         nt, plain = rep(1), rep(0)
-        return {"workload": "%d concurrent %s games: batched_policy_loop.choose_actions (reads obs + mask; masked softmax over obs-derived logits, "
-                            "multinomial sample) then sgx_step, %d rounds x %d steps per store policy, interleaved" % (n, version, rounds, steps_per_round),
+        na = env.mask[0].numel()
+        return {"workload": "%d concurrent %s games: policy logits from the observation (mean over the board + a fixed linear read-out, torch), "
+                            "sgx_choose_actions (reads the logits + the mask: masked softmax, one sample per game with the counter RNG), then sgx_step; "
+                            "%d rounds x %d steps per store policy, interleaved" % (n, version, rounds, steps_per_round),
                 "nt_stores": nt, "plain_stores": plain,
+                "chooser": {"kernel": "choose_kernel<%d,%d,4,false>" % (v.rows, v.columns), "bytes_per_game": 4 * na + na + 4 + 32,
+                            "frac": (4 * na + na + 36) * n / (nt["chooser_us_in_loop"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                "torch_composed_chooser": dict(rep('torch'), note="the round-4 consumer: masked_fill + softmax + multinomial as torch ops"),
                 "default_policy_at_this_size": "nt_stores (observation bytes per launch > 300 MB)",
                 "nt_over_plain_step_kernel": nt["step_kernel_us_in_loop"] / plain["step_kernel_us_in_loop"],
                 "verified_envs": int(len(ids)), "verified_steps": played, "placement": trial}
@@ -887,29 +1015,81 @@ def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, 
         torch.cuda.empty_cache()
 
 
-def scaling_leg(rk, args, per_gpu, total_envs, label):
-    """Another games-per-GPU size of the multi-GPU run, same K / W as the headline: {value, ms_per_step, ...}."""
+def solo_anchor(rk, env, steps, warmup, **kw):
+    """The per-GPU workload of a multi-GPU leg timed on rank 0 ALONE -- same process, same env object, same output buffers, same K / W,
+    the other ranks parked at the host-side gloo barrier with no GPU work -- directly before the ranks run it side by side.  The games
+    are put back where they were afterwards (env.snapshot / restore: records, counters, game numbers), so the side-by-side run and its
+    sharding-independent checksum are those of a run without the anchor.  Every rank calls this; -> {value, launch_us, ms_per_step}
+    on rank 0, None elsewhere (and None on one GPU, where the headline is its own anchor)."""
+    if rk.world == 1:
+        return None
+    out = None
+    if rk.rank == 0:
+        snap, played = env.snapshot(), env.bench_steps_played
+        elapsed, dev_ms, _, games, invalid = time_workload(rk.solo(), env, steps, warmup, **kw)
+        assert invalid == 0
+        out = {"value": env.num_envs * steps / elapsed, "unit": "env steps/s", "games": env.num_envs, "ms_per_step": elapsed / steps * 1e3,
+               "launch_us": (dev_ms or 0.0) / steps * 1e3,
+               "how": "rank 0 alone (the other ranks parked at a host-side barrier), same env object and buffers, same --steps / --warmup, "
+                      "directly before the side-by-side run; the games were put back afterwards (snapshot / restore)"}
+        env.restore(snap)
+        env.bench_steps_played = played
+        snap.close()
+    rk.barrier()
+    return out
+
+
+def scaling_fields(value_all, own, n, steps, solo, world):
+    """{scaling_x, per_gpu_min_over_solo, ...} of a multi-GPU leg against its solo anchor (rank 0 only has one)."""
+    if not solo:
+        return {"solo": None, "scaling_x": None, "per_gpu_value_min_over_solo": None}
+    return {"solo": solo, "scaling_x": value_all / solo["value"], "scaling_x_ideal": world,
+            "per_gpu_value_min_over_solo": (n * steps / own[1]) / solo["value"]}
+
+
+def ring_for(env, args, n_sets):
+    """alloc_output_ring with the bench's placement budgets -> the per-extra-set (plain, kept) us report."""
+    budget, wide = placement_budgets(args, max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if (args.placement == 'trial' and args.placement_gb > 0) else 0)
+    reps = env.alloc_output_ring(n_sets, tune=budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6, max_extra_bytes=budget,
+                                 trials=args.placement_trials, wide_extra_bytes=wide)
+    return reps
+
+
+def scaling_leg(rk, args, per_gpu, total_envs, label, output_sets=1):
+    """Another games-per-GPU size of the multi-GPU run, same K / W as the headline, anchored like it: rank 0 alone first (solo_anchor),
+    then all ranks side by side: {value, ms_per_step, solo, scaling_x, ...}.  output_sets > 1: a ring of output sets like the 1-GPU
+    headline's."""
     import torch
     first, n, total = shard_of(rk, per_gpu, total_envs)
     env = make_env(args.version, n, first, rk.device_index)
     try:
-        place_outputs(env, args)
-        elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup)
+        ring = output_sets >= 2
+        if not DRY_RUN:
+            place_outputs(env, args)
+            if ring:
+                ring_for(env, args, output_sets)
+        solo = solo_anchor(rk, env, args.steps, args.warmup, ring=ring)
+        elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, ring=ring)
         assert invalid == 0
-        checked = verify_against_oracle(env, args.version, min(args.verify_envs, 8)) if args.verify_envs else 0
+        checked = verify_against_oracle(env, args.version, min(args.verify_envs, 8)) if (args.verify_envs and not DRY_RUN) else 0
         _, (checked,) = rk.reduce([], [checked])
-        return {"workload": label, "scaling": "strong" if total_envs else "weak", "total_games": total, "games_per_gpu": n,
-                "value": total * args.steps / elapsed, "unit": "env steps/s", "ms_per_step": elapsed / args.steps * 1e3,
-                "per_gpu_value_min": n * args.steps / own[1], "per_gpu_value_max": n * args.steps / own[0],
-                "launch_us": dev_ms / args.steps * 1e3, "verified_envs": checked}
+        out = {"workload": label, "scaling": "strong" if total_envs else "weak", "total_games": total, "games_per_gpu": n,
+               "output_sets": output_sets if ring else 1,
+               "value": total * args.steps / elapsed, "unit": "env steps/s", "ms_per_step": elapsed / args.steps * 1e3,
+               "per_gpu_value_min": n * args.steps / own[1], "per_gpu_value_max": n * args.steps / own[0],
+               "launch_us": (dev_ms or 0.0) / args.steps * 1e3, "verified_envs": checked}
+        out.update(scaling_fields(out["value"], own, n, args.steps, solo, rk.world))
+        return out
     finally:
         env.close()
         del env
-        torch.cuda.empty_cache()
+        if not DRY_RUN:
+            torch.cuda.empty_cache()
 
 
-def run_rank(args):
-    dry = args.dry_run
+def run_rank(args):      # noqa: C901
+    global DRY_RUN, SETTLE_SECONDS
+    dry = DRY_RUN = args.dry_run
     if not dry:
         import torch
         if not torch.cuda.is_available():
@@ -920,47 +1100,26 @@ def run_rank(args):
     first, n, total = shard_of(rk, args.envs, args.total_envs)
     if n <= 0:
         raise SystemExit("bench.py: rank %d got no games (%d games over %d ranks)" % (rk.rank, total, rk.world))
-
-    if dry:
-        env = _StubEnv(first, n)
-        elapsed, _, _, (steps_x_games, _) = timed_steps(rk, lambda: env.rollout_steps(args.warmup),
-                                                        lambda: env.rollout_steps(args.steps), env.counters)
-        _, (covered, lo_gap) = rk.reduce([], [n, first if rk.rank == 0 else 0])
-        if rk.rank == 0:
-            print(json.dumps({"metric": "env steps/sec", "value": None, "unit": "env steps/s", "n_gpus": rk.world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                              "dry_run": True, "data": "none (launcher self-test)",
-                              "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external'),
-                              "scaling": "strong" if args.total_envs else "weak",
-                              "config": {"total_games": total, "games_covered_by_ranks": covered, "games_per_gpu": n,
-                                         "strong_leg_total_games": args.strong_total,
-                                         "reduction_backend": backend if rk.world > 1 else None,
-                                         "stub_steps_x_games": steps_x_games}}), flush=True)
-        rk.close()
-        return
-
-    import torch
-    global SETTLE_SECONDS
     SETTLE_SECONDS = args.settle_seconds
-    if args.wake_seconds > 0:   # bring the GPU out of its idle power state; touches no env state
-        scratch = torch.empty(1 << 28, dtype=torch.float32, device='cuda')
-        t_wake = time.perf_counter()
-        while time.perf_counter() - t_wake < args.wake_seconds:
-            scratch.fill_(1.0)
-            torch.cuda.synchronize()
-        del scratch
+    if not dry:
+        import torch
+        if args.wake_seconds > 0:   # bring the GPU out of its idle power state; touches no env state
+            scratch = torch.empty(1 << 28, dtype=torch.float32, device='cuda')
+            t_wake = time.perf_counter()
+            while time.perf_counter() - t_wake < args.wake_seconds:
+                scratch.fill_(1.0)
+                torch.cuda.synchronize()
+            del scratch
 
     from stratego_env_amd.config import VARIANTS
     v = VARIANTS[args.version]
     env = make_env(args.version, n, first, rk.device_index, full_obs=args.full_obs)
     build_id, rec_bytes = env.build_id, env.record_bytes
-    placement = place_outputs(env, args)
+    placement = place_outputs(env, args) if not dry else None
     headline_ring = args.output_sets >= 2 and not args.unfused and args.chains == 1
     ring_report = None
-    if headline_ring:      # the headline writes a ring of output sets: each extra set from its own placement trial, like the first
-        budget, wide = placement_budgets(args, max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if args.placement == 'trial' else 0)
-        reps = env.alloc_output_ring(args.output_sets, tune=budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6, max_extra_bytes=budget,
-                                     trials=args.placement_trials, wide_extra_bytes=wide)
+    if headline_ring and not dry:      # the headline writes a ring of output sets: each extra set from its own placement trial, like the first
+        reps = ring_for(env, args, args.output_sets)
         ring_report = [(round(r['obs'][0], 1), round(min(r['obs']), 1)) if (r and r.get('obs')) else None for r in reps[1:]]
         if reps[0]:            # the env's own set was slower than the extra ones and was searched again against them (alloc_output_ring)
             placement = dict(placement or {})
@@ -969,15 +1128,25 @@ def run_rank(args):
                                                      "used": reps[0]['used']}
             if reps[0]['used']:
                 placement["kept_us"] = round(min(reps[0]['obs']), 1)
+    # several GPUs: rank 0 times this per-GPU workload ALONE first (the others parked, no GPU work), so that the line carries its own anchor
+    solo = solo_anchor(rk, env, args.steps, args.warmup, unfused=args.unfused, chains=args.chains, ring=headline_ring)
     elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring)
     assert invalid == 0, "rollout produced invalid actions"
     # outside the timed region: the envs that were just timed against the CPU oracle, and the sharding-independent checksum
-    checked = verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if args.verify_envs else 0
+    checked = verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if (args.verify_envs and not dry) else 0
     verified_steps = env.bench_steps_played
-    _, (checked, checksum) = rk.reduce([], [checked, outputs_checksum(env)])
-    in_place, two_chains = None, None
+    _, (checked, checksum, covered) = rk.reduce([], [checked, outputs_checksum(env) if not dry else 0, n])
+    in_place, two_chains, no_settle = None, None, None
     per_step = b_min(v, args.full_obs, rec_bytes)
-    if rk.world == 1 and headline_ring and not args.no_in_place_leg:
+    if not dry and SETTLE_SECONDS > 0 and not args.no_settle_leg:
+        # what gpu_settle is worth: the same K steps on the same env object and buffers once more, W warm-up steps straight into the bracket
+        # (every rank takes part: same barriers)
+        e0, d0, _, _, inv0 = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring, settle=False)
+        assert inv0 == 0
+        no_settle = {"workload": "the headline's K steps once more WITHOUT gpu_settle: %d warm-up steps, then the bracket" % args.warmup,
+                     "value": total * args.steps / e0, "unit": "env steps/s", "launch_us": d0 / args.steps * 1e3,
+                     "frac": per_step * n / (d0 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
+    if rk.world == 1 and headline_ring and not args.no_in_place_leg and not dry:
         # The same K / W on the same env object into ONE set of tensors (the set the ring wrote last), step after step: what rounds 1-3
         # reported as the headline.  Rewriting the same 1-2 GB back to back is 8-10 % faster than anything that cannot reuse its lines
         # (DESIGN.md section 3.2), so its rate is a memory-side figure that can touch the 8 TB/s spec peak: a ratio, not a DRAM fraction.
@@ -989,7 +1158,7 @@ def run_rank(args):
                     "rate_is": "memory side including the 256 MiB Infinity Cache and whatever else favours rewriting the same lines; not a DRAM fraction",
                     "verified_envs": verify_against_oracle(env, args.version, min(args.verify_envs, 8), both=args.full_obs) if args.verify_envs else 0,
                     "verified_steps": env.bench_steps_played}
-    if rk.world == 1 and args.chains == 1 and not args.unfused and not args.no_two_chains and not (headline_ring and args.no_in_place_leg):
+    if rk.world == 1 and args.chains == 1 and not args.unfused and not args.no_two_chains and not (headline_ring and args.no_in_place_leg) and not dry:
         # The same K steps (in place) with the batch split into two ranges of games whose launches overlap (sgx_rollout, chains = 2)
         e2, d2, _, _, inv2 = time_workload(rk, env, args.steps, args.warmup, False, 2)
         assert inv2 == 0
@@ -1001,31 +1170,36 @@ def run_rank(args):
     out = None
     if rk.rank == 0:
         total_steps = total * args.steps
-        launch_s = dev_ms / 1e3 / args.steps                 # average device time per batched step (HIP events)
-        rf = roofline(args.version, v, n, launch_s, args.traffic_bytes, full_obs=args.full_obs,
-                      first_us=(placement or {}).get('fobs_plain_us' if args.full_obs else 'plain_us'), rec_bytes=rec_bytes, build_id=build_id,
-                      rotating=launch_s if headline_ring else None, ring_sets=args.output_sets if headline_ring else 1)
-        rf["in_place_rate_over_spec_peak"] = in_place["rate_over_spec_peak"] if in_place else None
+        launch_s = (dev_ms or 0.0) / 1e3 / args.steps                 # average device time per batched step (HIP events)
+        rf = None
+        if not dry:
+            rf = roofline(args.version, v, n, launch_s, args.traffic_bytes, full_obs=args.full_obs,
+                          first_us=(placement or {}).get('fobs_plain_us' if args.full_obs else 'plain_us'), rec_bytes=rec_bytes, build_id=build_id,
+                          rotating=launch_s if headline_ring else None, ring_sets=args.output_sets if headline_ring else 1)
+            rf["in_place_rate_over_spec_peak"] = in_place["rate_over_spec_peak"] if in_place else None
+        value = total_steps / elapsed
         out = {
-            "metric": "env steps/sec", "value": total_steps / elapsed, "unit": "env steps/s",
+            "metric": "env steps/sec", "value": None if dry else value, "unit": "env steps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_envs else "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic", "build_id": build_id,
+            "vs_baseline": None, "dtype": "u8", "data": "none (launcher self-test)" if dry else "synthetic", "build_id": build_id,
             "verified_envs": checked, "verified_steps": verified_steps,
             "config": {"workload": "%d concurrent %s games per GPU (%dx%d)%s, random-valid-action rollout with auto-reset, "
                                    "%s step+sample%s" % (n, args.version, v.rows, v.columns,
                                                          ", BOTH_OBSERVATIONS (67 + 79 channels)" if args.full_obs else "",
                                                          "separate" if args.unfused else "fused",
                                                          ", outputs written round-robin into %d sets (a trajectory buffer of the last %d steps)" % (args.output_sets, args.output_sets) if headline_ring else ", outputs written in place"),
-                       "games_per_gpu": n, "total_games": total, "version": args.version, "seed": BASE_SEED,
+                       "games_per_gpu": n, "total_games": total, "games_covered_by_ranks": covered, "version": args.version, "seed": BASE_SEED,
                        "arithmetic": "game logic on int8 / uint8 boards (dtype u8); outputs: float32 observation (85 % of the bytes), uint8 mask",
                        "games_finished_in_timed_region": games, "b_min_bytes_per_step": b_min(v, args.full_obs, rec_bytes),
                        "record_bytes": rec_bytes,
                        "untimed_before_bracket": "%d warm-up steps, then %.2f s of state-preserving sgx_observe launches (gpu_settle)" % (args.warmup, SETTLE_SECONDS),
+                       "no_settle": no_settle,
                        "output_sets": args.output_sets if headline_ring else 1, "ring_placement_plain_and_kept_us_per_extra_set": ring_report,
                        "concurrent_chains": args.chains, "in_place": in_place, "two_chains": two_chains,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),
                        "reduction_backend": backend if rk.world > 1 else None, "devices": args.devices,
+                       "strong_leg_total_games": args.strong_total,
                        # the slowest / fastest rank's own K steps (no waiting for the others): weak scaling without a data-path
                        # collective loses nothing as long as these stay at the 1-GPU rate of the same games-per-GPU size
                        "per_gpu_value_min": n * args.steps / own[1], "per_gpu_value_max": n * args.steps / own[0],
@@ -1034,29 +1208,42 @@ def run_rank(args):
                        "placement": placement},
             "roofline": rf,
         }
+        # several GPUs: the same per-GPU workload on rank 0 alone, and what the job makes of it (measured in this process, on this node)
+        out["config"].update(scaling_fields(value, own, n, args.steps, solo, rk.world))
+        if dry:
+            out["dry_run"] = True
+            out["launched_by"] = out["config"]["launched_by"]
+            out["config"]["stub_steps_x_games"] = games
     env.close()
     del env
-    torch.cuda.empty_cache()
+    if not dry:
+        import torch
+        torch.cuda.empty_cache()
     legs = None
-    if not args.no_other_workloads and rk.world > 1 and not args.total_envs and args.envs_defaulted:
-        # the other per-GPU sizes of the scaling study (every rank takes part)
-        legs = [scaling_leg(rk, args, GAMES_1GPU, 0, "%d games per GPU: the 1-GPU line's workload (BASELINE config 2) on every GPU" % GAMES_1GPU)]
-        if args.strong_total:
-            legs.append(scaling_leg(rk, args, 0, args.strong_total, "%d games in total split over the GPUs (BASELINE config 5, strong scaling)" % args.strong_total))
-    elif args.strong_total and not args.no_other_workloads:
-        legs = [scaling_leg(rk, args, 0, args.strong_total, "%d games in total split over the GPUs (BASELINE config 5, strong scaling)" % args.strong_total)]
+    if not args.no_scaling_legs and rk.world > 1 and not args.total_envs and args.leg_envs:
+        # the other per-GPU sizes of the scaling study (every rank takes part), each with its own solo anchor
+        legs = [scaling_leg(rk, args, args.leg_envs, 0,
+                            "%s%d games per GPU (%d on %d GPUs), outputs in place%s"
+                            % ("BASELINE config 5: " if args.leg_envs == GAMES_PER_GPU_MULTI else "", args.leg_envs, args.leg_envs * rk.world, rk.world,
+                               " (8 GB per set streams past every cache)" if args.leg_envs == GAMES_PER_GPU_MULTI else ""))]
+        if args.strong_total and args.strong_total != args.leg_envs * rk.world:
+            legs.append(scaling_leg(rk, args, 0, args.strong_total, "%d games in total split over the GPUs (BASELINE config 5's total, strong scaling)" % args.strong_total))
+    elif args.strong_total and not args.no_scaling_legs:
+        legs = [scaling_leg(rk, args, 0, args.strong_total, "%d games in total split over the GPUs (BASELINE config 5's total, strong scaling)" % args.strong_total)]
     if rk.rank == 0:
         out["config"]["scaling_legs"] = legs
         out["config"]["other_workloads"] = None
         out["config"]["consumer_in_loop"] = None
-        if rk.world == 1 and not args.no_other_workloads and args.version == 'barrage':
+        if rk.world == 1 and not args.no_other_workloads and args.version == 'barrage' and not dry:
             if not args.no_consumer_leg:
                 out["config"]["consumer_in_loop"] = consumer_leg(rk, args)
             out["config"]["other_workloads"] = [other_workload(rk, args, 'standard', 262144, chains=2),
                                                 other_workload(rk, args, 'micro', 65536, chains=2, rotate_sets=args.rotate_sets),
-                                                other_workload(rk, args, 'barrage', 65536, full_obs=True)]
+                                                other_workload(rk, args, 'barrage', 65536, full_obs=True),
+                                                # BASELINE config 5's per-GPU size on ONE GPU: the G = 1 anchor of the 1 / 2 / 4 / 8 curve
+                                                other_workload(rk, args, 'barrage', GAMES_PER_GPU_MULTI)]
             out["config"]["compact_outputs"] = compact_leg(rk, args)
-        if not args.no_cpu_baseline and rk.world == 1:         # the CPU leg is timed on rank 0 of the 1-GPU run only
+        if not args.no_cpu_baseline and rk.world == 1 and not dry:         # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None

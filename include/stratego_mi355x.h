@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 12
+#define SGX_ABI_VERSION 13
 #define SGX_MAX_CELLS 1024       /* rows*cols <= 1024 (largest reference variant: 15x15 = 225; the reference's StrategoProceduralEnv
                                     takes any size, penv:27-36: boards of more than 256 cells use 10-bit cell indices in the record) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
@@ -318,6 +318,18 @@ int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int32_t chai
  * picks the k-th set byte, k drawn with the same counter RNG as next_actions_dev (identical results). */
 int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actions_dev, void *stream);
 
+/* nnet_choose_action_example (examples/basic_game_loop.py:6-31 with softmax of examples/util.py:4-47) for a batch, on the device: the
+ * caller's policy writes logits float32 [N][R*C*K] in the shape of the valid-actions mask; invalid actions get probability 0, the rest
+ * softmax((logits - max) / temperature), and ONE action per game is drawn from it -- one wave per game, logits and mask read once.
+ * mask_dev: the mask the step kernel wrote, uint8 [N][R*C*K], or with flags = SGX_STEP_COMPACT_MASK the bit mask uint32
+ * [N][sgx_compact_mask_words] of a compact step.  temperature: a divisor, > 0; 0 = argmax (ties drawn uniformly).
+ * The draw is keyed like next_actions_dev -- counter RNG on (seed, global env id, game number, turn) -- and sampling is fixed point
+ * (weights floor(exp2(...) * 2^31), exact 64-bit sums, inverse CDF in ascending action order): a result depends on nothing but
+ * (logits, mask, seed, game, turn), and with equal logits it IS sgx_sample_valid's action.  NaN logits count as -inf; if no valid
+ * action has a logit above -inf the draw is uniform over the valid ones; actions_dev[i] = -1 where the mask is empty.
+ * No policy network lives in this library: the logits are the caller's. */
+int sgx_choose_actions(sgx_env *h, const float *logits_dev, const void *mask_dev, float temperature, int32_t flags, int32_t *actions_dev, void *stream);
+
 /* INTERNAL_STATE observation component / reset(initial_state_override=...) (maenv:494-495, 551-553):
  * convert between the library's packed int8 state and the reference's int64 [N,34,R,C] layout
  * (absolute coordinates).  player_dev int8 [N] = current mover (nullable on export; NULL on import = +1). */
@@ -337,7 +349,11 @@ int sgx_import_state_checked(sgx_env *h, const int64_t *state_dev, const int8_t 
  * flags of the functional API; no auto_reset, no next_actions_dev; io->actions_dev NULL = sgx_observe of the given states (their
  * movers' masks / observations, nothing is played).  The handle's own states are overwritten.  On boards of more than 32 cells with
  * the 67-channel observation kind the three steps are ONE launch (a 128-thread block per state, the packed record never leaves
- * LDS): 65,536 Barrage states 745 -> ~640 us; `chains` only matters on the other paths. */
+ * LDS): 65,536 Barrage states 745 -> ~640 us; `chains` only matters on the other paths.
+ * NO ALIASING while the general-state pass is on (the default, see sgx_set_general_states; boards of up to 256 cells): that pass reads
+ * state_in_dev / player_in_dev again after the outputs have been written, so state_out_dev must not overlap state_in_dev and
+ * player_out_dev must not overlap player_in_dev -- SGX_EINVAL otherwise.  With the pass off, stepping a batch in place is fine (every
+ * state is read completely before its successor is written). */
 int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_t *player_in_dev, uint8_t *sanitised_dev,
                     const sgx_step_io *io, int64_t *state_out_dev, int8_t *player_out_dev, int32_t chains, void *stream);
 

@@ -14,7 +14,7 @@ PO_OBS_CHANNELS = 67
 FO_OBS_CHANNELS = 79
 PO_OBS_CHANNELS_ORIGINAL = 32
 FO_OBS_CHANNELS_ORIGINAL = 33
-ABI_VERSION = 12
+ABI_VERSION = 13
 STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, STEP_ORIGINAL_CHANNELS = 1, 2, 4, 8, 16
 STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
 STEP_COMPACT_OBS, STEP_COMPACT_MASK = 128, 256
@@ -24,7 +24,7 @@ OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_build_id', 'sgx_supports_geometry', 'sgx_last_error', 'sgx_num_envs', 'sgx_record_bytes', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
     'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_nt_stores', 'sgx_set_lane_kernel', 'sgx_set_xcd_skew', 'sgx_set_xcd_shares', 'sgx_get_xcd_shares', 'sgx_set_setup_table', 'sgx_reset',
-    'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_alloc_outputs', 'sgx_set_placement_target', 'sgx_free_outputs', 'sgx_step', 'sgx_host_alloc', 'sgx_host_free', 'sgx_step_sync', 'sgx_step_n', 'sgx_step_ring', 'sgx_rollout', 'sgx_compact_obs_stride', 'sgx_compact_mask_words', 'sgx_decode_obs', 'sgx_decode_mask', 'sgx_sample_valid', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_step_states', 'sgx_set_general_states', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
+    'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_alloc_outputs', 'sgx_set_placement_target', 'sgx_free_outputs', 'sgx_step', 'sgx_host_alloc', 'sgx_host_free', 'sgx_step_sync', 'sgx_step_n', 'sgx_step_ring', 'sgx_rollout', 'sgx_compact_obs_stride', 'sgx_compact_mask_words', 'sgx_decode_obs', 'sgx_decode_mask', 'sgx_sample_valid', 'sgx_choose_actions', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_step_states', 'sgx_set_general_states', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
 )
 
 
@@ -136,6 +136,8 @@ def _bind(L):
     L.sgx_decode_mask.argtypes = [vp, vp, vp, vp]
     L.sgx_sample_valid.restype = C.c_int
     L.sgx_sample_valid.argtypes = [vp, vp, vp, vp]
+    L.sgx_choose_actions.restype = C.c_int
+    L.sgx_choose_actions.argtypes = [vp, vp, vp, C.c_float, C.c_int32, vp, vp]
     L.sgx_export_state.restype = C.c_int
     L.sgx_export_state.argtypes = [vp, vp, vp, vp]
     L.sgx_import_state.restype = C.c_int

@@ -83,6 +83,7 @@ const char g_build_id[] = "SGX_BUILD_ID=" SGX_BUILD_ID;
 #include "sgx_lane.h"
 #include "sgx_lane_kernel.h"
 #include "sgx_aux_kernels.h"
+#include "sgx_choose.h"
 #include "sgx_mem.h"
 
 
@@ -1157,6 +1158,40 @@ SGX_API int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actio
     return SGX_OK;
 }
 
+// The chooser of the reference's game loop for a batch (loop:6-31, examples/util.py:4-47): masked softmax over caller logits, one sample per game.
+SGX_API int sgx_choose_actions(sgx_env *h, const float *logits_dev, const void *mask_dev, float temperature, int32_t flags, int32_t *actions_dev, void *stream) {
+    if (!h || !logits_dev || !mask_dev || !actions_dev) return fail(SGX_EINVAL, "NULL argument%s");
+    if (!(temperature >= 0.f) || temperature > 3.0e38f) return fail(SGX_EINVAL, "sgx_choose_actions: temperature must be finite and >= 0 (0 = argmax)%s");
+    if (flags & ~SGX_STEP_COMPACT_MASK) return fail(SGX_EINVAL, "sgx_choose_actions: the only flag is SGX_STEP_COMPACT_MASK%s");
+    const bool bits = (flags & SGX_STEP_COMPACT_MASK) != 0;
+    if ((reinterpret_cast<uintptr_t>(logits_dev) & 3) || (bits && (reinterpret_cast<uintptr_t>(mask_dev) & 3)))
+        return fail(SGX_EINVAL, "sgx_choose_actions: logits_dev (and a compact mask_dev) must be 4-byte aligned%s");
+    SGX_ON_DEVICE(h->device);
+    const KParams p = make_params(h);
+    const float scale = temperature == 0.f ? __builtin_inff() : 1.4426950408889634f / temperature;     // (+inf: every weight below the maximum's is 0)
+    const int64_t na = (int64_t)h->cfg.rows * h->cfg.cols * h->K;
+    // rows of 4 actions per lane where every game's logits start on a 16-byte and its mask on a 4-byte boundary
+    const bool vec4 = na % 4 == 0 && !(reinterpret_cast<uintptr_t>(logits_dev) & 15) && !(reinterpret_cast<uintptr_t>(mask_dev) & 3);
+#define CALL_CHOOSE_K(R, C, V, B)                                                                                                    \
+    do {                                                                                                                             \
+        using CG_ = ChooseGeo<Geo<R, C>, V>;                                                                                         \
+        choose_kernel<R, C, V, B><<<(unsigned)((h->n_envs + CG_::GAMES - 1) / CG_::GAMES), 64 * CG_::WAVES, 0, (hipStream_t)stream>>>( \
+            p, logits_dev, mask_dev, scale, actions_dev);                                                                    \
+    } while (0)
+#define CALL_CHOOSE(R, C)                                                                 \
+    do {                                                                                  \
+        if constexpr ((Geo<R, C>::NA % 4) == 0) {                                         \
+            if (vec4) { if (bits) CALL_CHOOSE_K(R, C, 4, true); else CALL_CHOOSE_K(R, C, 4, false); break; } \
+        }                                                                                 \
+        if (bits) CALL_CHOOSE_K(R, C, 1, true); else CALL_CHOOSE_K(R, C, 1, false);       \
+    } while (0)
+    DISPATCH_GEOMETRY(h, CALL_CHOOSE);
+#undef CALL_CHOOSE
+#undef CALL_CHOOSE_K
+    HIP_TRY(hipGetLastError());
+    return SGX_OK;
+}
+
 namespace {
 // export / import of the envs [p.env_first, p.n_envs) of the handle
 // one state per workgroup, mapped onto the XCDs like the step's workgroups (group_of_block): contiguous ranges of states per XCD
@@ -1213,6 +1248,18 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
     if (io->auto_reset || io->next_actions_dev) return fail(SGX_EINVAL, "sgx_step_states: no auto_reset, no sampled next actions%s");
     if (io->flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) return fail(SGX_EINVAL, "sgx_step_states: no compact outputs%s");
     if (chains < 1 || chains > SGX_MAX_CHAINS) return fail(SGX_EINVAL, "chains out of range%s");
+    if (h->general_states != 0 && h->cfg.rows * h->cfg.cols <= 256) {
+        // The general-state pass re-reads the caller's INPUT after the first pass has written the outputs: a state stepped in place would
+        // be redone from its own successor (stepped twice, or judged invalid) without anybody noticing.
+        auto overlap = [](const void *a, int64_t na, const void *b, int64_t nb) {
+            const uintptr_t a0 = reinterpret_cast<uintptr_t>(a), b0 = reinterpret_cast<uintptr_t>(b);
+            return a && b && a0 < b0 + (uintptr_t)nb && b0 < a0 + (uintptr_t)na;
+        };
+        const int64_t state_bytes = h->n_envs * (int64_t)SGX_STATE_LAYERS * h->cfg.rows * h->cfg.cols * 8;
+        if (overlap(state_in_dev, state_bytes, state_out_dev, state_bytes) || overlap(player_in_dev, h->n_envs, player_out_dev, h->n_envs))
+            return fail(SGX_EINVAL, "sgx_step_states: state_out_dev / player_out_dev overlap the inputs, which the general-state pass reads again "
+                                    "after the outputs are written; pass distinct buffers or switch the pass off (sgx_set_general_states(h, 0))%s");
+    }
     SGX_ON_DEVICE(h->device);
     const int64_t unit = 64;
     int64_t per = (h->n_envs / chains) / unit * unit;

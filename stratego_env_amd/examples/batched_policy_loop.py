@@ -15,14 +15,27 @@ import torch
 from stratego_env_amd.vec_env import VecStrategoEnv
 
 
+def policy_logits(obs, readout, out=None):
+    """The stand-in for a network: obs float32 [N,R,C,67] -> logits float32 [N, R*C*K] (mean over the board, then a fixed linear read-out)."""
+    feat = obs.mean(dim=(1, 2))                                   # [N, 67]
+    return torch.matmul(feat, readout, out=out)                   # [N, R*C*K]
+
+
 def choose_actions(obs, mask, readout, generator):
-    """obs float32 [N,R,C,67], mask uint8 [N,R,C,K] -> int32 [N] flat action indices of the current movers."""
+    """obs float32 [N,R,C,67], mask uint8 [N,R,C,K] -> int32 [N] flat action indices of the current movers, composed from torch ops (the
+    round-4 consumer: masked_fill, softmax and multinomial make four more passes over [N, R*C*K])."""
     n = obs.shape[0]
-    feat = obs.mean(dim=(1, 2))                                   # [N, 67]  (stand-in for a network trunk)
-    logits = (feat @ readout).view(n, -1)                         # [N, R*C*K]
+    logits = policy_logits(obs, readout).view(n, -1)
     logits = logits.masked_fill(mask.view(n, -1) == 0, float('-inf'))
     probs = torch.softmax(logits, dim=1)
     return torch.multinomial(probs, 1, generator=generator).view(n).to(torch.int32)
+
+
+def choose_actions_fused(env, obs, readout, temperature=1.0, logits_out=None):
+    """The same policy with the library's chooser (sgx_choose_actions): the logits are read once, together with the mask the step kernel
+    wrote, and one action per game is drawn on the device with the env's counter RNG -- reproducible from (seed, env id, game, turn)."""
+    logits = policy_logits(obs, readout, out=logits_out)
+    return env.choose_actions(logits, temperature)
 
 
 def main():
@@ -31,6 +44,7 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--version', default='barrage')
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--torch-chooser', action='store_true', help='mask / softmax / sample composed from torch ops instead of sgx_choose_actions')
     args = ap.parse_args()
     env = VecStrategoEnv(args.version, args.games, seed=args.seed, auto_reset=True)
     obs, mask, player = env.reset()
@@ -41,8 +55,9 @@ def main():
     finished = torch.zeros((), dtype=torch.int64, device=env.device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    logits_buf = torch.empty((args.games, mask[0].numel()), dtype=torch.float32, device=env.device)
     for _ in range(args.steps):
-        actions = choose_actions(obs, mask, readout, g)
+        actions = choose_actions(obs, mask, readout, g) if args.torch_chooser else choose_actions_fused(env, obs, readout, logits_out=logits_buf)
         obs, mask, reward, done, player = env.step(actions)
         wins += (reward > 0).sum(dim=0)
         finished += done.sum()

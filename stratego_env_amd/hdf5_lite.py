@@ -43,7 +43,7 @@ def _guarded(fn):
             return fn(self, *a, **k)
         except (Hdf5LiteError, KeyError, OSError):
             raise
-        except (IndexError, TypeError, ValueError, OverflowError, RecursionError, MemoryError, UnicodeDecodeError, zlib.error) as e:
+        except (IndexError, TypeError, ValueError, ArithmeticError, RecursionError, MemoryError, UnicodeDecodeError, zlib.error) as e:
             raise Hdf5LiteError("malformed HDF5 file (%s: %s)" % (type(e).__name__, e)) from e
     wrapper.__doc__ = fn.__doc__
     return wrapper
@@ -373,7 +373,9 @@ class File:
                 if len(raw) > limit:
                     _malformed("a chunk inflates beyond its dimensions")
             elif fid == 2:                                   # shuffle: byte k of every element was stored together
-                es = cv[0] if cv else dtype.itemsize
+                es = int(cv[0]) if cv else dtype.itemsize
+                if not 1 <= es <= 16:                        # (h5py writes the element size; 0 would divide by zero below)
+                    _malformed("shuffle filter with element size %d" % es)
                 a = np.frombuffer(raw, dtype=np.uint8)
                 m = len(a) // es
                 raw = a[:m * es].reshape(es, m).T.tobytes() + a[m * es:].tobytes()

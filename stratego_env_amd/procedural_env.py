@@ -52,6 +52,7 @@ class BatchedStrategoProceduralEnv:
         self.device = self._vec.device
         self._held = None            # (states, players) objects held loaded by a `with env.loaded(...)` scope
         self._scratch_is_held = False
+        self._held_exact = True      # False: the held states include ones the packed record cannot carry -> no reuse inside the scope
         self.strict = False          # True: ValueError when an import had to alter a state (sanitised)
         self.last_sanitised = torch.zeros((self.batch_size,), dtype=torch.uint8, device=self.device)
         self._obstacles = torch.from_numpy(v.obstacle_map().astype(np.int64)).to(self.device)
@@ -72,7 +73,7 @@ class BatchedStrategoProceduralEnv:
         with torch.cuda.device(self.device):
             _lib.check(vec._L.sgx_import_state_checked(vec._h, st.data_ptr(), pl.data_ptr(), self.last_sanitised.data_ptr(),
                                                        vec._stream()), vec._L)
-        self._scratch_is_held = self._held is not None and states is self._held[0] and players is self._held[1]
+        self._scratch_is_held = self._held is not None and self._held_exact and states is self._held[0] and players is self._held[1]
         if self.strict and bool(self.last_sanitised.any()):
             raise ValueError("state is not one the packed record can carry (unreachable by play): see sgx_import_state_checked")
         return st, pl
@@ -85,15 +86,28 @@ class BatchedStrategoProceduralEnv:
     def loaded(self, states, players):
         """Opt-in: import `states` once and let the calls inside the scope that are given the same tensor objects reuse the
         import.  The caller promises not to modify the tensors inside the scope (writes through other libraries or streams
-        are invisible to this class); outside a scope every call imports."""
-        prev = self._held
+        are invisible to this class); outside a scope every call imports.
+
+        Results do not depend on the scope: if the import had to alter any of the states -- general (unreachable) states the packed
+        record cannot carry -- nothing is reused and the calls inside the scope import like calls outside it, through sgx_step_states'
+        general-state pass.  `last_sanitised` therefore means the same on both paths: what still had to be altered after every pass
+        the call ran; `strict=True` raises on exactly that."""
+        prev = (self._held, self._held_exact)
         self._held = (states, players)
         self._scratch_is_held = False
+        self._held_exact = True
         try:
-            self._load(states, players)
+            strict, self.strict = self.strict, False
+            try:
+                self._load(states, players)
+            finally:
+                self.strict = strict
+            if bool(self.last_sanitised.any()):              # one device -> host round trip per scope
+                self._held_exact = False
+                self._scratch_is_held = False
             yield self
         finally:
-            self._held = prev
+            self._held, self._held_exact = prev
             self._scratch_is_held = False
 
     def _in_loaded_scope(self, states, players):
@@ -123,7 +137,7 @@ class BatchedStrategoProceduralEnv:
             _lib.check(vec._L.sgx_step_states(vec._h, st.data_ptr(), pl.data_ptr(), self.last_sanitised.data_ptr(), io,
                                               _ptr_or_none(new_states), _ptr_or_none(new_players), 2, vec._stream()), vec._L)
         vec._next_actions_fresh = False
-        self._scratch_is_held = (actions is None and self._held is not None and states is self._held[0] and players is self._held[1])
+        self._scratch_is_held = (actions is None and self._held is not None and self._held_exact and states is self._held[0] and players is self._held[1])
         if self.strict and bool(self.last_sanitised.any()):
             raise ValueError("state is not one the packed record can carry (unreachable by play): see sgx_import_state_checked")
         return (new_states, new_players) if export else None
@@ -388,7 +402,7 @@ class PackedStates:
     `copy_from`, and only converted to the reference layout when somebody wants to look at them (`unpack`)."""
 
     def __init__(self, version, n, device=0):
-        self._vec = VecStrategoEnv(version, n, device=device, human_inits=False)
+        self._vec = VecStrategoEnv(version, n, device=device, human_inits=False, outputs=False)     # records only: no observation / mask tensors
         self.n = int(n)
         self.device = self._vec.device
         self.sanitised = torch.zeros((self.n,), dtype=torch.uint8, device=self.device)

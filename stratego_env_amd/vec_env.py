@@ -71,11 +71,14 @@ def _wrap_device(ptr, shape, dtype, device, owner):
 
 class VecStrategoEnv:
     def __init__(self, version='barrage', num_envs=1, device=0, seed=0, env_id_offset=0, human_inits=None,
-                 auto_reset=False, final_obs=False, full_obs=False, lib_path=None, obs_channel_mode='extended', compact_outputs=False):
+                 auto_reset=False, final_obs=False, full_obs=False, lib_path=None, obs_channel_mode='extended', compact_outputs=False,
+                 outputs=True):
         """human_inits: None = use the Gravon table when the variant has one (util.py:301-319), False = uniformly
         random back-row placement (util.py:33-53), True = require the table.
         obs_channel_mode: 'extended' (67 / 79 one-hot channels) or 'original' (the deprecated 32 / 33 value channels,
-        maenv:67, 368-375)."""
+        maenv:67, 368-375).
+        outputs=False: a pool of game records without observation / mask tensors (`obs`, `mask`, `fobs` are None): what
+        snapshot() and the packed search pools of procedural_env hold -- 0.5 KB per Barrage game instead of 31 KB."""
         if obs_channel_mode not in ('extended', 'original'):
             raise ValueError("obs_channel_mode must be 'extended' or 'original'")
         # compact_outputs=True (opt-in): `obs` is uint8 [N, compact_obs_stride] -- the 4-bit codes the float32 observation decodes from --
@@ -115,7 +118,12 @@ class VecStrategoEnv:
             _lib.check(self._L.sgx_set_setup_table(self._h, table.ctypes.data_as(C.c_void_p), table.shape[0]), self._L)
         self.human_inits = bool(human_inits)
         N, R, Cc, K, dev = self.num_envs, self.R, self.Cc, self.K, self.device
-        if self.compact:
+        self.has_outputs = bool(outputs)
+        if not outputs:
+            if compact_outputs or final_obs or full_obs:
+                raise ValueError("outputs=False is a pool of records: no compact_outputs / final_obs / full_obs")
+            self.obs = self.mask = None
+        elif self.compact:
             self.compact_obs_stride = int(self._L.sgx_compact_obs_stride(self._h))
             self.compact_mask_words = int(self._L.sgx_compact_mask_words(self._h))
             self.obs = torch.empty((N, self.compact_obs_stride), dtype=torch.uint8, device=dev)
@@ -137,6 +145,10 @@ class VecStrategoEnv:
         self.next_actions = torch.zeros((N,), dtype=torch.int32, device=dev)
         self._io = _lib.SgxStepIO()
         self._next_actions_fresh = False      # next_actions holds a draw for the CURRENT position of every env
+        self._ring = self._ring_owners = self._ring_ios = None     # alloc_output_ring()
+        self._ring_pos = 0
+        self._outputs_owner = self._outputs = None                 # tune_placement()
+        self.placement_peak_extra_bytes = 0
 
     # ---- lifecycle -----------------------------------------------------------------------------------
     def close(self):
@@ -311,60 +323,67 @@ class VecStrategoEnv:
         target = 0.0
         if tune and not self.compact and getattr(self, '_outputs', None) is not None and self._outputs.n_trials > 0:
             target = min(float(x) for x in self._outputs.trial_us[:self._outputs.n_trials])
-        _lib.check(self._L.sgx_set_placement_target(self._h, C.c_float(target)), self._L)
-        N, R, Cc, K, dev = self.num_envs, self.R, self.Cc, self.K, self.device
-        self._ring = [(self.obs, self.mask, self.fobs)]
-        self._ring_owners = [getattr(self, '_outputs_owner', None)]
-        reports = [None]
-        for _ in range(1, n_sets):
-            if tune and not self.compact:
-                out = _lib.SgxOutputs()
-                flags = self._mode_flags | (_lib.OUT_FULL_OBS if self.fobs is not None else 0)
-                with torch.cuda.device(self.device):
-                    _lib.check(self._L.sgx_alloc_outputs(self._h, flags, int(max_extra_bytes), int(trials or _lib.OUT_MAX_TRIALS),
-                                                         self._stream(), C.byref(out)), self._L)
-                owner = _OutputsOwner(self._L, out)
-                times = [float(x) for x in out.trial_us[:out.n_trials]]
-                report = {'obs': times}
-                if target > 0 and times and min(times) > 1.03 * target and wide_extra_bytes > max_extra_bytes:
-                    out2 = _lib.SgxOutputs()
+        if not self.has_outputs:
+            raise ValueError("alloc_output_ring: this env was created with outputs=False")
+        try:      # (whatever a placement call raises midway, the handle's search target goes back to 0: a later tune_placement() must not chase a stale one)
+            _lib.check(self._L.sgx_set_placement_target(self._h, C.c_float(target)), self._L)
+            N, R, Cc, K, dev = self.num_envs, self.R, self.Cc, self.K, self.device
+            self._ring = [(self.obs, self.mask, self.fobs)]
+            self._ring_owners = [getattr(self, '_outputs_owner', None)]
+            reports = [None]
+            for _ in range(1, n_sets):
+                if tune and not self.compact:
+                    out = _lib.SgxOutputs()
+                    flags = self._mode_flags | (_lib.OUT_FULL_OBS if self.fobs is not None else 0)
                     with torch.cuda.device(self.device):
-                        _lib.check(self._L.sgx_alloc_outputs(self._h, flags, int(wide_extra_bytes), int(trials or _lib.OUT_MAX_TRIALS),
-                                                             self._stream(), C.byref(out2)), self._L)
-                    owner2 = _OutputsOwner(self._L, out2)
-                    times2 = [float(x) for x in out2.trial_us[:out2.n_trials]]
-                    report['wide'] = {'obs': times2, 'used': bool(times2) and min(times2) < min(times)}
-                    if report['wide']['used']:
-                        out, owner = out2, owner2          # (the first search's buffers go with their owner)
-                        report['obs'] = times + times2     # min() over both = what is kept
-                    del out2, owner2
-                obs = _wrap_device(out.obs_dev, (N, R, Cc, self.p_channels), torch.float32, dev, owner)
-                mask = _wrap_device(out.mask_dev, (N, R, Cc, K), torch.uint8, dev, owner)
-                fobs = _wrap_device(out.fobs_dev, (N, R, Cc, self.f_channels), torch.float32, dev, owner) if out.fobs_dev else None
-                reports.append(report)
-                self._ring_owners.append(owner)
-            else:
-                obs, mask = torch.empty_like(self.obs), torch.empty_like(self.mask)       # (compact outputs: the same compact shapes)
-                fobs = torch.empty((N, R, Cc, self.f_channels), dtype=torch.float32, device=dev) if self.fobs is not None else None
-                reports.append(None)
-                self._ring_owners.append(None)
-            self._ring.append((obs, mask, fobs))
-        # The other way round: the env's OWN set may be the slow one (its search ran first, with no target -- one box: 298.5 us after 82
-        # candidates, then 274-281 us for the extra sets).  It is searched once more, against the best of the others, and replaced if
-        # that finds something faster; reports[0] = {'obs': [...], 'used': bool} then.
-        best_extra = min([min(r['obs']) for r in reports[1:] if r and r.get('obs')] or [0.0])
-        if target > 0 and 0 < best_extra < 0.97 * target and self.fobs is None:
-            _lib.check(self._L.sgx_set_placement_target(self._h, C.c_float(best_extra)), self._L)
-            first = (self.obs, self.mask, self._outputs_owner, self._outputs, self.placement_peak_extra_bytes)
-            rep0 = self.tune_placement_once(trials, max(int(max_extra_bytes), int(wide_extra_bytes)))
-            used = bool(rep0.get('obs')) and min(rep0['obs']) < target
-            if not used:
-                self.obs, self.mask, self._outputs_owner, self._outputs, self.placement_peak_extra_bytes = first
-                self.observe()
-            self._ring[0] = (self.obs, self.mask, self.fobs)
-            self._ring_owners[0] = self._outputs_owner
-            reports[0] = {'obs': rep0.get('obs') or [], 'used': used, 'target_us': best_extra, 'before_us': target}
-        _lib.check(self._L.sgx_set_placement_target(self._h, C.c_float(0.0)), self._L)
+                        _lib.check(self._L.sgx_alloc_outputs(self._h, flags, int(max_extra_bytes), int(trials or _lib.OUT_MAX_TRIALS),
+                                                             self._stream(), C.byref(out)), self._L)
+                    owner = _OutputsOwner(self._L, out)
+                    times = [float(x) for x in out.trial_us[:out.n_trials]]
+                    report = {'obs': times}
+                    if target > 0 and times and min(times) > 1.03 * target and wide_extra_bytes > max_extra_bytes:
+                        out2 = _lib.SgxOutputs()
+                        with torch.cuda.device(self.device):
+                            _lib.check(self._L.sgx_alloc_outputs(self._h, flags, int(wide_extra_bytes), int(trials or _lib.OUT_MAX_TRIALS),
+                                                                 self._stream(), C.byref(out2)), self._L)
+                        owner2 = _OutputsOwner(self._L, out2)
+                        times2 = [float(x) for x in out2.trial_us[:out2.n_trials]]
+                        report['wide'] = {'obs': times2, 'used': bool(times2) and min(times2) < min(times)}
+                        if report['wide']['used']:
+                            out, owner = out2, owner2          # (the first search's buffers go with their owner)
+                            report['obs'] = times + times2     # min() over both = what is kept
+                        del out2, owner2
+                    obs = _wrap_device(out.obs_dev, (N, R, Cc, self.p_channels), torch.float32, dev, owner)
+                    mask = _wrap_device(out.mask_dev, (N, R, Cc, K), torch.uint8, dev, owner)
+                    fobs = _wrap_device(out.fobs_dev, (N, R, Cc, self.f_channels), torch.float32, dev, owner) if out.fobs_dev else None
+                    reports.append(report)
+                    self._ring_owners.append(owner)
+                else:
+                    obs, mask = torch.empty_like(self.obs), torch.empty_like(self.mask)       # (compact outputs: the same compact shapes)
+                    fobs = torch.empty((N, R, Cc, self.f_channels), dtype=torch.float32, device=dev) if self.fobs is not None else None
+                    reports.append(None)
+                    self._ring_owners.append(None)
+                self._ring.append((obs, mask, fobs))
+            # The other way round: the env's OWN set may be the slow one (its search ran first, with no target -- one box: 298.5 us after 82
+            # candidates, then 274-281 us for the extra sets).  It is searched once more, against the best of the others, and replaced if
+            # that finds something faster; reports[0] = {'obs': [...], 'used': bool} then.
+            best_extra = min([min(r['obs']) for r in reports[1:] if r and r.get('obs')] or [0.0])
+            if target > 0 and 0 < best_extra < 0.97 * target and self.fobs is None:
+                _lib.check(self._L.sgx_set_placement_target(self._h, C.c_float(best_extra)), self._L)
+                first = (self.obs, self.mask, self._outputs_owner, self._outputs, self.placement_peak_extra_bytes)
+                rep0 = self.tune_placement_once(trials, max(int(max_extra_bytes), int(wide_extra_bytes)))
+                used = bool(rep0.get('obs')) and min(rep0['obs']) < target
+                if not used:
+                    self.obs, self.mask, self._outputs_owner, self._outputs, self.placement_peak_extra_bytes = first
+                    self.observe()
+                self._ring[0] = (self.obs, self.mask, self.fobs)
+                self._ring_owners[0] = self._outputs_owner
+                reports[0] = {'obs': rep0.get('obs') or [], 'used': used, 'target_us': best_extra, 'before_us': target}
+        except BaseException:
+            self._ring = self._ring_owners = None      # (no half-built ring)
+            raise
+        finally:
+            _lib.check(self._L.sgx_set_placement_target(self._h, C.c_float(0.0)), self._L)
         self._ring_pos = 1 % n_sets          # set 0 holds the current position's outputs: the next step writes set 1
         self._ring_ios = (_lib.SgxStepIO * n_sets)()
         return reports
@@ -403,10 +422,10 @@ class VecStrategoEnv:
     def _fill_io(self, a, want_next_actions, emit_obs, emit_mask, flags):
         io = self._io
         io.actions_dev = a.data_ptr()
-        io.obs_dev = self.obs.data_ptr() if emit_obs else None
+        io.obs_dev = self.obs.data_ptr() if (emit_obs and self.obs is not None) else None
         io.fobs_dev = self.fobs.data_ptr() if (emit_obs and self.fobs is not None) else None
         io.final_fobs_dev = self.final_fobs.data_ptr() if self.final_fobs is not None else None
-        io.mask_dev = self.mask.data_ptr() if emit_mask else None
+        io.mask_dev = self.mask.data_ptr() if (emit_mask and self.mask is not None) else None
         io.reward_dev = self.reward.data_ptr()
         io.done_dev = self.done.data_ptr()
         io.player_dev = self.player.data_ptr()
@@ -435,6 +454,8 @@ class VecStrategoEnv:
         if not self._next_actions_fresh:
             self.sample_valid_actions()
         if ring:
+            if not self._ring:
+                raise ValueError("rollout_steps(ring=True) needs alloc_output_ring() first")
             n_sets, n_steps = len(self._ring), int(n_steps)
             for k, (obs, mask, fobs) in enumerate(self._ring):
                 self.obs, self.mask, self.fobs = obs, mask, fobs
@@ -454,6 +475,50 @@ class VecStrategoEnv:
             else:
                 _lib.check(self._L.sgx_step_n(self._h, C.byref(io), int(n_steps), self._stream()), self._L)
         return self.obs, self.mask, self.reward, self.done, self.player
+
+    def choose_actions(self, logits, temperature=1.0, mask=None, out=None):
+        """The reference's chooser for a batch (examples/basic_game_loop.py:6-31): one action per game drawn from
+        softmax(logits / temperature) over the VALID actions of `mask` (default: the current mask -- bytes, or the bit mask of
+        compact_outputs=True), on the device (sgx_choose_actions).  logits: float32 [N, R, C, K] (or [N, R*C*K]) from the caller's
+        policy.  temperature 0 = argmax.  The draw is keyed by (seed, global env id, game, turn) like the fused sampler's, and with equal
+        logits it is that sampler's action.  -> int32 [N] (`out` or next_actions: ready for step())."""
+        lg = logits
+        if lg.dtype != torch.float32 or lg.device != self.device or not lg.is_contiguous():
+            lg = lg.to(device=self.device, dtype=torch.float32).contiguous()
+        if lg.numel() != self.num_envs * self.R * self.Cc * self.K:
+            raise ValueError("logits must hold num_envs x rows x columns x ways_to_move floats")
+        own = mask is None
+        mask = self.mask if mask is None else mask
+        bits = mask.dtype == torch.int32
+        if not bits and mask.numel() != lg.numel():
+            raise ValueError("mask must be uint8 [N, R, C, K] (or the int32 bit mask of a compact step)")
+        out = self.next_actions if out is None else out
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_choose_actions(self._h, _ptr(lg), _ptr(mask), C.c_float(float(temperature)),
+                                                  _lib.STEP_COMPACT_MASK if bits else 0, _ptr(out), self._stream()), self._L)
+        if own and out is self.next_actions:
+            self._next_actions_fresh = False      # (a policy's choice, not the uniform draw rollout_step() plays)
+        return out
+
+    # ---- snapshots: the packed records of every game, in a pool without output tensors -------------------------------
+    def snapshot(self, out=None):
+        """Copy every game's packed record (boards, counters, game number: everything the counter RNG and the rules depend on)
+        into a pool of records without output tensors (`out`, or a new one): sgx_copy_envs.  restore() puts it back."""
+        snap = out if out is not None else VecStrategoEnv(self.variant, self.num_envs, device=self.device.index, seed=self.seed,
+                                                          env_id_offset=self.env_id_offset, human_inits=False, outputs=False)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_copy_envs(snap._h, None, self._h, None, self.num_envs, self._stream()), self._L)
+        return snap
+
+    def restore(self, snap):
+        """The inverse of snapshot(): every game continues from the snapshot's position; returns observe() of it (the outputs and the
+        next random draw are those of the restored position again)."""
+        if snap.num_envs != self.num_envs:
+            raise ValueError("restore: the snapshot holds %d games, this env %d" % (snap.num_envs, self.num_envs))
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.sgx_copy_envs(self._h, None, snap._h, None, self.num_envs, self._stream()), self._L)
+        self._next_actions_fresh = False
+        return self.observe()
 
     def sample_valid_actions(self, mask=None, out=None):
         """Uniformly random valid action per env from `mask` (default: the current one) -- maenv:830-834."""

@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: multi-process launcher tests and the like (-m 'not gpu and not slow' is the quick CPU suite; -m 'not gpu' runs them too)")
 
 
 def _has_gpu():

@@ -42,35 +42,71 @@ def test_self_launch_two_ranks():
 
 
 def test_nccl_that_cannot_come_up_falls_back_to_gloo_and_says_so():
-    """RCCL carries only the reporting reductions (the games never interact).  If the nccl process group cannot come up -- here: no GPU at
-    all -- every rank falls back to gloo on a fresh store, the run completes, and the line names what happened."""
+    """RCCL carries only the reporting reductions (the games never interact).  If the nccl group cannot come up -- here: no GPU at
+    all -- every rank uses the host-side gloo group for them, the run completes, and the line names what happened."""
     p = _run(['--gpus', '2', '--dry-run', '--backend', 'nccl', '--steps', '4', '--warmup', '1', '--envs', '500'])
     assert p.returncode == 0, p.stderr[-2000:]
     lines = _json_lines(p.stdout)
     assert len(lines) == 1
     d = lines[0]
     assert d['n_gpus'] == 2 and d['config']['stub_steps_x_games'] == 4 * 1000
-    assert d['config']['reduction_backend'].startswith('gloo (nccl failed: '), d['config']['reduction_backend']
-    assert 'fall back to gloo' in p.stderr
+    assert d['config']['reduction_backend'].startswith('gloo (nccl failed: rank 0: '), d['config']['reduction_backend']
+    assert 'ALL ranks use gloo' in p.stderr
 
 
-def test_self_launch_eight_ranks_with_the_config5_defaults():
-    """BASELINE config 5 as the driver will launch it: --gpus 8 with no size argument = 262,144 games per GPU (2,097,152 in total,
-    weak) plus the strong leg of 2,097,152 games; all eight ranks rendezvous, shard and reduce."""
-    p = _run(['--gpus', '8', '--dry-run', '--steps', '3', '--warmup', '1'], timeout=600)
+def test_one_rank_failing_to_bring_up_nccl_moves_all_ranks_to_gloo():
+    """The ranks AGREE on the backend of the reporting reductions before using it (class Rank: verdicts all-gathered over the host-side
+    gloo group, which is always there).  A second gloo group stands in for RCCL on this CPU box (SGX_BENCH_FAKE_NCCL): with every rank
+    fine the job reduces over it; with ONE rank failing -- before the collective bring-up, or inside it while the others wait for it
+    until their timeout -- all of them end up on gloo, nobody hangs, and the line names the rank."""
+    common = ['--gpus', '4', '--dry-run', '--backend', 'nccl', '--steps', '3', '--warmup', '1', '--envs', '100']
+    p = _run(common, env=_clean_env(SGX_BENCH_FAKE_NCCL='1'))
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _json_lines(p.stdout)[0]
+    assert d['config']['reduction_backend'].startswith('nccl (simulated') and d['config']['stub_steps_x_games'] == 3 * 400
+    p = _run(common, env=_clean_env(SGX_BENCH_FAKE_NCCL='1', SGX_BENCH_FAIL_NCCL_RANKS='2'))
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _json_lines(p.stdout)[0]
+    assert d['config']['reduction_backend'].startswith('gloo (nccl failed: rank 2: '), d['config']['reduction_backend']
+    assert d['config']['games_covered_by_ranks'] == 400 and d['config']['stub_steps_x_games'] == 3 * 400
+    assert p.stderr.count('ALL ranks use gloo') == 4                       # every rank took the same decision
+    p = _run(common, env=_clean_env(SGX_BENCH_FAKE_NCCL='1', SGX_BENCH_FAIL_NCCL_STAGE2_RANKS='1', SGX_BENCH_NCCL_TIMEOUT='4'))
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _json_lines(p.stdout)[0]
+    assert d['config']['reduction_backend'].startswith('gloo (nccl failed: ') and 'rank 1: RuntimeError: simulated failure inside' in d['config']['reduction_backend']
+    assert d['config']['stub_steps_x_games'] == 3 * 400 and p.stderr.count('ALL ranks use gloo') == 4
+
+
+@pytest.mark.slow
+def test_self_launch_eight_ranks_with_the_default_workloads_is_self_anchoring():
+    """The multi-GPU line as the driver will launch it: --gpus 8 with no size argument = the 1-GPU line's workload on every GPU (65,536
+    games per GPU, a ring of three output sets: `value` over 1 / 2 / 4 / 8 GPUs is one workload's weak-scaling curve), and BASELINE
+    config 5 -- 262,144 games per GPU, 2,097,152 in total -- as scaling_legs[0]; the headline and every leg carry a solo anchor (rank 0
+    alone, the others parked) and scaling_x = value / solo value.  One rank's nccl failure is simulated on top: all eight agree on gloo."""
+    p = _run(['--gpus', '8', '--dry-run', '--backend', 'nccl', '--steps', '3', '--warmup', '1'],
+             env=_clean_env(SGX_BENCH_FAKE_NCCL='1', SGX_BENCH_FAIL_NCCL_RANKS='5'), timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = _json_lines(p.stdout)
     assert len(lines) == 1
     d = lines[0]
+    c = d['config']
     assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['launched_by'] == 'bench.py'
-    assert d['config']['games_per_gpu'] == 262144 and d['config']['total_games'] == 2097152
-    assert d['config']['games_covered_by_ranks'] == 2097152 and d['config']['stub_steps_x_games'] == 3 * 2097152
-    assert d['config']['strong_leg_total_games'] == 2097152
+    assert c['reduction_backend'].startswith('gloo (nccl failed: rank 5: ')
+    assert c['games_per_gpu'] == 65536 and c['total_games'] == 8 * 65536 and c['output_sets'] == 3
+    assert c['games_covered_by_ranks'] == 8 * 65536 and c['stub_steps_x_games'] == 3 * 8 * 65536
+    assert c['solo']['games'] == 65536 and c['solo']['value'] > 0 and c['scaling_x'] > 0 and c['scaling_x_ideal'] == 8
+    assert 0 < c['per_gpu_value_min_over_solo'] and c['strong_leg_total_games'] == 2097152
+    legs = c['scaling_legs']
+    assert len(legs) == 1                                                  # on 8 GPUs the strong split of 2,097,152 IS config 5's 262,144 per GPU
+    leg = legs[0]
+    assert leg['games_per_gpu'] == 262144 and leg['total_games'] == 2097152 and leg['scaling'] == 'weak' and leg['output_sets'] == 1
+    assert leg['solo']['games'] == 262144 and leg['scaling_x'] > 0 and leg['per_gpu_value_min_over_solo'] > 0
     # the strong split of the same total over 8 ranks, and one that does not divide evenly
     p = _run(['--gpus', '8', '--dry-run', '--steps', '2', '--warmup', '1', '--total-envs', '2097152'], timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     d = _json_lines(p.stdout)[0]
     assert d['scaling'] == 'strong' and d['config']['games_per_gpu'] == 262144 and d['config']['games_covered_by_ranks'] == 2097152
+    assert d['config']['solo']['games'] == 262144 and d['config']['scaling_x'] > 0
     p = _run(['--gpus', '8', '--dry-run', '--steps', '2', '--warmup', '1', '--total-envs', '65541'], timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     d = _json_lines(p.stdout)[0]
@@ -131,17 +167,22 @@ def test_measured_run_refuses_to_run_without_a_gpu():
 
 
 def test_defaults_follow_the_baseline_configs_and_the_parent_never_loads_torch():
-    """--gpus 1: 65,536 games (BASELINE config 2); --gpus N > 1: 262,144 games per GPU (config 5: 2,097,152 on 8 GPUs) plus the
-    strong-scaling leg of 2,097,152 games in total; the launcher parent counts GPUs from sysfs without importing torch."""
+    """65,536 games per GPU (BASELINE config 2) on any number of GPUs -- the same per-GPU workload, so that `value` over the GPU counts
+    is one curve -- with config 5 (262,144 per GPU) and the strong split of 2,097,152 games as legs of a multi-GPU line, each with its
+    solo anchor; the launcher parent counts GPUs from sysfs without importing torch."""
     p = _run(['--gpus', '1', '--dry-run', '--steps', '2', '--warmup', '1'])
     assert p.returncode == 0, p.stderr
     d = _json_lines(p.stdout)[0]
-    assert d['config']['games_per_gpu'] == 65536 and d['config']['strong_leg_total_games'] == 0
+    assert d['config']['games_per_gpu'] == 65536 and d['config']['strong_leg_total_games'] == 0 and d['config']['output_sets'] == 3
+    assert d['config']['solo'] is None and d['config']['scaling_x'] is None and d['config']['scaling_legs'] is None
     p = _run(['--gpus', '2', '--dry-run', '--steps', '2', '--warmup', '1'])
     assert p.returncode == 0, p.stderr
     d = _json_lines(p.stdout)[0]
-    assert d['config']['games_per_gpu'] == 262144 and d['config']['total_games'] == 524288
-    assert d['config']['strong_leg_total_games'] == 2097152
+    c = d['config']
+    assert c['games_per_gpu'] == 65536 and c['total_games'] == 131072 and c['output_sets'] == 3
+    assert c['strong_leg_total_games'] == 2097152 and c['solo']['games'] == 65536 and c['scaling_x_ideal'] == 2
+    assert [(l['games_per_gpu'], l['total_games'], l['scaling']) for l in c['scaling_legs']] == [(262144, 524288, 'weak'), (1048576, 2097152, 'strong')]
+    assert all(l['solo']['games'] == l['games_per_gpu'] and l['scaling_x'] > 0 for l in c['scaling_legs'])
     code = ("import sys; sys.path.insert(0, %r); import bench; n = bench.visible_gpus(); "
             "assert isinstance(n, int) and n >= 0; assert 'torch' not in sys.modules; print('ok', n)" % ROOT)
     q = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)

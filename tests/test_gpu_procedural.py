@@ -447,3 +447,80 @@ def test_general_states_are_reproduced_not_sanitised(name):
     pe.get_valid_moves_as_1d_mask(states, players)
     assert int(pe.last_sanitised.sum()) == n
     pe.close()
+
+
+def test_step_states_refuses_outputs_that_alias_its_inputs_while_the_general_pass_is_on():
+    """The general-state pass reads the caller's input again after the first pass has written the outputs (round-4 advisor finding):
+    stepping in place would redo flagged states from their own successors.  SGX_EINVAL names the way out; with the pass off, in place works
+    and equals the out-of-place result."""
+    import torch
+    from stratego_env_amd import _lib
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    name, n = 'barrage', 32
+    v = VARIANTS[name]
+    pe = BatchedStrategoProceduralEnv(name, n)
+    cv = oracle_cvariant(name)
+    states = np.stack([orc.reset_state(cv, 5, e, 0) for e in range(n)])
+    players = np.ones(n, dtype=np.int8)
+    ru = orc.OracleRules(v.rows, v.columns)
+    acts = np.asarray([np.flatnonzero(ru.get_valid_moves_as_1d_mask(states[e], 1))[e % 3] for e in range(n)], dtype=np.int64)
+    want, want_pl, ok = pe.get_next_state(states, players, acts)
+    assert bool(ok.all())
+    st = torch.from_numpy(states).to(pe.device)
+    pl = torch.from_numpy(players).to(pe.device)
+    a = torch.from_numpy(acts.astype(np.int32)).to(pe.device)
+    vec = pe._vec
+    io = vec._fill_io(a, False, False, False, _lib.STEP_ACTIONS_1D)
+    io.auto_reset = 0
+    args = lambda so, po: (vec._h, st.data_ptr(), pl.data_ptr(), pe.last_sanitised.data_ptr(), io, so.data_ptr(), po.data_ptr(), 2, vec._stream())
+    other_pl = torch.empty_like(pl)
+    assert vec._L.sgx_step_states(*args(st, other_pl)) != 0
+    assert b'overlap the inputs' in vec._L.sgx_last_error()
+    assert vec._L.sgx_step_states(*args(torch.empty_like(st), pl)) != 0                       # the players alone overlap
+    half = st.view(-1)[st.numel() // 2:]                                                      # a partial overlap is an overlap
+    assert vec._L.sgx_step_states(vec._h, st.data_ptr(), pl.data_ptr(), pe.last_sanitised.data_ptr(), io, half.data_ptr(), other_pl.data_ptr(), 2, vec._stream()) != 0
+    assert torch.equal(st.cpu(), torch.from_numpy(states))                                    # nothing was launched
+    _lib.check(vec._L.sgx_set_general_states(vec._h, 0), vec._L)
+    _lib.check(vec._L.sgx_step_states(*args(st, pl)), vec._L)                                 # in place, pass off: fine
+    assert torch.equal(st, want) and torch.equal(pl, want_pl)
+    pe.close()
+
+
+def test_loaded_scope_gives_the_same_results_for_general_states():
+    """`with env.loaded(states, players)` is an optimisation, not another semantics (round-4 advisor finding): when the import had to alter
+    any of the held states nothing is reused, every call inside the scope goes through the general-state pass like a call outside, and
+    last_sanitised / strict mean the same on both paths."""
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    name, n = 'barrage', 48
+    v = VARIANTS[name]
+    rs = np.random.RandomState(77)
+    states, players = general_states(name, n, rs)
+    ru = orc.OracleRules(v.rows, v.columns)
+    pe = BatchedStrategoProceduralEnv(name, n)
+    pe.strict = True                                              # must not raise: after the general pass nothing is altered
+    acts = np.asarray([rs.choice(np.flatnonzero(ru.get_valid_moves_as_1d_mask(states[e], int(players[e])))) for e in range(n)], dtype=np.int64)
+    out_ns, out_pl, out_ok = pe.get_next_state(states, players, acts)
+    out_mask = pe.get_valid_moves_as_1d_mask(states, players)
+    out_obs = pe.get_partially_observable_observation_extended_channels(states, players)
+    with pe.loaded(states, players):
+        assert not pe._in_loaded_scope(states, players)           # general states: no reuse inside the scope
+        in_mask = pe.get_valid_moves_as_1d_mask(states, players)
+        assert int(pe.last_sanitised.sum()) == 0
+        in_obs = pe.get_partially_observable_observation_extended_channels(states, players)
+        in_ns, in_pl, in_ok = pe.get_next_state(states, players, acts)
+        assert int(pe.last_sanitised.sum()) == 0
+    import torch
+    assert torch.equal(in_mask, out_mask) and torch.equal(in_obs, out_obs) and torch.equal(in_ns, out_ns) and torch.equal(in_pl, out_pl)
+    assert bool(in_ok.all()) and bool(out_ok.all())
+    for e in range(0, n, 5):
+        w, wp = ru.get_next_state(states[e], int(players[e]), int(acts[e]))
+        assert np.array_equal(in_ns[e].cpu().numpy(), w) and int(in_pl[e]) == wp
+    # reachable states: the scope does reuse its import, with identical results
+    cv = oracle_cvariant(name)
+    reach = np.stack([orc.reset_state(cv, 9, e, 0) for e in range(n)])
+    ones = np.ones(n, dtype=np.int8)
+    m_out = pe.get_valid_moves_as_1d_mask(reach, ones)
+    with pe.loaded(reach, ones):
+        assert pe._in_loaded_scope(reach, ones)
+        assert torch.equal(pe.get_valid_moves_as_1d_mask(reach, ones), m_out)
+    pe.close()

@@ -15,9 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, 'bench.py')
 
 
-def _run(args, timeout=600):
+def _run(args, timeout=600, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
                                                             'TORCHELASTIC_RUN_ID', 'SGX_BENCH_LAUNCHER')}
+    env.update(extra_env or {})
     p = subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
     lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
@@ -38,25 +39,55 @@ def test_two_ranks_on_one_gpu_equal_one_rank_and_the_oracle(version, per_rank):
     assert two['config']['games_per_gpu'] == per_rank and two['scaling'] == 'weak'
     assert two['verified_envs'] >= 32 and one['verified_envs'] >= 16          # both ranks checked their sample against the oracle
     assert two['verified_steps'] == one['verified_steps'] == 30
-    # one GPU: the headline writes a ring of three output sets (DRAM-side figures); several GPUs: in place.  Same games either way.
-    assert one['config']['output_sets'] == 3 and two['config']['output_sets'] == 1
+    # the headline writes a ring of three output sets (DRAM-side figures) on any number of GPUs: the same per-GPU workload, same games
+    assert one['config']['output_sets'] == 3 and two['config']['output_sets'] == 3
+    # rank 0 timed its 'per_rank' games ALONE before the two ranks ran side by side, and put the games back afterwards: the checksum of
+    # checksums still equals the 1-rank run's (which has no anchor: it is its own)
     assert two['config']['outputs_checksum'] == one['config']['outputs_checksum']
+    solo = two['config']['solo']
+    assert solo['games'] == per_rank and solo['value'] > 0 and two['config']['scaling_x'] == pytest.approx(two['value'] / solo['value'])
+    assert two['config']['scaling_x_ideal'] == 2 and two['config']['per_gpu_value_min_over_solo'] > 0
+    assert one['config']['solo'] is None and one['config']['scaling_x'] is None
     assert two['value'] > 0 and two['config']['per_gpu_value_min'] <= two['config']['per_gpu_value_max']
-    # the 1-rank run then played the in-place leg and its two-chains variant on the same env object, each verified against the oracle
+    # both runs then played the headline's steps once more without gpu_settle (config.no_settle); the 1-rank run went on with the
+    # in-place leg and its two-chains variant on the same env object, each verified against the oracle
+    assert one['config']['no_settle']['launch_us'] > 0 and two['config']['no_settle']['value'] > 0
     inp = one['config']['in_place']
-    assert inp['verified_steps'] == 60 and inp['verified_envs'] >= 8 and inp['rate_over_spec_peak'] > 0
-    assert one['config']['two_chains']['verified_steps'] == 90 and one['config']['two_chains']['verified_envs'] >= 16
+    assert inp['verified_steps'] == 90 and inp['verified_envs'] >= 8 and inp['rate_over_spec_peak'] > 0
+    assert one['config']['two_chains']['verified_steps'] == 120 and one['config']['two_chains']['verified_envs'] >= 16
     assert one['roofline']['frac_dram'] == one['roofline']['frac'] and one['roofline']['in_place_rate_over_spec_peak'] == inp['rate_over_spec_peak']
-    assert two['roofline']['frac_dram'] is None and len(one['build_id']) == 16
+    assert two['roofline']['frac_dram'] == two['roofline']['frac'] and len(one['build_id']) == 16
+
+
+def test_scaling_legs_are_self_anchoring_on_two_ranks():
+    """A multi-GPU line's legs (BASELINE config 5's games per GPU and the strong split; small stand-ins here: two ranks share the test
+    box's one GPU) each carry their solo anchor -- rank 0 alone on the leg's per-GPU size, the other rank parked -- and scaling_x; the
+    per-GPU workload of the HEADLINE is the 1-GPU line's (ring of three output sets)."""
+    two = _run(['--gpus', '2', '--devices', '0,0', '--backend', 'gloo', '--envs', '4096', '--leg-envs', '8192', '--strong-total', '6000'] + COMMON)
+    c = two['config']
+    assert c['output_sets'] == 3 and c['solo']['games'] == 4096 and c['scaling_x'] > 0
+    legs = c['scaling_legs']
+    assert [(l['games_per_gpu'], l['total_games'], l['scaling'], l['output_sets']) for l in legs] == [(8192, 16384, 'weak', 1), (3000, 6000, 'strong', 1)]
+    for l in legs:
+        assert l['solo']['games'] == l['games_per_gpu'] and l['solo']['launch_us'] > 0
+        assert l['scaling_x'] == pytest.approx(l['value'] / l['solo']['value']) and l['scaling_x_ideal'] == 2
+        assert l['per_gpu_value_min_over_solo'] > 0 and l['verified_envs'] >= 16
 
 
 def test_rccl_refusing_the_job_falls_back_to_gloo():
     """The default backend of the reporting reductions is nccl (= RCCL).  Two ranks on ONE GPU are something RCCL refuses ("invalid usage"):
     the real failure path -- every rank falls back to gloo on the host, the run completes with the same games, and the line says what
     happened.  (On a node with a GPU per rank the same code comes up on RCCL; that is the driver's to run.)"""
-    two = _run(['--gpus', '2', '--devices', '0,0', '--envs', '4096'] + COMMON)
     ref = _run(['--gpus', '2', '--devices', '0,0', '--backend', 'gloo', '--envs', '4096'] + COMMON)
-    assert two['n_gpus'] == 2 and two['config']['reduction_backend'].startswith('gloo (nccl failed: ')
+    # (a) class Rank's own check before the collective bring-up: a device shared by two ranks
+    two = _run(['--gpus', '2', '--devices', '0,0', '--envs', '4096'] + COMMON)
+    assert two['n_gpus'] == 2 and two['config']['reduction_backend'].startswith('gloo (nccl failed: rank 0: ')
+    assert 'shared by 2 ranks' in two['config']['reduction_backend']
+    assert two['config']['outputs_checksum'] == ref['config']['outputs_checksum'] and two['verified_envs'] >= 32 and two['value'] > 0
+    # (b) that check switched off: RCCL itself refuses inside the collective bring-up, on every rank; the ranks agree on gloo afterwards
+    two = _run(['--gpus', '2', '--devices', '0,0', '--envs', '4096'] + COMMON, extra_env={'SGX_BENCH_SKIP_DEVICE_CHECK': '1', 'SGX_BENCH_NCCL_TIMEOUT': '60'})
+    assert two['n_gpus'] == 2 and two['config']['reduction_backend'].startswith('gloo (nccl failed: rank 0: ')
+    assert 'shared by 2 ranks' not in two['config']['reduction_backend']
     assert two['config']['outputs_checksum'] == ref['config']['outputs_checksum'] and two['verified_envs'] >= 32 and two['value'] > 0
 
 

@@ -48,7 +48,7 @@ def main():
         for f in files:
             print('#', f)
             for (ff, k, c), v in sorted(agg.items()):
-                if ff == f and ('step_kernel' in k or 'sample_kernel' in k or 'lane_kernel' in k):
+                if ff == f and any(x in k for x in ('step_kernel', 'sample_kernel', 'lane_kernel', 'export_kernel', 'import_kernel', 'states_kernel', 'choose_kernel')):
                     print('%-42s %-26s n=%-3d mean=%.1f' % (k, c, len(v), sum(v) / len(v)))
 
 
