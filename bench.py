@@ -88,15 +88,20 @@ def record_bytes(v):
     return (st_off + 2 * sb + 32 + (4 if rc > 256 else 2) * max_events + 127) & ~127
 
 
-def b_min(v, full_obs=False, rec_bytes=None):
+def b_min(v, full_obs=False, rec_bytes=None, fused_steps=1):
     """The packed layout's own byte minimum of one env step -- what `roofline` is priced on: the record read
     once and written once, the action read (4) and the next action written (4), the float32 observation(s), the uint8 mask and
     12 B of results (two float32 rewards, done, invalid_action, ending_invalid, player).  Barrage 31,544 B, Standard 31,800 B,
-    Micro 3,624 B."""
+    Micro 3,624 B.  fused_steps = K > 1: the K steps of one multi-step launch (boards of at most 16 cells: the games stay in registers,
+    DESIGN.md section 3.3) move the record and the action once per LAUNCH: per step (2 x record + 8) / K + outputs -- Micro 3,368 B + 264 / K."""
     rc = v.rows * v.columns
     k = 2 * (v.rows - 1) + 2 * (v.columns - 1) + 1
     rb = rec_bytes if rec_bytes else record_bytes(v)
-    return 2 * rb + 4 + 4 + 4 * 67 * rc + rc * k + 12 + (4 * 79 * rc if full_obs else 0)
+    per_launch = 2 * rb + 4 + 4
+    outputs = 4 * 67 * rc + rc * k + 12 + (4 * 79 * rc if full_obs else 0)
+    if fused_steps and fused_steps > 1:
+        return outputs + per_launch / float(fused_steps)
+    return per_launch + outputs
 
 
 def usable_cores():
@@ -748,14 +753,14 @@ def place_outputs(env, args):
 
 
 def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, first_us=None, rec_bytes=None, build_id=None,
-             rotating=None, ring_sets=1):
+             rotating=None, ring_sets=1, fused_steps=1):
     """The roofline object of one workload.  Every `frac*` is B_min x games / time / 8 TB/s -- bytes the kernel cannot avoid moving
     (b_min), so none of them overstates the traffic; `frac_dram` comes from the rotating-outputs leg (`rotating` = its launch
     seconds), where the Infinity Cache cannot hold anything back from DRAM."""
     key = version + ('+full_obs' if full_obs else '')
     if ring_sets > 1 and measured_traffic(key + '+rotating', n, build_id)[0]:
         key += '+rotating'
-    per_step = b_min(v, full_obs, rec_bytes)
+    per_step = b_min(v, full_obs, rec_bytes, fused_steps)
     min_bytes = per_step * n
     traffic, source = (traffic_override, "--traffic-bytes") if traffic_override is not None else measured_traffic(key, n, build_id)
     ach = min_bytes / launch_s / 1e9
@@ -767,7 +772,8 @@ def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, fir
                              "again: DRAM side" % ring_sets if ring_sets > 1 else
                              "outputs written in place (one set of tensors): memory side including the 256 MiB Infinity Cache where a set fits it"),
            "bytes_per_launch": min_bytes, "b_min_bytes_per_step": per_step,
-           "kernel": "step_kernel<%d,%d,%d,false>" % (v.rows, v.columns, 1 if full_obs else 0), "launch_us": launch_s * 1e6,
+           "kernel": ("lane_steps_kernel<%d,%d> (%d steps per launch: launch_us and the bytes are per STEP)" % (v.rows, v.columns, fused_steps)) if fused_steps > 1
+                     else "step_kernel<%d,%d,%d,false>" % (v.rows, v.columns, 1 if full_obs else 0), "launch_us": launch_s * 1e6,
            "frac_dram": None, "traffic": traffic, "traffic_source": source,
            "traffic_over_b_min": (traffic / min_bytes) if traffic else None,
            # the same kernel writing the allocation the process got first (observe launch of the placement trial's first candidate):
@@ -782,6 +788,12 @@ def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, fir
     return out
 
 
+def fused_launch(env):
+    """True if the env's last rollout was ONE multi-step launch (sgx_last_launch_kind: boards of at most 16 cells)."""
+    from stratego_env_amd import _lib
+    return (not DRY_RUN) and env.last_launch_kind == _lib.LAUNCH_MULTI_STEP
+
+
 def rotating_leg(rk, env, args, version, v, steps, warmup, n_sets, full_obs=False, verify=8):
     """The rotating-outputs leg on the env object that was just timed: n_sets output sets (the env's own + n_sets - 1 more, each from
     its own placement trial) written round-robin, sgx_step_ring.  With 3 x 2 GB of outputs nothing a launch writes can still be in
@@ -793,6 +805,7 @@ def rotating_leg(rk, env, args, version, v, steps, warmup, n_sets, full_obs=Fals
     reports = env.alloc_output_ring(n_sets, tune=tune, max_extra_bytes=budget, trials=args.placement_trials, wide_extra_bytes=wide)
     elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, warmup, ring=True)
     assert invalid == 0
+    fused = steps if fused_launch(env) else 1
     checked = verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
     launch_s = dev_ms / 1e3 / steps
     per_set = [(round(r['obs'][0], 1), round(min(r['obs']), 1)) if (r and r.get('obs')) else None for r in reports]
@@ -800,7 +813,8 @@ def rotating_leg(rk, env, args, version, v, steps, warmup, n_sets, full_obs=Fals
     return {"workload": "the same rollout writing %d output sets round-robin (sgx_step_ring: a trajectory buffer of the last %d steps)" % (n_sets, n_sets),
             "output_sets": n_sets, "bytes_per_set": set_bytes, "exceeds_infinity_cache": bool((n_sets - 1) * set_bytes > (256 << 20)),
             "value": env.num_envs * steps / elapsed, "unit": "env steps/s", "steps": steps, "warmup": warmup, "launch_us": launch_s * 1e6,
-            "frac_dram": b_min(v, full_obs, env.record_bytes) * env.num_envs / launch_s / 1e9 / HBM_PEAK_GBS,
+            "frac_dram": b_min(v, full_obs, env.record_bytes, fused) * env.num_envs / launch_s / 1e9 / HBM_PEAK_GBS,
+            "steps_per_launch": fused,
             "placement_plain_and_kept_us_per_extra_set": per_set[1:], "games_finished_in_timed_region": games,
             "verified_envs": checked, "verified_steps": env.bench_steps_played}, launch_s
 
@@ -832,7 +846,7 @@ def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_
         chosen = torch.empty((n,), dtype=torch.int32, device=dev)
         ids = np.unique(np.linspace(0, n - 1, n_check).astype(np.int64))
         idx = torch.from_numpy(ids).to(dev)
-        total_steps = 2 * rounds * steps_per_round + steps_per_round + 4
+        total_steps = 2 * rounds * steps_per_round + steps_per_round + 8
         act_log = torch.zeros((total_steps, len(ids)), dtype=torch.int32, device=dev)
         done_log = torch.zeros((total_steps, len(ids)), dtype=torch.uint8, device=dev)
         obs, mask = env.obs, env.mask
@@ -858,6 +872,7 @@ def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_
                 played += 1
 
         loop(4)                                             # untimed: allocator warm-up of the policy's temporaries
+        loop(4, fused=False)                                # ... and of the torch-composed chooser's (its first calls load kernels and grow the cache)
         res = {m: {"s": 0.0, "kernel_ms": 0.0, "chooser_ms": 0.0, "steps": 0} for m in (1, 0, 'torch')}
         for rnd in range(rounds + 1):
             for mode in ((1, 0) if rnd < rounds else ('torch',)):
@@ -983,19 +998,27 @@ def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, 
         _, probe_ms, _, _, _ = time_workload(rk, env, 8, 8)
         steps = int(max(16, min(4096, seconds * 1e3 / max(probe_ms / 8, 1e-3))))
         elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, 4)
-        two = None
+        fused = steps if fused_launch(env) else 1          # boards of at most 16 cells: the timed steps were ONE launch, the games in registers
+        two, per_step_launches = None, None
         if chains > 1:                     # the same steps with the batch split over concurrent chains of launches (sgx_rollout)
             e2, d2, _, _, inv2 = time_workload(rk, env, steps, 4, chains=chains)
             assert inv2 == 0
             two = {"chains": chains, "value": n * steps / e2, "us_per_step": d2 / steps * 1e3,
                    "frac": b_min(v, full_obs, env.record_bytes) * n / (d2 / 1e3 / steps) / 1e9 / HBM_PEAK_GBS}
+        if fused > 1:                      # ... and one launch per step (what every round before this one measured), same env object
+            env.set_multi_step(False)
+            e3, d3, _, _, inv3 = time_workload(rk, env, steps, 4)
+            env.set_multi_step(True)
+            assert inv3 == 0
+            per_step_launches = {"value": n * steps / e3, "us_per_step": d3 / steps * 1e3,
+                                 "frac": b_min(v, full_obs, env.record_bytes) * n / (d3 / 1e3 / steps) / 1e9 / HBM_PEAK_GBS}
         assert invalid == 0
         checked = verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
         launch_s = dev_ms / 1e3 / steps
         rot, rot_s = None, None
         if rotate_sets >= 2:               # (toy boards: 3 x 248 MB of outputs rotate past the Infinity Cache too)
             rot, rot_s = rotating_leg(rk, env, args, version, v, steps, 4, rotate_sets, full_obs=full_obs, verify=verify)
-        rf = roofline(version, v, n, launch_s, full_obs=full_obs, rec_bytes=env.record_bytes, build_id=env.build_id, rotating=rot_s)
+        rf = roofline(version, v, n, launch_s, full_obs=full_obs, rec_bytes=env.record_bytes, build_id=env.build_id, rotating=rot_s, fused_steps=fused)
         # on the plain first allocation: this leg's step time scaled by the trial's observe launches, first candidate / kept one (the
         # observe launch itself is not this leg's step: cheaper on the toy boards, and in BOTH mode the candidates were timed per buffer)
         tr = trial or {}
@@ -1008,6 +1031,7 @@ def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, 
                 "b_min_bytes_per_step": rf["b_min_bytes_per_step"], "traffic": rf["traffic"], "traffic_source": rf["traffic_source"],
                 "survey_8d": rf["survey_8d"], "kernel": rf["kernel"],
                 "games_finished_in_timed_region": games, "concurrent_chains": two, "rotating_outputs": rot, "verified_envs": checked,
+                "steps_per_launch": fused, "one_launch_per_step": per_step_launches,
                 "placement": trial}
     finally:
         env.close()
@@ -1132,12 +1156,13 @@ def run_rank(args):      # noqa: C901
     solo = solo_anchor(rk, env, args.steps, args.warmup, unfused=args.unfused, chains=args.chains, ring=headline_ring)
     elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring)
     assert invalid == 0, "rollout produced invalid actions"
+    fused = args.steps if (not dry and fused_launch(env)) else 1        # boards of at most 16 cells: the K timed steps were ONE launch
     # outside the timed region: the envs that were just timed against the CPU oracle, and the sharding-independent checksum
     checked = verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if (args.verify_envs and not dry) else 0
     verified_steps = env.bench_steps_played
     _, (checked, checksum, covered) = rk.reduce([], [checked, outputs_checksum(env) if not dry else 0, n])
     in_place, two_chains, no_settle = None, None, None
-    per_step = b_min(v, args.full_obs, rec_bytes)
+    per_step = b_min(v, args.full_obs, rec_bytes, fused)
     if not dry and SETTLE_SECONDS > 0 and not args.no_settle_leg:
         # what gpu_settle is worth: the same K steps on the same env object and buffers once more, W warm-up steps straight into the bracket
         # (every rank takes part: same barriers)
@@ -1175,7 +1200,7 @@ def run_rank(args):      # noqa: C901
         if not dry:
             rf = roofline(args.version, v, n, launch_s, args.traffic_bytes, full_obs=args.full_obs,
                           first_us=(placement or {}).get('fobs_plain_us' if args.full_obs else 'plain_us'), rec_bytes=rec_bytes, build_id=build_id,
-                          rotating=launch_s if headline_ring else None, ring_sets=args.output_sets if headline_ring else 1)
+                          rotating=launch_s if headline_ring else None, ring_sets=args.output_sets if headline_ring else 1, fused_steps=fused)
             rf["in_place_rate_over_spec_peak"] = in_place["rate_over_spec_peak"] if in_place else None
         value = total_steps / elapsed
         out = {
@@ -1191,7 +1216,7 @@ def run_rank(args):      # noqa: C901
                                                          ", outputs written round-robin into %d sets (a trajectory buffer of the last %d steps)" % (args.output_sets, args.output_sets) if headline_ring else ", outputs written in place"),
                        "games_per_gpu": n, "total_games": total, "games_covered_by_ranks": covered, "version": args.version, "seed": BASE_SEED,
                        "arithmetic": "game logic on int8 / uint8 boards (dtype u8); outputs: float32 observation (85 % of the bytes), uint8 mask",
-                       "games_finished_in_timed_region": games, "b_min_bytes_per_step": b_min(v, args.full_obs, rec_bytes),
+                       "games_finished_in_timed_region": games, "b_min_bytes_per_step": per_step, "steps_per_launch": fused,
                        "record_bytes": rec_bytes,
                        "untimed_before_bracket": "%d warm-up steps, then %.2f s of state-preserving sgx_observe launches (gpu_settle)" % (args.warmup, SETTLE_SECONDS),
                        "no_settle": no_settle,

@@ -188,6 +188,20 @@ int sgx_set_nt_stores(sgx_env *h, int32_t mode);
  * default of handles created afterwards.  Results are identical either way (tests/test_gpu_lane_kernel.py).  No reference counterpart. */
 int sgx_set_lane_kernel(sgx_env *h, int32_t mode);
 
+/* sgx_step_n / sgx_step_ring on boards of at most 16 cells (Micro, Tiny): where the call is eligible (the lane kernel's conditions for every
+ * output set, flat perspective actions, an observation tensor, n_steps >= 2, at most 8 output sets) all n_steps run in ONE launch -- a
+ * 256-thread workgroup keeps 64 games in the registers of one wave, which plays step t + 1 while the other three waves store the
+ * observations of step t (lane_steps_kernel); the records travel to and from HBM once per call.  Same results as n_steps launches.
+ * mode 1 (default): on; 0: one launch per step.  SGX_MULTI_STEP=0 sets the default of handles created afterwards; sgx_set_lane_kernel(h, 0)
+ * switches it off as well.  No reference counterpart. */
+int sgx_set_multi_step(sgx_env *h, int32_t mode);
+/* Which kernel the handle's last sgx_step / sgx_observe / sgx_step_n / sgx_step_ring / sgx_rollout / sgx_expand launch was (diagnostics,
+ * benchmarks that price a launch by its own bytes, tests that must not pass on another kernel): */
+#define SGX_LAUNCH_WAVE 0        /* one wave per game (boards of up to 32 cells: a wave's lanes shared by 2 or 4 games), one launch per step */
+#define SGX_LAUNCH_LANE 1        /* one game per lane (boards of at most 16 cells), one launch per step */
+#define SGX_LAUNCH_MULTI_STEP 2  /* one game per lane, all steps of the call in one launch (sgx_set_multi_step) */
+int sgx_last_launch_kind(const sgx_env *h);
+
 /* Shares of the eight XCDs in a launch of sgx_step / sgx_observe.  Under a saturating write stream the odd XCDs of MI355X drain their
  * eighth of the games ~20 % slower than the even ones, so with equal eighths the even XCDs idle at the end of every launch; the
  * library gives the even XCD of each pair `per_mille` more than the mean share and the odd one as much less (DESIGN.md section 3.1:

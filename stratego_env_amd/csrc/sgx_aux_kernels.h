@@ -351,6 +351,7 @@ __device__ __forceinline__ void import_to_image(const KParams &P, StateLds<G, NT
         bool dropped = total_events > max_events_of<G>(P);
         if (player_in && player_in[env] != 1 && player_in[env] != -1) dropped = true;
         if (sanitised) sanitised[env] = (W.altered || dropped) ? 1 : 0;
+        if ((W.altered || dropped) && P.flag_count) P.flag_list[atomicAdd(P.flag_count, 1)] = (int32_t)env;     // (first pass of sgx_step_states)
         const int old_game = rec_scal<G>(P.boards, P.rec_bytes, env)[0].w;
         int4 *scg = reinterpret_cast<int4 *>(img + G::SC_OFF);
         scg[0] = make_int4(W.scal[0], flags, W.scal[3], old_game < 0 ? 0 : old_game);
@@ -434,7 +435,8 @@ constexpr int states_threads() { return (!MAPPED && !OBS) ? 192 : 128; }
 // 'original' channels) instead of the partial 'extended' one -- the first pass of those kinds is the three-launch path on packed records.
 template <int R_, int C_, bool MAPPED, bool OBS, int VAR = 0, int KINDX = -1>
 __global__ __launch_bounds__((states_threads<MAPPED, OBS>())) void states_kernel(const KParams P, const int64_t *__restrict__ in, const int8_t *__restrict__ player_in,
-                                                     uint8_t *__restrict__ sanitised, int64_t *__restrict__ out, int8_t *__restrict__ player_out, const int nt) {
+                                                     uint8_t *__restrict__ sanitised, int64_t *__restrict__ out, int8_t *__restrict__ player_out, const int nt,
+                                                     const int32_t *__restrict__ redo_list, const int32_t *__restrict__ redo_count) {
     using G = Geo<R_, C_, VAR>;
     static_assert(G::LPG == 64, "one game per wave");
     static_assert(KINDX < 0 || (VAR == 1 && OBS && !MAPPED && KINDX >= 1 && KINDX <= 3), "other kinds: general-state pass, observing, unmapped");
@@ -444,10 +446,17 @@ __global__ __launch_bounds__((states_threads<MAPPED, OBS>())) void states_kernel
     __shared__ alignas(16) uint8_t shared[OBS ? shared_table_bytes<G, KIND>() : 16];
     __shared__ alignas(16) uint8_t obst_s[G::OBST_BYTES + COMBAT_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t env = P.env_first + group_of_block(P);
-    if (env >= P.n_envs) return;
-    if constexpr (G::BIG)
-        if (sanitised[env] == 0) return;                                     // (block-uniform) nothing to redo for this state
+    // first pass: one block per state (mapped onto the XCDs like the step's workgroups); general-state pass: a small persistent grid that
+    // walks the list of the states the first pass had to alter (usually empty: the launch costs a few microseconds, not one block per state)
+    int64_t env = 0;
+    int n_redo = 0, k_redo = (int)blockIdx.x;
+    if constexpr (G::BIG) {
+        n_redo = *redo_count;
+        if (k_redo >= n_redo) return;
+    } else {
+        env = P.env_first + group_of_block(P);
+        if (env >= P.n_envs) return;
+    }
     {   // the step's workgroup-shared tables (game_kernel_body): default-code templates, code table, obstacle map, combat outcomes
         if constexpr (KINDX >= 0) {
             stage_kind_tables<G, KIND>(P, shared, tid, NT);
@@ -462,17 +471,24 @@ __global__ __launch_bounds__((states_threads<MAPPED, OBS>())) void states_kernel
         for (int i = tid; i < G::S / 4; i += NT) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
         for (int i = tid; i < COMBAT_BYTES / 4; i += NT) reinterpret_cast<int *>(obst_s + G::OBST_BYTES)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
     }
-    import_to_image(P, W, in, player_in, sanitised, env, tid);              // (ends with a barrier: image and tables are in place)
-    if (tid < 64) {
-        const GameInput gin = load_game_from<G>(P, reinterpret_cast<const int4 *>(W.img), env, lane);
-        env_step<R_, C_, KIND, MAPPED, false, VAR>(P, L, shared, obst_s, env, lane, gin, reinterpret_cast<int8_t *>(W.img));
+    for (;;) {
+        if constexpr (G::BIG) env = redo_list[k_redo];
+        import_to_image(P, W, in, player_in, sanitised, env, tid);              // (ends with a barrier: image and tables are in place)
+        if (tid < 64) {
+            const GameInput gin = load_game_from<G>(P, reinterpret_cast<const int4 *>(W.img), env, lane);
+            env_step<R_, C_, KIND, MAPPED, false, VAR>(P, L, shared, obst_s, env, lane, gin, reinterpret_cast<int8_t *>(W.img));
+        }
+        __syncthreads();
+        if constexpr (!G::BIG) {                                                   // (a general-state image does not fit the handle's packed records)
+            int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;                   // the handle keeps the successor, like after sgx_step
+            for (int i = tid; i < P.rec_bytes / 16; i += NT) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(W.img)[i];
+        }
+        if (out) export_from_image(P, W, out, player_out, env, tid, nt);
+        if constexpr (!G::BIG) break;
+        k_redo += (int)gridDim.x;
+        if (k_redo >= n_redo) break;
+        __syncthreads();                                                           // (the next state reuses W and L)
     }
-    __syncthreads();
-    if constexpr (!G::BIG) {                                                   // (a general-state image does not fit the handle's packed records)
-        int8_t *rec = P.boards + env * (int64_t)P.rec_bytes;                   // the handle keeps the successor, like after sgx_step
-        for (int i = tid; i < P.rec_bytes / 16; i += NT) reinterpret_cast<int4 *>(rec)[i] = reinterpret_cast<const int4 *>(W.img)[i];
-    }
-    if (out) export_from_image(P, W, out, player_out, env, tid, nt);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -186,6 +186,9 @@ struct KParams {
     // records and written to record i of this one, whether or not the move was valid
     const int8_t *src_boards;
     const int32_t *src_index;
+    // sgx_step_states: the states an import had to alter are appended here (count by atomicAdd), so that the general-state pass visits
+    // only those instead of launching a block per state; NULL elsewhere
+    int32_t *flag_list, *flag_count;
 #ifdef SGX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [N][16] s_memtime stamps per phase
 #endif

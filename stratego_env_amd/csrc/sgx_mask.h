@@ -24,9 +24,17 @@ __device__ __forceinline__ void mask_noop_only(Lds<G, NB> &L, int lane) {
     wave_sync<G>();
 }
 
+// SGX_ABLATE (diagnostic builds only, tools/ablate_logic.py): parts of the game logic are SKIPPED by the bits of SGX_MAP="0,<bits>" so that
+// their cost can be read off the launch time of state-preserving observe launches.  Results are wrong by construction.
+#ifdef SGX_ABLATE
+#define SGX_ABLATED(P_, bit) (((P_) >> (bit)) & 1)
+#else
+#define SGX_ABLATED(P_, bit) 0
+#endif
 template <class G, int NB>
-__device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over, int lane) {
+__device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over, int lane, int ablate = 0) {
     constexpr int R = G::R, C = G::C, RC = G::RC, K = G::K;
+    if (SGX_ABLATED(ablate, 1)) return 1;                       // no mask generation at all
     constexpr int OCC_OWN = 1, OCC_ENEMY = 2, OCC_OBST = 4, OCC_CAME_FROM = 8;
     const int8_t *own = L.b[B_PIECES + qi], *enemy = L.b[B_PIECES + 1 - qi], *rec = L.b[B_RECENT + qi], *obst = L.b[B_OBST];
     {
@@ -53,6 +61,7 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over
             npieces += __popcll(bm);
         }
         wave_sync<G>();
+        if (SGX_ABLATED(ablate, 4)) return npieces;                  // pass 1 only
         // pass 2: one ray per lane, perspective direction order +r, -r, +c, -c (impl:427-490 / 494-495)
         const int sgn = qi ? -1 : 1;  // perspective +r is absolute -r for player -1 (impl:678-695)
         const int nrays = 4 * npieces;
@@ -71,6 +80,7 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over
             int lim = act ? (t == SP_SCOUT ? avail : min(avail, 1)) : 0;
             int e = i, n = 0;
             for (int k = 1; k < (R > C ? R : C); ++k) {
+                if (SGX_ABLATED(ablate, 0)) break;                   // no ray walk
                 if (!__any(k <= lim)) break;
                 if (k <= lim) {
                     e += delta;

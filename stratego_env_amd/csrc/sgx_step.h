@@ -210,6 +210,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     int n_events = min(uni<G>(sc2.x), (int)G::EVL_MAX);
     int rp0 = uni<G>(sc2.y), rp1 = uni<G>(sc2.z);   // recent-move pairs of player +1 / -1 (two named scalars: a runtime-indexed
                                               // array would live in scratch memory)
+    if (!SGX_ABLATED(P.map_arg, 2))
     {   // ---- rebuild the derived boards: never-moved bitmaps, recent-move pairs (capture events stay a list)
         const uint32_t *stb = reinterpret_cast<const uint32_t *>(L.tail);
 #pragma unroll
@@ -379,7 +380,12 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     STAMP(2);   // move applied
     // ---- next mover's mask; opponent-stuck and max-turn endings (impl:1031-1043)
     int qi = player == 1 ? 0 : 1;
+#ifdef SGX_ABLATE
+    if (SGX_ABLATED(P.map_arg, 3)) return;                              // staging only
+    int nvalid = gen_mask(L, qi, over, lane, P.map_arg);
+#else
     int nvalid = gen_mask(L, qi, over, lane);
+#endif
     bool ended_now = false;
     if (applied && !noop_path) {
         const bool was_over = over;

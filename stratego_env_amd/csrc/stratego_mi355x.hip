@@ -120,7 +120,11 @@ struct sgx_env {
     uint32_t sync_seq;
     int no_single;               // SGX_NO_SINGLE=1: sgx_step_sync never takes the single_kernel path (A/B measurements)
     uint8_t *san_flags;          // sgx_step_states: per-state "had to be altered" flags when the caller passes none (created on first use)
+    int32_t *redo_list;          // sgx_step_states: [n_envs] ids of the states the first pass had to alter, then the counter (created on first use)
     int general_states;          // sgx_set_general_states: 0 = flagged states stay sanitised, otherwise the second, general-state pass redoes them
+    int no_multi_step;           // SGX_MULTI_STEP=0 (or a runtime that refuses the LDS size): sgx_step_n / sgx_step_ring never take lane_steps_kernel
+    int multi_step_attr;         // lane_steps_kernel's dynamic-LDS attribute has been raised
+    int last_kind;               // sgx_last_launch_kind: which kernel the last step / observe launch of this handle was
 };
 
 namespace {
@@ -392,6 +396,7 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     if (const char *e = getenv("SGX_XCD_SKEW")) { if (strcmp(e, "auto")) h->xcd_skew = atoi(e); }   // SGX_XCD_SKEW=<per mille>|auto
     if (h->xcd_skew > 900) h->xcd_skew = 900;
     if (const char *e = getenv("SGX_NO_SINGLE")) h->no_single = atoi(e);
+    if (const char *e = getenv("SGX_MULTI_STEP")) h->no_multi_step = !strcmp(e, "0");
     if (const char *e = getenv("SGX_MAP")) { h->map_mode = atoi(e); if (const char *c = strchr(e, ',')) h->map_arg = atoi(c + 1); }
     const int rc_cells = cfg->rows * cfg->cols;
     {
@@ -465,6 +470,7 @@ SGX_API int sgx_destroy(sgx_env *h) {
     if (h->sync_flag_host) (void)hipHostFree(h->sync_flag_host);
     if (h->sync_count) (void)hipFree(h->sync_count);
     if (h->san_flags) (void)hipFree(h->san_flags);
+    if (h->redo_list) (void)hipFree(h->redo_list);
     delete h;
     return SGX_OK;
 }
@@ -484,6 +490,14 @@ SGX_API int sgx_set_placement_target(sgx_env *h, float target_us) {
 SGX_API int sgx_set_general_states(sgx_env *h, int32_t mode) {
     if (!h || mode < 0 || mode > 1) return fail(SGX_EINVAL, "sgx_set_general_states: mode must be 0 or 1%s");
     h->general_states = mode;
+    return SGX_OK;
+}
+
+SGX_API int sgx_last_launch_kind(const sgx_env *h) { return h ? h->last_kind : -1; }
+
+SGX_API int sgx_set_multi_step(sgx_env *h, int32_t mode) {
+    if (!h || mode < 0 || mode > 1) return fail(SGX_EINVAL, "sgx_set_multi_step: mode must be 0 or 1%s");
+    h->no_multi_step = mode ? 0 : 1;
     return SGX_OK;
 }
 
@@ -591,11 +605,12 @@ static void launch_shares(const sgx_env *h, bool streaming, int32_t *w) {
 }
 
 // The lane-per-game kernel plays this launch?  (sgx_lane_kernel.h: what it covers; everything else is the wave-per-game kernel.)
-static bool lane_eligible(const sgx_env *h, const KParams &p, bool full, bool original) {
+static bool lane_eligible(const sgx_env *h, const KParams &p, bool full, bool original, bool multi_step = false) {
     const int cells = h->cfg.rows * h->cfg.cols;
     auto aligned = [](const void *ptr, uintptr_t a) { return (reinterpret_cast<uintptr_t>(ptr) & (a - 1)) == 0; };
-    // -1 (auto): only where it is the faster kernel -- launches that emit no observation (2 x on Micro / Tiny)
-    if (h->lane_mode < 0 && p.io.obs_dev) return false;
+    // -1 (auto): only where it is the faster kernel -- launches that emit no observation (2 x on Micro / Tiny) and
+    // the fused multi-step launches of sgx_step_n / sgx_step_ring (lane_steps_kernel: the logic of step t + 1 under the stores of step t)
+    if (h->lane_mode < 0 && p.io.obs_dev && !multi_step) return false;
     return h->lane_mode != 0 && !p.multi_ev && !(p.io.flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) && cells <= 16 && cells % 4 == 0 && !full && !original && h->map_mode == 0 &&
            !(p.io.flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) && !p.src_boards && !p.io.final_obs_dev && !p.io.final_fobs_dev &&
            (h->rec_bytes == 128 || h->rec_bytes == 256) && (p.env_first & 63) == 0 &&
@@ -604,6 +619,61 @@ static bool lane_eligible(const sgx_env *h, const KParams &p, bool full, bool or
 
 static int check_step_io(sgx_env *h, const KParams &p) {
     if (p.mode == 0 && p.io.auto_reset) return check_random_setups(h);
+    return SGX_OK;
+}
+
+// sgx_step_n / sgx_step_ring on boards of at most 16 cells: all n_steps in ONE launch of lane_steps_kernel (sgx_lane_kernel.h) where the call
+// is eligible -- the lane kernel's conditions for every output set, flat perspective actions, observations wanted.  *launched tells.
+static int launch_lane_steps(sgx_env *h, const KParams &p_in, const sgx_step_io *ios, int32_t n_sets, int32_t first_set, int32_t n_steps, void *stream,
+                             bool *launched) {
+    *launched = false;
+    if (n_steps < 2 || n_sets > KSTEP_MAX_SETS || h->lane_mode == 0 || h->no_multi_step) return SGX_OK;
+    KParams p = p_in;
+    p.mode = 0;
+    p.io = ios[first_set];
+    if (!p.io.obs_dev || (p.io.flags & (SGX_STEP_ACTIONS_1D | SGX_STEP_ACTIONS_POSITIONS))) return SGX_OK;
+    StepsParams sp;
+    memset(&sp, 0, sizeof(sp));
+    for (int32_t k = 0; k < n_sets; ++k) {
+        KParams pk = p;
+        pk.io = ios[k];
+        const bool full = pk.io.fobs_dev || pk.io.final_fobs_dev, original = (pk.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
+        if (!pk.io.obs_dev || !lane_eligible(h, pk, full, original, true)) return SGX_OK;
+        // everything but the observation / mask tensors is shared by the sets (the kernel writes the results through set first_set's pointers)
+        if (pk.io.reward_dev != p.io.reward_dev || pk.io.done_dev != p.io.done_dev || pk.io.player_dev != p.io.player_dev ||
+            pk.io.invalid_action_dev != p.io.invalid_action_dev || pk.io.ending_invalid_dev != p.io.ending_invalid_dev) return SGX_OK;
+        sp.obs[k] = pk.io.obs_dev;
+        sp.mask[k] = pk.io.mask_dev;
+    }
+    if (int rc = check_step_io(h, p)) return rc;
+    p.map_mode = h->map_mode; p.map_arg = h->map_arg;
+    const bool streaming = launch_streams_past_cache(h, p, n_sets);
+    p.nt_stores = h->nt_mode < 0 ? (streaming ? 1 : 0) : h->nt_mode;
+    int32_t skew[8];
+    launch_shares(h, streaming, skew);
+    sp.n_steps = n_steps; sp.n_sets = n_sets; sp.first_set = first_set;
+#define CALL_LANE_STEPS(R, C)                                                                                      \
+    do {                                                                                                           \
+        if constexpr (lane_geometry<Geo<R, C>>()) {                                                                \
+            const unsigned grid = shares_for(p, (p.n_envs - p.env_first + 63) / 64, skew);                         \
+            const size_t dyn = 2 * 64 * (size_t)(p.rec_bytes + 16);                                                \
+            if (dyn + sizeof(StepsLds<Geo<R, C>>) > 64 * 1024 && !h->multi_step_attr) {                            \
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&lane_steps_kernel<R, C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { \
+                    (void)hipGetLastError();                                                                       \
+                    h->no_multi_step = 1;                  /* this runtime keeps workgroups to 64 KiB: per-step launches */ \
+                    break;                                                                                         \
+                }                                                                                                  \
+                h->multi_step_attr = 1;                                                                            \
+            }                                                                                                      \
+            sp.k = p;                                                                                              \
+            lane_steps_kernel<R, C><<<grid, 64 * (1 + KSTEP_EMITTERS), dyn, (hipStream_t)stream>>>(sp);            \
+            *launched = true;                                                                                      \
+            h->last_kind = SGX_LAUNCH_MULTI_STEP;                                                                  \
+        }                                                                                                          \
+    } while (0)
+    DISPATCH_GEOMETRY(h, CALL_LANE_STEPS);
+#undef CALL_LANE_STEPS
+    if (*launched) HIP_TRY(hipGetLastError());
     return SGX_OK;
 }
 
@@ -638,6 +708,7 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
         DISPATCH_GEOMETRY(h, CALL_LANE);
 #undef CALL_LANE
         HIP_TRY(hipGetLastError());
+        h->last_kind = SGX_LAUNCH_LANE;
         return SGX_OK;
     }
 #define CALL_STEP_KIND(R, C, KIND)                                                                 \
@@ -690,6 +761,7 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
 #undef CALL_STEP8
 #undef CALL_STEP_KIND
     HIP_TRY(hipGetLastError());
+    h->last_kind = SGX_LAUNCH_WAVE;
     return SGX_OK;
 }
 
@@ -1042,6 +1114,11 @@ SGX_API int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void 
     KParams p = make_params(h);
     p.mode = 0;
     p.io = *io;
+    {   // boards of at most 16 cells: the n_steps in one launch, the games in registers (lane_steps_kernel)
+        bool launched = false;
+        if (int rc = launch_lane_steps(h, p, io, 1, 0, n_steps, stream, &launched)) return rc;
+        if (launched) return SGX_OK;
+    }
     for (int32_t i = 0; i < n_steps; ++i)
         if (int rc = launch_step(h, p, stream)) return rc;
     return SGX_OK;
@@ -1059,6 +1136,11 @@ SGX_API int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, in
     SGX_ON_DEVICE(h->device);
     KParams p = make_params(h);
     p.mode = 0;
+    {
+        bool launched = false;
+        if (int rc = launch_lane_steps(h, p, ios, n_sets, first_set, n_steps, stream, &launched)) return rc;
+        if (launched) return SGX_OK;
+    }
     for (int32_t i = 0; i < n_steps; ++i) {
         p.io = ios[(first_set + i) % n_sets];
         if (int rc = launch_step(h, p, stream, n_sets)) return rc;
@@ -1240,6 +1322,20 @@ SGX_API int sgx_import_state_checked(sgx_env *h, const int64_t *state_dev, const
     return launch_import(h, make_params(h), state_dev, player_dev, sanitised_dev, (hipStream_t)stream);
 }
 
+namespace {
+// sgx_step_states' list of the states its first pass had to alter: created on first use, emptied (on the caller's stream) before every
+// first pass; p.flag_list / p.flag_count make the imports of that pass append to it
+int redo_list_reset(sgx_env *h, KParams &p, hipStream_t stream) {
+    if (!h->redo_list) HIP_TRY(hipMalloc((void **)&h->redo_list, ((size_t)h->n_envs + 1) * sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(h->redo_list + h->n_envs, 0, sizeof(int32_t), stream));
+    p.flag_list = h->redo_list;
+    p.flag_count = h->redo_list + h->n_envs;
+    return SGX_OK;
+}
+// the general-state pass: a small persistent grid that walks the list
+unsigned redo_grid(const sgx_env *h) { return (unsigned)(h->n_envs < 2048 ? h->n_envs : 2048); }
+}  // namespace
+
 // get_next_state (penv:148-155) and friends on caller-provided int64 states in ONE call: import -> step -> export, the batch split
 // into `chains` ranges of states that run on streams of their own, so that one range's reads overlap another's writes.
 SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_t *player_in_dev, uint8_t *sanitised_dev,
@@ -1286,7 +1382,12 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
             if (!h->san_flags) HIP_TRY(hipMalloc((void **)&h->san_flags, (size_t)h->n_envs));
             flags_dev = h->san_flags;
         }
-#define CALL_STATES_K(R, C, M, O, V) states_kernel<R, C, M, O, V><<<grid, states_threads<M, O>(), 0, (hipStream_t)stream>>>(p, state_in_dev, player_in_dev, flags_dev, state_out_dev, player_out_dev, nt)
+        if (general)
+            if (int rc = redo_list_reset(h, p, (hipStream_t)stream)) return rc;
+        KParams pbig = p;                                   // the general-state pass appends nothing
+        pbig.flag_list = pbig.flag_count = nullptr;
+        const unsigned grid_big = redo_grid(h);
+#define CALL_STATES_K(R, C, M, O, V) states_kernel<R, C, M, O, V><<<(V) ? grid_big : grid, states_threads<M, O>(), 0, (hipStream_t)stream>>>((V) ? pbig : p, state_in_dev, player_in_dev, flags_dev, state_out_dev, player_out_dev, nt, h->redo_list, h->redo_list ? h->redo_list + h->n_envs : nullptr)
 #define CALL_STATES_V(R, C, V)                                                                                              \
     do {                                                                                                                    \
         if constexpr (Geo<R, C>::LPG == 64 && !Geo<R, C>::WIDE) {                                                           \
@@ -1322,19 +1423,22 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
         if (!h->san_flags) HIP_TRY(hipMalloc((void **)&h->san_flags, (size_t)h->n_envs));
         flags_small = h->san_flags;
     }
+    if (general_small)
+        if (int rc = redo_list_reset(h, p, (hipStream_t)stream)) return rc;       // (before the chains fork: their imports append to the list)
     auto second_pass_small = [&]() -> int {
         if (!general_small) return SGX_OK;
         if (int rc = check_step_io(h, p)) return rc;
         KParams q = p;
         q.env_first = 0;
         q.n_envs = h->n_envs;
+        q.flag_list = q.flag_count = nullptr;
         const int nt = h->nt_mode < 0 ? states_stream_past_cache(h) : h->nt_mode;
-        const unsigned grid = state_grid(h, q);
+        const unsigned grid = redo_grid(h);
         q.nt_stores = h->nt_mode < 0 ? (launch_streams_past_cache(h, q) ? 1 : 0) : h->nt_mode;
         const bool obs = io->obs_dev || io->final_obs_dev;
         const int kindx = ((io->fobs_dev || io->final_fobs_dev) ? 1 : 0) | ((io->flags & SGX_STEP_ORIGINAL_CHANNELS) ? 2 : 0);
-#define CALL_STATES_SMALL_K(R, C, M, O) states_kernel<R, C, M, O, 1><<<grid, states_threads<M, O>(), 0, (hipStream_t)stream>>>(q, state_in_dev, player_in_dev, flags_small, state_out_dev, player_out_dev, nt)
-#define CALL_STATES_KIND_K(R, C, KX) states_kernel<R, C, false, true, 1, KX><<<grid, states_threads<false, true>(), 0, (hipStream_t)stream>>>(q, state_in_dev, player_in_dev, flags_small, state_out_dev, player_out_dev, nt)
+#define CALL_STATES_SMALL_K(R, C, M, O) states_kernel<R, C, M, O, 1><<<grid, states_threads<M, O>(), 0, (hipStream_t)stream>>>(q, state_in_dev, player_in_dev, flags_small, state_out_dev, player_out_dev, nt, h->redo_list, h->redo_list + h->n_envs)
+#define CALL_STATES_KIND_K(R, C, KX) states_kernel<R, C, false, true, 1, KX><<<grid, states_threads<false, true>(), 0, (hipStream_t)stream>>>(q, state_in_dev, player_in_dev, flags_small, state_out_dev, player_out_dev, nt, h->redo_list, h->redo_list + h->n_envs)
 #define CALL_STATES_SMALL(R, C)                                                                                             \
     do {                                                                                                                    \
         if constexpr (!Geo<R, C>::WIDE) {                                                                                   \

@@ -206,6 +206,17 @@ class VecStrategoEnv:
         m = -1 if mode in ('auto', None) else int(bool(mode))
         _lib.check(self._L.sgx_set_lane_kernel(self._h, m), self._L)
 
+    def set_multi_step(self, on=True):
+        """rollout_steps() on boards of at most 16 cells: True (default) = all steps of a call in one launch where eligible
+        (sgx_set_multi_step: the games stay in registers, the logic of step t + 1 runs under the stores of step t); False = one launch
+        per step.  Results are identical either way."""
+        _lib.check(self._L.sgx_set_multi_step(self._h, 1 if on else 0), self._L)
+
+    @property
+    def last_launch_kind(self):
+        """Which kernel the last step / observe launch was: _lib.LAUNCH_WAVE, LAUNCH_LANE or LAUNCH_MULTI_STEP (sgx_last_launch_kind)."""
+        return int(self._L.sgx_last_launch_kind(self._h))
+
     def set_xcd_skew(self, per_mille='auto'):
         """Shares of the eight XCDs in a launch (sgx_set_xcd_skew): 'auto' (100 per mille more for the even XCDs when the launch streams
         past the Infinity Cache, equal shares otherwise) or 0 .. 900.  Results are identical for every value."""

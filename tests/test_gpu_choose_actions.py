@@ -133,7 +133,7 @@ def test_rollout_driven_by_the_chooser_replays_on_the_oracle():
     """basic_game_loop for a batch, chooser on the device: the logged actions of sampled envs replay on the CPU oracle step for step
     (auto-reset included) and the last step's mask / observation / rewards match bit for bit."""
     import torch
-    from helpers import oracle_cvariant
+    from tests.helpers import oracle_cvariant
     from oracle import oracle as orc
     from stratego_env_amd import setups as S
     from stratego_env_amd.config import VARIANTS

@@ -102,3 +102,74 @@ def test_lane_kernel_rollout_digests_at_full_size():
             assert int(r['last_digests'][0]) == orc.step_digest(mk[i], ob[i], rw[i], dn[i], pl[i], ei[i]), (name, e)
             assert np.array_equal(r['info'][0], info[i]), (name, e)
         env.close()
+
+
+@pytest.mark.parametrize('name,n,T', [('micro', 64, 2), ('micro', 200, 33), ('micro', 4097, 64), ('tiny', 130, 41), ('zoo44', 777, 50),
+                                      ('thirds44', 513, 120), ('tall43', 70, 64)])
+def test_multi_step_launch_equals_step_by_step(name, n, T):
+    """sgx_step_n / sgx_step_ring on boards of at most 16 cells run all steps of a call in ONE launch (lane_steps_kernel: the games in the
+    registers of one wave per workgroup, three more waves emitting the observations of the step before): every output of the last step,
+    every output set of a ring (the last three steps), the int64 states, counters and the next draw equal those of one wave-per-game
+    launch per step -- ragged batches (partial workgroups, partial sub-batches), piece sets with uncoded thirds, a first action that is
+    garbage."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    a = VecStrategoEnv(name, n, seed=777, env_id_offset=9, auto_reset=True)          # default: the multi-step launch where eligible
+    b = VecStrategoEnv(name, n, seed=777, env_id_offset=9, auto_reset=True)
+    b.set_lane_kernel(False)                                                          # one wave-per-game launch per step
+    a.reset(); b.reset()
+    a.sample_valid_actions(); b.sample_valid_actions()
+    # some envs start from a garbage action: not applied, the next one is drawn afresh
+    bad = torch.arange(n, device=a.device) % 7 == 3
+    for e in (a, b):
+        e.next_actions[bad] = -5
+        e._next_actions_fresh = True
+    from stratego_env_amd import _lib
+    a.rollout_steps(T)
+    assert a.last_launch_kind == _lib.LAUNCH_MULTI_STEP                              # (the test must not pass on another kernel)
+    for _ in range(T):
+        b.rollout_steps(1)
+    assert b.last_launch_kind == _lib.LAUNCH_WAVE
+    for x, y in ((a.obs, b.obs), (a.mask, b.mask), (a.reward, b.reward), (a.done, b.done), (a.player, b.player), (a.next_actions, b.next_actions),
+                 (a.ending_invalid, b.ending_invalid), (a.env_info(), b.env_info())):
+        assert torch.equal(x, y), (name, n, T)
+    sa, pa = a.export_state()
+    sb, pb = b.export_state()
+    assert torch.equal(sa, sb) and torch.equal(pa, pb)
+    # a ring of three output sets: the last three steps' observations and masks, set by set; then in place again, and one more single step
+    ra = a.alloc_output_ring(3)
+    rb = b.alloc_output_ring(3)
+    del ra, rb
+    a.rollout_steps(T + 1, ring=True)
+    assert a.last_launch_kind == _lib.LAUNCH_MULTI_STEP
+    b.rollout_steps(T + 1, ring=True)
+    for (oa, ma, _), (ob, mb, _) in zip(a._ring, b._ring):
+        assert torch.equal(oa, ob) and torch.equal(ma, mb), (name, n, T, 'ring')
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.env_info(), b.env_info()) and torch.equal(a.next_actions, b.next_actions)
+    a.set_multi_step(False)                                                          # the same env object, one launch per step again
+    a.rollout_steps(5); b.rollout_steps(5)
+    assert a.last_launch_kind == _lib.LAUNCH_WAVE
+    a.set_multi_step(True)
+    a.rollout_steps(3); b.rollout_steps(3)
+    a.rollout_step(); b.rollout_step()
+    for x, y in ((a.obs, b.obs), (a.mask, b.mask), (a.reward, b.reward), (a.done, b.done), (a.next_actions, b.next_actions), (a.env_info(), b.env_info())):
+        assert torch.equal(x, y)
+    assert int(a.invalid_action.sum()) == int(b.invalid_action.sum())
+    a.close(); b.close()
+
+
+def test_multi_step_launch_with_forced_non_temporal_stores_and_raw_players():
+    """The multi-step launch under sgx_set_nt_stores(1) and without auto-reset (finished games stay finished: their no-op-only masks and
+    terminal observations repeat) equals the per-step launches."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    for auto in (True, False):
+        a = VecStrategoEnv('micro', 1000, seed=5, auto_reset=auto)
+        b = VecStrategoEnv('micro', 1000, seed=5, auto_reset=auto)
+        a.set_nt_stores(True)
+        b.set_multi_step(False)
+        a.reset(); b.reset()
+        a.rollout_steps(30); b.rollout_steps(30)
+        for x, y in ((a.obs, b.obs), (a.mask, b.mask), (a.reward, b.reward), (a.done, b.done), (a.player, b.player), (a.env_info(), b.env_info())):
+            assert torch.equal(x, y), auto
+        a.close(); b.close()
