@@ -31,13 +31,16 @@ __device__ __forceinline__ void mask_noop_only(Lds<G, NB> &L, int lane) {
 #else
 #define SGX_ABLATED(P_, bit) 0
 #endif
-template <class G, int NB>
+// ANY = true: the caller only asks WHETHER player qi has a move (launches that emit neither mask nor next action: search expansion, the
+// legality of a no-op): no bits, no counts -- every (piece, direction) lane looks at its first cell, and only a scout whose first cell is
+// the vetoed one (impl:439-445: the ray goes on past it) walks further.  Returns 1 / 0; L.mbits and L.cnt are left alone.
+template <class G, int NB, bool ANY = false>
 __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over, int lane, int ablate = 0) {
     constexpr int R = G::R, C = G::C, RC = G::RC, K = G::K;
     if (SGX_ABLATED(ablate, 1)) return 1;                       // no mask generation at all
     constexpr int OCC_OWN = 1, OCC_ENEMY = 2, OCC_OBST = 4, OCC_CAME_FROM = 8;
     const int8_t *own = L.b[B_PIECES + qi], *enemy = L.b[B_PIECES + 1 - qi], *rec = L.b[B_RECENT + qi], *obst = L.b[B_OBST];
-    {
+    if constexpr (!ANY) {
         const int4 z = make_int4(0, 0, 0, 0);
         for (int i = lane; i < G::MB_WORDS / 4; i += G::LPG) reinterpret_cast<int4 *>(L.mbits)[i] = z;
         for (int i = lane; i < G::CNT_PAD / 4; i += G::LPG) reinterpret_cast<int *>(L.cnt)[i] = 0;
@@ -90,25 +93,39 @@ __device__ SGX_GENMASK_INLINE int gen_mask(Lds<G, NB> &L, int qi, bool game_over
                     } else {
                         // two-square veto: this cell is skipped but the ray goes on (impl:439-445)
                         if (!(pinned && (v & OCC_CAME_FROM) && !(v & OCC_ENEMY))) {
-                            const int bit = bit0 + k;
-                            atomicOr(&L.mbits[bit >> 5], 1u << (bit & 31));
+                            if constexpr (!ANY) {
+                                const int bit = bit0 + k;
+                                atomicOr(&L.mbits[bit >> 5], 1u << (bit & 31));
+                            }
                             ++n;
                         }
                         if (v & OCC_ENEMY) lim = 0;                               // an attacked piece ends the ray
                     }
                 }
+                if constexpr (ANY)
+                    if (gballot<G>(n > 0) != 0ull) return 1;                      // somebody has a move: that is all that was asked
             }
-            n = quad_sum(n);                                                      // moves of the piece = its 4 rays
-            if (act && d == 0) { L.cnt[pcell] = (uint8_t)n; mine += n; }
+            if constexpr (!ANY) {
+                n = quad_sum(n);                                                  // moves of the piece = its 4 rays
+                if (act && d == 0) { L.cnt[pcell] = (uint8_t)n; mine += n; }
+            }
         }
+        if constexpr (ANY) return 0;
         total = uni<G>(glane<G>(gscan_incl<G>(mine), G::LPG - 1));
     }
+    if constexpr (ANY) return 0;                                                   // (a finished game)
     if (total == 0 && lane == 0) {
         L.mbits[(K - 1) >> 5] = 1u << ((K - 1) & 31);  // valid_moves_mask[0, 0, -1] (impl:514-515); mbits was just zeroed
         L.cnt[0] = 1;
     }
     wave_sync<G>();
     return total;
+}
+
+// "does player qi have a move at all?" (gen_mask<..., ANY = true>)
+template <class G, int NB>
+__device__ SGX_GENMASK_INLINE int gen_any(Lds<G, NB> &L, int qi, bool game_over, int lane) {
+    return gen_mask<G, NB, true>(L, qi, game_over, lane);
 }
 
 // 4 mask bits -> 4 mask bytes

@@ -300,7 +300,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
         if (valid && noop_path) {
             // no-op is legal only if the mover has no move (or the game is over); finished games stay unchanged
             if (!over) {
-                const int nmoves = gen_mask(L, pi, false, lane);
+                const int nmoves = gen_any(L, pi, false, lane);          // (only whether there is one)
                 if (nmoves != 0) valid = false;
                 else { turn += 1; over = true; flags |= F_OVER | (player == 1 ? F_WIN_M1 : F_WIN_P1); }  // impl:916-920
             }
@@ -380,22 +380,27 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     STAMP(2);   // move applied
     // ---- next mover's mask; opponent-stuck and max-turn endings (impl:1031-1043)
     int qi = player == 1 ? 0 : 1;
+    // Launches of the no-observation kind that want neither the mask nor a next action (search expansion, sgx_expand; logic-only steps)
+    // only need to know WHETHER the next mover has a move (the opponent-stuck ending): no mask bits, no counts, one cell per ray.
+    const bool want_bits = !NOOBS || SPLIT || P.io.mask_dev != nullptr || (P.mode == 0 && P.io.next_actions_dev != nullptr);
 #ifdef SGX_ABLATE
     if (SGX_ABLATED(P.map_arg, 3)) return;                              // staging only
     int nvalid = gen_mask(L, qi, over, lane, P.map_arg);
 #else
-    int nvalid = gen_mask(L, qi, over, lane);
+    int nvalid;
+    if constexpr (NOOBS) nvalid = want_bits ? gen_mask(L, qi, over, lane) : gen_any(L, qi, over, lane);
+    else nvalid = gen_mask(L, qi, over, lane);
 #endif
     bool ended_now = false;
     if (applied && !noop_path) {
         const bool was_over = over;
         if (nvalid == 0) { over = true; flags = (flags & ~(F_WIN_P1 | F_WIN_M1)) | F_OVER | (mover == 1 ? F_WIN_P1 : F_WIN_M1); }
         if (turn >= max_turns && !over) { over = true; flags |= F_OVER | F_END_INVALID; }
-        if (over && !was_over && nvalid != 0) { mask_noop_only(L, lane); nvalid = 0; }  // finished: the no-op only
+        if (over && !was_over && nvalid != 0) { if (want_bits) mask_noop_only(L, lane); nvalid = 0; }  // finished: the no-op only
         ended_now = over;
     } else if (applied && noop_path) {
         ended_now = over;
-        if (nvalid != 0) { mask_noop_only(L, lane); nvalid = 0; }
+        if (nvalid != 0) { if (want_bits) mask_noop_only(L, lane); nvalid = 0; }
     }
     flags = (flags & ~F_PLAYER_M1) | (player == -1 ? F_PLAYER_M1 : 0);
     STAMP(3);   // mask generated
@@ -481,7 +486,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
         sample_boards(L, P, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, lane);
         turn = 0; flags = 0; player = 1; qi = 0; over = false;
         n_events = 0; rp0 = rp1 = 0;
-        nvalid = gen_mask(L, 0, false, lane);
+        nvalid = want_bits ? gen_mask(L, 0, false, lane) : 1;          // (without mask and sampler nobody looks at the count of a fresh game)
         wrote_reset = true;
     }
 

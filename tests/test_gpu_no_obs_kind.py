@@ -70,3 +70,41 @@ def test_garbage_actions_without_observation():
     assert torch.equal(sa, sb)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize('name,n', VARIANTS + [('short_barrage', 2048)])
+def test_steps_that_only_ask_whether_a_move_exists(name, n):
+    """A launch that wants neither observation nor mask nor a next action (search expansion, logic-only steps) does not build the mask:
+    it only asks WHETHER the next mover has a move (gen_mask<..., ANY>: one cell per ray, further only behind a vetoed cell).  Endings by
+    a stuck opponent, rewards, flags and states must be those of the full step -- over whole games on every board size, with garbage
+    actions and the no-op (whose legality is the same question) injected."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    a = VecStrategoEnv(name, n, seed=23, auto_reset=True)
+    b = VecStrategoEnv(name, n, seed=23, auto_reset=True)
+    b.set_lane_kernel(0)
+    a.reset()
+    b.reset()
+    na = a.variant.num_spatial_actions
+    g = torch.Generator(device='cpu').manual_seed(9)
+    ended = 0
+    for t in range(120):
+        a.sample_valid_actions()
+        acts = a.next_actions.clone()
+        junk = torch.randint(-3, na + 3, (n,), generator=g, dtype=torch.int32).to(acts.device)
+        junk = torch.where((torch.rand(n, generator=g) < 0.5).to(acts.device), torch.full_like(junk, a.K - 1), junk)     # the spatial no-op [0,0,K-1]
+        acts = torch.where((torch.rand(n, generator=g) < 0.1).to(acts.device), junk, acts)
+        a.step(acts)
+        b.step(acts, emit_obs=False, emit_mask=False, want_next_actions=False)
+        for x, y, what in ((a.reward, b.reward, 'reward'), (a.done, b.done, 'done'), (a.player, b.player, 'player'),
+                           (a.invalid_action, b.invalid_action, 'invalid'), (a.ending_invalid, b.ending_invalid, 'ending_invalid')):
+            assert torch.equal(x, y), (name, t, what)
+        ended += int(a.done.sum())
+        if t % 30 == 29:
+            assert torch.equal(a.env_info(), b.env_info()), (name, t)
+    assert ended > 0
+    sa, pa = a.export_state()
+    sb, pb = b.export_state()
+    assert torch.equal(sa, sb) and torch.equal(pa, pb)
+    a.close()
+    b.close()

@@ -315,6 +315,12 @@ def test_packed_states_expand_equals_get_next_state(name):
     assert torch.equal(got_states, want_states) and torch.equal(got_players, want_players) and torch.equal(child_players, want_players)
     assert torch.equal(mask_out, pch.get_valid_moves_as_1d_mask(want_states, want_players))
     assert torch.equal(children.valid_moves_as_1d_mask(), mask_out)
+    # the same expansion WITHOUT a mask: the launch only asks whether the next mover has a move (gen_mask<..., ANY>) -- same successors
+    bare = pch.new_packed()
+    valid2, players2 = bare.expand(parents, acts, parent_index=pidx)
+    bs, bp = bare.unpack()
+    assert torch.equal(valid2, want_valid) and torch.equal(bs, want_states) and torch.equal(bp, want_players) and torch.equal(players2, want_players)
+    bare.close()
     # the parents are untouched; copy_from scatters records between pools
     ps, pp = parents.unpack()
     assert torch.equal(ps, states) and torch.equal(pp, players)
@@ -324,6 +330,62 @@ def test_packed_states_expand_equals_get_next_state(name):
     cs, cp = pool.unpack()
     assert torch.equal(cs.flip(0), got_states) and torch.equal(cp.flip(0), got_players)
     for x in (env, ppar, pch, parents, children, pool):
+        x.close()
+
+
+def test_stuck_opponent_behind_a_vetoed_cell_without_a_mask():
+    """The opponent-stuck ending (impl:1031-1036) when the next mover's only way out is the two-square-vetoed cell (impl:439-445): a
+    sergeant is stuck (game over), a scout walks on past the vetoed cell (game goes on) unless the cell behind it is blocked too.
+    Through every path that answers 'does a move exist' without building the mask (sgx_expand, logic-only sgx_step) and through the
+    ones that build it, against the oracle."""
+    import torch
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    v = VARIANTS['barrage']
+    ru = orc.OracleRules(10, 10)
+    states, expect_over = [], []
+    for piece, behind in ((4, 0), (2, 0), (2, 12), (2, -1), (4, -1)):     # X, what stands on (7,9): empty / own bomb / an ENEMY piece there
+        st = np.zeros((34, 10, 10), dtype=np.int64)
+        for r, c in v.obstacle_locations:
+            st[2, r, c] = 1
+        st[5, 0, 0], st[5, 1, 0] = 10, v.max_turns
+        st[0, 0, 0], st[0, 0, 9] = 4, 11                                   # player +1: a sergeant (moves now) and the flag
+        st[1, 9, 9], st[1, 9, 8], st[1, 9, 7] = piece, 12, 11              # player -1: X in the corner, a bomb beside it, the flag
+        if behind > 0:
+            st[1, 7, 9] = behind
+        elif behind < 0:
+            st[0, 7, 9] = 5                                                 # an enemy (player +1) lieutenant: X can attack it ... only a scout reaches it
+        for layer in (0, 1):
+            st[3 + layer] = np.where(st[layer] != 0, 13, 0)
+            st[32 + layer] = (st[layer] != 0)
+        st[7, 9, 9], st[7, 8, 9] = -3, 1                                    # X came (8,9) -> (9,9) and may not go straight back
+        states.append(st)
+    states = np.stack(states)
+    n = len(states)
+    players = np.ones(n, dtype=np.int8)
+    acts = np.full(n, ru.get_action_1d_index_from_positions(0, 0, 1, 0), dtype=np.int64)
+    want = [ru.get_next_state(states[i], 1, int(acts[i])) for i in range(n)]
+    over = [int(w[0][5, 0, 1]) for w in want]
+    assert over == [1, 0, 1, 0, 1], over                                    # sergeant stuck; scout passes; scout blocked behind; scout attacks; sergeant stuck
+    pe = BatchedStrategoProceduralEnv('barrage', n)
+    ns, npl, ok = pe.get_next_state(states, players, acts)
+    parents = pe.pack(states, players)
+    assert int(parents.sanitised.sum()) == 0
+    kids = pe.new_packed()
+    valid, kp = kids.expand(parents, acts)                                   # no mask, no next action: the any-move question
+    ks, kpl = kids.unpack()
+    vec = VecStrategoEnv('barrage', n, auto_reset=False, human_inits=False)
+    vec.import_state(states, players)
+    a32 = torch.from_numpy(acts.astype(np.int32)).to(vec.device)
+    from stratego_env_amd import _lib
+    vec.step(a32, emit_obs=False, emit_mask=False, flags=_lib.STEP_ACTIONS_1D)   # logic-only step: the same question
+    vs, vpl = vec.export_state()
+    for i in range(n):
+        for got, gpl, what in ((ns, npl, 'get_next_state'), (ks, kpl, 'expand'), (vs, vpl, 'logic-only step')):
+            assert np.array_equal(got[i].cpu().numpy(), want[i][0]) and int(gpl[i]) == want[i][1], (i, what)
+        assert bool(ok[i]) and bool(valid[i])
+    assert vec.done.cpu().numpy().tolist() == over
+    for x in (pe, parents, kids, vec):
         x.close()
 
 

@@ -22,7 +22,8 @@ def step_row(f):
 
 def main():
     out = 'gpurun_out/' + sys.argv[1]
-    tags = ('r04_headline', 'r04_inplace', 'r04_micro', 'r04_standard', 'r04_both')
+    rnd = sys.argv[2] if len(sys.argv) > 2 else 'r05'
+    tags = tuple('%s_%s' % (rnd, t) for t in ('untuned_headline', 'inplace', 'micro', 'standard', 'both'))
     for tag in tags:
         d = 'gpurun_out/prof_%s' % tag
         shutil.copy(d + '/summary.txt', 'profiles/%s_pmc_summary.txt' % tag)
@@ -30,16 +31,20 @@ def main():
         shutil.copy(d + '/stats_line.json', 'profiles/%s_stats_line.json' % tag)
         shutil.copy(d + '/traffic_entry.json', 'profiles/%s_traffic_entry.json' % tag)
     for tag in ('headline', 'inplace'):
-        shutil.copy(newest('gpurun_out/r04_tuned/%s/*/*kernel_stats.csv' % tag), 'profiles/r04_tuned_%s_kernel_stats.csv' % tag)
-        shutil.copy('gpurun_out/r04_tuned/%s_line.json' % tag, 'profiles/r04_tuned_%s_line.json' % tag)
-    for src, dst in (('pytest.log', 'r04_gputest.log'), ('smoke.log', 'r04_smoke.log'), ('variant_bench.log', 'r04_variant_bench.log'),
-                     ('lane_ab.log', 'r04_lane_ab.log'), ('procedural_bench.log', 'r04_procedural_bench.log'),
-                     ('soak_parity.log', 'r04_soak_parity.log'), ('soak_procedural.log', 'r04_soak_procedural.log'),
-                     ('phase_cost.log', 'r04_phase_cost_final.log'), ('bench_default.json', 'r04_default_bench_line.json'),
-                     ('bench_driver_style.json', 'r04_driver_style_line.json'), ('bench_default_run2.json', 'r04_default_bench_line_run2.json'),
-                     ('bench_default_run3.json', 'r04_default_bench_line_run3.json')):
+        shutil.copy(newest('gpurun_out/%s_tuned/%s/*/*kernel_stats.csv' % (rnd, tag)), 'profiles/%s_tuned_%s_kernel_stats.csv' % (rnd, tag))
+        shutil.copy('gpurun_out/%s_tuned/%s_line.json' % (rnd, tag), 'profiles/%s_tuned_%s_line.json' % (rnd, tag))
+    for src, dst in (('pytest.log', 'gputest.log'), ('smoke.log', 'smoke.log'), ('variant_bench.log', 'variant_bench.log'),
+                     ('lane_ab.log', 'lane_ab.log'), ('procedural_bench.log', 'procedural_bench.log'),
+                     ('soak_parity.log', 'soak_parity.log'), ('soak_procedural.log', 'soak_procedural.log'),
+                     ('phase_cost.log', 'phase_cost_final.log'), ('bench_default.json', 'default_bench_line.json'),
+                     ('bench_driver_style.json', 'driver_style_line.json'), ('bench_default_run2.json', 'default_bench_line_run2.json'),
+                     ('bench_default_run3.json', 'default_bench_line_run3.json')):
         if os.path.exists(os.path.join(out, src)):
-            shutil.copy(os.path.join(out, src), 'profiles/' + dst)
+            shutil.copy(os.path.join(out, src), 'profiles/%s_%s' % (rnd, dst))
+    for tag in ('procedural', 'kstep_micro'):
+        f = 'gpurun_out/prof_%s_%s/summary.txt' % (rnd, tag)
+        if os.path.exists(f):
+            shutil.copy(f, 'profiles/%s_%s_summary.txt' % (rnd, tag))
     t = json.load(open('profiles/traffic.json'))
     for tag in tags:
         t.update(json.load(open('profiles/%s_traffic_entry.json' % tag)))
@@ -51,8 +56,8 @@ def main():
         d = json.load(open('profiles/%s_stats_line.json' % tag))
         print(tag, step_row('profiles/%s_kernel_stats.csv' % tag), 'line launch_us %.2f' % d['roofline']['launch_us'], 'sets', d['config']['output_sets'], d['build_id'])
     for tag in ('headline', 'inplace'):
-        d = json.load(open('profiles/r04_tuned_%s_line.json' % tag))
-        print('tuned', tag, step_row('profiles/r04_tuned_%s_kernel_stats.csv' % tag),
+        d = json.load(open('profiles/%s_tuned_%s_line.json' % (rnd, tag)))
+        print('tuned', tag, step_row('profiles/%s_tuned_%s_kernel_stats.csv' % (rnd, tag)),
               'line launch_us %.2f value %.1fM frac %.3f' % (d['roofline']['launch_us'], d['value'] / 1e6, d['roofline']['frac']), d['config']['output_sets'])
     for f in ('bench_default', 'bench_default_run2', 'bench_default_run3', 'bench_driver_style'):
         if not os.path.exists('%s/%s.json' % (out, f)):

@@ -2,6 +2,7 @@
 # The round's measurement campaign, ONE gpurun call on the GPU box:  gpurun --timeout 4000 -- 'bash tools/final_campaign.sh <outdir name>'
 # Everything lands under gpurun_out/; tools/collect_profiles.py (in the build container, afterwards) copies what is quoted into profiles/.
 OUT=${1:-final}
+RND=${2:-r05}                                  # prefix of everything this round commits under profiles/
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
@@ -10,20 +11,22 @@ python -m pytest tests -m gpu -q > gpurun_out/$OUT/pytest.log 2>&1; echo PYTEST_
 python bench.py > gpurun_out/$OUT/bench_default.json 2> gpurun_out/$OUT/bench_default.err; echo BENCH_RC $?
 python bench.py --steps 20 --warmup 5 > gpurun_out/$OUT/bench_driver_style.json 2> gpurun_out/$OUT/bench_driver_style.err; echo BENCH2_RC $?
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$OUT/smoke.log 2>&1; tail -1 gpurun_out/$OUT/smoke.log
-bash tools/gpu_profile.sh r04_headline barrage+rotating 65536 > gpurun_out/prof_r04_headline.log 2>&1
-bash tools/gpu_profile.sh r04_inplace barrage 65536 --output-sets 1 > gpurun_out/prof_r04_inplace.log 2>&1
-bash tools/gpu_profile.sh r04_micro micro 65536 --version micro --output-sets 1 > gpurun_out/prof_r04_micro.log 2>&1
-bash tools/gpu_profile.sh r04_standard standard 262144 --version standard --envs 262144 --warmup 300 --output-sets 1 > gpurun_out/prof_r04_standard.log 2>&1
-bash tools/gpu_profile.sh r04_both barrage+full_obs 65536 --full-obs --output-sets 1 > gpurun_out/prof_r04_both.log 2>&1
-cd /tmp; mkdir -p $R/gpurun_out/r04_tuned
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_tuned/headline -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --no-in-place-leg > $R/gpurun_out/r04_tuned/headline_line.json 2> $R/gpurun_out/r04_tuned/headline.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r04_tuned/inplace -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --output-sets 1 > $R/gpurun_out/r04_tuned/inplace_line.json 2> $R/gpurun_out/r04_tuned/inplace.err
-find $R/gpurun_out/r04_tuned -name "*kernel_trace.csv" -delete; find $R/gpurun_out/r04_tuned -name "*.db" -delete
+bash tools/gpu_profile.sh ${RND}_untuned_headline barrage+rotating 65536 > gpurun_out/prof_${RND}_untuned_headline.log 2>&1
+bash tools/gpu_profile.sh ${RND}_inplace barrage 65536 --output-sets 1 > gpurun_out/prof_${RND}_inplace.log 2>&1
+bash tools/gpu_profile.sh ${RND}_micro micro 65536 --version micro --output-sets 1 > gpurun_out/prof_${RND}_micro.log 2>&1
+bash tools/gpu_profile.sh ${RND}_standard standard 262144 --version standard --envs 262144 --warmup 300 --output-sets 1 > gpurun_out/prof_${RND}_standard.log 2>&1
+bash tools/gpu_profile.sh ${RND}_both barrage+full_obs 65536 --full-obs --output-sets 1 > gpurun_out/prof_${RND}_both.log 2>&1
+cd /tmp; mkdir -p $R/gpurun_out/${RND}_tuned
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_tuned/headline -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --no-in-place-leg > $R/gpurun_out/${RND}_tuned/headline_line.json 2> $R/gpurun_out/${RND}_tuned/headline.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_tuned/inplace -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --output-sets 1 > $R/gpurun_out/${RND}_tuned/inplace_line.json 2> $R/gpurun_out/${RND}_tuned/inplace.err
+find $R/gpurun_out/${RND}_tuned -name "*kernel_trace.csv" -delete; find $R/gpurun_out/${RND}_tuned -name "*.db" -delete
 cd $R
 bash tools/variant_bench.sh tuned > gpurun_out/$OUT/variant_bench.log 2>&1
 python tools/soak_parity.py ${SOAK_SECONDS:-150} > gpurun_out/$OUT/soak_parity.log 2>&1; tail -1 gpurun_out/$OUT/soak_parity.log
 python tools/soak_procedural.py 60 > gpurun_out/$OUT/soak_procedural.log 2>&1; tail -1 gpurun_out/$OUT/soak_procedural.log
-python tools/lane_ab.py --specs micro:65536,tiny:65536 --rounds 2 > gpurun_out/$OUT/lane_ab.log 2>&1
+python tools/lane_ab.py --specs micro:65536,tiny:65536,micro:262144 --rounds 2 > gpurun_out/$OUT/lane_ab.log 2>&1
+bash tools/procedural_profile.sh ${RND}_procedural barrage 65536 > gpurun_out/$OUT/procedural_profile.log 2>&1
+bash tools/kstep_profile.sh ${RND}_kstep_micro micro 65536 256 > gpurun_out/$OUT/kstep_micro.log 2>&1
 python tools/procedural_bench.py > gpurun_out/$OUT/procedural_bench.log 2>&1
 for v in barrage standard micro tiny fives; do python tools/phase_cost.py $v 65536 2>&1 | grep -v "^/opt"; done > gpurun_out/$OUT/phase_cost.log
 for i in 2 3; do python bench.py > gpurun_out/$OUT/bench_default_run$i.json 2> gpurun_out/$OUT/bench_default_run$i.err; done

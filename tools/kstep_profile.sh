@@ -16,23 +16,32 @@ for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc$i -- python3 $R/tools/kstep_probe.py $VERSION $GAMES $STEPS > $OUT/pmc$i.log 2>&1
 done
 cd $R
-python3 - "$OUT" "$STEPS" > $OUT/summary.txt <<'PY'
+python3 - "$OUT" "$STEPS" "$GAMES" > $OUT/summary.txt <<'PY'
 import csv, glob, sys, collections
-out, steps = sys.argv[1], int(sys.argv[2])
+out, steps, games = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+# tools/kstep_probe.py launches lane_steps_kernel 7 times: 8 warm-up steps, then 3 x `steps` in place, then 3 x `steps` into a ring of three
+def mode_of(k, n):
+    return 'warm-up' if k == 0 else ('in place' if k < n - 3 else 'ring of 3')
 for f in glob.glob(out + '/trace/**/*kernel_trace.csv', recursive=True):
     rows = [r for r in csv.DictReader(open(f)) if 'lane_steps_kernel' in r['Kernel_Name']]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
     for k, r in enumerate(rows):
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-        print("launch %d (%s): %.1f us = %.2f us per step" % (k, 'in place' if k < len(rows) - 3 else 'ring of 3', d, d / steps))
+        n = 8 if k == 0 else steps
+        print("launch %d (%s, %d steps): %.1f us = %.2f us per step" % (k, mode_of(k, len(rows)), n, d, d / n))
 agg = collections.defaultdict(list)
 for f in sorted(glob.glob(out + '/pmc*/**/*counter_collection.csv', recursive=True)):
     rows = [r for r in csv.DictReader(open(f)) if 'lane_steps_kernel' in r['Kernel_Name']]
     ids = sorted({int(r['Dispatch_Id']) for r in rows})
     for r in rows:
         k = ids.index(int(r['Dispatch_Id']))
-        agg[(r['Counter_Name'], 'in place' if k < len(ids) - 3 else 'ring of 3')].append(float(r['Counter_Value']))
+        agg[(r['Counter_Name'], mode_of(k, len(ids)))].append(float(r['Counter_Value']))
+print("# counters of %d games: mean per launch of %d steps, per step, per game and step" % (games, steps))
 for (c, mode), v in sorted(agg.items()):
-    print("%-24s %-10s n=%d mean per launch %.4g   per step %.4g" % (c, mode, len(v), sum(v) / len(v), sum(v) / len(v) / steps))
+    if mode == 'warm-up':
+        continue
+    m = sum(v) / len(v)
+    print("%-24s %-10s n=%d per launch %.4g   per step %.4g   per game-step %.4g" % (c, mode, len(v), m, m / steps, m / steps / games))
 PY
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
 cat $OUT/summary.txt

@@ -28,11 +28,16 @@ def collect(pat):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == '--traffic-entry':
         key, games, pat, src = sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+        total_steps = int(sys.argv[6]) if len(sys.argv) > 6 else 8        # steps a PMC pass of tools/gpu_profile.sh plays: --warmup 2 + --steps 6
         _, agg = collect(pat)
         mean = {}
         for (f, k, c), v in agg.items():
             if k.startswith('void step_kernel'):
                 mean[c] = sum(v) / len(v)
+        if not mean:      # boards of at most 16 cells: the steps of a call are ONE launch (lane_steps_kernel): counters per STEP = sum over launches / steps
+            for (f, k, c), v in agg.items():
+                if k.startswith('void lane_steps_kernel'):
+                    mean[c] = sum(v) / total_steps
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from stratego_env_amd import build as B
         e = {"games_per_launch": games, "fetch_size_kib": mean.get('FETCH_SIZE'), "write_size_kib": mean.get('WRITE_SIZE'),
