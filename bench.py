@@ -889,6 +889,17 @@ def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_
                 res[mode]["steps"] += steps_per_round
         env.set_nt_stores('auto')
         assert int(env.invalid_action.sum()) == 0
+        # the chooser on its own: back-to-back calls on the last logits and the current mask (the in-loop figure brackets the copy of the
+        # logged actions too and starts from the caches the matmul left behind)
+        ce = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for _ in range(3):
+            env.choose_actions(logits_buf, 1.0, out=chosen)
+        ce[0].record()
+        for _ in range(20):
+            env.choose_actions(logits_buf, 1.0, out=chosen)
+        ce[1].record()
+        torch.cuda.synchronize()
+        chooser_us = ce[0].elapsed_time(ce[1]) / 20 * 1e3
         # ---- replay the logged actions of the sampled envs on the CPU oracle
         orc, cv = oracle_variant(version)
         acts, dones = act_log.cpu().numpy(), done_log.cpu().numpy()
@@ -935,7 +946,8 @@ def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_
                             "%d rounds x %d steps per store policy, interleaved" % (n, version, rounds, steps_per_round),
                 "nt_stores": nt, "plain_stores": plain,
                 "chooser": {"kernel": "choose_kernel<%d,%d,4,false>" % (v.rows, v.columns), "bytes_per_game": 4 * na + na + 4 + 32,
-                            "frac": (4 * na + na + 36) * n / (nt["chooser_us_in_loop"] * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                            "us_per_call_back_to_back": chooser_us, "bound": "hbm (reads)",
+                            "frac": (4 * na + na + 36) * n / (chooser_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
                 "torch_composed_chooser": dict(rep('torch'), note="the round-4 consumer: masked_fill + softmax + multinomial as torch ops"),
                 "default_policy_at_this_size": "nt_stores (observation bytes per launch > 300 MB)",
                 "nt_over_plain_step_kernel": nt["step_kernel_us_in_loop"] / plain["step_kernel_us_in_loop"],

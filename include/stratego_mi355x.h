@@ -292,8 +292,9 @@ int sgx_step(sgx_env *h, const sgx_step_io *io, void *stream);
  * complete) makes env.step() ONE library call: no upload, no download, no second launch.  Meant for a handful of games; batches
  * belong in HBM.  Up to 8 games on a board of more than 32 cells with a multiple of 4 cells, 'extended' channel modes, are played by a
  * kernel of their own -- one workgroup per game: one wave plays the move, all eight emit the mask and the observations -- which
- * publishes its completion in a host-mapped word that sgx_step_sync polls (a busy wait on the calling thread, like a spinning stream
- * synchronisation; it looks at the stream now and then so that a failed launch ends it): the call returns when the outputs are visible to the host,
+ * publishes its completion in a host-mapped word that sgx_step_sync polls -- spinning for about a millisecond (a step is ~6 us), then
+ * yielding the core between polls, then backing off to sleeps of 2 ... 64 us, looking at the stream so that a failed launch ends the
+ * wait: a long wait costs the host next to nothing -- and the call returns when the outputs are visible to the host,
  * typically before `stream` has retired the kernel (later work on `stream` is ordered behind it as usual).  Every other case is
  * sgx_step + hipStreamSynchronize.  Same results either way (tests/test_gpu_step_sync.py).
  * No reference counterpart (the reference is one game per object on the host, maenv:659-828). */
@@ -323,8 +324,9 @@ int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, int32_t fi
  * stream waits for all chains; results are identical to sgx_step_n.  Measured with chains = 2 on 65,536 games: Micro 41.3 -> 37.2 us per
  * step of all games, 5x5 107.6 -> 96.0 us, 8x8 198 -> 183 us, Barrage 322 -> 304 us.  chains = 0 lets the
  * library choose by the rule measured on the current kernels (2 for boards of up to 36 cells and for boards whose cell count is no
- * multiple of 4, else 1: 8x8 and 10x10 launches already stream at the memory rate and lose 2-5 % to a second chain).  No reference
- * counterpart. */
+ * multiple of 4, else 1: 8x8 and 10x10 launches already stream at the memory rate and lose 2-5 % to a second chain; boards of at most
+ * 16 cells take the multi-step launch of sgx_set_multi_step instead wherever the call is eligible: faster than two chains).  No
+ * reference counterpart. */
 #define SGX_MAX_CHAINS 4
 int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int32_t chains, void *stream);
 

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <sched.h>
+#include <time.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -1052,13 +1053,19 @@ int step_single(sgx_env *h, const KParams &p, bool full, hipStream_t stream, boo
     // poll the word the last workgroup writes after a system-scope fence; look at the stream now and then, so that a launch that
     // failed on the device ends the wait with its error instead of hanging
     volatile uint32_t *flag = h->sync_flag_host;
-    // a step is ~6 us of kernel: spin with `pause` for the first ~2^14 polls (about a millisecond), then yield the core between
-    // polls and look at the stream every 256th time, so that a launch that failed on the device -- or a device that hangs -- neither
-    // pins a host core nor waits for ever without noticing
+    // a step is ~6 us of kernel: spin with `pause` for the first ~2^14 polls (about a millisecond); then yield the core between polls
+    // for ~4,000 polls; then BACK OFF -- sleep between polls, 2 us doubling up to 64 us -- so that a long wait (a queue backed up behind
+    // other work, a device that hangs) costs next to nothing on the host.  From the yielding phase on the stream is looked at every 256th
+    // poll (every poll once sleeping), so that a launch that failed on the device ends the wait with its error instead of hanging.
     for (uint32_t spins = 0; *flag != seq; ++spins) {
-        const bool slow = spins >= (1u << 14);
-        if (slow) sched_yield(); else __builtin_ia32_pause();
-        if (slow && (spins & 0xFF) == 0) {
+        const bool slow = spins >= (1u << 14), sleeping = spins >= (1u << 14) + 4096u;
+        if (sleeping) {
+            const uint32_t k = (spins - ((1u << 14) + 4096u)) >> 4;                  // 16 polls per back-off level
+            struct timespec ts = {0, (long)(2000u << (k < 5u ? k : 5u))};
+            nanosleep(&ts, nullptr);
+        } else if (slow) sched_yield();
+        else __builtin_ia32_pause();
+        if (sleeping || (slow && (spins & 0xFF) == 0)) {
             const hipError_t q = hipStreamQuery(stream);
             if (q == hipSuccess) break;                          // the kernel has retired: its stores are visible
             if (q != hipErrorNotReady) return fail(SGX_EDEVICE, "sgx_step_sync: %s", hipGetErrorString(q));
@@ -1158,11 +1165,20 @@ SGX_API int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int3
     // chains = 0: the measured rule (profiles/r04_variant_bench.log, 65,536 games in place): two chains gain where one launch leaves
     // the chip part empty -- boards of up to 36 cells (Micro +19 %, Tiny +4 %, 5x5 +3 %, 6x6 +5 %) and boards whose cell count is no
     // multiple of 4 (15x15 +4 %) -- and lose 2-5 % on 8x8 / 10x10, whose single launch already streams at the memory rate
-    if (chains == 0) chains = (cells <= 36 || cells % 4 != 0) ? 2 : 1;
+    SGX_ON_DEVICE(h->device);
+    if (chains == 0) {
+        // ... and since round 5 boards of at most 16 cells have something better than two chains of launches: all steps in ONE launch
+        // (lane_steps_kernel: Micro 29 us per step against 35 with two chains) wherever the call is eligible
+        KParams p0 = make_params(h);
+        p0.mode = 0;
+        bool launched = false;
+        if (int rc = launch_lane_steps(h, p0, io, 1, 0, n_steps, stream, &launched)) return rc;
+        if (launched) return SGX_OK;
+        chains = (cells <= 36 || cells % 4 != 0) ? 2 : 1;
+    }
     const int64_t unit = 8 * 8 * (cells <= 16 ? 4 : (cells <= 32 ? 2 : 1));     // 8 workgroups x SGX_WPB waves x Geo::GPW games
     int64_t per = (h->n_envs / chains) / unit * unit;
     if (chains == 1 || per == 0 || n_steps == 0) return sgx_step_n(h, io, n_steps, stream);
-    SGX_ON_DEVICE(h->device);
     if (!h->chain_fork) HIP_TRY(hipEventCreateWithFlags(&h->chain_fork, hipEventDisableTiming));
     for (int c = 0; c < chains; ++c) {
         if (!h->chain_stream[c]) HIP_TRY(hipStreamCreateWithFlags(&h->chain_stream[c], hipStreamNonBlocking));
