@@ -64,6 +64,7 @@ if ROOT not in sys.path:
 
 BASE_SEED = 0x5712A7E60
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PIN_RATE_GBS = 8192.0   # 8 stacks x 1,024 pins x 8 Gbit/s: what the "8 TB/s" of the data sheet rounds
 GAMES_1GPU, GAMES_PER_GPU_MULTI, STRONG_TOTAL = 65536, 262144, 2097152
 
 
@@ -136,6 +137,60 @@ def measured_traffic(key, n_envs, build_id=None):
         return e['hbm_bytes_per_launch'] * (n_envs / e['games_per_launch']), src + " (measured at %d games per launch, scaled per game)" % e['games_per_launch']
     except Exception:
         return None, None
+
+
+def live_traffic(version, n_envs, output_sets, full_obs=False, timeout=240):
+    """HBM bytes per launch of the headline's kernel measured NOW, on this box and this binary: two short child processes of this
+    script (`--traffic-probe`: the same env, 2 + 6 rollout steps into the same number of output sets) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- separate passes, run from /tmp with TMPDIR=/tmp, the program
+    itself after `--`: MI355X_MICROARCH.md's recipe -- and the guide's gfx950 correction: bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024,
+    mean over the step kernel's dispatches.  The children start after every timed region of this process is over.
+    -> (bytes per launch, source) or (None, why not)."""
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    if 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):
+        return None, "this run is itself under a profiler: no nested rocprofv3"
+    vals = {}
+    probe_steps = 2 + 6                  # what traffic_probe plays
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = tempfile.mkdtemp(prefix='sgx_traffic_', dir='/tmp')
+            cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.abspath(__file__),
+                   '--traffic-probe', '--version', version, '--envs', str(n_envs), '--output-sets', str(output_sets)] + (['--full-obs'] if full_obs else [])
+            env = dict(os.environ, TMPDIR='/tmp')
+            p = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+            rows = []
+            for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
+                rows += [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter and 'observe_kernel' not in r['Kernel_Name'] and
+                         any(k in r['Kernel_Name'] for k in ('step_kernel<', 'steps_kernel<'))]
+            shutil.rmtree(out, ignore_errors=True)
+            if p.returncode != 0 or not rows:
+                return None, "rocprofv3 --pmc %s over the probe gave no step kernel rows (rc %d: %s)" % (counter, p.returncode, p.stderr.decode('utf-8', 'replace')[-200:].replace('\n', ' '))
+            multi = any('steps_kernel<' in r['Kernel_Name'] for r in rows)          # multi-step launches: counters per STEP = sum over the launches / steps played
+            total = sum(float(r['Counter_Value']) for r in rows)
+            vals[counter] = (total / probe_steps if multi else total / len(rows), probe_steps if multi else len(rows))
+    except Exception as e:          # noqa: BLE001 -- a profiler that is not usable here must not cost the run its line
+        return None, "%s: %s" % (type(e).__name__, str(e)[:160])
+    byts = (2.0 * vals['FETCH_SIZE'][0] + vals['WRITE_SIZE'][0]) * 1024.0
+    return byts, ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two passes) over a child of this run on this box and binary "
+                  "(the same env, %d + %d steps averaged), (2 x FETCH_SIZE %.0f KiB + WRITE_SIZE %.0f KiB) x 1024 per step" %
+                  (vals['FETCH_SIZE'][1], vals['WRITE_SIZE'][1], vals['FETCH_SIZE'][0], vals['WRITE_SIZE'][0]))
+
+
+def traffic_probe(args):
+    """--traffic-probe (the child of live_traffic, under rocprofv3): the headline's env, 2 + 6 rollout steps, nothing printed."""
+    import torch
+    env = make_env(args.version, args.envs, 0, 0, full_obs=args.full_obs)
+    if args.output_sets >= 2:
+        env.alloc_output_ring(args.output_sets)
+    env.rollout_steps(2, ring=args.output_sets >= 2)
+    env.rollout_steps(6, ring=args.output_sets >= 2)
+    torch.cuda.synchronize()
+    env.close()
 
 
 def oracle_variant(version):
@@ -235,6 +290,10 @@ def parse_args(argv=None):
                          '(tests/test_gpu_two_ranks.py)')
     ap.add_argument('--backend', default=None, choices=('nccl', 'gloo'),
                     help='process-group backend of the reporting reductions (default nccl = RCCL; gloo when ranks share a GPU)')
+    ap.add_argument('--no-live-traffic', action='store_true',
+                    help="roofline.traffic from profiles/traffic.json only (static); default on one GPU: measured now by two short children of this "
+                         "run under rocprofv3 --pmc (about 20 s), the static entry kept as roofline.traffic_static")
+    ap.add_argument('--traffic-probe', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--dry-run', action='store_true',
                     help="launcher self-test on CPU: gloo, stub env, no measurement (value is null)")
     args = ap.parse_args(argv)
@@ -772,8 +831,13 @@ def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, fir
                              "again: DRAM side" % ring_sets if ring_sets > 1 else
                              "outputs written in place (one set of tensors): memory side including the 256 MiB Infinity Cache where a set fits it"),
            "bytes_per_launch": min_bytes, "b_min_bytes_per_step": per_step,
-           "kernel": ("lane_steps_kernel<%d,%d> (%d steps per launch: launch_us and the bytes are per STEP)" % (v.rows, v.columns, fused_steps)) if fused_steps > 1
-                     else "step_kernel<%d,%d,%d,false>" % (v.rows, v.columns, 1 if full_obs else 0), "launch_us": launch_s * 1e6,
+           "kernel": ("%s<%d,%d%s> (multi-step launches of %g steps: launch_us and the bytes are per STEP; a kernel trace's duration of this kernel / its steps "
+                      "is the same figure)" % ("lane_steps_kernel" if v.rows * v.columns <= 16 and (v.rows * v.columns) % 4 == 0 else "steps_kernel", v.rows, v.columns,
+                                               "" if v.rows * v.columns <= 16 and (v.rows * v.columns) % 4 == 0 else (",1" if full_obs else ",0"), fused_steps)) if fused_steps > 1
+                     else "step_kernel<%d,%d,%d,false>" % (v.rows, v.columns, 1 if full_obs else 0), "launch_us": launch_s * 1e6, "steps_per_launch": fused_steps,
+           # (a multi-step launch on well-placed buffers reads 1.00-1.02 here: the guide's 8 TB/s is the data sheet's rounded figure; the pins' own
+           #  rate is 8,192 GB/s, and the bytes are the run's own counter bytes -- `traffic`, rocprofv3 WRITE_SIZE + 2 x FETCH_SIZE)
+           "peak_pin_rate": HBM_PIN_RATE_GBS, "frac_of_pin_rate": ach / HBM_PIN_RATE_GBS,
            "frac_dram": None, "traffic": traffic, "traffic_source": source,
            "traffic_over_b_min": (traffic / min_bytes) if traffic else None,
            # the same kernel writing the allocation the process got first (observe launch of the placement trial's first candidate):
@@ -788,10 +852,27 @@ def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, fir
     return out
 
 
+WSTEPS_MAX_PER_LAUNCH = 256       # SGX_WSTEPS_MAX_PER_LAUNCH: a rollout call of the wave-per-game kernels goes out in launches of at most this many steps
+
+
 def fused_launch(env):
-    """True if the env's last rollout was ONE multi-step launch (sgx_last_launch_kind: boards of at most 16 cells)."""
+    """True if the env's last rollout ran as multi-step launches (sgx_last_launch_kind): the games stay on the chip between the steps of a
+    launch -- registers on boards of at most 16 cells (lane_steps_kernel), LDS elsewhere (steps_kernel) -- and the record travels once per
+    LAUNCH."""
     from stratego_env_amd import _lib
-    return (not DRY_RUN) and env.last_launch_kind == _lib.LAUNCH_MULTI_STEP
+    return (not DRY_RUN) and env.last_launch_kind in (_lib.LAUNCH_MULTI_STEP, _lib.LAUNCH_MULTI_STEP_WAVE)
+
+
+def fused_steps_of(env, steps):
+    """Steps per launch of the env's last rollout of `steps` steps (1 = one launch per step): what the per-step byte minimum divides the
+    record traffic by.  The wave-per-game multi-step kernel chunks a call into launches of at most WSTEPS_MAX_PER_LAUNCH steps."""
+    from stratego_env_amd import _lib
+    if DRY_RUN or not fused_launch(env):
+        return 1
+    if env.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE:
+        n_launches = -(-steps // WSTEPS_MAX_PER_LAUNCH)
+        return steps / float(n_launches)
+    return steps
 
 
 def rotating_leg(rk, env, args, version, v, steps, warmup, n_sets, full_obs=False, verify=8):
@@ -805,7 +886,7 @@ def rotating_leg(rk, env, args, version, v, steps, warmup, n_sets, full_obs=Fals
     reports = env.alloc_output_ring(n_sets, tune=tune, max_extra_bytes=budget, trials=args.placement_trials, wide_extra_bytes=wide)
     elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, warmup, ring=True)
     assert invalid == 0
-    fused = steps if fused_launch(env) else 1
+    fused = fused_steps_of(env, steps)
     checked = verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
     launch_s = dev_ms / 1e3 / steps
     per_set = [(round(r['obs'][0], 1), round(min(r['obs']), 1)) if (r and r.get('obs')) else None for r in reports]
@@ -1010,14 +1091,14 @@ def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, 
         _, probe_ms, _, _, _ = time_workload(rk, env, 8, 8)
         steps = int(max(16, min(4096, seconds * 1e3 / max(probe_ms / 8, 1e-3))))
         elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, 4)
-        fused = steps if fused_launch(env) else 1          # boards of at most 16 cells: the timed steps were ONE launch, the games in registers
+        fused = fused_steps_of(env, steps)                 # multi-step launches: the games stay on the chip between the steps, the record travels once per launch
         two, per_step_launches = None, None
         if chains > 1:                     # the same steps with the batch split over concurrent chains of launches (sgx_rollout)
             e2, d2, _, _, inv2 = time_workload(rk, env, steps, 4, chains=chains)
             assert inv2 == 0
             two = {"chains": chains, "value": n * steps / e2, "us_per_step": d2 / steps * 1e3,
                    "frac": b_min(v, full_obs, env.record_bytes) * n / (d2 / 1e3 / steps) / 1e9 / HBM_PEAK_GBS}
-        if fused > 1:                      # ... and one launch per step (what every round before this one measured), same env object
+        if fused > 1 and chains > 1:       # ... and one launch per step (what every round before this one measured), same env object
             env.set_multi_step(False)
             e3, d3, _, _, inv3 = time_workload(rk, env, steps, 4)
             env.set_multi_step(True)
@@ -1168,7 +1249,7 @@ def run_rank(args):      # noqa: C901
     solo = solo_anchor(rk, env, args.steps, args.warmup, unfused=args.unfused, chains=args.chains, ring=headline_ring)
     elapsed, dev_ms, own, games, invalid = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring)
     assert invalid == 0, "rollout produced invalid actions"
-    fused = args.steps if (not dry and fused_launch(env)) else 1        # boards of at most 16 cells: the K timed steps were ONE launch
+    fused = fused_steps_of(env, args.steps) if not dry else 1           # multi-step launches: the record travels once per launch, not per step
     # outside the timed region: the envs that were just timed against the CPU oracle, and the sharding-independent checksum
     checked = verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if (args.verify_envs and not dry) else 0
     verified_steps = env.bench_steps_played
@@ -1183,6 +1264,16 @@ def run_rank(args):      # noqa: C901
         no_settle = {"workload": "the headline's K steps once more WITHOUT gpu_settle: %d warm-up steps, then the bracket" % args.warmup,
                      "value": total * args.steps / e0, "unit": "env steps/s", "launch_us": d0 / args.steps * 1e3,
                      "frac": per_step * n / (d0 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
+    per_step_launches = None
+    if not dry and fused > 1 and not args.no_settle_leg:
+        # ... and with one launch per step (sgx_set_multi_step(0): what every round before this one measured), same env object and buffers
+        env.set_multi_step(False)
+        e4, d4, _, _, inv4 = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring)
+        env.set_multi_step(True)
+        assert inv4 == 0
+        per_step_launches = {"workload": "the headline's K steps once more as K launches of the per-step kernel (step_kernel)", "value": total * args.steps / e4,
+                             "unit": "env steps/s", "launch_us": d4 / args.steps * 1e3,
+                             "frac": b_min(v, args.full_obs, rec_bytes) * n / (d4 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
     if rk.world == 1 and headline_ring and not args.no_in_place_leg and not dry:
         # The same K / W on the same env object into ONE set of tensors (the set the ring wrote last), step after step: what rounds 1-3
         # reported as the headline.  Rewriting the same 1-2 GB back to back is 8-10 % faster than anything that cannot reuse its lines
@@ -1231,7 +1322,7 @@ def run_rank(args):      # noqa: C901
                        "games_finished_in_timed_region": games, "b_min_bytes_per_step": per_step, "steps_per_launch": fused,
                        "record_bytes": rec_bytes,
                        "untimed_before_bracket": "%d warm-up steps, then %.2f s of state-preserving sgx_observe launches (gpu_settle)" % (args.warmup, SETTLE_SECONDS),
-                       "no_settle": no_settle,
+                       "no_settle": no_settle, "one_launch_per_step": per_step_launches,
                        "output_sets": args.output_sets if headline_ring else 1, "ring_placement_plain_and_kept_us_per_extra_set": ring_report,
                        "concurrent_chains": args.chains, "in_place": in_place, "two_chains": two_chains,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),
@@ -1280,6 +1371,16 @@ def run_rank(args):      # noqa: C901
                                                 # BASELINE config 5's per-GPU size on ONE GPU: the G = 1 anchor of the 1 / 2 / 4 / 8 curve
                                                 other_workload(rk, args, 'barrage', GAMES_PER_GPU_MULTI)]
             out["config"]["compact_outputs"] = compact_leg(rk, args)
+        if rk.world == 1 and not dry and not args.no_live_traffic and not args.unfused:
+            # the counter bytes of the headline's kernel, measured now (after every timed region): two children under rocprofv3 --pmc
+            rf = out["roofline"]
+            rf["traffic_static"], rf["traffic_static_source"] = rf["traffic"], rf["traffic_source"]
+            live, src = live_traffic(args.version, n, args.output_sets if headline_ring else 1, full_obs=args.full_obs)
+            if live:
+                rf["traffic"], rf["traffic_source"] = live, src
+                rf["traffic_over_b_min"] = live / rf["bytes_per_launch"]
+            else:
+                rf["traffic_live_failed"] = src
         if not args.no_cpu_baseline and rk.world == 1 and not dry:         # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
         else:
@@ -1291,6 +1392,8 @@ def run_rank(args):      # noqa: C901
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
+    if args.traffic_probe:
+        return traffic_probe(args)
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ and args.gpus > 1:

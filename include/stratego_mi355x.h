@@ -200,6 +200,7 @@ int sgx_set_multi_step(sgx_env *h, int32_t mode);
 #define SGX_LAUNCH_WAVE 0        /* one wave per game (boards of up to 32 cells: a wave's lanes shared by 2 or 4 games), one launch per step */
 #define SGX_LAUNCH_LANE 1        /* one game per lane (boards of at most 16 cells), one launch per step */
 #define SGX_LAUNCH_MULTI_STEP 2  /* one game per lane, all steps of the call in one launch (sgx_set_multi_step) */
+#define SGX_LAUNCH_MULTI_STEP_WAVE 3   /* one wave per game, all steps of the call in one launch: the boards stay in LDS between the steps */
 int sgx_last_launch_kind(const sgx_env *h);
 
 /* Shares of the eight XCDs in a launch of sgx_step / sgx_observe.  Under a saturating write stream the odd XCDs of MI355X drain their

@@ -19,7 +19,7 @@ STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, S
 STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
 STEP_COMPACT_OBS, STEP_COMPACT_MASK = 128, 256
 OUT_FULL_OBS, OUT_MAX_TRIALS = 1024, 64
-LAUNCH_WAVE, LAUNCH_LANE, LAUNCH_MULTI_STEP = 0, 1, 2
+LAUNCH_WAVE, LAUNCH_LANE, LAUNCH_MULTI_STEP, LAUNCH_MULTI_STEP_WAVE = 0, 1, 2, 3
 
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (

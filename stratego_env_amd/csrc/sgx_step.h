@@ -140,12 +140,12 @@ __device__ __forceinline__ GameInput load_game(const KParams &P, const int64_t e
 // The compact observation of one game (SGX_STEP_COMPACT_OBS): build the code buffer exactly as render() does, then store it as it is.
 // One call site (env_step), outside render(): see there.
 template <class G, class Spec, int NB>
-__device__ __forceinline__ void compact_obs(const KParams &P, Lds<G, NB> &L, const uint8_t *shared, const uint8_t *codetab, const float *glut, bool raw, int qi,
+__device__ __forceinline__ void compact_obs(const KParams &P, float *obs_dev, Lds<G, NB> &L, const uint8_t *shared, const uint8_t *codetab, const float *glut, bool raw, int qi,
                                          int n_events, int rp0, int rp1, int64_t env, int lane) {
     const uint8_t *tmpl = shared;
     if constexpr (G::WIDE) tmpl = P.tab->tmpl[raw ? 2 : 0];
     const int n_unc = build_codes<G, Spec>(L, tmpl, codetab, glut, qi, n_events, rp0, rp1, lane, P.piece_counts, raw, P.multi_ev != 0);
-    store_compact<G, Spec>(L, reinterpret_cast<uint8_t *>(P.io.obs_dev) + env * (int64_t)P.compact_stride, n_unc, lane);
+    store_compact<G, Spec>(L, reinterpret_cast<uint8_t *>(obs_dev) + env * (int64_t)P.compact_stride, n_unc, lane);
 }
 
 // What the emission of the next mover's mask and observations needs from the step (SPLIT instantiation: single_kernel)
@@ -153,13 +153,27 @@ struct StepOut {
     int qi, n_events, rp0, rp1, n_unc;
 };
 
+// What a game carries from one step of a multi-step launch (steps_kernel) to the next while its boards stay in LDS: the record's scalars, the
+// action the step drew, and whether the record in HBM is stale.
+struct StepCarry {
+    int turn, flags, max_turns, game_no, n_events, rp0, rp1, na;
+    bool dirty;
+    float *obs, *fobs;        // this step's output tensors (the output set of an sgx_step_ring): the caller sets them before every step
+    uint8_t *mask;
+};
+
 // One game's env.step() by one wave (called with the wave's private LDS region).
 // `shared` = the workgroup's tables (shared_table_bytes): templates + code table, or LUTs + quad tables
 // SPLIT: the next mover's mask and observations are NOT emitted here -- the caller does it with the whole workgroup from the LDS
 // state this function leaves behind and the scalars in *so.
-template <int R_, int C_, int KIND, bool MAPPED, bool SPLIT = false, int VAR = 0>
+// PERSIST_ (steps_kernel): the call is one of several consecutive steps of the same game by the same wave.  Only the FIRST stages the record;
+// later ones find the boards -- dense, never-moved bytes, recent-move codes, the event list -- where the step before left them in LDS,
+// take the scalars and the action from *carry, and only the LAST writes the record back (if any step changed it).
+template <int R_, int C_, int KIND, bool MAPPED, bool SPLIT = false, int VAR = 0, int PERSIST_ = 0>
 __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>, ObsKind<KIND>::NIB_CH> &L, const uint8_t *shared, const uint8_t *obst_s,
-                                         const int64_t env, const int lane, const GameInput &in, int8_t *rec_out = nullptr, StepOut *so = nullptr) {
+                                         const int64_t env, const int lane, const GameInput &in, int8_t *rec_out = nullptr, StepOut *so = nullptr,
+                                         StepCarry *carry = nullptr, const bool last = true) {
+    constexpr bool PERSIST = PERSIST_ != 0, first = PERSIST_ != 2;      // PERSIST_: 0 = a launch of its own, 1 = the first step of a multi-step launch, 2 = a later one
     using G = Geo<R_, C_, VAR>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
@@ -167,6 +181,9 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     const uint8_t *combat_s = obst_s + G::OBST_BYTES;           // the combat table follows the obstacle map in the shared LDS
     constexpr int R = G::R, C = G::C, RC = G::RC, S = G::S, K = G::K, NA = G::NA, MPA = G::MPA, AS = G::AS;
     STAMP(0);
+    // the step's output tensors: the launch's, or -- one of several steps of a multi-step launch -- this step's output set
+    float *const io_obs = PERSIST ? carry->obs : P.io.obs_dev, *const io_fobs = PERSIST ? carry->fobs : P.io.fobs_dev;
+    uint8_t *const io_mask = PERSIST ? carry->mask : P.io.mask_dev;
 
     int8_t *rec_g = rec_out ? rec_out : P.boards + env * (int64_t)P.rec_bytes;   // (rec_out: the LDS record image of sgx_step_states)
     // ---- stage.  Every global read of the step has been issued up front (load_game) -- the whole record (a few 128-byte lines)
@@ -175,8 +192,9 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     //      capture events are then read from the LDS image of the record (L.tail has the record's layout from ST_OFF on).
     constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + G::LPG - 1) / G::LPG;
     const int4 rq0 = in.rq0, rq1 = in.rq1;
-    const int a_raw = in.a_raw;
+    const int a_raw = (PERSIST && !first) ? carry->na : in.a_raw;
     const int4 pos_raw = in.pos_raw;
+    if (!PERSIST || first)
     {   // (the loads may still be in flight) clear the recent-move boards and the zero board, copy the obstacle map (shared per
         // workgroup).  (The never-moved boards are written cell by cell below; captured counts are never dense.)
         int4 *dst = reinterpret_cast<int4 *>(&L.b[0][0]);
@@ -204,13 +222,19 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
         }
     }
     wave_sync<G>();
-    const int4 sc = reinterpret_cast<const int4 *>(L.tail + 2 * G::SB)[0], sc2 = reinterpret_cast<const int4 *>(L.tail + 2 * G::SB)[1];
-    int turn = uni<G>(sc.x), flags = uni<G>(sc.y), game_no = uni<G>(sc.w);
-    const int max_turns = uni<G>(sc.z);
-    int n_events = min(uni<G>(sc2.x), (int)G::EVL_MAX);
-    int rp0 = uni<G>(sc2.y), rp1 = uni<G>(sc2.z);   // recent-move pairs of player +1 / -1 (two named scalars: a runtime-indexed
-                                              // array would live in scratch memory)
-    if (!SGX_ABLATED(P.map_arg, 2))
+    int turn, flags, game_no, max_turns, n_events, rp0, rp1;   // (rp0 / rp1: recent-move pairs of player +1 / -1 -- two named scalars: a
+                                                               //  runtime-indexed array would live in scratch memory)
+    if (PERSIST && !first) {
+        turn = carry->turn; flags = carry->flags; game_no = carry->game_no; max_turns = carry->max_turns;
+        n_events = carry->n_events; rp0 = carry->rp0; rp1 = carry->rp1;
+    } else {
+        const int4 sc = reinterpret_cast<const int4 *>(L.tail + 2 * G::SB)[0], sc2 = reinterpret_cast<const int4 *>(L.tail + 2 * G::SB)[1];
+        turn = uni<G>(sc.x); flags = uni<G>(sc.y); game_no = uni<G>(sc.w);
+        max_turns = uni<G>(sc.z);
+        n_events = min(uni<G>(sc2.x), (int)G::EVL_MAX);
+        rp0 = uni<G>(sc2.y); rp1 = uni<G>(sc2.z);
+    }
+    if (!SGX_ABLATED(P.map_arg, 2) && (!PERSIST || first))
     {   // ---- rebuild the derived boards: never-moved bitmaps, recent-move pairs (capture events stay a list)
         const uint32_t *stb = reinterpret_cast<const uint32_t *>(L.tail);
 #pragma unroll
@@ -382,7 +406,7 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     int qi = player == 1 ? 0 : 1;
     // Launches of the no-observation kind that want neither the mask nor a next action (search expansion, sgx_expand; logic-only steps)
     // only need to know WHETHER the next mover has a move (the opponent-stuck ending): no mask bits, no counts, one cell per ray.
-    const bool want_bits = !NOOBS || SPLIT || P.io.mask_dev != nullptr || (P.mode == 0 && P.io.next_actions_dev != nullptr);
+    const bool want_bits = !NOOBS || SPLIT || io_mask != nullptr || (P.mode == 0 && P.io.next_actions_dev != nullptr);
 #ifdef SGX_ABLATE
     if (SGX_ABLATED(P.map_arg, 3)) return;                              // staging only
     int nvalid = gen_mask(L, qi, over, lane, P.map_arg);
@@ -496,49 +520,57 @@ __device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>,
     if constexpr (SPLIT) {
         if (lane == 0) { so->qi = qi; so->n_events = n_events; so->rp0 = rp0; so->rp1 = rp1; }
     } else {
-    if (P.io.mask_dev) {
+    if (io_mask) {
         // MAPPED: the separate instantiation behind SGX_STEP_MASK_1D / SGX_STEP_MASK_STATE_COORDS (kept out of the hot kernel: its
         // 16 index computations per lane cost 30 VGPRs)
-        if (MAPPED && NOOBS && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped_inl(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
-        else if (MAPPED && NOOBS && qi) emit_mask_mapped_inl(L, P.io.mask_dev + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
-        else if (MAPPED && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
-        else if (MAPPED && qi) emit_mask_mapped(L, P.io.mask_dev + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
+        if (MAPPED && NOOBS && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped_inl(L, io_mask + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
+        else if (MAPPED && NOOBS && qi) emit_mask_mapped_inl(L, io_mask + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
+        else if (MAPPED && (P.io.flags & SGX_STEP_MASK_1D)) emit_mask_mapped(L, io_mask + env * (int64_t)AS, AS, Src1D<G>{qi}, lane);
+        else if (MAPPED && qi) emit_mask_mapped(L, io_mask + env * (int64_t)NA, NA, SrcSpatialFlipped<G>{}, lane);
         else if (COMPACT && (P.io.flags & SGX_STEP_COMPACT_MASK)) {   // the mask as bits: uint32 [MB_WORDS] per game, bit a = action a
-            int4 *mdst = reinterpret_cast<int4 *>(reinterpret_cast<uint32_t *>(P.io.mask_dev) + env * (int64_t)G::MB_WORDS);
+            int4 *mdst = reinterpret_cast<int4 *>(reinterpret_cast<uint32_t *>(io_mask) + env * (int64_t)G::MB_WORDS);
             for (int i = lane; i < G::MB_WORDS / 4; i += G::LPG) mdst[i] = reinterpret_cast<const int4 *>(L.mbits)[i];
         }
-        else emit_mask(L, P.io.mask_dev + env * (int64_t)NA, lane);
+        else emit_mask(L, io_mask + env * (int64_t)NA, lane);
     }
     STAMP(5);   // mask stores issued
     // (rendering the observation before the mask, so that its stores drain during mask generation, measured 6 % slower)
     if constexpr (!NOOBS)
-    if (P.io.obs_dev) {
+    if (io_obs) {
         // compact output (opt-in, KIND bit 2): the codes themselves, 1/8 of the bytes; sgx_decode_obs expands them.  An instantiation of
         // its own: as a run-time branch it took the 8x8 hot kernel from 35 to 64 VGPRs + scratch
         bool done_compact = false;
         if constexpr (COMPACT) {
             if (P.io.flags & SGX_STEP_COMPACT_OBS) {
-                compact_obs<G, PS>(P, L, shared, codetab, glut_p, raw, qi, n_events, rp0, rp1, env, lane);
+                compact_obs<G, PS>(P, io_obs, L, shared, codetab, glut_p, raw, qi, n_events, rp0, rp1, env, lane);
                 done_compact = true;
             }
         }
-        if (!done_compact) render(PS{}, false, qi, P.io.obs_dev + env * (int64_t)(RC * PS::NCH));
+        if (!done_compact) render(PS{}, false, qi, io_obs + env * (int64_t)(RC * PS::NCH));
     }
     if constexpr (FULL)
-        if (P.io.fobs_dev) render(FS{}, true, qi, P.io.fobs_dev + env * (int64_t)(RC * FS::NCH));
+        if (io_fobs) render(FS{}, true, qi, io_fobs + env * (int64_t)(RC * FS::NCH));
     }
     STAMP(6);   // obs stores issued
     if (P.mode == 0 && P.io.next_actions_dev) {
         const int total = nvalid == 0 ? 1 : nvalid;
         const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, STREAM_ACTION, (uint32_t)turn), (uint32_t)total);
         const int na = kth_valid(L, (int)k, lane);
-        if (lane == 0) P.io.next_actions_dev[env] = na;
+        if constexpr (PERSIST) carry->na = na;
+        if (lane == 0 && (!PERSIST || last)) P.io.next_actions_dev[env] = na;
     }
 
     STAMP(7);   // next action sampled
     // ---- write the record back as whole 128-byte lines: dense boards, scalars, capture events.  (Scattered stores
     //      of only the <= 9 touched bytes + 32 B of scalars are partial-line writes: measured 7 % slower.)
-    if (applied || wrote_reset || (MAPPED && P.src_boards))
+    bool dirty = applied || wrote_reset || (MAPPED && P.src_boards);
+    if constexpr (PERSIST) {
+        dirty = dirty || (!first && carry->dirty);
+        carry->turn = turn; carry->flags = flags; carry->game_no = game_no; carry->max_turns = max_turns;
+        carry->n_events = n_events; carry->rp0 = rp0; carry->rp1 = rp1; carry->dirty = dirty;
+        if (!last) dirty = false;                  // (the boards stay in LDS; the last step of the launch writes the record)
+    }
+    if (dirty)
         write_record(L, rec_g, G::BIG ? (int)G::IMG_BYTES : P.rec_bytes, make_int4(turn, flags, max_turns, game_no), make_int4(n_events, rp0, rp1, 0), n_events, lane);
     STAMP(8);   // write-back issued
 #ifdef SGX_STAMPS
@@ -606,6 +638,94 @@ __global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_
 template <int R_, int C_, int KIND, bool MAPPED = false>
 __global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND, MAPPED>())) void observe_kernel(const KParams P) {
     game_kernel_body<R_, C_, KIND, MAPPED>(P);
+}
+
+// ---------------------------------------------------------------------------------------------
+// steps_kernel: ALL steps of an sgx_step_n / sgx_step_ring call in one launch, wave-per-game boards.  A workgroup stages its games once and
+// every wave then plays its game step after step (env_step<PERSIST>): the boards stay in LDS, the scalars and the drawn action in
+// registers; the record is read once and written once per launch.  No barrier after the table staging: the waves of a workgroup -- and
+// of the chip -- drift out of phase within a few steps, so one wave's stores run under another's game logic (with one launch per step
+// every residency round starts, plays and stores together: DESIGN.md section 7).  Same results as n_steps launches of step_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int WSTEPS_MAX_SETS = 8;
+struct WaveStepsParams {
+    KParams k;
+    int32_t n_steps, n_sets, first_set;
+    float *obs[WSTEPS_MAX_SETS], *fobs[WSTEPS_MAX_SETS];      // the output tensors of set s (sgx_step_ring); one set: in place
+    uint8_t *mask[WSTEPS_MAX_SETS];
+};
+template <int R_, int C_, int KIND>
+__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND, false>())) void steps_kernel(const WaveStepsParams SP) {
+    using G = Geo<R_, C_>;
+    using PS = typename ObsKind<KIND>::P;
+    using FS = typename ObsKind<KIND>::F;
+    constexpr bool FULL = ObsKind<KIND>::FULL, ORIG = ObsKind<KIND>::ORIG;
+    // The parameters are read through the kernel-argument segment's address, and the loop below hides that address from the optimiser once
+    // per step: otherwise every field env_step looks at is hoisted out of the loop and held in scalar registers for its whole length (106 of
+    // 106 SGPRs, 324 bytes of scratch); re-read per step they cost a few scalar loads from the constant cache.
+#if defined(__HIP_DEVICE_COMPILE__)
+    const WaveStepsParams *spp = (const WaveStepsParams *)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    const WaveStepsParams *spp = &SP;             // (host pass of the single-source compile: never executed)
+#endif
+    const KParams &P = spp->k;
+    __shared__ Lds<G, ObsKind<KIND>::NIB_CH> LW[G::WPB * G::GPW];
+    __shared__ alignas(16) uint8_t shared[shared_table_bytes<G, KIND>()];
+    __shared__ alignas(16) uint8_t obst_s[G::OBST_BYTES + COMBAT_BYTES];
+    const int lane = threadIdx.x & (G::LPG - 1), slot = threadIdx.x / G::LPG;
+    const int64_t env = P.env_first + group_of_block(P) * (G::WPB * G::GPW) + slot;
+    const GameInput in = load_game<G, false>(P, env, lane);
+    const bool raw = (P.io.flags & SGX_STEP_RAW_OBS) != 0;
+    if constexpr (ObsKind<KIND>::NOOBS) {
+    } else if constexpr (ORIG) {
+        float *lut_s = reinterpret_cast<float *>(shared);
+        const f32x4 *lsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[4 + (raw ? 2 : 0)]);
+        for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * G::WPB) reinterpret_cast<f32x4 *>(lut_s)[i] = lsrc[i];
+        build_quad_table<G, PS>(reinterpret_cast<uint32_t *>(lut_s + LUT_DWORDS), threadIdx.x, 64 * G::WPB);
+        if constexpr (FULL) {
+            const f32x4 *fsrc = reinterpret_cast<const f32x4 *>(P.tab->lut[4 + (raw ? 2 : 0) + 1]);
+            for (int i = threadIdx.x; i < LUT_DWORDS / 4; i += 64 * G::WPB) reinterpret_cast<f32x4 *>(lut_s + OBS_TAB_DWORDS)[i] = fsrc[i];
+            build_quad_table<G, FS>(reinterpret_cast<uint32_t *>(lut_s + OBS_TAB_DWORDS + LUT_DWORDS), threadIdx.x, 64 * G::WPB);
+        }
+    } else {
+        constexpr int NP = tmpl_lds_bytes<G, KIND>(false), NF = FULL ? tmpl_lds_bytes<G, KIND>(true) : 0;
+        const int4 *tp = reinterpret_cast<const int4 *>(P.tab->tmpl[raw ? 2 : 0]);
+        for (int i = threadIdx.x; i < NP / 16; i += 64 * G::WPB) reinterpret_cast<int4 *>(shared)[i] = tp[i];
+        if constexpr (FULL) {
+            const int4 *tf = reinterpret_cast<const int4 *>(P.tab->tmpl[(raw ? 2 : 0) + 1]);
+            for (int i = threadIdx.x; i < NF / 16; i += 64 * G::WPB) reinterpret_cast<int4 *>(shared + NP)[i] = tf[i];
+        }
+        const int4 *ct = reinterpret_cast<const int4 *>(P.tab->codetab[raw ? 1 : 0]);
+        for (int i = threadIdx.x; i < CODETAB_BYTES / 16; i += 64 * G::WPB) reinterpret_cast<int4 *>(shared + NP + NF)[i] = ct[i];
+    }
+    for (int i = threadIdx.x; i < G::S / 4; i += 64 * G::WPB) reinterpret_cast<int *>(obst_s)[i] = reinterpret_cast<const int *>(P.tab->obstacles)[i];
+    for (int i = threadIdx.x; i < COMBAT_BYTES / 4; i += 64 * G::WPB)
+        reinterpret_cast<int *>(obst_s + G::OBST_BYTES)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
+    __syncthreads();   // from here on every wave works on its own game, for all n_steps
+    if (env >= P.n_envs) return;
+    StepCarry carry{0, 0, 0, 0, 0, 0, 0, 0, false, nullptr, nullptr, nullptr};
+    int set = spp->first_set;
+    const int n_steps = spp->n_steps;
+    {   // the first step stages the record (its loads were issued before the table staging); its code is a copy of its own, so that the record's
+        // registers are dead in the loop below
+        carry.obs = spp->obs[set];
+        carry.fobs = spp->fobs[set];
+        carry.mask = spp->mask[set];
+        env_step<R_, C_, KIND, false, false, 0, 1>(P, LW[slot], shared, obst_s, env, lane, in, nullptr, nullptr, &carry, n_steps == 1);
+        set = set + 1 == spp->n_sets ? 0 : set + 1;
+    }
+    for (int t = 1; t < n_steps; ++t) {
+        const WaveStepsParams *sp = spp;
+        int lane_t = lane, slot_t = slot;
+        // (the step's reads of the parameters start here; and what a step derives from the lane -- dozens of cell / entry offsets -- is
+        //  recomputed in every step like in a launch of its own, not hoisted out of the loop and spilled: 244 bytes of scratch otherwise)
+        asm volatile("" : "+s"(sp), "+v"(lane_t), "+v"(slot_t));
+        carry.obs = sp->obs[set];
+        carry.fobs = sp->fobs[set];
+        carry.mask = sp->mask[set];
+        env_step<R_, C_, KIND, false, false, 0, 2>(sp->k, LW[slot_t], shared, obst_s, env, lane_t, in, nullptr, nullptr, &carry, t == n_steps - 1);
+        set = set + 1 == sp->n_sets ? 0 : set + 1;
+    }
 }
 
 // sgx_step_sync on a handful of games (the N = 1 facade, config 1): latency, not throughput.  ONE game per 512-thread workgroup: wave 0

@@ -126,6 +126,7 @@ struct sgx_env {
     int no_multi_step;           // SGX_MULTI_STEP=0 (or a runtime that refuses the LDS size): sgx_step_n / sgx_step_ring never take lane_steps_kernel
     int multi_step_attr;         // lane_steps_kernel's dynamic-LDS attribute has been raised
     int last_kind;               // sgx_last_launch_kind: which kernel the last step / observe launch of this handle was
+    int multi_step_wave;         // SGX_MULTI_STEP_WAVE: the multi-step launch of the wave-per-game kernels (steps_kernel) too
 };
 
 namespace {
@@ -398,6 +399,8 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     if (h->xcd_skew > 900) h->xcd_skew = 900;
     if (const char *e = getenv("SGX_NO_SINGLE")) h->no_single = atoi(e);
     if (const char *e = getenv("SGX_MULTI_STEP")) h->no_multi_step = !strcmp(e, "0");
+    h->multi_step_wave = 1;
+    if (const char *e = getenv("SGX_MULTI_STEP_WAVE")) h->multi_step_wave = strcmp(e, "0") != 0;
     if (const char *e = getenv("SGX_MAP")) { h->map_mode = atoi(e); if (const char *c = strchr(e, ',')) h->map_arg = atoi(c + 1); }
     const int rc_cells = cfg->rows * cfg->cols;
     {
@@ -678,7 +681,85 @@ static int launch_lane_steps(sgx_env *h, const KParams &p_in, const sgx_step_io 
     return SGX_OK;
 }
 
-static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_sets = 1) {
+static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_sets = 1);
+
+// The same for the wave-per-game kernels (steps_kernel, sgx_step.h): all n_steps of an sgx_step_n / sgx_step_ring call in ONE launch -- the games'
+// boards stay in LDS, the record travels once per launch, the waves drift out of phase -- for the 67-channel 'extended' kind, BOTH
+// observations, compact outputs and launches without an observation; perspective actions and masks, at most 8 output sets.
+#define SGX_WSTEPS_MAX_PER_LAUNCH 256
+static int launch_wave_steps(sgx_env *h, const KParams &p_in, const sgx_step_io *ios, int32_t n_sets, int32_t first_set, int32_t n_steps, void *stream,
+                             bool *launched) {
+    *launched = false;
+    if (n_steps < 2 || n_sets > WSTEPS_MAX_SETS || h->no_multi_step || !h->multi_step_wave || h->map_mode != 0) return SGX_OK;
+    KParams p = p_in;
+    p.mode = 0;
+    p.io = ios[first_set];
+    const sgx_step_io &io0 = p.io;
+    if (io0.flags & (SGX_STEP_ACTIONS_1D | SGX_STEP_ACTIONS_POSITIONS | SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS | SGX_STEP_ORIGINAL_CHANNELS)) return SGX_OK;
+    const bool compact = (io0.flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) != 0;
+    const bool full = io0.fobs_dev || io0.final_fobs_dev;
+    const bool no_obs = !io0.obs_dev && !io0.fobs_dev && !io0.final_obs_dev && !io0.final_fobs_dev && !compact;
+    if (compact && (full || io0.final_obs_dev)) return SGX_OK;             // (launch_step refuses these: let it say so)
+    if (compact && ((reinterpret_cast<uintptr_t>(io0.obs_dev) | reinterpret_cast<uintptr_t>(io0.mask_dev)) & 15)) return SGX_OK;
+    WaveStepsParams sp;
+    memset(&sp, 0, sizeof(sp));
+    for (int32_t k = 0; k < n_sets; ++k) {
+        const sgx_step_io &io = ios[k];
+        // the sets differ in their output tensors only, and every set has the tensors the first one has
+        if (io.reward_dev != io0.reward_dev || io.done_dev != io0.done_dev || io.player_dev != io0.player_dev || io.invalid_action_dev != io0.invalid_action_dev ||
+            io.ending_invalid_dev != io0.ending_invalid_dev || io.final_obs_dev != io0.final_obs_dev || io.final_fobs_dev != io0.final_fobs_dev ||
+            (io.obs_dev == nullptr) != (io0.obs_dev == nullptr) || (io.fobs_dev == nullptr) != (io0.fobs_dev == nullptr) ||
+            (io.mask_dev == nullptr) != (io0.mask_dev == nullptr)) return SGX_OK;
+        if (compact && ((reinterpret_cast<uintptr_t>(io.obs_dev) | reinterpret_cast<uintptr_t>(io.mask_dev)) & 15)) return SGX_OK;
+        sp.obs[k] = io.obs_dev; sp.fobs[k] = io.fobs_dev; sp.mask[k] = io.mask_dev;
+    }
+    if (int rc = check_step_io(h, p)) return rc;
+    p.map_mode = 0; p.map_arg = h->map_arg;
+    const bool streaming = launch_streams_past_cache(h, p, n_sets);
+    p.nt_stores = h->nt_mode < 0 ? (streaming ? 1 : 0) : h->nt_mode;
+    int32_t skew[8];
+    launch_shares(h, streaming, skew);
+    const int kind = compact ? 4 : no_obs ? 8 : full ? 1 : 0;
+    sp.n_sets = n_sets;
+    // (long rollouts go out in launches of at most SGX_WSTEPS_MAX_PER_LAUNCH steps: a workgroup should not own the chip for seconds)
+    for (int32_t done = 0; done < n_steps; ) {
+        const int32_t now = n_steps - done > SGX_WSTEPS_MAX_PER_LAUNCH ? SGX_WSTEPS_MAX_PER_LAUNCH : n_steps - done;
+        if (now < 2) {                                                      // a single step left over: the ordinary launch
+            KParams p1 = p_in;
+            p1.mode = 0;
+            p1.io = ios[(first_set + done) % n_sets];
+            if (int rc = launch_step(h, p1, stream, n_sets)) return rc;
+            done += now;
+            continue;
+        }
+        sp.n_steps = now;
+        sp.first_set = (first_set + done) % n_sets;
+#define CALL_WSTEPS_K(R, C, KIND)                                                                          \
+    do {                                                                                                   \
+        using G_ = Geo<R, C>;                                                                              \
+        const unsigned grid = shares_for(p, (p.n_envs - p.env_first + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW), skew); \
+        sp.k = p;                                                                                          \
+        steps_kernel<R, C, KIND><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(sp);                      \
+    } while (0)
+#define CALL_WSTEPS(R, C)                                                                                  \
+    do {                                                                                                   \
+        if (kind == 0) CALL_WSTEPS_K(R, C, 0);                                                             \
+        else if (kind == 1) CALL_WSTEPS_K(R, C, 1);                                                        \
+        else if (kind == 4) CALL_WSTEPS_K(R, C, 4);                                                        \
+        else CALL_WSTEPS_K(R, C, 8);                                                                       \
+    } while (0)
+        DISPATCH_GEOMETRY(h, CALL_WSTEPS);
+#undef CALL_WSTEPS
+#undef CALL_WSTEPS_K
+        HIP_TRY(hipGetLastError());
+        done += now;
+    }
+    *launched = true;
+    h->last_kind = SGX_LAUNCH_MULTI_STEP_WAVE;
+    return SGX_OK;
+}
+
+static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_sets) {
     KParams p = p_in;
     if (p.mode == 0 && p.io.auto_reset)
         if (int rc = check_random_setups(h)) return rc;
@@ -1125,6 +1206,8 @@ SGX_API int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void 
         bool launched = false;
         if (int rc = launch_lane_steps(h, p, io, 1, 0, n_steps, stream, &launched)) return rc;
         if (launched) return SGX_OK;
+        if (int rc = launch_wave_steps(h, p, io, 1, 0, n_steps, stream, &launched)) return rc;
+        if (launched) return SGX_OK;
     }
     for (int32_t i = 0; i < n_steps; ++i)
         if (int rc = launch_step(h, p, stream)) return rc;
@@ -1146,6 +1229,8 @@ SGX_API int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, in
     {
         bool launched = false;
         if (int rc = launch_lane_steps(h, p, ios, n_sets, first_set, n_steps, stream, &launched)) return rc;
+        if (launched) return SGX_OK;
+        if (int rc = launch_wave_steps(h, p, ios, n_sets, first_set, n_steps, stream, &launched)) return rc;
         if (launched) return SGX_OK;
     }
     for (int32_t i = 0; i < n_steps; ++i) {
@@ -1174,6 +1259,12 @@ SGX_API int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int3
         bool launched = false;
         if (int rc = launch_lane_steps(h, p0, io, 1, 0, n_steps, stream, &launched)) return rc;
         if (launched) return SGX_OK;
+        // ... and the other boards the multi-step launch of the wave-per-game kernels (steps_kernel), except where two chains of launches
+        // measured faster still: boards of 17 .. 36 cells (6x6: 101 against 108 us per step, 5x5: 93 against 94; tools/multi_step_ab.py)
+        if (cells > 36) {
+            if (int rc = launch_wave_steps(h, p0, io, 1, 0, n_steps, stream, &launched)) return rc;
+            if (launched) return SGX_OK;
+        }
         chains = (cells <= 36 || cells % 4 != 0) ? 2 : 1;
     }
     const int64_t unit = 8 * 8 * (cells <= 16 ? 4 : (cells <= 32 ? 2 : 1));     // 8 workgroups x SGX_WPB waves x Geo::GPW games

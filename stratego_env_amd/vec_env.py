@@ -214,7 +214,7 @@ class VecStrategoEnv:
 
     @property
     def last_launch_kind(self):
-        """Which kernel the last step / observe launch was: _lib.LAUNCH_WAVE, LAUNCH_LANE or LAUNCH_MULTI_STEP (sgx_last_launch_kind)."""
+        """Which kernel the last step / observe launch was: _lib.LAUNCH_WAVE, LAUNCH_LANE, LAUNCH_MULTI_STEP or LAUNCH_MULTI_STEP_WAVE (sgx_last_launch_kind)."""
         return int(self._L.sgx_last_launch_kind(self._h))
 
     def set_xcd_skew(self, per_mille='auto'):
@@ -455,13 +455,15 @@ class VecStrategoEnv:
             self.sample_valid_actions()
         return self.step(self.next_actions, want_next_actions=True)
 
-    def rollout_steps(self, n_steps, chains=1, ring=False):
+    def rollout_steps(self, n_steps, chains=1, ring=False, emit_obs=True, emit_mask=True):
         """`n_steps` rollout steps enqueued by one library call (sgx_step_n): same results as calling rollout_step()
         n_steps times, without a Python round trip per step (toy boards are launch-bound otherwise).  chains > 1 (sgx_rollout):
         the batch is split into that many contiguous ranges of games whose launches overlap on streams of their own; chains = 0 /
         'auto': as many as the library's measured rule says (2 on boards of up to 36 cells and on odd boards, else 1).
         ring=True (after alloc_output_ring): the steps write the ring's output sets in turn (sgx_step_ring); self.obs / self.mask /
-        self.fobs are the set the LAST step wrote afterwards."""
+        self.fobs are the set the LAST step wrote afterwards.  emit_obs / emit_mask = False: rollouts that write no observation / no mask
+        (logic-only playouts, e.g. of a search).  Where the call is eligible all steps run in ONE launch (sgx_set_multi_step): the games stay on
+        the chip between the steps."""
         if not self._next_actions_fresh:
             self.sample_valid_actions()
         if ring:
@@ -470,7 +472,7 @@ class VecStrategoEnv:
             n_sets, n_steps = len(self._ring), int(n_steps)
             for k, (obs, mask, fobs) in enumerate(self._ring):
                 self.obs, self.mask, self.fobs = obs, mask, fobs
-                io = self._fill_io(self.next_actions, True, True, True, 0)
+                io = self._fill_io(self.next_actions, True, emit_obs, emit_mask, 0)
                 C.memmove(C.byref(self._ring_ios[k]), C.byref(io), C.sizeof(_lib.SgxStepIO))
             first = self._ring_pos
             with torch.cuda.device(self.device):
@@ -479,7 +481,7 @@ class VecStrategoEnv:
             self.obs, self.mask, self.fobs = self._ring[last]
             self._ring_pos = (first + n_steps) % n_sets
             return self.obs, self.mask, self.reward, self.done, self.player
-        io = self._fill_io(self.next_actions, True, True, True, 0)
+        io = self._fill_io(self.next_actions, True, emit_obs, emit_mask, 0)
         with torch.cuda.device(self.device):
             if chains in (0, 'auto') or chains > 1:        # 0 / 'auto': the library's measured rule (2 chains on small and odd boards)
                 _lib.check(self._L.sgx_rollout(self._h, C.byref(io), int(n_steps), 0 if chains == 'auto' else int(chains), self._stream()), self._L)

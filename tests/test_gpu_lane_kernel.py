@@ -173,3 +173,32 @@ def test_multi_step_launch_with_forced_non_temporal_stores_and_raw_players():
         for x, y in ((a.obs, b.obs), (a.mask, b.mask), (a.reward, b.reward), (a.done, b.done), (a.player, b.player), (a.env_info(), b.env_info())):
             assert torch.equal(x, y), auto
         a.close(); b.close()
+
+
+def test_multi_step_launch_falls_back_where_it_does_not_apply():
+    """More output sets than the multi-step kernel takes (8), a call of ONE step, a call without an observation: one launch per step, same
+    results as ever; `chains='auto'` prefers the multi-step launch to two chains where it applies."""
+    import torch
+    from stratego_env_amd import _lib
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    a = VecStrategoEnv('micro', 300, seed=8, auto_reset=True)
+    b = VecStrategoEnv('micro', 300, seed=8, auto_reset=True)
+    b.set_multi_step(False)
+    a.reset(); b.reset()
+    a.rollout_steps(1); b.rollout_steps(1)
+    assert a.last_launch_kind == _lib.LAUNCH_WAVE
+    a.rollout_steps(7, chains='auto'); b.rollout_steps(7)
+    assert a.last_launch_kind == _lib.LAUNCH_MULTI_STEP
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.mask, b.mask) and torch.equal(a.env_info(), b.env_info())
+    a.alloc_output_ring(9); b.alloc_output_ring(9)
+    a.rollout_steps(20, ring=True); b.rollout_steps(20, ring=True)
+    assert a.last_launch_kind == _lib.LAUNCH_WAVE                     # nine sets: one launch per step
+    for (oa, ma, _), (ob, mb, _) in zip(a._ring, b._ring):
+        assert torch.equal(oa, ob) and torch.equal(ma, mb)
+    a.alloc_output_ring(8); b.alloc_output_ring(8)
+    a.rollout_steps(20, ring=True); b.rollout_steps(20, ring=True)
+    assert a.last_launch_kind == _lib.LAUNCH_MULTI_STEP               # eight fit
+    for (oa, ma, _), (ob, mb, _) in zip(a._ring, b._ring):
+        assert torch.equal(oa, ob) and torch.equal(ma, mb)
+    assert torch.equal(a.next_actions, b.next_actions) and torch.equal(a.env_info(), b.env_info())
+    a.close(); b.close()

@@ -27,7 +27,7 @@ def _run(args, timeout=600, extra_env=None):
 
 
 COMMON = ['--steps', '24', '--warmup', '6', '--no-cpu-baseline', '--no-other-workloads', '--verify-envs', '16', '--placement', 'plain',
-          '--wake-seconds', '0']
+          '--wake-seconds', '0', '--no-live-traffic']
 
 
 @pytest.mark.parametrize('version,per_rank', [('barrage', 4096), ('micro', 6000)])
@@ -53,8 +53,10 @@ def test_two_ranks_on_one_gpu_equal_one_rank_and_the_oracle(version, per_rank):
     # in-place leg and its two-chains variant on the same env object, each verified against the oracle
     assert one['config']['no_settle']['launch_us'] > 0 and two['config']['no_settle']['value'] > 0
     inp = one['config']['in_place']
-    assert inp['verified_steps'] == 90 and inp['verified_envs'] >= 8 and inp['rate_over_spec_peak'] > 0
-    assert one['config']['two_chains']['verified_steps'] == 120 and one['config']['two_chains']['verified_envs'] >= 16
+    # (headline 30 + the same without the settle 30 + the same as one launch per step 30, then the in-place leg's 30)
+    assert one['config']['one_launch_per_step']['launch_us'] > 0 and one['config']['steps_per_launch'] == 24
+    assert inp['verified_steps'] == 120 and inp['verified_envs'] >= 8 and inp['rate_over_spec_peak'] > 0
+    assert one['config']['two_chains']['verified_steps'] == 150 and one['config']['two_chains']['verified_envs'] >= 16
     assert one['roofline']['frac_dram'] == one['roofline']['frac'] and one['roofline']['in_place_rate_over_spec_peak'] == inp['rate_over_spec_peak']
     assert two['roofline']['frac_dram'] == two['roofline']['frac'] and len(one['build_id']) == 16
 
@@ -112,3 +114,40 @@ def test_strong_split_with_a_remainder_on_one_gpu():
     assert two['scaling'] == 'strong' and two['config']['total_games'] == 8191
     assert two['config']['outputs_checksum'] == one['config']['outputs_checksum']
     assert two['verified_envs'] >= 32
+
+
+def test_under_torch_distributed_run_on_the_gpu():
+    """The driver's launch form on hardware: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 (ranks from the
+    environment; the two ranks share the test box's one GPU): one line, launched_by external, the anchors and the checksum of a
+    self-launched run of the same games."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'TORCHELASTIC_RUN_ID', 'SGX_BENCH_LAUNCHER')}
+    args = ['--gpus', '2', '--devices', '0,0', '--backend', 'gloo', '--envs', '4096'] + COMMON
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), BENCH] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    ext = lines[0]
+    own = _run(args)
+    assert ext['n_gpus'] == 2 and ext['config']['launched_by'] == 'external' and own['config']['launched_by'] == 'bench.py'
+    assert ext['config']['outputs_checksum'] == own['config']['outputs_checksum'] and ext['verified_envs'] >= 32
+    assert ext['config']['solo']['games'] == 4096 and ext['config']['scaling_x'] > 0
+
+
+def test_live_counter_traffic_of_the_headline():
+    """roofline.traffic is measured in the run itself: two short children of bench.py under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE), the
+    guide's gfx950 correction; it must agree with the byte minimum of the launch (the kernel moves its minimum and little else) and the
+    static entry of profiles/traffic.json stays next to it."""
+    line = _run(['--gpus', '1', '--envs', '16384', '--steps', '12', '--warmup', '4', '--no-cpu-baseline', '--no-other-workloads', '--no-two-chains',
+                 '--no-in-place-leg', '--no-settle-leg', '--verify-envs', '8', '--placement', 'plain', '--wake-seconds', '0'], timeout=900)
+    rf = line['roofline']
+    assert 'traffic_live_failed' not in rf, rf.get('traffic_live_failed')
+    assert rf['traffic_source'].startswith('live: rocprofv3') and rf['traffic_static_source'] is None or rf['traffic_static_source'].startswith('static')
+    assert 0.97 < rf['traffic_over_b_min'] < 1.06, rf['traffic_over_b_min']
+    assert abs(rf['traffic'] / rf['bytes_per_launch'] - rf['traffic_over_b_min']) < 1e-9

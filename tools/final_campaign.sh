@@ -17,8 +17,8 @@ bash tools/gpu_profile.sh ${RND}_micro micro 65536 --version micro --output-sets
 bash tools/gpu_profile.sh ${RND}_standard standard 262144 --version standard --envs 262144 --warmup 300 --output-sets 1 > gpurun_out/prof_${RND}_standard.log 2>&1
 bash tools/gpu_profile.sh ${RND}_both barrage+full_obs 65536 --full-obs --output-sets 1 > gpurun_out/prof_${RND}_both.log 2>&1
 cd /tmp; mkdir -p $R/gpurun_out/${RND}_tuned
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_tuned/headline -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --no-in-place-leg > $R/gpurun_out/${RND}_tuned/headline_line.json 2> $R/gpurun_out/${RND}_tuned/headline.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_tuned/inplace -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --output-sets 1 > $R/gpurun_out/${RND}_tuned/inplace_line.json 2> $R/gpurun_out/${RND}_tuned/inplace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_tuned/headline -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --no-in-place-leg --no-live-traffic > $R/gpurun_out/${RND}_tuned/headline_line.json 2> $R/gpurun_out/${RND}_tuned/headline.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_tuned/inplace -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --no-live-traffic --output-sets 1 > $R/gpurun_out/${RND}_tuned/inplace_line.json 2> $R/gpurun_out/${RND}_tuned/inplace.err
 find $R/gpurun_out/${RND}_tuned -name "*kernel_trace.csv" -delete; find $R/gpurun_out/${RND}_tuned -name "*.db" -delete
 cd $R
 bash tools/variant_bench.sh tuned > gpurun_out/$OUT/variant_bench.log 2>&1

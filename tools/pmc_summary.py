@@ -36,7 +36,7 @@ def main():
                 mean[c] = sum(v) / len(v)
         if not mean:      # boards of at most 16 cells: the steps of a call are ONE launch (lane_steps_kernel): counters per STEP = sum over launches / steps
             for (f, k, c), v in agg.items():
-                if k.startswith('void lane_steps_kernel'):
+                if k.startswith('void lane_steps_kernel') or k.startswith('void steps_kernel'):
                     mean[c] = sum(v) / total_steps
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from stratego_env_amd import build as B
@@ -53,7 +53,7 @@ def main():
         for f in files:
             print('#', f)
             for (ff, k, c), v in sorted(agg.items()):
-                if ff == f and any(x in k for x in ('step_kernel', 'sample_kernel', 'lane_kernel', 'export_kernel', 'import_kernel', 'states_kernel', 'choose_kernel')):
+                if ff == f and any(x in k for x in ('step_kernel', 'steps_kernel', 'sample_kernel', 'lane_kernel', 'export_kernel', 'import_kernel', 'states_kernel', 'choose_kernel')):
                     print('%-42s %-26s n=%-3d mean=%.1f' % (k, c, len(v), sum(v) / len(v)))
 
 

@@ -23,6 +23,7 @@ def timed(fn, reps=5):
 def main():
     version = sys.argv[1] if len(sys.argv) > 1 else 'barrage'
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+    only = sys.argv[3].split(',') if len(sys.argv) > 3 else None      # e.g. get_next_state: a kernel trace then holds that path's launches only
     env = VecStrategoEnv(version, n, seed=3, auto_reset=True)
     env.reset()
     env.sample_valid_actions()
@@ -44,6 +45,8 @@ def main():
                      ('is_move_valid_by_1d_index', lambda: penv.is_move_valid_by_1d_index(states, players, acts)),
                      ('get_valid_moves_as_1d_mask', lambda: penv.get_valid_moves_as_1d_mask(states, players)),
                      ('partial obs (raw)', lambda: penv.get_partially_observable_observation_extended_channels(states, players))):
+        if only and name not in only:
+            continue
         t = timed(fn)
         print("%-32s %9.1f us per batch of %d  -> %8.1f M states/s" % (name, t * 1e6, n, n / t / 1e6), flush=True)
 
