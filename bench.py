@@ -663,6 +663,20 @@ def gpu_settle(env, seconds):
         torch.cuda.synchronize()
 
 
+MULTI_STEP_TALLY = {"launches": 0, "steps": 0}      # multi-step launches of this process and the steps they played (config.multi_step_tally)
+
+
+def _tally(env, k):
+    """After a rollout call of k steps: count it if it went out as multi-step launches (a kernel trace's total duration of steps_kernel /
+    lane_steps_kernel divided by the tally's steps is the per-step time the line reports)."""
+    from stratego_env_amd import _lib
+    if DRY_RUN or k <= 0 or not fused_launch(env):
+        return
+    per = WSTEPS_MAX_PER_LAUNCH if env.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE else k
+    MULTI_STEP_TALLY["launches"] += -(-k // per)
+    MULTI_STEP_TALLY["steps"] += k
+
+
 def time_workload(rk, env, steps, warmup, unfused=False, chains=1, ring=False, settle=True):     # noqa: C901
     """(elapsed s, device ms, (min, max) of the ranks' own seconds, games finished, invalid actions) of `steps` batched steps on
     `env`, MAX / SUM over ranks.  ring: the steps write the env's ring of output sets in turn (env.alloc_output_ring).
@@ -680,8 +694,10 @@ def time_workload(rk, env, steps, warmup, unfused=False, chains=1, ring=False, s
         env.sample_valid_actions()
         if ring:
             env.rollout_steps(warmup, ring=True)
-        elif chains > 1 and not unfused:       # (the chains' streams are created on first use: not inside the timed region)
+            _tally(env, warmup)
+        elif not unfused:                      # (the chains' streams are created on first use: not inside the timed region)
             env.rollout_steps(warmup, chains=chains)
+            _tally(env, warmup)
         else:
             for _ in range(warmup):
                 one_step()
@@ -692,6 +708,7 @@ def time_workload(rk, env, steps, warmup, unfused=False, chains=1, ring=False, s
                 one_step()
         else:
             env.rollout_steps(steps, chains=chains, ring=ring)    # the same K batched steps, enqueued by one C-ABI call (sgx_step_n / sgx_rollout / sgx_step_ring)
+            _tally(env, steps)
 
     def counters():
         if DRY_RUN:
@@ -842,7 +859,8 @@ def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, fir
            "traffic_over_b_min": (traffic / min_bytes) if traffic else None,
            # the same kernel writing the allocation the process got first (observe launch of the placement trial's first candidate):
            # what an integrator who passes plain torch.empty tensors may get
-           "frac_untuned": (min_bytes / (first_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if first_us else None,
+           # (a single launch of the per-step kernel: its own byte minimum, the record included)
+           "frac_untuned": (b_min(v, full_obs, rec_bytes) * n / (first_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if first_us else None,
            # SURVEY 8d's formula (state as 32 dense int8 boards): a labelled comparison, not a fraction -- the kernel reads a 512-byte
            # record instead of 3,216 B of boards, so this rate counts bytes that are never moved
            "survey_8d": {"bytes_per_step": b_alg(v.rows, v.columns, full_obs), "gbps_if_those_bytes_moved": b_alg(v.rows, v.columns, full_obs) * n / launch_s / 1e9}}
@@ -1323,6 +1341,9 @@ def run_rank(args):      # noqa: C901
                        "record_bytes": rec_bytes,
                        "untimed_before_bracket": "%d warm-up steps, then %.2f s of state-preserving sgx_observe launches (gpu_settle)" % (args.warmup, SETTLE_SECONDS),
                        "no_settle": no_settle, "one_launch_per_step": per_step_launches,
+                       # multi-step launches of the WHOLE process so far and the steps they played (a kernel trace of this command: total
+                       # duration of steps_kernel / lane_steps_kernel over these steps = the per-step time of the legs that used them)
+                       "multi_step_tally": dict(MULTI_STEP_TALLY),
                        "output_sets": args.output_sets if headline_ring else 1, "ring_placement_plain_and_kept_us_per_extra_set": ring_report,
                        "concurrent_chains": args.chains, "in_place": in_place, "two_chains": two_chains,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),

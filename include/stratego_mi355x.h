@@ -188,12 +188,21 @@ int sgx_set_nt_stores(sgx_env *h, int32_t mode);
  * default of handles created afterwards.  Results are identical either way (tests/test_gpu_lane_kernel.py).  No reference counterpart. */
 int sgx_set_lane_kernel(sgx_env *h, int32_t mode);
 
-/* sgx_step_n / sgx_step_ring on boards of at most 16 cells (Micro, Tiny): where the call is eligible (the lane kernel's conditions for every
- * output set, flat perspective actions, an observation tensor, n_steps >= 2, at most 8 output sets) all n_steps run in ONE launch -- a
- * 256-thread workgroup keeps 64 games in the registers of one wave, which plays step t + 1 while the other three waves store the
- * observations of step t (lane_steps_kernel); the records travel to and from HBM once per call.  Same results as n_steps launches.
- * mode 1 (default): on; 0: one launch per step.  SGX_MULTI_STEP=0 sets the default of handles created afterwards; sgx_set_lane_kernel(h, 0)
- * switches it off as well.  No reference counterpart. */
+/* Multi-step launches.  A rollout call -- sgx_step_n / sgx_step_ring: n_steps >= 2 consecutive steps, each playing the action the one
+ * before drew -- runs its steps in ONE launch (launches of at most 256 steps) where it is eligible: flat perspective actions, masks in the
+ * mover's perspective, an 'extended' channel mode, at most 8 output sets that differ in their observation / mask tensors only.
+ *  - Boards of more than 16 cells (steps_kernel): a workgroup stages its games once and every wave plays its game step after step -- the
+ *    dense boards, never-moved flags, recent-move codes and capture events stay in LDS, the record's scalars and the drawn action in
+ *    registers; every step's outputs are written like those of a launch of its own; the record is read once and written once per LAUNCH.
+ *    No barrier after the prologue: the waves drift out of phase, one wave's stores run under another's game logic.  The 67-channel kind,
+ *    BOTH observations, compact outputs and calls without an observation.  65,536 Barrage games into a ring of three output sets:
+ *    284-287 -> 246-249 us per step; 262,144 Standard games 1,210-1,233 -> 977-991 us.
+ *  - Boards of at most 16 cells with a multiple of 4 cells, the 67-channel kind with an observation tensor (lane_steps_kernel): a 256-thread
+ *    workgroup keeps 64 games in the registers of one wave, which plays step t + 1 while the other three waves store the observations of
+ *    step t.  65,536 Micro games 42.1 -> 29.2 us per step.
+ * Same results as n_steps launches of sgx_step (tests/test_gpu_multi_step.py, tests/test_gpu_lane_kernel.py).  mode 1 (default): on; 0: one
+ * launch per step.  SGX_MULTI_STEP=0 sets the default of handles created afterwards (SGX_MULTI_STEP_WAVE=0: the first kind only off);
+ * sgx_set_lane_kernel(h, 0) switches the second kind off as well.  No reference counterpart. */
 int sgx_set_multi_step(sgx_env *h, int32_t mode);
 /* Which kernel the handle's last sgx_step / sgx_observe / sgx_step_n / sgx_step_ring / sgx_rollout / sgx_expand launch was (diagnostics,
  * benchmarks that price a launch by its own bytes, tests that must not pass on another kernel): */
@@ -303,8 +312,8 @@ int sgx_host_alloc(sgx_env *h, int64_t bytes, void **host_ptr, void **dev_ptr);
 int sgx_host_free(sgx_env *h, void *host_ptr);
 int sgx_step_sync(sgx_env *h, const sgx_step_io *io, void *stream);
 
-/* n_steps consecutive sgx_step calls with the same buffers, enqueued back to back without returning to the host language:
- * the random-action game loop of examples/basic_game_loop.py:34-63 (sample a valid action, step, repeat) for N games.
+/* n_steps consecutive sgx_step calls with the same buffers, enqueued back to back without returning to the host language (ONE launch for
+ * all of them where the call is eligible: sgx_set_multi_step): the random-action game loop of examples/basic_game_loop.py:34-63 (sample a valid action, step, repeat) for N games.
  * Requires io->next_actions_dev == io->actions_dev, so that every step plays the action the previous one drew; the
  * output buffers hold the last step's results afterwards.  (Toy boards finish a batched step in tens of microseconds:
  * driving them one call at a time from Python is launch-bound.) */
@@ -325,9 +334,9 @@ int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, int32_t fi
  * stream waits for all chains; results are identical to sgx_step_n.  Measured with chains = 2 on 65,536 games: Micro 41.3 -> 37.2 us per
  * step of all games, 5x5 107.6 -> 96.0 us, 8x8 198 -> 183 us, Barrage 322 -> 304 us.  chains = 0 lets the
  * library choose by the rule measured on the current kernels (2 for boards of up to 36 cells and for boards whose cell count is no
- * multiple of 4, else 1: 8x8 and 10x10 launches already stream at the memory rate and lose 2-5 % to a second chain; boards of at most
- * 16 cells take the multi-step launch of sgx_set_multi_step instead wherever the call is eligible: faster than two chains).  No
- * reference counterpart. */
+ * multiple of 4, else 1: 8x8 and 10x10 launches already stream at the memory rate and lose 2-5 % to a second chain) -- after trying
+ * the multi-step launch of sgx_set_multi_step, which is faster than any number of chains wherever the call is eligible, except on
+ * boards of 17 .. 36 cells.  No reference counterpart. */
 #define SGX_MAX_CHAINS 4
 int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int32_t chains, void *stream);
 

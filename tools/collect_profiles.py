@@ -14,10 +14,18 @@ def newest(pat):
     return fs[-1]
 
 
-def step_row(f):
+def step_row(f, multi_steps=None):
+    """(calls, average us) of the per-step kernel in a kernel_stats.csv; with multi_steps = the steps the run's multi-step launches played:
+    ('N launches of steps_kernel', total us / steps = us per STEP) for the multi-step kernel too."""
+    out = []
     for r in csv.DictReader(open(f)):
-        if 'step_kernel' in r['Name']:
-            return r['Calls'], round(float(r['AverageNs']) / 1e3, 2)
+        name = r['Name'].replace('(anonymous namespace)::', '')
+        if name.startswith('void step_kernel'):
+            out.append(('step_kernel', r['Calls'], round(float(r['AverageNs']) / 1e3, 2)))
+        if multi_steps and (name.startswith('void steps_kernel') or name.startswith('void lane_steps_kernel')):
+            out.append((name.split('<')[0].replace('void ', '') + ': %s launches, %d steps' % (r['Calls'], multi_steps), 'us per step',
+                        round(float(r['TotalDurationNs']) / 1e3 / multi_steps, 2)))
+    return out
 
 
 def main():
@@ -54,10 +62,11 @@ def main():
             print(k, v['hbm_bytes_per_launch'], v['build_id'], v['tcc_ea0_wrreq'], v['tcc_ea0_wrreq_dram'], v['fetch_size_kib'], v['write_size_kib'])
     for tag in tags:
         d = json.load(open('profiles/%s_stats_line.json' % tag))
-        print(tag, step_row('profiles/%s_kernel_stats.csv' % tag), 'line launch_us %.2f' % d['roofline']['launch_us'], 'sets', d['config']['output_sets'], d['build_id'])
+        print(tag, step_row('profiles/%s_kernel_stats.csv' % tag, (d['config'].get('multi_step_tally') or {}).get('steps') or (8 + 64 if d['config']['output_sets'] > 1 else 64)),
+              'line launch_us %.2f' % d['roofline']['launch_us'], 'sets', d['config']['output_sets'], d['build_id'])
     for tag in ('headline', 'inplace'):
         d = json.load(open('profiles/%s_tuned_%s_line.json' % (rnd, tag)))
-        print('tuned', tag, step_row('profiles/%s_tuned_%s_kernel_stats.csv' % (rnd, tag)),
+        print('tuned', tag, step_row('profiles/%s_tuned_%s_kernel_stats.csv' % (rnd, tag), (d['config'].get('multi_step_tally') or {}).get('steps') or (2 * (64 + 512) if d['config']['output_sets'] > 1 else 2 * 512)),
               'line launch_us %.2f value %.1fM frac %.3f' % (d['roofline']['launch_us'], d['value'] / 1e6, d['roofline']['frac']), d['config']['output_sets'])
     for f in ('bench_default', 'bench_default_run2', 'bench_default_run3', 'bench_driver_style'):
         if not os.path.exists('%s/%s.json' % (out, f)):
