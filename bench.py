@@ -476,6 +476,9 @@ class Rank:
                     group = dist.new_group(backend='gloo', timeout=timeout)
                     probe = torch.ones(1)
                 else:
+                    # (a collective that cannot complete must RAISE after the timeout, so that this rank joins the agreement below, instead of
+                    #  having the watchdog abort the process: blocking wait; the group only ever carries two tiny reductions)
+                    os.environ.setdefault('TORCH_NCCL_BLOCKING_WAIT', '1')
                     group = dist.new_group(backend='nccl', timeout=timeout)
                     probe = torch.ones(1, device='cuda')
                 dist.all_reduce(probe, group=group)
