@@ -158,6 +158,15 @@ struct DevTables {
     alignas(16) uint8_t combat[COMBAT_BYTES];
 };
 
+// Kernel parameters read INSIDE a loop of steps / games are read through the kernel-argument segment's own address space: a load from
+// address space 4 is a scalar load wherever the address is uniform.  Through a generic pointer the compiler cannot prove that the
+// loop's global stores leave the parameters alone and falls back to VECTOR loads (+ v_readfirstlane) -- which also retire in order
+// with the wave's outstanding stores, so every re-read waited for the step's own observation stores.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SGX_KERNARG __attribute__((address_space(4)))
+#else
+#define SGX_KERNARG
+#endif
 struct KParams {
     int8_t *boards;
     const DevTables *tab;
@@ -253,8 +262,8 @@ __device__ inline int4 *rec_scal(int8_t *boards, int rec_bytes, int64_t env) {
 }
 
 // capacity of a game's capture-event list: the handle's (2 x pieces, at most one per cell), or every (layer, cell) pair in a general-state image
-template <class G>
-__device__ inline int max_events_of(const KParams &P) { return G::BIG ? (int)G::EVL_MAX : P.max_events; }
+template <class G, class KP>
+__device__ inline int max_events_of(const KP &P) { return G::BIG ? (int)G::EVL_MAX : P.max_events; }
 
 // A value that is the same in every lane of a game: an SGPR when the game is the whole wave, left alone otherwise.
 template <class G>
@@ -309,7 +318,8 @@ __device__ inline int quad_sum(int x) {
 // on them.  (Measuring the shares per output buffer from the workgroups' own end times -- an sgx_calibrate_xcd_shares -- was built and
 // dropped: it reproduces the odd / even skew (1090 / 900 per mille on every buffer, fast or slow) and nothing more, and on boards bound
 // by their game logic the observe launch it measures is balanced differently from the step: Micro +8 ... +12 %, profiles/r03_calib_ab.log.)
-__device__ inline int64_t group_of_block(const KParams &P) {
+template <class KP>
+__device__ inline int64_t group_of_block(const KP &P) {
     const int64_t nb = gridDim.x, b = blockIdx.x;
     const int x = (int)(b & 7);                                      // grid is a multiple of 8
     const int64_t i = b >> 3;

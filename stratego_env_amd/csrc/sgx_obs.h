@@ -84,9 +84,9 @@ __device__ inline bool merged_event(const Lds<G, NB> &L, int i, int n_events, in
 // Fills L.nib with the codes of Spec's observation from player index qi's perspective.  tmpl = the variant's default codes,
 // codetab = codes of captured counts / recent-move codes (both workgroup-shared LDS copies), glut = this kind's LUT in global
 // memory.  Returns the number of entries whose value has no code (L.unc_entry / L.unc_val; the same for every lane of the game).
-template <class G, class Spec, int NB>
+template <class G, class Spec, int NB, class PC>     // PC: pointer to the variant's piece counts (KParams::piece_counts, possibly in the kernel-argument address space)
 __device__ inline int build_codes(Lds<G, NB> &L, const uint8_t *tmpl, const uint8_t *codetab, const float *__restrict__ glut, int qi, int n_events,
-                                  int rp0, int rp1, int lane, const int32_t *piece_counts = nullptr, bool raw = false, bool multi = false) {
+                                  int rp0, int rp1, int lane, PC piece_counts, bool raw = false, bool multi = false) {
     constexpr int RC = G::RC, NCH = Spec::NCH, NBYTES = ((RC * NCH + 1) / 2 + 15) & ~15;
     static_assert(NBYTES <= Lds<G, NB>::NIB_BYTES, "code buffer too small for this observation kind");
     for (int i = lane; i < NBYTES / 16; i += G::LPG) reinterpret_cast<int4 *>(L.nib)[i] = reinterpret_cast<const int4 *>(tmpl)[i];
@@ -308,9 +308,9 @@ __device__ inline void patch_uncoded_floats(const Lds<G, NB> &L, float *__restri
 
 // 'original' kinds: the LUT path leaves the captured-count channels at their default; every capture event is written as a single
 // float afterwards (`lut` = this kind's LUT in global memory).  The caller has waited for the bulk stores of `dst`.
-template <class G, class Spec, int NB>
+template <class G, class Spec, int NB, class PC>
 __device__ inline void emit_obs_patches(const Lds<G, NB> &L, const float *__restrict__ lut, int qi, float *__restrict__ dst, int n_events, int lane,
-                                        bool raw = false, bool multi = false, const int32_t *piece_counts = nullptr) {
+                                        bool raw, bool multi, PC piece_counts) {
     static_assert(!Spec::CODES, "");
     for (int i = lane; i < n_events; i += G::LPG) {
         int entry, ch, v, ti;

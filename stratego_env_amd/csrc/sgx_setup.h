@@ -22,8 +22,8 @@ __device__ inline void place(Lds<G, NB> &L, int pi, int cell, int t) {
     L.b[B_STILL + pi][cell] = t ? 1 : 0;
 }
 
-template <class G, int NB>
-__device__ void sample_boards(Lds<G, NB> &L, const KParams &P, uint64_t g, uint64_t j, int lane) {
+template <class G, int NB, class KP>
+__device__ void sample_boards(Lds<G, NB> &L, const KP &P, uint64_t g, uint64_t j, int lane) {
     constexpr int C = G::C, RC = G::RC;
     const int U = P.usable_rows, n = U * C;
     clear_boards(L, lane);

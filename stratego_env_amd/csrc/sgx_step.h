@@ -110,8 +110,8 @@ struct GameInput {
     const int4 *src;      // WIDE boards (a record of more than two int4 per lane): staged straight from here in env_step
 };
 // (src: the game's record -- global memory, or the LDS image of sgx_step_states' fused kernel)
-template <class G>
-__device__ __forceinline__ GameInput load_game_from(const KParams &P, const int4 *src, const int64_t env, const int lane) {
+template <class G, class KP>
+__device__ __forceinline__ GameInput load_game_from(const KP &P, const int4 *src, const int64_t env, const int lane) {
     constexpr int Q_BOARDS = G::ST_OFF / 16, Q_REC = Q_BOARDS + G::TAIL_BYTES / 16, NLOAD = (Q_REC + G::LPG - 1) / G::LPG;
     static_assert(G::TAIL_BYTES % 16 == 0 && (NLOAD <= 2 || G::WIDE || G::BIG), "record image must fit two int4 per lane");
     const int4 zero4 = make_int4(0, 0, 0, 0);
@@ -128,8 +128,8 @@ __device__ __forceinline__ GameInput load_game_from(const KParams &P, const int4
     }
     return in;
 }
-template <class G, bool MAPPED>
-__device__ __forceinline__ GameInput load_game(const KParams &P, const int64_t env, const int lane) {
+template <class G, bool MAPPED, class KP>
+__device__ __forceinline__ GameInput load_game(const KP &P, const int64_t env, const int lane) {
     if (env >= P.n_envs) { const int4 zero4 = make_int4(0, 0, 0, 0); return GameInput{zero4, zero4, zero4, 0, nullptr}; }
     const int8_t *rec_src = P.boards + env * (int64_t)P.rec_bytes;
     if constexpr (MAPPED)        // sgx_expand: the game comes from another handle's records (functional-API instantiation only)
@@ -139,8 +139,8 @@ __device__ __forceinline__ GameInput load_game(const KParams &P, const int64_t e
 
 // The compact observation of one game (SGX_STEP_COMPACT_OBS): build the code buffer exactly as render() does, then store it as it is.
 // One call site (env_step), outside render(): see there.
-template <class G, class Spec, int NB>
-__device__ __forceinline__ void compact_obs(const KParams &P, float *obs_dev, Lds<G, NB> &L, const uint8_t *shared, const uint8_t *codetab, const float *glut, bool raw, int qi,
+template <class G, class Spec, int NB, class KP>
+__device__ __forceinline__ void compact_obs(const KP &P, float *obs_dev, Lds<G, NB> &L, const uint8_t *shared, const uint8_t *codetab, const float *glut, bool raw, int qi,
                                          int n_events, int rp0, int rp1, int64_t env, int lane) {
     const uint8_t *tmpl = shared;
     if constexpr (G::WIDE) tmpl = P.tab->tmpl[raw ? 2 : 0];
@@ -169,8 +169,8 @@ struct StepCarry {
 // PERSIST_ (steps_kernel): the call is one of several consecutive steps of the same game by the same wave.  Only the FIRST stages the record;
 // later ones find the boards -- dense, never-moved bytes, recent-move codes, the event list -- where the step before left them in LDS,
 // take the scalars and the action from *carry, and only the LAST writes the record back (if any step changed it).
-template <int R_, int C_, int KIND, bool MAPPED, bool SPLIT = false, int VAR = 0, int PERSIST_ = 0>
-__device__ __forceinline__ void env_step(const KParams &P, Lds<Geo<R_, C_, VAR>, ObsKind<KIND>::NIB_CH> &L, const uint8_t *shared, const uint8_t *obst_s,
+template <int R_, int C_, int KIND, bool MAPPED, bool SPLIT = false, int VAR = 0, int PERSIST_ = 0, class KP = KParams>
+__device__ __forceinline__ void env_step(const KP &P, Lds<Geo<R_, C_, VAR>, ObsKind<KIND>::NIB_CH> &L, const uint8_t *shared, const uint8_t *obst_s,
                                          const int64_t env, const int lane, const GameInput &in, int8_t *rec_out = nullptr, StepOut *so = nullptr,
                                          StepCarry *carry = nullptr, const bool last = true) {
     constexpr bool PERSIST = PERSIST_ != 0, first = PERSIST_ != 2;      // PERSIST_: 0 = a launch of its own, 1 = the first step of a multi-step launch, 2 = a later one
@@ -654,21 +654,33 @@ struct WaveStepsParams {
     float *obs[WSTEPS_MAX_SETS], *fobs[WSTEPS_MAX_SETS];      // the output tensors of set s (sgx_step_ring); one set: in place
     uint8_t *mask[WSTEPS_MAX_SETS];
 };
+// occupancy promise of steps_kernel: the per-step kernel's, except on small boards of an odd cell count (5x5: two games per wave, the
+// unaligned observation sweep) with an observation to render -- the 64 registers of the 8-wave promise spill inside the steps loop there,
+// and a scratch access retires in order with the wave's outstanding observation stores (in-process A/B on one set of buffers, 65,536
+// games: ring of three 99.8 -> 92.7 us, in place 93.5 -> 91.3, compact 42.8 -> 40.1; without an observation 8 waves stay faster)
+template <class G, int KIND>
+constexpr int steps_waves_per_simd() {
+    constexpr int w = waves_per_simd<G, KIND, false>();
+    return (G::RC <= 64 && G::RC % 4 != 0 && !ObsKind<KIND>::NOOBS && w > 6) ? 6 : w;
+}
 template <int R_, int C_, int KIND>
-__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND, false>())) void steps_kernel(const WaveStepsParams SP) {
+__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (steps_waves_per_simd<Geo<R_, C_>, KIND>())) void steps_kernel(const WaveStepsParams SP) {
     using G = Geo<R_, C_>;
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
     constexpr bool FULL = ObsKind<KIND>::FULL, ORIG = ObsKind<KIND>::ORIG;
-    // The parameters are read through the kernel-argument segment's address, and the loop below hides that address from the optimiser once
-    // per step: otherwise every field env_step looks at is hoisted out of the loop and held in scalar registers for its whole length (106 of
-    // 106 SGPRs, 324 bytes of scratch); re-read per step they cost a few scalar loads from the constant cache.
+    // The parameters are read through the kernel-argument segment's address IN ITS OWN ADDRESS SPACE (SGX_KERNARG, sgx_layout.h), and the loop
+    // below hides that address from the optimiser once per step: otherwise every field env_step looks at is hoisted out of the loop and held
+    // in scalar registers for its whole length (106 of 106 SGPRs, 324 bytes of scratch); re-read per step they cost a few scalar loads from
+    // the constant cache.  (Through a generic pointer -- the first version of this kernel -- the re-reads were 17 VECTOR loads per game and
+    // step, each followed by a wait for everything the wave had in flight, its observation stores included: 5x5 95 -> 76 us per step, 15x15
+    // 369 -> 311, 6x6 111 -> 99, 10x10 246 -> 241 on one set of buffers, tools/lib_ab.py.)
 #if defined(__HIP_DEVICE_COMPILE__)
-    const WaveStepsParams *spp = (const WaveStepsParams *)__builtin_amdgcn_kernarg_segment_ptr();
+    const SGX_KERNARG WaveStepsParams *spp = (const SGX_KERNARG WaveStepsParams *)__builtin_amdgcn_kernarg_segment_ptr();
 #else
     const WaveStepsParams *spp = &SP;             // (host pass of the single-source compile: never executed)
 #endif
-    const KParams &P = spp->k;
+    const SGX_KERNARG KParams &P = spp->k;
     __shared__ Lds<G, ObsKind<KIND>::NIB_CH> LW[G::WPB * G::GPW];
     __shared__ alignas(16) uint8_t shared[shared_table_bytes<G, KIND>()];
     __shared__ alignas(16) uint8_t obst_s[G::OBST_BYTES + COMBAT_BYTES];
@@ -715,7 +727,7 @@ __global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_
         set = set + 1 == spp->n_sets ? 0 : set + 1;
     }
     for (int t = 1; t < n_steps; ++t) {
-        const WaveStepsParams *sp = spp;
+        const SGX_KERNARG WaveStepsParams *sp = spp;
         int lane_t = lane, slot_t = slot;
         // (the step's reads of the parameters start here; and what a step derives from the lane -- dozens of cell / entry offsets -- is
         //  recomputed in every step like in a launch of its own, not hoisted out of the loop and spilled: 244 bytes of scratch otherwise)

@@ -46,7 +46,8 @@ def main():
                      ('soak_parity.log', 'soak_parity.log'), ('soak_procedural.log', 'soak_procedural.log'),
                      ('phase_cost.log', 'phase_cost_final.log'), ('bench_default.json', 'default_bench_line.json'),
                      ('bench_driver_style.json', 'driver_style_line.json'), ('bench_default_run2.json', 'default_bench_line_run2.json'),
-                     ('bench_default_run3.json', 'default_bench_line_run3.json')):
+                     ('bench_default_run3.json', 'default_bench_line_run3.json'),
+                     ('multi_step_ab.log', 'multi_step_ab_plain_buffers.log'), ('ring_size_probe_tuned.log', 'ring_size_probe_tuned.log')):
         if os.path.exists(os.path.join(out, src)):
             shutil.copy(os.path.join(out, src), 'profiles/%s_%s' % (rnd, dst))
     for tag in ('procedural', 'kstep_micro'):

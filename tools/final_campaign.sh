@@ -29,4 +29,6 @@ bash tools/procedural_profile.sh ${RND}_procedural barrage 65536 > gpurun_out/$O
 bash tools/kstep_profile.sh ${RND}_kstep_micro micro 65536 256 > gpurun_out/$OUT/kstep_micro.log 2>&1
 python tools/procedural_bench.py > gpurun_out/$OUT/procedural_bench.log 2>&1
 for v in barrage standard micro tiny fives; do python tools/phase_cost.py $v 65536 2>&1 | grep -v "^/opt"; done > gpurun_out/$OUT/phase_cost.log
+python tools/multi_step_ab.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/multi_step_ab.log
+python tools/ring_size_probe_tuned.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/ring_size_probe_tuned.log
 for i in 2 3; do python bench.py > gpurun_out/$OUT/bench_default_run$i.json 2> gpurun_out/$OUT/bench_default_run$i.err; done
