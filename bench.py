@@ -65,6 +65,23 @@ if ROOT not in sys.path:
 BASE_SEED = 0x5712A7E60
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_PIN_RATE_GBS = 8192.0   # 8 stacks x 1,024 pins x 8 Gbit/s: what the "8 TB/s" of the data sheet rounds
+
+
+def hbm_mclk_mhz():
+    """The memory clock the driver reports for this rank's device (sysfs pp_dpm_mclk, the level marked '*'); 2,000 MHz x 4 transfers = the
+    8 Gbit/s per pin behind HBM_PIN_RATE_GBS.  None where the file is not readable."""
+    import glob
+    import re
+    best = None
+    for f in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_mclk')):
+        try:
+            for line in open(f):
+                m = re.match(r'\s*\d+:\s*(\d+)\s*Mhz\s*\*', line, re.I)
+                if m:
+                    best = max(best or 0, int(m.group(1)))
+        except OSError:
+            pass
+    return best
 GAMES_1GPU, GAMES_PER_GPU_MULTI, STRONG_TOTAL = 65536, 262144, 2097152      # SURVEY 8d configs 2 and 5
 
 
@@ -857,7 +874,7 @@ def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, fir
                      else "step_kernel<%d,%d,%d,false>" % (v.rows, v.columns, 1 if full_obs else 0), "launch_us": launch_s * 1e6, "steps_per_launch": fused_steps,
            # (a multi-step launch on well-placed buffers reads 1.00-1.02 here: the guide's 8 TB/s is the data sheet's rounded figure; the pins' own
            #  rate is 8,192 GB/s, and the bytes are the run's own counter bytes -- `traffic`, rocprofv3 WRITE_SIZE + 2 x FETCH_SIZE)
-           "peak_pin_rate": HBM_PIN_RATE_GBS, "frac_of_pin_rate": ach / HBM_PIN_RATE_GBS,
+           "peak_pin_rate": HBM_PIN_RATE_GBS, "frac_of_pin_rate": ach / HBM_PIN_RATE_GBS, "hbm_mclk_mhz": hbm_mclk_mhz(),
            "frac_dram": None, "traffic": traffic, "traffic_source": source,
            "traffic_over_b_min": (traffic / min_bytes) if traffic else None,
            # the same kernel writing the allocation the process got first (observe launch of the placement trial's first candidate):
