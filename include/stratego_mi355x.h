@@ -335,8 +335,8 @@ int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, int32_t fi
  * step of all games, 5x5 107.6 -> 96.0 us, 8x8 198 -> 183 us, Barrage 322 -> 304 us.  chains = 0 lets the
  * library choose by the rule measured on the current kernels (2 for boards of up to 36 cells and for boards whose cell count is no
  * multiple of 4, else 1: 8x8 and 10x10 launches already stream at the memory rate and lose 2-5 % to a second chain) -- after trying
- * the multi-step launch of sgx_set_multi_step, which is faster than any number of chains wherever the call is eligible, except on
- * boards of 17 .. 36 cells.  No reference counterpart. */
+ * the multi-step launch of sgx_set_multi_step, which is faster than any number of chains wherever the call is eligible.  No reference
+ * counterpart. */
 #define SGX_MAX_CHAINS 4
 int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int32_t chains, void *stream);
 

@@ -1259,12 +1259,10 @@ SGX_API int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int3
         bool launched = false;
         if (int rc = launch_lane_steps(h, p0, io, 1, 0, n_steps, stream, &launched)) return rc;
         if (launched) return SGX_OK;
-        // ... and the other boards the multi-step launch of the wave-per-game kernels (steps_kernel), except where two chains of launches
-        // measured faster still: boards of 17 .. 36 cells (6x6: 101 against 108 us per step, 5x5: 93 against 94; tools/multi_step_ab.py)
-        if (cells > 36) {
-            if (int rc = launch_wave_steps(h, p0, io, 1, 0, n_steps, stream, &launched)) return rc;
-            if (launched) return SGX_OK;
-        }
+        // ... and the other boards the multi-step launch of the wave-per-game kernels (steps_kernel): faster than two chains of launches on
+        // every board since its parameter reads are scalar loads (6x6: 97-99 against 101 us per step, 5x5: 71 against 91; profiles/r05_variant_bench.log)
+        if (int rc = launch_wave_steps(h, p0, io, 1, 0, n_steps, stream, &launched)) return rc;
+        if (launched) return SGX_OK;
         chains = (cells <= 36 || cells % 4 != 0) ? 2 : 1;
     }
     const int64_t unit = 8 * 8 * (cells <= 16 ? 4 : (cells <= 32 ? 2 : 1));     // 8 workgroups x SGX_WPB waves x Geo::GPW games

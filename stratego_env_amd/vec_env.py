@@ -459,7 +459,8 @@ class VecStrategoEnv:
         """`n_steps` rollout steps enqueued by one library call (sgx_step_n): same results as calling rollout_step()
         n_steps times, without a Python round trip per step (toy boards are launch-bound otherwise).  chains > 1 (sgx_rollout):
         the batch is split into that many contiguous ranges of games whose launches overlap on streams of their own; chains = 0 /
-        'auto': as many as the library's measured rule says (2 on boards of up to 36 cells and on odd boards, else 1).
+        'auto': the multi-step launch where the call is eligible, else as many chains as the library's measured rule says (2 on boards of
+        up to 36 cells and on odd boards, else 1).
         ring=True (after alloc_output_ring): the steps write the ring's output sets in turn (sgx_step_ring); self.obs / self.mask /
         self.fobs are the set the LAST step wrote afterwards.  emit_obs / emit_mask = False: rollouts that write no observation / no mask
         (logic-only playouts, e.g. of a search).  Where the call is eligible all steps run in ONE launch (sgx_set_multi_step): the games stay on

@@ -127,3 +127,15 @@ def test_multi_step_launch_is_not_taken_where_it_does_not_apply():
     a.rollout_steps(6, chains=2)
     assert a.last_launch_kind == _lib.LAUNCH_WAVE                     # explicit chains of launches
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('name,n', [('fives', 777), ('medium', 1000), ('octa_barrage', 513), ('barrage', 300)])
+def test_auto_chains_take_the_multi_step_launch_on_every_wave_board(name, n):
+    """sgx_rollout(chains = 0): the multi-step launch wherever the call is eligible -- also on boards of 17 .. 36 cells, where two chains of
+    per-step launches were the rule until the kernel's parameter reads became scalar loads -- with the results of one launch per step."""
+    from stratego_env_amd import _lib
+    a, b = _pair(name, n)
+    a.rollout_steps(23, chains='auto'); b.rollout_steps(23)
+    assert a.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE and b.last_launch_kind == _lib.LAUNCH_WAVE
+    _same(a, b, name)
+    a.close(); b.close()
