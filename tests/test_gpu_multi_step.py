@@ -139,3 +139,19 @@ def test_auto_chains_take_the_multi_step_launch_on_every_wave_board(name, n):
     assert a.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE and b.last_launch_kind == _lib.LAUNCH_WAVE
     _same(a, b, name)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('name,n,T', [('barrage', 65536, 48), ('standard', 262144, 24), ('micro', 65536, 64), ('fives', 65536 + 17, 40), ('standard2', 32768 + 5, 16)])
+def test_multi_step_launch_at_the_baseline_sizes_equals_one_launch_per_step(name, n, T):
+    """BASELINE configs 2 / 3 / 4 (and two ragged odd boards) at full size: ONE rollout call (multi-step launches: steps_kernel, on Micro
+    lane_steps_kernel) against the same steps as one launch per step -- every output tensor of the last step, rewards / flags, the next draw
+    and the int64 state of EVERY game.  (The per-step kernel itself is pinned to the oracle at these sizes by tests/test_gpu_parity.py.)"""
+    import torch
+    from stratego_env_amd import _lib
+    a, b = _pair(name, n)
+    a.rollout_steps(T); b.rollout_steps(T)
+    assert a.last_launch_kind in (_lib.LAUNCH_MULTI_STEP_WAVE, _lib.LAUNCH_MULTI_STEP) and b.last_launch_kind in (_lib.LAUNCH_WAVE, _lib.LAUNCH_LANE)
+    _same(a, b, name)
+    assert int(a.invalid_action.sum()) == 0 and int(a.env_info()[:, 0].min()) >= 0
+    a.close(); b.close()
+    torch.cuda.empty_cache()
