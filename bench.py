@@ -310,6 +310,11 @@ def parse_args(argv=None):
     ap.add_argument('--no-live-traffic', action='store_true',
                     help="roofline.traffic from profiles/traffic.json only (static); default on one GPU: measured now by two short children of this "
                          "run under rocprofv3 --pmc (about 20 s), the static entry kept as roofline.traffic_static")
+    ap.add_argument('--no-store-probe', action='store_true',
+                    help='skip roofline.store_probe (the store-only kernel on the headline ring buffers: three payloads per set and one long launch)')
+    ap.add_argument('--no-trajectory-leg', action='store_true', help='skip config.trajectory (the rollout into a 64-slot trajectory buffer, sgx_step_traj)')
+    ap.add_argument('--trajectory-slots', type=int, default=64)
+    ap.add_argument('--no-facade-leg', action='store_true', help='skip config.facade_n1 (BASELINE config 1: one game behind the dict API)')
     ap.add_argument('--traffic-probe', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--dry-run', action='store_true',
                     help="launcher self-test on CPU: gloo, stub env, no measurement (value is null)")
@@ -434,6 +439,7 @@ class Rank:
         self.use_cuda = use_cuda
         self.dist = None
         self.red_group = None                  # None = the default (gloo) group
+        self.bringup_seconds = 0.0
         self.backend, self.backend_note = ('gloo' if self.world > 1 else backend), None
         self.reduce_device = 'cpu'
         if use_cuda:
@@ -454,7 +460,9 @@ class Rank:
                     raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), gpus))
                 self.dist = dist
                 if backend == 'nccl':
+                    t_up = time.perf_counter()
                     self._bring_up_rccl(torch, dist, dmap, datetime.timedelta(seconds=int(os.environ.get('SGX_BENCH_NCCL_TIMEOUT', '120'))))
+                    self.bringup_seconds = time.perf_counter() - t_up         # (config.reduction_bringup_s: a first-time RCCL bring-up must not stall the job)
             finally:
                 sys.stdout.flush()
                 os.dup2(saved, 1)
@@ -567,6 +575,45 @@ class _SoloRank:
 
     def reduce(self, maxes, sums):
         return list(maxes), list(sums)
+
+
+def legs_for(rank, world, args, dry=False):
+    """Which of the line's optional legs THIS rank runs (a pure function of its arguments: tests/test_bench_launcher_cpu.py checks every
+    rank of an 8-rank job).  The CPU baseline, the live counter passes (children of rank 0 under rocprofv3), the store probe, the facade
+    and the other workloads belong to rank 0 of a ONE-GPU run only; a multi-GPU line spends its time on the scaling legs, which every
+    rank takes part in."""
+    legs = set()
+    # (the scaling legs: every rank takes part, same barriers)
+    if not args.no_scaling_legs and ((world > 1 and not args.total_envs and args.leg_envs) or args.strong_total):
+        legs.add('scaling_legs')
+    if dry:
+        return legs
+    if SETTLE_SECONDS > 0 and not args.no_settle_leg:
+        legs.update(('no_settle', 'one_launch_per_step'))
+    if world > 1:
+        return legs
+    if rank != 0:
+        return legs
+    headline_ring = args.output_sets >= 2 and not args.unfused and args.chains == 1
+    if headline_ring and not args.no_in_place_leg:
+        legs.add('in_place')
+    if args.chains == 1 and not args.unfused and not args.no_two_chains and not (headline_ring and args.no_in_place_leg):
+        legs.add('two_chains')
+    if not args.no_store_probe and not args.unfused and not args.full_obs:
+        legs.add('store_probe')
+    if not args.no_other_workloads and args.version == 'barrage':
+        legs.add('other_workloads')
+        if not args.no_consumer_leg:
+            legs.add('consumer_in_loop')
+        if not args.no_trajectory_leg:
+            legs.add('trajectory')
+    if not args.no_facade_leg:
+        legs.add('facade_n1')
+    if not args.no_live_traffic and not args.unfused:
+        legs.add('live_traffic')
+    if not args.no_cpu_baseline:
+        legs.add('cpu_baseline')
+    return legs
 
 
 def shard_of(rk, per_gpu, total_envs):
@@ -1256,6 +1303,7 @@ def run_rank(args):      # noqa: C901
     if n <= 0:
         raise SystemExit("bench.py: rank %d got no games (%d games over %d ranks)" % (rk.rank, total, rk.world))
     SETTLE_SECONDS = args.settle_seconds
+    legs_on = legs_for(rk.rank, rk.world, args, dry)
     if not dry:
         import torch
         if args.wake_seconds > 0:   # bring the GPU out of its idle power state; touches no env state
@@ -1294,7 +1342,7 @@ def run_rank(args):      # noqa: C901
     _, (checked, checksum, covered) = rk.reduce([], [checked, outputs_checksum(env) if not dry else 0, n])
     in_place, two_chains, no_settle = None, None, None
     per_step = b_min(v, args.full_obs, rec_bytes, fused)
-    if not dry and SETTLE_SECONDS > 0 and not args.no_settle_leg:
+    if 'no_settle' in legs_on:
         # what gpu_settle is worth: the same K steps on the same env object and buffers once more, W warm-up steps straight into the bracket
         # (every rank takes part: same barriers)
         e0, d0, _, _, inv0 = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring, settle=False)
@@ -1303,7 +1351,7 @@ def run_rank(args):      # noqa: C901
                      "value": total * args.steps / e0, "unit": "env steps/s", "launch_us": d0 / args.steps * 1e3,
                      "frac": per_step * n / (d0 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
     per_step_launches = None
-    if not dry and fused > 1 and not args.no_settle_leg:
+    if fused > 1 and 'one_launch_per_step' in legs_on:
         # ... and with one launch per step (sgx_set_multi_step(0): what every round before this one measured), same env object and buffers
         env.set_multi_step(False)
         e4, d4, _, _, inv4 = time_workload(rk, env, args.steps, args.warmup, args.unfused, args.chains, ring=headline_ring)
@@ -1312,7 +1360,7 @@ def run_rank(args):      # noqa: C901
         per_step_launches = {"workload": "the headline's K steps once more as K launches of the per-step kernel (step_kernel)", "value": total * args.steps / e4,
                              "unit": "env steps/s", "launch_us": d4 / args.steps * 1e3,
                              "frac": b_min(v, args.full_obs, rec_bytes) * n / (d4 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
-    if rk.world == 1 and headline_ring and not args.no_in_place_leg and not dry:
+    if 'in_place' in legs_on:
         # The same K / W on the same env object into ONE set of tensors (the set the ring wrote last), step after step: what rounds 1-3
         # reported as the headline.  Rewriting the same 1-2 GB back to back is 8-10 % faster than anything that cannot reuse its lines
         # (DESIGN.md section 3.2), so its rate is a memory-side figure that can touch the 8 TB/s spec peak: a ratio, not a DRAM fraction.
@@ -1324,7 +1372,7 @@ def run_rank(args):      # noqa: C901
                     "rate_is": "memory side including the 256 MiB Infinity Cache and whatever else favours rewriting the same lines; not a DRAM fraction",
                     "verified_envs": verify_against_oracle(env, args.version, min(args.verify_envs, 8), both=args.full_obs) if args.verify_envs else 0,
                     "verified_steps": env.bench_steps_played}
-    if rk.world == 1 and args.chains == 1 and not args.unfused and not args.no_two_chains and not (headline_ring and args.no_in_place_leg) and not dry:
+    if 'two_chains' in legs_on:
         # The same K steps (in place) with the batch split into two ranges of games whose launches overlap (sgx_rollout, chains = 2)
         e2, d2, _, _, inv2 = time_workload(rk, env, args.steps, args.warmup, False, 2)
         assert inv2 == 0
@@ -1332,6 +1380,13 @@ def run_rank(args):      # noqa: C901
                       "rate_over_spec_peak": per_step * n / (d2 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS,
                       "verified_envs": verify_against_oracle(env, args.version, args.verify_envs, both=args.full_obs) if args.verify_envs else 0,
                       "verified_steps": env.bench_steps_played}
+
+    store_probe = None
+    if 'store_probe' in legs_on:
+        # the step kernel's store stream without the game, on the very buffers the headline wrote (they are re-rendered afterwards)
+        import bench_legs
+        store_probe = bench_legs.store_probe_leg(sys.modules[__name__], env, per_step * n / ((dev_ms or 0.0) / 1e3 / args.steps) / 1e9)
+        env.observe()
 
     out = None
     if rk.rank == 0:
@@ -1343,12 +1398,24 @@ def run_rank(args):      # noqa: C901
                           first_us=(placement or {}).get('fobs_plain_us' if args.full_obs else 'plain_us'), rec_bytes=rec_bytes, build_id=build_id,
                           rotating=launch_s if headline_ring else None, ring_sets=args.output_sets if headline_ring else 1, fused_steps=fused)
             rf["in_place_rate_over_spec_peak"] = in_place["rate_over_spec_peak"] if in_place else None
+            # what a caller with a policy BETWEEN the steps gets from the same buffers: one launch per step
+            rf["frac_one_launch_per_step"] = per_step_launches["frac"] if per_step_launches else None
+            if store_probe:
+                rf.update(store_probe)
+                sp = store_probe["store_peak_measured"]
+                rf["frac_dram_basis"] = (
+                    "B_min bytes over the launch time of a run that writes a ring of output sets; the store-only kernel of the same shape takes %.0f GB/s on the "
+                    "same buffers (store_probe), so this launch runs at %.3f of what the memory takes from this store stream -- a memory-side rate at the "
+                    "device's boundary, not a count of DRAM pin transfers" % (sp, store_probe["frac_of_store_peak"] or 0.0))
         value = total_steps / elapsed
         out = {
             "metric": "env steps/sec", "value": None if dry else value, "unit": "env steps/s",
             "n_gpus": rk.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.total_envs else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "none (launcher self-test)" if dry else "synthetic", "build_id": build_id,
+            # `value` is a rollout call (all K steps known in advance: multi-step launches); with a consumer between the steps -- env.step(), a
+            # policy, env.step() -- every step is a launch of its own: the same K steps on the same buffers that way
+            "value_one_launch_per_step": per_step_launches["value"] if per_step_launches else None,
             "verified_envs": checked, "verified_steps": verified_steps,
             "config": {"workload": "%d concurrent %s games per GPU (%dx%d)%s, random-valid-action rollout with auto-reset, "
                                    "%s step+sample%s" % (n, args.version, v.rows, v.columns,
@@ -1367,7 +1434,8 @@ def run_rank(args):      # noqa: C901
                        "output_sets": args.output_sets if headline_ring else 1, "ring_placement_plain_and_kept_us_per_extra_set": ring_report,
                        "concurrent_chains": args.chains, "in_place": in_place, "two_chains": two_chains,
                        "launched_by": os.environ.get('SGX_BENCH_LAUNCHER', 'external' if rk.world > 1 else 'direct'),
-                       "reduction_backend": backend if rk.world > 1 else None, "devices": args.devices,
+                       "reduction_backend": backend if rk.world > 1 else None, "reduction_bringup_s": round(rk.bringup_seconds, 2) if rk.world > 1 else None,
+                       "legs_of_this_line": sorted(legs_on), "devices": args.devices,
                        "strong_leg_total_games": args.strong_total,
                        # the slowest / fastest rank's own K steps (no waiting for the others): weak scaling without a data-path
                        # collective loses nothing as long as these stay at the 1-GPU rate of the same games-per-GPU size
@@ -1403,8 +1471,8 @@ def run_rank(args):      # noqa: C901
         out["config"]["scaling_legs"] = legs
         out["config"]["other_workloads"] = None
         out["config"]["consumer_in_loop"] = None
-        if rk.world == 1 and not args.no_other_workloads and args.version == 'barrage' and not dry:
-            if not args.no_consumer_leg:
+        if 'other_workloads' in legs_on:
+            if 'consumer_in_loop' in legs_on:
                 out["config"]["consumer_in_loop"] = consumer_leg(rk, args)
             out["config"]["other_workloads"] = [other_workload(rk, args, 'standard', 262144, chains=2),
                                                 other_workload(rk, args, 'micro', 65536, chains=2, rotate_sets=args.rotate_sets),
@@ -1412,7 +1480,12 @@ def run_rank(args):      # noqa: C901
                                                 # BASELINE config 5's per-GPU size on ONE GPU: the G = 1 anchor of the 1 / 2 / 4 / 8 curve
                                                 other_workload(rk, args, 'barrage', GAMES_PER_GPU_MULTI)]
             out["config"]["compact_outputs"] = compact_leg(rk, args)
-        if rk.world == 1 and not dry and not args.no_live_traffic and not args.unfused:
+            import bench_legs
+            out["config"]["trajectory"] = bench_legs.trajectory_leg(sys.modules[__name__], rk, args, slots=args.trajectory_slots) if 'trajectory' in legs_on else None
+        if 'facade_n1' in legs_on:
+            import bench_legs
+            out["config"]["facade_n1"] = bench_legs.facade_leg(sys.modules[__name__])
+        if 'live_traffic' in legs_on:
             # the counter bytes of the headline's kernel, measured now (after every timed region): two children under rocprofv3 --pmc
             rf = out["roofline"]
             rf["traffic_static"], rf["traffic_static_source"] = rf["traffic"], rf["traffic_source"]
@@ -1422,7 +1495,7 @@ def run_rank(args):      # noqa: C901
                 rf["traffic_over_b_min"] = live / rf["bytes_per_launch"]
             else:
                 rf["traffic_live_failed"] = src
-        if not args.no_cpu_baseline and rk.world == 1 and not dry:         # the CPU leg is timed on rank 0 of the 1-GPU run only
+        if 'cpu_baseline' in legs_on:         # the CPU leg is timed on rank 0 of the 1-GPU run only
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None

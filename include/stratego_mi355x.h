@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 13
+#define SGX_ABI_VERSION 14
 #define SGX_MAX_CELLS 1024       /* rows*cols <= 1024 (largest reference variant: 15x15 = 225; the reference's StrategoProceduralEnv
                                     takes any size, penv:27-36: boards of more than 256 cells use 10-bit cell indices in the record) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
@@ -189,8 +189,9 @@ int sgx_set_nt_stores(sgx_env *h, int32_t mode);
 int sgx_set_lane_kernel(sgx_env *h, int32_t mode);
 
 /* Multi-step launches.  A rollout call -- sgx_step_n / sgx_step_ring: n_steps >= 2 consecutive steps, each playing the action the one
- * before drew -- runs its steps in ONE launch (launches of at most 256 steps) where it is eligible: flat perspective actions, masks in the
- * mover's perspective, an 'extended' channel mode, at most 8 output sets that differ in their observation / mask tensors only.
+ * before drew -- runs its steps in ONE launch (launches of at most 256 steps, on every board) where it is eligible: flat perspective actions,
+ * masks in the mover's perspective, an 'extended' channel mode, at most 8 output sets that differ in their observation / mask tensors only
+ * (sgx_step_ring; a trajectory buffer of ANY number of slots goes through sgx_step_traj, which names its slots by a stride).
  *  - Boards of more than 16 cells (steps_kernel): a workgroup stages its games once and every wave plays its game step after step -- the
  *    dense boards, never-moved flags, recent-move codes and capture events stay in LDS, the record's scalars and the drawn action in
  *    registers; every step's outputs are written like those of a launch of its own; the record is read once and written once per LAUNCH.
@@ -256,6 +257,22 @@ int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int32_t laun
  * an allocation is.  ptr_dev 1 KiB aligned; `launches` timed launches after one untimed; synchronises `stream`.  No reference
  * counterpart. */
 int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t launches, void *stream, float *gb_per_s);
+
+/* The store stream of the step kernel WITHOUT the game, for pricing the roofline against what the memory takes from exactly this store
+ * shape (bench.py: roofline.store_peak_measured).  One wave per `seg_bytes` segment (a multiple of 16; 26,800 = one 10x10 observation),
+ * eight waves per 512-thread workgroup at 6 waves per SIMD, workgroups mapped to segments like games to workgroups (eight contiguous XCD
+ * ranges); a wave sweeps its segment in 16-byte-per-lane store instructions on 1 KiB ADDRESS boundaries, whole 128-byte lines
+ * non-temporal, the two edge lines a segment shares with its neighbours through L2 -- emit_codes' pattern (sgx_obs.h).  The range
+ * [ptr_dev, ptr_dev + bytes) holds floor(bytes / seg_bytes) segments; ONE launch writes all of them `passes` times, pass after pass, so a
+ * launch of passes x bytes >> 288 MB (L2 + Infinity Cache) leaves a negligible share of its bytes in the caches when it ends.
+ * payload: 0 = zeros, 1 = observation-like floats (0 / 1 / -1 / 0.5 from a per-lane code pattern), 2 = incompressible bits (a hash of
+ * the address and the launch number).  OVERWRITES the range.  Returns the average duration of `launches` timed launches (HIP events on
+ * `stream`, one untimed launch first; synchronises the stream) and bytes written per launch / that time.  No reference counterpart. */
+#define SGX_PROBE_ZEROS 0
+#define SGX_PROBE_OBS_LIKE 1
+#define SGX_PROBE_RANDOM 2
+int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t seg_bytes, int32_t passes, int32_t payload, int32_t nt_stores,
+                    int32_t launches, void *stream, float *microseconds_per_launch, float *gb_per_s);
 
 /* Library-owned output buffers with a bounded placement trial.  On MI355X the same launch takes
  * 313-400 us depending on which physical memory backs the big observation buffer: device memory comes in regions of two
@@ -328,6 +345,30 @@ int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void *stream)
  * examples/basic_game_loop.py:34-63. */
 int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, int32_t first_set, int32_t n_steps, void *stream);
 
+/* sgx_step_n into a TRAJECTORY buffer: step t of the call (t = 0 .. n_steps-1) writes its outputs into slot (first_slot + t) % n_slots of
+ * tensors that carry a leading slot axis -- obs float32 [n_slots][slot_envs][R][C][67], mask uint8 [n_slots][slot_envs][R][C][K], ... --
+ * named by the pointers of slot 0 (`io`) and ONE stride, `slot_envs` (>= N; = N for dense [T][N]... tensors).  This is the batched
+ * counterpart of what the reference's caller gets: a FRESH observation / mask array from every env.step() (impl:905, maenv:447-497), so a
+ * learner that keeps T steps keeps T arrays.  Unlike sgx_step_ring the number of slots is not limited (n_slots = n_steps = 64 ... 1024 is the
+ * intended use), and with results_per_slot != 0 the per-step results are kept as well: reward float32 [n_slots][slot_envs][2], done /
+ * invalid_action / ending_invalid uint8 [n_slots][slot_envs], player int8 [n_slots][slot_envs] (0: they are overwritten in place like
+ * sgx_step_n's).  actions_log_dev (nullable) int32 [n_slots][slot_envs] receives the action every env DREW in the step -- the action the
+ * next step plays, i.e. the action chosen from the observation / mask of the same slot: (obs_t, mask_t, action_t) line up, and
+ * reward / done of slot t + 1 are what that action earned.  final_obs_dev / final_fobs_dev have no slot axis (they are written on
+ * terminal steps only).  io->actions_dev == io->next_actions_dev (the chain of drawn actions, int32 [N], no slot axis); tensors that are
+ * NULL in `io` are skipped.  Where the call is eligible for the multi-step kernels (sgx_set_multi_step) all steps run in ONE launch
+ * (launches of at most 256 steps); everything else takes one launch per step with the same results (tests/test_gpu_trajectory.py compares
+ * every slot with the oracle stepped alongside).  Compact outputs: the slot strides are those of the compact tensors
+ * (uint8 [n_slots][slot_envs][sgx_compact_obs_stride], uint32 [n_slots][slot_envs][sgx_compact_mask_words]). */
+typedef struct sgx_traj_io {
+    sgx_step_io io;               /* the tensors of slot 0 */
+    int32_t n_slots;              /* >= 1 */
+    int32_t results_per_slot;     /* 0: reward / done / player / invalid_action / ending_invalid in place; != 0: [n_slots][slot_envs]... */
+    int64_t slot_envs;            /* envs per slot of every tensor that has a slot axis, >= N */
+    int32_t *actions_log_dev;     /* [n_slots][slot_envs] out (nullable): the action drawn in each step */
+} sgx_traj_io;
+int sgx_step_traj(sgx_env *h, const sgx_traj_io *t, int32_t first_slot, int32_t n_steps, void *stream);
+
 /* sgx_step_n with the batch split into `chains` (1..SGX_MAX_CHAINS) contiguous ranges of games, each range playing its n_steps on a
  * stream of its own: games never interact, so the ranges' launches may overlap, and the ramp-up / drain of one range's step is filled
  * by the other's (a launch that lasts tens of microseconds spends a third of its time with the chip half empty).  The caller's
@@ -349,10 +390,13 @@ int sgx_sample_valid(sgx_env *h, const uint8_t *mask_dev, int32_t *actions_dev, 
  * softmax((logits - max) / temperature), and ONE action per game is drawn from it -- one wave per game, logits and mask read once.
  * mask_dev: the mask the step kernel wrote, uint8 [N][R*C*K], or with flags = SGX_STEP_COMPACT_MASK the bit mask uint32
  * [N][sgx_compact_mask_words] of a compact step.  temperature: a divisor, > 0; 0 = argmax (ties drawn uniformly).
- * The draw is keyed like next_actions_dev -- counter RNG on (seed, global env id, game number, turn) -- and sampling is fixed point
- * (weights floor(exp2(...) * 2^31), exact 64-bit sums, inverse CDF in ascending action order): a result depends on nothing but
- * (logits, mask, seed, game, turn), and with equal logits it IS sgx_sample_valid's action.  NaN logits count as -inf; if no valid
- * action has a logit above -inf the draw is uniform over the valid ones; actions_dev[i] = -1 where the mask is empty.
+ * The draw is keyed like next_actions_dev -- counter RNG on (seed, global env id, game number, turn) -- and sampling is fixed point:
+ * weight of a valid action = floor(exp2((logit - max) * log2(e) / temperature + 23)), i.e. 2^23 for the maximum, exact integer sums,
+ * inverse CDF in ascending action order.  A result depends on nothing but (logits, mask, seed, game, turn), and with equal logits it IS
+ * sgx_sample_valid's action.  The truncation means an action whose probability relative to the most likely one is below 2^-23
+ * (~1.2e-7) has weight 0 and is never drawn.  NaN logits count as -inf.  actions_dev[i] = -1 where NO action can be drawn: the mask
+ * is empty, or every valid action's logit is -inf / NaN -- the caller must not feed that -1 to sgx_step (it is an invalid action); a
+ * terminal env's mask holds the no-op only, which is drawn like any other action.
  * No policy network lives in this library: the logits are the caller's. */
 int sgx_choose_actions(sgx_env *h, const float *logits_dev, const void *mask_dev, float temperature, int32_t flags, int32_t *actions_dev, void *stream);
 

@@ -332,8 +332,14 @@ constexpr int KSTEP_SUB = 8, KSTEP_EMITTERS = 3, KSTEP_MAX_SETS = 8;
 struct StepsParams {
     KParams k;
     int32_t n_steps, n_sets, first_set;
+    int32_t strided;                      // sgx_step_traj: set s = the tensors of set 0 + s x the byte strides below (any number of slots)
+    int64_t obs_slot_bytes, mask_slot_bytes;
     float *obs[KSTEP_MAX_SETS];           // the observation / mask tensor of output set s (sgx_step_ring); one set: sgx_step_n, in place
     uint8_t *mask[KSTEP_MAX_SETS];
+    __device__ __forceinline__ float *obs_of(int set) const {
+        return strided ? reinterpret_cast<float *>(reinterpret_cast<char *>(obs[0]) + (int64_t)set * obs_slot_bytes) : obs[set];
+    }
+    __device__ __forceinline__ uint8_t *mask_of(int set) const { return strided ? (mask[0] ? mask[0] + (int64_t)set * mask_slot_bytes : nullptr) : mask[set]; }
 };
 
 template <class G>
@@ -422,6 +428,8 @@ __global__ __launch_bounds__(64 * (1 + KSTEP_EMITTERS), 4) void lane_steps_kerne
             }
             g.flags = (g.flags & ~F_PLAYER_M1) | (player == -1 ? F_PLAYER_M1 : 0);
             const bool ended_now = ap.applied && over;
+            const int set = (SP.first_set + t) % SP.n_sets;
+            const int64_t renv = env + (int64_t)set * P.traj_res_envs;     // (sgx_step_traj with per-slot results; else traj_res_envs = 0)
             if (act) {                                                     // rewards / dones (maenv:699-805)
                 const bool end_invalid = over && (g.flags & F_END_INVALID);
                 float rew_p1 = 0.f, rew_m1 = 0.f;
@@ -430,10 +438,10 @@ __global__ __launch_bounds__(64 * (1 + KSTEP_EMITTERS), 4) void lane_steps_kerne
                     rew_p1 = w == 0 ? 1e-4f : (float)w;                    // impl:838-840
                     rew_m1 = w == 0 ? 1e-4f : (float)-w;
                 }
-                if (P.io.reward_dev) reinterpret_cast<float2 *>(P.io.reward_dev)[env] = make_float2(rew_p1, rew_m1);
-                if (P.io.done_dev) P.io.done_dev[env] = over ? 1 : 0;
-                if (P.io.invalid_action_dev) P.io.invalid_action_dev[env] = invalid_action ? 1 : 0;
-                if (P.io.ending_invalid_dev) P.io.ending_invalid_dev[env] = end_invalid ? 1 : 0;
+                if (P.io.reward_dev) reinterpret_cast<float2 *>(P.io.reward_dev)[renv] = make_float2(rew_p1, rew_m1);
+                if (P.io.done_dev) P.io.done_dev[renv] = over ? 1 : 0;
+                if (P.io.invalid_action_dev) P.io.invalid_action_dev[renv] = invalid_action ? 1 : 0;
+                if (P.io.ending_invalid_dev) P.io.ending_invalid_dev[renv] = end_invalid ? 1 : 0;
             }
             if (P.io.auto_reset && ended_now && act) {                     // the finished env starts its next game now
                 g.game_no += 1;
@@ -444,18 +452,18 @@ __global__ __launch_bounds__(64 * (1 + KSTEP_EMITTERS), 4) void lane_steps_kerne
                     if (i < P.max_events) ev[i] = 0;
                 nvalid = lane_gen_moves<G>(g, 0, obst_abs, false, V);
             }
-            if (act && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
+            if (act && P.io.player_dev) P.io.player_dev[renv] = (int8_t)player;
             lane_store<G>(g, myrec);                                       // (always: the emitters read this step's image)
             // mask rows (coalesced out by this wave) and the next action
-            const int set = (SP.first_set + t) % SP.n_sets;
             {
                 uint32_t *row = reinterpret_cast<uint32_t *>(L.maskrows) + lane * (NA / 4);
                 const int total = nvalid == 0 ? 1 : nvalid;
                 const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)g.game_no, STREAM_ACTION, (uint32_t)g.turn), (uint32_t)total);
                 na = lane_emit_mask<G>(V, nvalid == 0, (int)k, [&](int j, uint32_t d) { row[j] = d; });
+                if (act && P.traj_act_log) P.traj_act_log[env + (int64_t)set * P.traj_out_envs] = na;
                 wave_sync<G>();
-                if (SP.mask[set]) {
-                    uint8_t *dst = SP.mask[set] + env0 * (int64_t)NA;      // 16-byte aligned: env0 is a multiple of 64
+                if (uint8_t *mset = SP.mask_of(set)) {
+                    uint8_t *dst = mset + env0 * (int64_t)NA;              // 16-byte aligned: env0 is a multiple of 64
                     const int n16 = (n_act * NA) >> 4, nd = (n_act * NA) >> 2;
                     for (int j = lane; j < n16; j += 64) reinterpret_cast<int4 *>(dst)[j] = reinterpret_cast<const int4 *>(L.maskrows)[j];
                     if (4 * n16 + lane < nd) reinterpret_cast<uint32_t *>(dst)[4 * n16 + lane] = reinterpret_cast<const uint32_t *>(L.maskrows)[4 * n16 + lane];
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(64 * (1 + KSTEP_EMITTERS), 4) void lane_steps_kerne
         for (int t = 0; t < SP.n_steps; ++t) {
             __syncthreads();                                               // barrier t
             const int set = (SP.first_set + t) % SP.n_sets;
-            float *obs = SP.obs[set];
+            float *obs = SP.obs_of(set);
             const uint8_t *img = steps_rec + (t & 1) * buf_bytes;
             for (int b = 0, g0 = 0; g0 < n_act; ++b, g0 += KSTEP_SUB) {
                 if ((b + t) % KSTEP_EMITTERS != wave - 1) continue;

@@ -198,6 +198,10 @@ struct KParams {
     // sgx_step_states: the states an import had to alter are appended here (count by atomicAdd), so that the general-state pass visits
     // only those instead of launching a block per state; NULL elsewhere
     int32_t *flag_list, *flag_count;
+    // sgx_step_traj (multi-step launches only): the step that writes slot s of a trajectory buffer writes its per-step results (rewards,
+    // flags, player) at env + s * traj_res_envs (0: in place) and the action it drew to traj_act_log[env + s * traj_out_envs]
+    int64_t traj_out_envs, traj_res_envs;
+    int32_t *traj_act_log;
 #ifdef SGX_STAMPS
     unsigned long long *stamps;  // diagnostic build only: [N][16] s_memtime stamps per phase
 #endif

@@ -158,8 +158,9 @@ struct StepOut {
 struct StepCarry {
     int turn, flags, max_turns, game_no, n_events, rp0, rp1, na;
     bool dirty;
-    float *obs, *fobs;        // this step's output tensors (the output set of an sgx_step_ring): the caller sets them before every step
+    float *obs, *fobs;        // this step's output tensors (the output set of an sgx_step_ring / the slot of an sgx_step_traj): the caller sets them before every step
     uint8_t *mask;
+    int slot;                 // ... and the slot number (per-slot results and the action log of sgx_step_traj: KParams::traj_*)
 };
 
 // One game's env.step() by one wave (called with the wave's private LDS region).
@@ -184,6 +185,10 @@ __device__ __forceinline__ void env_step(const KP &P, Lds<Geo<R_, C_, VAR>, ObsK
     // the step's output tensors: the launch's, or -- one of several steps of a multi-step launch -- this step's output set
     float *const io_obs = PERSIST ? carry->obs : P.io.obs_dev, *const io_fobs = PERSIST ? carry->fobs : P.io.fobs_dev;
     uint8_t *const io_mask = PERSIST ? carry->mask : P.io.mask_dev;
+    // where this step's results go: env, or -- a multi-step launch into a trajectory buffer that keeps every step's results -- the env's
+    // place in this step's slot
+    int64_t renv = env;
+    if constexpr (PERSIST) renv = env + (int64_t)carry->slot * P.traj_res_envs;
 
     int8_t *rec_g = rec_out ? rec_out : P.boards + env * (int64_t)P.rec_bytes;   // (rec_out: the LDS record image of sgx_step_states)
     // ---- stage.  Every global read of the step has been issued up front (load_game) -- the whole record (a few 128-byte lines)
@@ -440,10 +445,10 @@ __device__ __forceinline__ void env_step(const KP &P, Lds<Geo<R_, C_, VAR>, ObsK
     }
     if (P.mode == 0) {
         // one store instruction for the rewards (lanes 0/1) and one for the three byte flags (lanes 0..2)
-        if (lane < 2 && P.io.reward_dev) P.io.reward_dev[2 * env + lane] = lane ? rew_m1 : rew_p1;
+        if (lane < 2 && P.io.reward_dev) P.io.reward_dev[2 * renv + lane] = lane ? rew_m1 : rew_p1;
         uint8_t *fp = lane == 0 ? P.io.done_dev : lane == 1 ? P.io.invalid_action_dev : lane == 2 ? P.io.ending_invalid_dev : nullptr;
         const uint8_t fv = lane == 0 ? (done ? 1 : 0) : lane == 1 ? (invalid_action ? 1 : 0) : (end_invalid ? 1 : 0);
-        if (fp) fp[env] = fv;
+        if (fp) fp[renv] = fv;
     }
 
     // ---- observation rendering (sgx_obs.h).  render() writes one observation.  'extended' kinds on 4-aligned boards need no
@@ -516,7 +521,7 @@ __device__ __forceinline__ void env_step(const KP &P, Lds<Geo<R_, C_, VAR>, ObsK
 
     STAMP(4);   // results / terminal handling done
     // ---- outputs for the next mover
-    if (lane == 0 && P.io.player_dev) P.io.player_dev[env] = (int8_t)player;
+    if (lane == 0 && P.io.player_dev) P.io.player_dev[renv] = (int8_t)player;
     if constexpr (SPLIT) {
         if (lane == 0) { so->qi = qi; so->n_events = n_events; so->rp0 = rp0; so->rp1 = rp1; }
     } else {
@@ -556,7 +561,10 @@ __device__ __forceinline__ void env_step(const KP &P, Lds<Geo<R_, C_, VAR>, ObsK
         const int total = nvalid == 0 ? 1 : nvalid;
         const uint32_t k = rng_below(sgx_rng(P.seed, (uint64_t)(P.env_id_offset + env), (uint64_t)game_no, STREAM_ACTION, (uint32_t)turn), (uint32_t)total);
         const int na = kth_valid(L, (int)k, lane);
-        if constexpr (PERSIST) carry->na = na;
+        if constexpr (PERSIST) {
+            carry->na = na;
+            if (lane == 0 && P.traj_act_log) P.traj_act_log[env + (int64_t)carry->slot * P.traj_out_envs] = na;
+        }
         if (lane == 0 && (!PERSIST || last)) P.io.next_actions_dev[env] = na;
     }
 
@@ -651,9 +659,27 @@ constexpr int WSTEPS_MAX_SETS = 8;
 struct WaveStepsParams {
     KParams k;
     int32_t n_steps, n_sets, first_set;
+    // sgx_step_traj: the n_sets "sets" are the slots of a trajectory buffer -- slot s = the tensors of slot 0 (obs[0] / fobs[0] / mask[0]) + s x
+    // these byte strides (0 for a tensor that is NULL); any number of slots.  0: the tensors of set s are obs[s] / fobs[s] / mask[s].
+    int32_t strided;
+    int64_t obs_slot_bytes, fobs_slot_bytes, mask_slot_bytes;
     float *obs[WSTEPS_MAX_SETS], *fobs[WSTEPS_MAX_SETS];      // the output tensors of set s (sgx_step_ring); one set: in place
     uint8_t *mask[WSTEPS_MAX_SETS];
 };
+// the output tensors of set / slot `set` (scalar arithmetic on kernel arguments)
+template <class SPP>
+__device__ __forceinline__ void steps_outputs_of(const SPP sp, const int set, StepCarry &carry) {
+    if (sp->strided) {
+        carry.obs = reinterpret_cast<float *>(reinterpret_cast<char *>(sp->obs[0]) + (int64_t)set * sp->obs_slot_bytes);
+        carry.fobs = reinterpret_cast<float *>(reinterpret_cast<char *>(sp->fobs[0]) + (int64_t)set * sp->fobs_slot_bytes);
+        carry.mask = sp->mask[0] + (int64_t)set * sp->mask_slot_bytes;
+    } else {
+        carry.obs = sp->obs[set];
+        carry.fobs = sp->fobs[set];
+        carry.mask = sp->mask[set];
+    }
+    carry.slot = set;
+}
 // occupancy promise of steps_kernel: the per-step kernel's, except on small boards of an odd cell count (5x5: two games per wave, the
 // unaligned observation sweep) with an observation to render -- the 64 registers of the 8-wave promise spill inside the steps loop there,
 // and a scratch access retires in order with the wave's outstanding observation stores (in-process A/B on one set of buffers, 65,536
@@ -715,14 +741,12 @@ __global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (steps_waves_per_simd<Geo<
         reinterpret_cast<int *>(obst_s + G::OBST_BYTES)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
     __syncthreads();   // from here on every wave works on its own game, for all n_steps
     if (env >= P.n_envs) return;
-    StepCarry carry{0, 0, 0, 0, 0, 0, 0, 0, false, nullptr, nullptr, nullptr};
+    StepCarry carry{0, 0, 0, 0, 0, 0, 0, 0, false, nullptr, nullptr, nullptr, 0};
     int set = spp->first_set;
     const int n_steps = spp->n_steps;
     {   // the first step stages the record (its loads were issued before the table staging); its code is a copy of its own, so that the record's
         // registers are dead in the loop below
-        carry.obs = spp->obs[set];
-        carry.fobs = spp->fobs[set];
-        carry.mask = spp->mask[set];
+        steps_outputs_of(spp, set, carry);
         env_step<R_, C_, KIND, false, false, 0, 1>(P, LW[slot], shared, obst_s, env, lane, in, nullptr, nullptr, &carry, n_steps == 1);
         set = set + 1 == spp->n_sets ? 0 : set + 1;
     }
@@ -732,9 +756,7 @@ __global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (steps_waves_per_simd<Geo<
         // (the step's reads of the parameters start here; and what a step derives from the lane -- dozens of cell / entry offsets -- is
         //  recomputed in every step like in a launch of its own, not hoisted out of the loop and spilled: 244 bytes of scratch otherwise)
         asm volatile("" : "+s"(sp), "+v"(lane_t), "+v"(slot_t));
-        carry.obs = sp->obs[set];
-        carry.fobs = sp->fobs[set];
-        carry.mask = sp->mask[set];
+        steps_outputs_of(sp, set, carry);
         env_step<R_, C_, KIND, false, false, 0, 2>(sp->k, LW[slot_t], shared, obst_s, env, lane_t, in, nullptr, nullptr, &carry, t == n_steps - 1);
         set = set + 1 == sp->n_sets ? 0 : set + 1;
     }

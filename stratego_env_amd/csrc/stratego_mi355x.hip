@@ -626,36 +626,101 @@ static int check_step_io(sgx_env *h, const KParams &p) {
     return SGX_OK;
 }
 
-// sgx_step_n / sgx_step_ring on boards of at most 16 cells: all n_steps in ONE launch of lane_steps_kernel (sgx_lane_kernel.h) where the call
-// is eligible -- the lane kernel's conditions for every output set, flat perspective actions, observations wanted.  *launched tells.
-static int launch_lane_steps(sgx_env *h, const KParams &p_in, const sgx_step_io *ios, int32_t n_sets, int32_t first_set, int32_t n_steps, void *stream,
-                             bool *launched) {
+// The output sets of a rollout call: sgx_step_n (one set, in place), sgx_step_ring (n_sets separate sets: ios[0 .. n_sets)), or the slots of
+// an sgx_step_traj trajectory buffer (strided: ios[0] names slot 0, slot s lies s x the byte strides further; KParams::traj_* carry the
+// strides of the per-step results and of the action log).
+struct OutSets {
+    const sgx_step_io *ios;
+    int32_t n_sets;
+    bool strided;
+    int64_t obs_b, fobs_b, mask_b;
+};
+
+static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_sets = 1);
+
+// ONE step of a rollout call as a launch of its own, writing output set / slot `set`: what the multi-step launches fall back to (calls
+// they do not cover, the odd step a chunk leaves over).
+static int launch_set_step(sgx_env *h, const KParams &p_in, const OutSets &sets, int32_t set, void *stream) {
+    KParams p1 = p_in;
+    p1.mode = 0;
+    if (!sets.strided) {
+        p1.io = sets.ios[set];
+        return launch_step(h, p1, stream, sets.n_sets);
+    }
+    sgx_step_io io = sets.ios[0];
+    auto at = [](auto *ptr, int64_t bytes) { return ptr ? reinterpret_cast<decltype(ptr)>(reinterpret_cast<char *>(ptr) + bytes) : ptr; };
+    io.obs_dev = at(io.obs_dev, set * sets.obs_b);
+    io.fobs_dev = at(io.fobs_dev, set * sets.fobs_b);
+    io.mask_dev = at(io.mask_dev, set * sets.mask_b);
+    const int64_t r = set * p_in.traj_res_envs;
+    io.reward_dev = at(io.reward_dev, 8 * r);
+    io.done_dev = at(io.done_dev, r);
+    io.player_dev = at(io.player_dev, r);
+    io.invalid_action_dev = at(io.invalid_action_dev, r);
+    io.ending_invalid_dev = at(io.ending_invalid_dev, r);
+    p1.io = io;
+    if (int rc = launch_step(h, p1, stream, sets.n_sets)) return rc;
+    if (p_in.traj_act_log && io.next_actions_dev)
+        HIP_TRY(hipMemcpyAsync(p_in.traj_act_log + set * p_in.traj_out_envs, io.next_actions_dev, (size_t)h->n_envs * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream));
+    return SGX_OK;
+}
+
+// A rollout call goes out in launches of at most SGX_STEPS_MAX_PER_LAUNCH steps (a workgroup should not own the chip for seconds: work on
+// other streams, or a second rank sharing the GPU, gets in between the launches).
+#define SGX_STEPS_MAX_PER_LAUNCH 256
+
+// sgx_step_n / sgx_step_ring / sgx_step_traj on boards of at most 16 cells: the steps in launches of lane_steps_kernel (sgx_lane_kernel.h)
+// where the call is eligible -- the lane kernel's conditions for every output set, flat perspective actions, observations wanted.
+// *launched tells.
+static int launch_lane_steps(sgx_env *h, const KParams &p_in, const OutSets &sets, int32_t first_set, int32_t n_steps, void *stream, bool *launched) {
     *launched = false;
-    if (n_steps < 2 || n_sets > KSTEP_MAX_SETS || h->lane_mode == 0 || h->no_multi_step) return SGX_OK;
+    const int32_t n_sets = sets.n_sets;
+    if (n_steps < 2 || (!sets.strided && n_sets > KSTEP_MAX_SETS) || h->lane_mode == 0 || h->no_multi_step) return SGX_OK;
     KParams p = p_in;
     p.mode = 0;
-    p.io = ios[first_set];
+    p.io = sets.ios[sets.strided ? 0 : first_set];
     if (!p.io.obs_dev || (p.io.flags & (SGX_STEP_ACTIONS_1D | SGX_STEP_ACTIONS_POSITIONS))) return SGX_OK;
     StepsParams sp;
     memset(&sp, 0, sizeof(sp));
-    for (int32_t k = 0; k < n_sets; ++k) {
-        KParams pk = p;
-        pk.io = ios[k];
-        const bool full = pk.io.fobs_dev || pk.io.final_fobs_dev, original = (pk.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
-        if (!pk.io.obs_dev || !lane_eligible(h, pk, full, original, true)) return SGX_OK;
-        // everything but the observation / mask tensors is shared by the sets (the kernel writes the results through set first_set's pointers)
-        if (pk.io.reward_dev != p.io.reward_dev || pk.io.done_dev != p.io.done_dev || pk.io.player_dev != p.io.player_dev ||
-            pk.io.invalid_action_dev != p.io.invalid_action_dev || pk.io.ending_invalid_dev != p.io.ending_invalid_dev) return SGX_OK;
-        sp.obs[k] = pk.io.obs_dev;
-        sp.mask[k] = pk.io.mask_dev;
-    }
+    if (sets.strided) {
+        const bool full = p.io.fobs_dev || p.io.final_fobs_dev, original = (p.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
+        // every slot as aligned as slot 0 (the kernel's 16-byte stores), per-slot results as aligned as the results of slot 0
+        if (!lane_eligible(h, p, full, original, true) || ((sets.obs_b | sets.mask_b) & 15) || (p.traj_res_envs & 1)) return SGX_OK;
+        sp.strided = 1;
+        sp.obs_slot_bytes = sets.obs_b;
+        sp.mask_slot_bytes = sets.mask_b;
+        sp.obs[0] = p.io.obs_dev;
+        sp.mask[0] = p.io.mask_dev;
+    } else
+        for (int32_t k = 0; k < n_sets; ++k) {
+            KParams pk = p;
+            pk.io = sets.ios[k];
+            const bool full = pk.io.fobs_dev || pk.io.final_fobs_dev, original = (pk.io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
+            if (!pk.io.obs_dev || !lane_eligible(h, pk, full, original, true)) return SGX_OK;
+            // everything but the observation / mask tensors is shared by the sets (the kernel writes the results through set first_set's pointers)
+            if (pk.io.reward_dev != p.io.reward_dev || pk.io.done_dev != p.io.done_dev || pk.io.player_dev != p.io.player_dev ||
+                pk.io.invalid_action_dev != p.io.invalid_action_dev || pk.io.ending_invalid_dev != p.io.ending_invalid_dev) return SGX_OK;
+            sp.obs[k] = pk.io.obs_dev;
+            sp.mask[k] = pk.io.mask_dev;
+        }
     if (int rc = check_step_io(h, p)) return rc;
     p.map_mode = h->map_mode; p.map_arg = h->map_arg;
     const bool streaming = launch_streams_past_cache(h, p, n_sets);
     p.nt_stores = h->nt_mode < 0 ? (streaming ? 1 : 0) : h->nt_mode;
     int32_t skew[8];
     launch_shares(h, streaming, skew);
-    sp.n_steps = n_steps; sp.n_sets = n_sets; sp.first_set = first_set;
+    sp.n_sets = n_sets;
+    for (int32_t done = 0; done < n_steps; ) {
+        const int32_t now = n_steps - done > SGX_STEPS_MAX_PER_LAUNCH ? SGX_STEPS_MAX_PER_LAUNCH : n_steps - done;
+        const int32_t set = (int32_t)(((int64_t)first_set + done) % n_sets);
+        if (now < 2) {                                                      // a single step left over: the ordinary launch
+            if (int rc = launch_set_step(h, p_in, sets, set, stream)) return rc;
+            done += now;
+            continue;
+        }
+        sp.n_steps = now; sp.first_set = set;
+        bool ok = false;
 #define CALL_LANE_STEPS(R, C)                                                                                      \
     do {                                                                                                           \
         if constexpr (lane_geometry<Geo<R, C>>()) {                                                                \
@@ -671,29 +736,34 @@ static int launch_lane_steps(sgx_env *h, const KParams &p_in, const sgx_step_io 
             }                                                                                                      \
             sp.k = p;                                                                                              \
             lane_steps_kernel<R, C><<<grid, 64 * (1 + KSTEP_EMITTERS), dyn, (hipStream_t)stream>>>(sp);            \
-            *launched = true;                                                                                      \
-            h->last_kind = SGX_LAUNCH_MULTI_STEP;                                                                  \
+            ok = true;                                                                                             \
         }                                                                                                          \
     } while (0)
-    DISPATCH_GEOMETRY(h, CALL_LANE_STEPS);
+        DISPATCH_GEOMETRY(h, CALL_LANE_STEPS);
 #undef CALL_LANE_STEPS
-    if (*launched) HIP_TRY(hipGetLastError());
+        if (!ok) {
+            if (done == 0) return SGX_OK;                                   // (not this board / this runtime: nothing was launched)
+            return fail(SGX_EDEVICE, "lane_steps_kernel became unavailable in the middle of a call%s");
+        }
+        HIP_TRY(hipGetLastError());
+        done += now;
+    }
+    *launched = true;
+    h->last_kind = SGX_LAUNCH_MULTI_STEP;
     return SGX_OK;
 }
 
-static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_sets = 1);
-
-// The same for the wave-per-game kernels (steps_kernel, sgx_step.h): all n_steps of an sgx_step_n / sgx_step_ring call in ONE launch -- the games'
-// boards stay in LDS, the record travels once per launch, the waves drift out of phase -- for the 67-channel 'extended' kind, BOTH
-// observations, compact outputs and launches without an observation; perspective actions and masks, at most 8 output sets.
-#define SGX_WSTEPS_MAX_PER_LAUNCH 256
-static int launch_wave_steps(sgx_env *h, const KParams &p_in, const sgx_step_io *ios, int32_t n_sets, int32_t first_set, int32_t n_steps, void *stream,
-                             bool *launched) {
+// The same for the wave-per-game kernels (steps_kernel, sgx_step.h): the steps of an sgx_step_n / sgx_step_ring / sgx_step_traj call in launches
+// of up to 256 steps -- the games' boards stay in LDS, the record travels once per launch, the waves drift out of phase -- for the 67-channel
+// 'extended' kind, BOTH observations, compact outputs and launches without an observation; perspective actions and masks; at most 8
+// separate output sets, or any number of slots of a trajectory buffer.
+static int launch_wave_steps(sgx_env *h, const KParams &p_in, const OutSets &sets, int32_t first_set, int32_t n_steps, void *stream, bool *launched) {
     *launched = false;
-    if (n_steps < 2 || n_sets > WSTEPS_MAX_SETS || h->no_multi_step || !h->multi_step_wave || h->map_mode != 0) return SGX_OK;
+    const int32_t n_sets = sets.n_sets;
+    if (n_steps < 2 || (!sets.strided && n_sets > WSTEPS_MAX_SETS) || h->no_multi_step || !h->multi_step_wave || h->map_mode != 0) return SGX_OK;
     KParams p = p_in;
     p.mode = 0;
-    p.io = ios[first_set];
+    p.io = sets.ios[sets.strided ? 0 : first_set];
     const sgx_step_io &io0 = p.io;
     if (io0.flags & (SGX_STEP_ACTIONS_1D | SGX_STEP_ACTIONS_POSITIONS | SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS | SGX_STEP_ORIGINAL_CHANNELS)) return SGX_OK;
     const bool compact = (io0.flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) != 0;
@@ -701,18 +771,27 @@ static int launch_wave_steps(sgx_env *h, const KParams &p_in, const sgx_step_io 
     const bool no_obs = !io0.obs_dev && !io0.fobs_dev && !io0.final_obs_dev && !io0.final_fobs_dev && !compact;
     if (compact && (full || io0.final_obs_dev)) return SGX_OK;             // (launch_step refuses these: let it say so)
     if (compact && ((reinterpret_cast<uintptr_t>(io0.obs_dev) | reinterpret_cast<uintptr_t>(io0.mask_dev)) & 15)) return SGX_OK;
+    // Logic-only rollouts on boards of at most 16 cells (no observation pointer): the lane-per-game kernel, one launch per step, plays these
+    // twice as fast as a wave-per-game kernel (Micro 13 against 25 us per step, DESIGN.md lane section) -- leave them to it
+    if (no_obs && lane_eligible(h, p, false, false)) return SGX_OK;
     WaveStepsParams sp;
     memset(&sp, 0, sizeof(sp));
-    for (int32_t k = 0; k < n_sets; ++k) {
-        const sgx_step_io &io = ios[k];
-        // the sets differ in their output tensors only, and every set has the tensors the first one has
-        if (io.reward_dev != io0.reward_dev || io.done_dev != io0.done_dev || io.player_dev != io0.player_dev || io.invalid_action_dev != io0.invalid_action_dev ||
-            io.ending_invalid_dev != io0.ending_invalid_dev || io.final_obs_dev != io0.final_obs_dev || io.final_fobs_dev != io0.final_fobs_dev ||
-            (io.obs_dev == nullptr) != (io0.obs_dev == nullptr) || (io.fobs_dev == nullptr) != (io0.fobs_dev == nullptr) ||
-            (io.mask_dev == nullptr) != (io0.mask_dev == nullptr)) return SGX_OK;
-        if (compact && ((reinterpret_cast<uintptr_t>(io.obs_dev) | reinterpret_cast<uintptr_t>(io.mask_dev)) & 15)) return SGX_OK;
-        sp.obs[k] = io.obs_dev; sp.fobs[k] = io.fobs_dev; sp.mask[k] = io.mask_dev;
-    }
+    if (sets.strided) {
+        if (compact && ((sets.obs_b | sets.mask_b) & 15)) return SGX_OK;
+        sp.strided = 1;
+        sp.obs_slot_bytes = sets.obs_b; sp.fobs_slot_bytes = sets.fobs_b; sp.mask_slot_bytes = sets.mask_b;
+        sp.obs[0] = io0.obs_dev; sp.fobs[0] = io0.fobs_dev; sp.mask[0] = io0.mask_dev;
+    } else
+        for (int32_t k = 0; k < n_sets; ++k) {
+            const sgx_step_io &io = sets.ios[k];
+            // the sets differ in their output tensors only, and every set has the tensors the first one has
+            if (io.reward_dev != io0.reward_dev || io.done_dev != io0.done_dev || io.player_dev != io0.player_dev || io.invalid_action_dev != io0.invalid_action_dev ||
+                io.ending_invalid_dev != io0.ending_invalid_dev || io.final_obs_dev != io0.final_obs_dev || io.final_fobs_dev != io0.final_fobs_dev ||
+                (io.obs_dev == nullptr) != (io0.obs_dev == nullptr) || (io.fobs_dev == nullptr) != (io0.fobs_dev == nullptr) ||
+                (io.mask_dev == nullptr) != (io0.mask_dev == nullptr)) return SGX_OK;
+            if (compact && ((reinterpret_cast<uintptr_t>(io.obs_dev) | reinterpret_cast<uintptr_t>(io.mask_dev)) & 15)) return SGX_OK;
+            sp.obs[k] = io.obs_dev; sp.fobs[k] = io.fobs_dev; sp.mask[k] = io.mask_dev;
+        }
     if (int rc = check_step_io(h, p)) return rc;
     p.map_mode = 0; p.map_arg = h->map_arg;
     const bool streaming = launch_streams_past_cache(h, p, n_sets);
@@ -721,19 +800,16 @@ static int launch_wave_steps(sgx_env *h, const KParams &p_in, const sgx_step_io 
     launch_shares(h, streaming, skew);
     const int kind = compact ? 4 : no_obs ? 8 : full ? 1 : 0;
     sp.n_sets = n_sets;
-    // (long rollouts go out in launches of at most SGX_WSTEPS_MAX_PER_LAUNCH steps: a workgroup should not own the chip for seconds)
     for (int32_t done = 0; done < n_steps; ) {
-        const int32_t now = n_steps - done > SGX_WSTEPS_MAX_PER_LAUNCH ? SGX_WSTEPS_MAX_PER_LAUNCH : n_steps - done;
+        const int32_t now = n_steps - done > SGX_STEPS_MAX_PER_LAUNCH ? SGX_STEPS_MAX_PER_LAUNCH : n_steps - done;
+        const int32_t set = (int32_t)(((int64_t)first_set + done) % n_sets);
         if (now < 2) {                                                      // a single step left over: the ordinary launch
-            KParams p1 = p_in;
-            p1.mode = 0;
-            p1.io = ios[(first_set + done) % n_sets];
-            if (int rc = launch_step(h, p1, stream, n_sets)) return rc;
+            if (int rc = launch_set_step(h, p_in, sets, set, stream)) return rc;
             done += now;
             continue;
         }
         sp.n_steps = now;
-        sp.first_set = (first_set + done) % n_sets;
+        sp.first_set = set;
 #define CALL_WSTEPS_K(R, C, KIND)                                                                          \
     do {                                                                                                   \
         using G_ = Geo<R, C>;                                                                              \
@@ -915,6 +991,44 @@ SGX_API int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t laun
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
+}
+
+// The step kernel's store stream without the game (sgx_mem.h: store_probe_kernel): what the memory takes from exactly this store shape.
+SGX_API int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t seg_bytes, int32_t passes, int32_t payload, int32_t nt_stores,
+                            int32_t launches, void *stream, float *microseconds_per_launch, float *gb_per_s) {
+    if (!ptr_dev || !microseconds_per_launch || !gb_per_s || launches <= 0 || passes <= 0 || bytes <= 0) return fail(SGX_EINVAL, "sgx_store_probe: bad argument%s");
+    if (seg_bytes < 16 || (seg_bytes & 15) || (reinterpret_cast<uintptr_t>(ptr_dev) & 15)) return fail(SGX_EINVAL, "sgx_store_probe: segments and the range are 16-byte aligned%s");
+    if (payload < 0 || payload > 2) return fail(SGX_EINVAL, "sgx_store_probe: payload 0 (zeros), 1 (observation-like) or 2 (random bits)%s");
+    const int64_t n_seg = (bytes / seg_bytes) & ~(int64_t)63;                 // eight waves per workgroup, eight XCD shares
+    if (n_seg < 64) return fail(SGX_EINVAL, "sgx_store_probe: the range holds fewer than 64 segments%s");
+    const int64_t groups_per_pass = n_seg / 8, grid = groups_per_pass * passes;
+    if (grid > 0x7fffffff) return fail(SGX_EINVAL, "sgx_store_probe: passes x segments exceed one grid%s");
+    SGX_ON_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    static uint32_t salt = 0x5EED5EEDu;
+    auto go = [&]() {
+        salt = salt * 1664525u + 1013904223u;
+        if (payload == 0) store_probe_kernel<0><<<(unsigned)grid, 512, 0, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt);
+        else if (payload == 1) store_probe_kernel<1><<<(unsigned)grid, 512, 0, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt);
+        else store_probe_kernel<2><<<(unsigned)grid, 512, 0, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt);
+    };
+    go();                                                                      // untimed first touch
+    hipError_t e = hipEventRecord(e0, st);
+    for (int32_t i = 0; i < launches; ++i) go();
+    if (e == hipSuccess) e = hipEventRecord(e1, st);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipGetLastError();
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(SGX_EDEVICE, "sgx_store_probe: %s", hipGetErrorString(e));
+    *microseconds_per_launch = ms * 1000.f / (float)launches;
+    *gb_per_s = (float)((double)n_seg * seg_bytes * passes * launches / (ms * 1e-3) / 1e9);
+    return SGX_OK;
 }
 
 // ---- library-owned output buffers with a bounded placement trial
@@ -1204,9 +1318,10 @@ SGX_API int sgx_step_n(sgx_env *h, const sgx_step_io *io, int32_t n_steps, void 
     p.io = *io;
     {   // boards of at most 16 cells: the n_steps in one launch, the games in registers (lane_steps_kernel)
         bool launched = false;
-        if (int rc = launch_lane_steps(h, p, io, 1, 0, n_steps, stream, &launched)) return rc;
+        const OutSets one{io, 1, false, 0, 0, 0};
+        if (int rc = launch_lane_steps(h, p, one, 0, n_steps, stream, &launched)) return rc;
         if (launched) return SGX_OK;
-        if (int rc = launch_wave_steps(h, p, io, 1, 0, n_steps, stream, &launched)) return rc;
+        if (int rc = launch_wave_steps(h, p, one, 0, n_steps, stream, &launched)) return rc;
         if (launched) return SGX_OK;
     }
     for (int32_t i = 0; i < n_steps; ++i)
@@ -1228,15 +1343,51 @@ SGX_API int sgx_step_ring(sgx_env *h, const sgx_step_io *ios, int32_t n_sets, in
     p.mode = 0;
     {
         bool launched = false;
-        if (int rc = launch_lane_steps(h, p, ios, n_sets, first_set, n_steps, stream, &launched)) return rc;
+        const OutSets ring{ios, n_sets, false, 0, 0, 0};
+        if (int rc = launch_lane_steps(h, p, ring, first_set, n_steps, stream, &launched)) return rc;
         if (launched) return SGX_OK;
-        if (int rc = launch_wave_steps(h, p, ios, n_sets, first_set, n_steps, stream, &launched)) return rc;
+        if (int rc = launch_wave_steps(h, p, ring, first_set, n_steps, stream, &launched)) return rc;
         if (launched) return SGX_OK;
     }
     for (int32_t i = 0; i < n_steps; ++i) {
         p.io = ios[(first_set + i) % n_sets];
         if (int rc = launch_step(h, p, stream, n_sets)) return rc;
     }
+    return SGX_OK;
+}
+
+// sgx_step_n into a trajectory buffer: slot (first_slot + t) % n_slots of tensors with a leading slot axis receives step t's outputs.
+SGX_API int sgx_step_traj(sgx_env *h, const sgx_traj_io *t, int32_t first_slot, int32_t n_steps, void *stream) {
+    if (!h || !t) return fail(SGX_EINVAL, "handle or t is NULL%s");
+    const sgx_step_io &io = t->io;
+    if (!io.actions_dev || io.next_actions_dev != io.actions_dev)
+        return fail(SGX_EINVAL, "sgx_step_traj needs next_actions_dev == actions_dev (each step plays the action the previous one drew)%s");
+    if (t->n_slots < 1 || first_slot < 0 || first_slot >= t->n_slots || n_steps < 0) return fail(SGX_EINVAL, "sgx_step_traj: n_slots, first_slot or n_steps out of range%s");
+    if (t->slot_envs < h->n_envs) return fail(SGX_EINVAL, "sgx_step_traj: slot_envs is smaller than the number of envs%s");
+    SGX_ON_DEVICE(h->device);
+    KParams p = make_params(h);
+    p.mode = 0;
+    p.io = io;
+    p.traj_out_envs = t->slot_envs;
+    p.traj_res_envs = t->results_per_slot ? t->slot_envs : 0;
+    p.traj_act_log = t->actions_log_dev;
+    // bytes between the slots of each tensor, by the layout the flags ask for
+    const bool original = (io.flags & SGX_STEP_ORIGINAL_CHANNELS) != 0;
+    const int64_t cells = (int64_t)h->cfg.rows * h->cfg.cols;
+    const int64_t obs_env = (io.flags & SGX_STEP_COMPACT_OBS) ? compact_obs_stride(h) : cells * lut_channels(false, original) * 4;
+    const int64_t mask_env = (io.flags & SGX_STEP_COMPACT_MASK) ? 4 * (int64_t)mask_words(h)
+                           : (io.flags & SGX_STEP_MASK_1D)      ? cells * (h->cfg.rows + h->cfg.cols) + 1 : cells * h->K;
+    const OutSets slots{&t->io, t->n_slots, true, io.obs_dev ? t->slot_envs * obs_env : 0, io.fobs_dev ? t->slot_envs * cells * lut_channels(true, original) * 4 : 0,
+                        io.mask_dev ? t->slot_envs * mask_env : 0};
+    {
+        bool launched = false;
+        if (int rc = launch_lane_steps(h, p, slots, first_slot, n_steps, stream, &launched)) return rc;
+        if (launched) return SGX_OK;
+        if (int rc = launch_wave_steps(h, p, slots, first_slot, n_steps, stream, &launched)) return rc;
+        if (launched) return SGX_OK;
+    }
+    for (int32_t i = 0; i < n_steps; ++i)
+        if (int rc = launch_set_step(h, p, slots, (int32_t)(((int64_t)first_slot + i) % t->n_slots), stream)) return rc;
     return SGX_OK;
 }
 
@@ -1257,11 +1408,12 @@ SGX_API int sgx_rollout(sgx_env *h, const sgx_step_io *io, int32_t n_steps, int3
         KParams p0 = make_params(h);
         p0.mode = 0;
         bool launched = false;
-        if (int rc = launch_lane_steps(h, p0, io, 1, 0, n_steps, stream, &launched)) return rc;
+        const OutSets one{io, 1, false, 0, 0, 0};
+        if (int rc = launch_lane_steps(h, p0, one, 0, n_steps, stream, &launched)) return rc;
         if (launched) return SGX_OK;
         // ... and the other boards the multi-step launch of the wave-per-game kernels (steps_kernel): faster than two chains of launches on
         // every board since its parameter reads are scalar loads (6x6: 97-99 against 101 us per step, 5x5: 71 against 91; profiles/r05_variant_bench.log)
-        if (int rc = launch_wave_steps(h, p0, io, 1, 0, n_steps, stream, &launched)) return rc;
+        if (int rc = launch_wave_steps(h, p0, one, 0, n_steps, stream, &launched)) return rc;
         if (launched) return SGX_OK;
         chains = (cells <= 36 || cells % 4 != 0) ? 2 : 1;
     }
@@ -1449,9 +1601,18 @@ SGX_API int sgx_step_states(sgx_env *h, const int64_t *state_in_dev, const int8_
     if (io->auto_reset || io->next_actions_dev) return fail(SGX_EINVAL, "sgx_step_states: no auto_reset, no sampled next actions%s");
     if (io->flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) return fail(SGX_EINVAL, "sgx_step_states: no compact outputs%s");
     if (chains < 1 || chains > SGX_MAX_CHAINS) return fail(SGX_EINVAL, "chains out of range%s");
-    if (h->general_states != 0 && h->cfg.rows * h->cfg.cols <= 256) {
+    // Will a general-state pass run behind this call?  (The fused one-launch path always has one; the three-launch paths have one except for
+    // state-coordinate masks together with another observation kind: the same conditions as `general` / `general_small` below.)
+    const bool will_redo = [&] {
+        const int cells = h->cfg.rows * h->cfg.cols;
+        const bool k0 = !io->fobs_dev && !io->final_fobs_dev && !(io->flags & SGX_STEP_ORIGINAL_CHANNELS);
+        const bool mapped = (io->flags & (SGX_STEP_MASK_1D | SGX_STEP_MASK_STATE_COORDS)) != 0;
+        return h->general_states != 0 && cells <= 256 && (k0 || !mapped);
+    }();
+    if (will_redo) {
         // The general-state pass re-reads the caller's INPUT after the first pass has written the outputs: a state stepped in place would
-        // be redone from its own successor (stepped twice, or judged invalid) without anybody noticing.
+        // be redone from its own successor (stepped twice, or judged invalid) without anybody noticing.  (Calls behind which no such pass
+        // runs may step a batch in place: every state is read completely before its successor is written.)
         auto overlap = [](const void *a, int64_t na, const void *b, int64_t nb) {
             const uintptr_t a0 = reinterpret_cast<uintptr_t>(a), b0 = reinterpret_cast<uintptr_t>(b);
             return a && b && a0 < b0 + (uintptr_t)nb && b0 < a0 + (uintptr_t)na;

@@ -83,15 +83,21 @@ def test_self_launch_eight_ranks_with_the_default_workloads_is_self_anchoring():
     games per GPU, a ring of three output sets: `value` over 1 / 2 / 4 / 8 GPUs is one workload's weak-scaling curve), and BASELINE
     config 5 -- 262,144 games per GPU, 2,097,152 in total -- as scaling_legs[0]; the headline and every leg carry a solo anchor (rank 0
     alone, the others parked) and scaling_x = value / solo value.  One rank's nccl failure is simulated on top: all eight agree on gloo."""
+    import time
+    t0 = time.perf_counter()
     p = _run(['--gpus', '8', '--dry-run', '--backend', 'nccl', '--steps', '3', '--warmup', '1'],
              env=_clean_env(SGX_BENCH_FAKE_NCCL='1', SGX_BENCH_FAIL_NCCL_RANKS='5'), timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
+    # the whole 8-rank line -- start of the ranks, rendezvous, agreement on the backend after one rank's failure, headline, anchors, config 5
+    # leg -- in well under two minutes of host time (on 8 CPUs shared by 8 ranks here): nothing in the launcher path waits for a timeout
+    assert time.perf_counter() - t0 < 120
     lines = _json_lines(p.stdout)
     assert len(lines) == 1
     d = lines[0]
     c = d['config']
     assert d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['launched_by'] == 'bench.py'
-    assert c['reduction_backend'].startswith('gloo (nccl failed: rank 5: ')
+    assert c['reduction_backend'].startswith('gloo (nccl failed: rank 5: ') and 0 <= c['reduction_bringup_s'] < 30
+    assert c['legs_of_this_line'] == ['scaling_legs'] and d.get('cpu_baseline') is None
     assert c['games_per_gpu'] == 65536 and c['total_games'] == 8 * 65536 and c['output_sets'] == 3
     assert c['games_covered_by_ranks'] == 8 * 65536 and c['stub_steps_x_games'] == 3 * 8 * 65536
     assert c['solo']['games'] == 65536 and c['solo']['value'] > 0 and c['scaling_x'] > 0 and c['scaling_x_ideal'] == 8
@@ -187,3 +193,21 @@ def test_defaults_follow_the_baseline_configs_and_the_parent_never_loads_torch()
             "assert isinstance(n, int) and n >= 0; assert 'torch' not in sys.modules; print('ok', n)" % ROOT)
     q = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=60)
     assert q.returncode == 0 and q.stdout.startswith('ok'), q.stderr
+
+
+def test_only_rank_0_of_a_one_gpu_run_takes_the_single_gpu_legs():
+    """legs_for: the CPU baseline, the live counter passes, the store probe, the facade, the other workloads and the trajectory leg run on
+    rank 0 of a ONE-GPU run and nowhere else; every rank of a multi-GPU job runs the same (barrier-carrying) legs, so nobody waits at a
+    barrier for a rank that is busy elsewhere."""
+    import bench
+    solo_only = {'cpu_baseline', 'live_traffic', 'store_probe', 'facade_n1', 'other_workloads', 'consumer_in_loop', 'trajectory', 'in_place', 'two_chains'}
+    a1 = bench.parse_args(['--gpus', '1'])
+    assert solo_only <= bench.legs_for(0, 1, a1) and 'scaling_legs' not in bench.legs_for(0, 1, a1)
+    for world in (2, 4, 8):
+        a = bench.parse_args(['--gpus', str(world)])
+        per_rank = [bench.legs_for(r, world, a) for r in range(world)]
+        assert all(l == per_rank[0] for l in per_rank), world            # the same legs on every rank
+        assert not (per_rank[0] & solo_only) and 'scaling_legs' in per_rank[0] and {'no_settle', 'one_launch_per_step'} <= per_rank[0]
+        assert bench.legs_for(3 % world, world, a, dry=True) == {'scaling_legs'}
+    a = bench.parse_args(['--gpus', '1', '--no-cpu-baseline', '--no-other-workloads', '--no-live-traffic', '--no-store-probe', '--no-facade-leg'])
+    assert not (bench.legs_for(0, 1, a) & {'cpu_baseline', 'live_traffic', 'store_probe', 'facade_n1', 'other_workloads', 'trajectory'})

@@ -155,3 +155,25 @@ def test_multi_step_launch_at_the_baseline_sizes_equals_one_launch_per_step(name
     assert int(a.invalid_action.sum()) == 0 and int(a.env_info()[:, 0].min()) >= 0
     a.close(); b.close()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize('name', ['micro', 'tiny'])
+def test_logic_only_rollouts_on_toy_boards_stay_on_the_lane_kernel(name):
+    """A rollout WITHOUT an observation on a board of at most 16 cells: the lane-per-game kernel (one launch per step) plays these twice as fast as
+    any wave-per-game kernel (lane section), so the multi-step launch of the wave-per-game kernels leaves them to it; with
+    the lane kernel switched off the same call is a multi-step launch -- same results either way."""
+    import torch
+    from stratego_env_amd import _lib
+    a, b = _pair(name, 3000)
+    b.set_multi_step(True)
+    b.set_lane_kernel(False)
+    for emit_mask in (True, False):
+        a.rollout_steps(9, emit_obs=False, emit_mask=emit_mask); b.rollout_steps(9, emit_obs=False, emit_mask=emit_mask)
+        assert a.last_launch_kind == _lib.LAUNCH_LANE and b.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE
+        assert torch.equal(a.env_info(), b.env_info()) and torch.equal(a.next_actions, b.next_actions) and torch.equal(a.reward, b.reward)
+        if emit_mask:
+            assert torch.equal(a.mask, b.mask)
+    a.rollout_steps(5); b.rollout_steps(5)
+    assert a.last_launch_kind == _lib.LAUNCH_MULTI_STEP and b.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE
+    _same(a, b, name)
+    a.close(); b.close()

@@ -1,0 +1,376 @@
+"""The multi-step kernels (steps_kernel, lane_steps_kernel: what bench.py times) pinned to the ORACLE at EVERY step, directly.
+
+A rollout into a trajectory buffer (sgx_step_traj: slot t of [T][N]... tensors receives step t's outputs, any number of slots; all steps of
+a call in one launch per 256 steps) keeps what every step wrote -- mask bytes, observation bytes (both kinds), rewards, done, player,
+invalid-ending flag and the action the step drew -- so every step of a multi-step launch is compared with the oracle stepped alongside
+(reference: a fresh observation array per env.step(), impl:905, maenv:447-497, 659-828).  The buffers are poisoned before every call: a step
+whose stores were skipped leaves the poison behind and fails the comparison.  Also here: the same through sgx_step_ring with one separate
+set per step, the literal BASELINE config-2 check (256 held-out seeds to termination) through the multi-step kernel, and the calls the
+multi-step kernels do not cover (one launch per step behind the same entry point)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from stratego_env_amd.config import VARIANTS
+from tests.helpers import oracle_cvariant
+from tests.test_gpu_parity import _table
+
+pytestmark = pytest.mark.gpu
+MASK, POBS, FOBS = 'valid_actions_mask', 'partial_observation', 'full_observation'
+
+
+def _oracles(name, seed, g0, n, both=False):
+    v = VARIANTS[name]
+    cv = oracle_cvariant(name, setups=_table(name))
+    envs = []
+    for e in range(n):
+        oe = orc.OracleEnv(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts,
+                           observation_mode='both_observations' if both else 'partially_observable')
+        oe.reset(initial_state_override=orc.reset_state(cv, seed, g0 + e, 0))
+        oe.game_no = 0
+        envs.append(oe)
+    return cv, envs
+
+
+def _poison(traj):
+    import torch
+    for k, t in traj.items():
+        if t.dtype == torch.float32:
+            t.fill_(float('nan'))
+        elif t.dtype == torch.int32:
+            t.fill_(-12345)
+        else:
+            t.fill_(0x5A)
+
+
+class Follower:
+    """The oracle stepped alongside a batch of GPU games: check_slot() plays ONE step of every game on the oracle and compares it with one
+    slot of a trajectory buffer (already on the host)."""
+
+    def __init__(self, name, seed, g0, n, auto_reset, both=False):
+        self.name, self.seed, self.g0, self.n, self.auto_reset, self.both = name, seed, g0, n, auto_reset, both
+        self.cv, self.oenvs = _oracles(name, seed, g0, n, both)
+        self.cur = [oe._obs(1) for oe in self.oenvs]
+        self.finished = [False] * n            # (without auto-reset: a finished game only takes invalid actions from then on)
+        self.games_done = 0
+        self.steps = 0
+
+    def drawn(self, e):
+        """the action the rollout plays next for game e: k-th valid of the current mask, k from the counter RNG (maenv:830-834 for a batch)"""
+        oe = self.oenvs[e]
+        return orc.sample_action(self.cur[e][MASK].astype(np.uint8), self.seed, self.g0 + e, oe.game_no, int(oe.state[5, 0, 0]))
+
+    def check_reset(self, obs_h, mask_h, fobs_h=None):
+        for e in range(self.n):
+            o = self.cur[e]
+            assert np.array_equal(o[MASK], mask_h[e]) and o[POBS].tobytes() == obs_h[e].tobytes(), (self.name, 'reset', e)
+            assert fobs_h is None or o[FOBS].tobytes() == fobs_h[e].tobytes()
+
+    def check_slot(self, acts, h, s, what):
+        """acts[e]: the action game e plays in this step; h: dict of host arrays with a leading slot axis; s: the slot this step wrote."""
+        tag = (self.name, what, 'step', self.steps, 'slot', s)
+        for e, oe in enumerate(self.oenvs):
+            a = int(acts[e])
+            try:
+                if self.finished[e]:
+                    raise ValueError
+                o, rew, done, info = oe.step({oe.player: a})
+            except ValueError:
+                assert h['invalid_action'][s, e] == 1, tag + (e, a, 'the oracle raises, the GPU accepted')
+                assert h['done'][s, e] == (1 if self.finished[e] else 0), tag + (e,)
+                assert np.array_equal(self.cur[e][MASK], h['mask'][s, e]) and self.cur[e][POBS].tobytes() == h['obs'][s, e].tobytes(), tag + (e, 'outputs after an invalid action')
+                assert h['player'][s, e] == oe.player
+                assert h['actions'][s, e] == self.drawn(e), tag + (e, 'draw after an invalid action')
+                continue
+            assert h['invalid_action'][s, e] == 0, tag + (e, a, 'the GPU flags a move the oracle accepts')
+            assert bool(h['done'][s, e]) == done['__all__'], tag + (e, 'done')
+            if done['__all__']:
+                self.games_done += 1
+                assert (h['reward'][s, e, 0], h['reward'][s, e, 1]) == (rew[1], rew[-1]), tag + (e, 'reward')
+                assert bool(h['ending_invalid'][s, e]) == info[1]['game_result_was_invalid'], tag + (e, 'ending_invalid')
+                if self.auto_reset:
+                    oe.game_no += 1
+                    o = oe.reset(initial_state_override=orc.reset_state(self.cv, self.seed, self.g0 + e, oe.game_no))
+                else:
+                    self.finished[e] = True
+                    o = {oe.player: o[oe.player]}                     # both terminal observations: the mover's is what the slot holds
+            else:
+                assert h['reward'][s, e, 0] == 0 and h['reward'][s, e, 1] == 0 and h['ending_invalid'][s, e] == 0, tag + (e,)
+            p = oe.player
+            assert h['player'][s, e] == p, tag + (e, 'player')
+            assert np.array_equal(o[p][MASK], h['mask'][s, e]), tag + (e, 'mask')
+            assert o[p][POBS].tobytes() == h['obs'][s, e].tobytes(), tag + (e, 'observation')
+            if self.both:
+                assert o[p][FOBS].tobytes() == h['fobs'][s, e].tobytes(), tag + (e, 'full observation')
+            self.cur[e] = o[p]
+            assert h['actions'][s, e] == self.drawn(e), tag + (e, 'drawn action')
+        self.steps += 1
+
+
+def _host(traj):
+    return {k: t.cpu().numpy() for k, t in traj.items()}
+
+
+MULTI = None
+
+
+def _multi_kinds():
+    from stratego_env_amd import _lib
+    return (_lib.LAUNCH_MULTI_STEP_WAVE, _lib.LAUNCH_MULTI_STEP)
+
+
+@pytest.mark.parametrize('name,n_envs,chunk,n_calls,garbage', [
+    ('barrage', 48, 64, 10, 0.2), ('standard', 16, 48, 8, 0.1), ('short_barrage', 64, 40, 8, 0.2), ('octa_barrage', 32, 64, 5, 0.2),
+    ('medium', 40, 50, 6, 0.2), ('fives', 33, 30, 6, 0.2), ('standard2', 5, 24, 4, 0.1), ('tiny', 100, 64, 4, 0.2), ('micro', 130, 20, 8, 0.2),
+])
+def test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk, n_calls, garbage, both=False, auto_reset=True, kw=None):
+    """Calls of `chunk` steps into a trajectory buffer of `chunk` slots: every slot of every call against the oracle.  Some games start
+    every call from a garbage action (flagged, state unchanged, the same draw again); games end and restart inside the launches and across
+    their boundaries."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    v = VARIANTS[name]
+    seed, g0 = 0x7A3B00 + 97 * len(name) + n_envs, 7000
+    env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=auto_reset, full_obs=both, **(kw or {}))
+    fo = Follower(name, seed, g0, n_envs, auto_reset, both)
+    env.reset()
+    fo.check_reset(env.obs.cpu().numpy(), env.mask.cpu().numpy(), env.fobs.cpu().numpy() if both else None)
+    env.sample_valid_actions()
+    traj = env.alloc_trajectory(chunk)
+    rs = np.random.RandomState(11)
+    NA = v.num_spatial_actions
+    for call in range(n_calls):
+        nxt = env.next_actions.cpu().numpy().copy()
+        for e in range(n_envs):
+            assert nxt[e] == fo.drawn(e), (name, call, e, 'the draw a call starts from')
+            if rs.rand() < garbage:
+                nxt[e] = int(rs.choice([rs.randint(NA), -1, NA + 5, rs.randint(v.cells) * v.spatial_channels + v.spatial_channels - 1]))
+        env.next_actions.copy_(torch.from_numpy(nxt))
+        _poison(traj)
+        env.rollout_trajectory(chunk, traj)
+        assert env.last_launch_kind in _multi_kinds(), (name, 'the test must not pass on the per-step kernel')
+        h = _host(traj)
+        acts = nxt
+        for s in range(chunk):
+            fo.check_slot(acts, h, s, 'call %d' % call)
+            acts = h['actions'][s]
+        # the env's own views are the last slot
+        assert env.obs.data_ptr() == traj['obs'][chunk - 1].data_ptr() and torch.equal(env.next_actions, traj['actions'][chunk - 1])
+    st, pl = env.export_state()
+    assert np.array_equal(st.cpu().numpy(), np.stack([oe.state for oe in fo.oenvs])), (name, 'final states')
+    assert np.array_equal(pl.cpu().numpy(), np.asarray([oe.player for oe in fo.oenvs], dtype=np.int8))
+    if auto_reset:
+        assert fo.games_done > 0 or name in ('standard', 'standard2')
+    env.close()
+
+
+@pytest.mark.parametrize('name,n_envs,chunk,n_calls', [('barrage', 24, 48, 6), ('octa_barrage', 16, 40, 4), ('fives', 20, 30, 4)])
+def test_every_step_with_both_observations(name, n_envs, chunk, n_calls):
+    """BOTH_OBSERVATIONS (the reference's default mode, maenv:53): steps_kernel<..., 1> writes the 79-channel observation as well."""
+    test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk, n_calls, 0.1, both=True)
+
+
+@pytest.mark.parametrize('name,n_envs,chunk,n_calls', [('short_barrage', 48, 64, 4), ('micro', 96, 25, 3)])
+def test_every_step_without_auto_reset(name, n_envs, chunk, n_calls):
+    """Without auto-reset a finished game stays finished: every later step of the launch draws the no-op of its one-entry mask, which is
+    not playable -- flagged invalid, nothing changes."""
+    test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk, n_calls, 0.0, auto_reset=False)
+
+
+@pytest.mark.parametrize('name,n_envs,n_steps', [('barrage', 12, 300), ('micro', 70, 530)])
+def test_every_step_across_the_256_step_chunks(name, n_envs, n_steps):
+    """ONE call longer than a launch may be (256 steps): 256 + 44 steps on Barrage, 256 + 256 + 18 on Micro (lane_steps_kernel goes out in
+    chunks as well since this round) -- the boundary is invisible in the slots."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    seed, g0 = 0xC0FFEE + n_steps, 31
+    env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True)
+    fo = Follower(name, seed, g0, n_envs, True)
+    env.reset()
+    env.sample_valid_actions()
+    traj = env.alloc_trajectory(n_steps)
+    _poison(traj)
+    acts = env.next_actions.cpu().numpy().copy()
+    env.rollout_trajectory(n_steps, traj)
+    assert env.last_launch_kind in _multi_kinds()
+    h = _host(traj)
+    for s in range(n_steps):
+        fo.check_slot(acts, h, s, 'one call')
+        acts = h['actions'][s]
+    assert fo.games_done > 0
+    env.close()
+
+
+@pytest.mark.parametrize('name,n_envs', [('barrage', 20), ('tiny', 80)])
+def test_slots_wrap_around_from_a_first_slot(name, n_envs):
+    """n_steps > n_slots from first_slot != 0: slot (first_slot + t) % T holds step t, the last T steps survive."""
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    T, n_steps, first = 5, 13, 3
+    seed, g0 = 0xBEE5, 900
+    env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True)
+    fo = Follower(name, seed, g0, n_envs, True)
+    env.reset()
+    env.sample_valid_actions()
+    # the oracle needs the outputs of every step to follow the games: a second, twin env writes all 13 steps into 13 slots
+    twin = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True)
+    twin.reset(); twin.sample_valid_actions()
+    full = twin.alloc_trajectory(n_steps)
+    acts = twin.next_actions.cpu().numpy().copy()
+    twin.rollout_trajectory(n_steps, full)
+    hf = _host(full)
+    for s in range(n_steps):
+        fo.check_slot(acts, hf, s, 'twin')
+        acts = hf['actions'][s]
+    traj = env.alloc_trajectory(T)
+    _poison(traj)
+    env.rollout_trajectory(n_steps, traj, first_slot=first)
+    assert env.last_launch_kind in _multi_kinds()
+    h = _host(traj)
+    for t in range(n_steps - T, n_steps):
+        s = (first + t) % T
+        for k in h:
+            assert np.array_equal(h[k][s], hf[k][t], equal_nan=(h[k].dtype == np.float32)), (name, k, 'step', t, 'slot', s)
+    assert env.obs.data_ptr() == traj['obs'][(first + n_steps - 1) % T].data_ptr()
+    env.close(); twin.close()
+
+
+def test_ring_of_separate_sets_every_set_equals_the_oracle():
+    """sgx_step_ring with one separately allocated output set per step (n_sets = n_steps = 8, the most a ring may have): every SET's mask and
+    observation against the oracle; the shared results are the last step's."""
+    import torch
+    from stratego_env_amd import _lib
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    for name, n_envs in (('barrage', 40), ('micro', 128)):
+        seed, g0 = 0x51DE, 40
+        env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True)
+        fo = Follower(name, seed, g0, n_envs, True)
+        env.reset()
+        env.sample_valid_actions()
+        env.alloc_output_ring(8)
+        log = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True)    # per-step results / draws of the same games
+        log.reset(); log.sample_valid_actions()
+        for call in range(6):
+            acts = env.next_actions.cpu().numpy().copy()
+            first = env._ring_pos
+            for o, m, _ in env._ring:
+                o.fill_(float('nan')); m.fill_(0x5A)
+            env.rollout_steps(8, ring=True)
+            assert env.last_launch_kind in _multi_kinds()
+            res = log.alloc_trajectory(8)
+            log.rollout_trajectory(8, res)
+            hr = _host(res)
+            h = dict(hr)
+            order = [(first + t) % 8 for t in range(8)]
+            h['obs'] = np.stack([env._ring[s][0].cpu().numpy() for s in order])
+            h['mask'] = np.stack([env._ring[s][1].cpu().numpy() for s in order])
+            for t in range(8):
+                fo.check_slot(acts, h, t, 'ring call %d' % call)
+                acts = h['actions'][t]
+            for k, t in (('reward', env.reward), ('done', env.done), ('player', env.player), ('ending_invalid', env.ending_invalid)):
+                assert np.array_equal(t.cpu().numpy(), hr[k][7]), (name, k)
+            assert torch.equal(env.next_actions, res['actions'][7])
+        env.close(); log.close()
+
+
+def test_config2_256_heldout_seeds_to_termination_through_the_multi_step_kernel():
+    """BASELINE config 2's bit-exact check on the kernel bench.py times: 256 held-out seeds BASE_SEED + 1 .. + 256, env id 0,
+    each played by multi-step launches of 64 steps into a 64-slot trajectory buffer until its first game ends -- every step's drawn action,
+    mask, observation, reward, done, player and invalid-ending flag against the oracle, and the final state."""
+    import torch
+    from bench import BASE_SEED
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    name, n, chunk = 'barrage', 256, 64
+    v = VARIANTS[name]
+    total_steps = 0
+    for i in range(n):
+        seed = BASE_SEED + 1 + i
+        env = VecStrategoEnv(name, 1, seed=seed, env_id_offset=0, auto_reset=False)
+        fo = Follower(name, seed, 0, 1, False)
+        env.reset()
+        fo.check_reset(env.obs.cpu().numpy(), env.mask.cpu().numpy())
+        env.sample_valid_actions()
+        traj = env.alloc_trajectory(chunk)
+        while not fo.finished[0]:
+            acts = env.next_actions.cpu().numpy().copy()
+            assert acts[0] == fo.drawn(0)
+            _poison(traj)
+            env.rollout_trajectory(chunk, traj)
+            assert env.last_launch_kind in _multi_kinds()
+            h = _host(traj)
+            for s in range(chunk):
+                fo.check_slot(acts, h, s, 'seed %d' % i)
+                acts = h['actions'][s]
+            assert fo.steps <= v.max_turns + chunk
+        st, _ = env.export_state()
+        assert np.array_equal(st.cpu().numpy()[0], fo.oenvs[0].state), (i, 'final state')
+        total_steps += fo.steps
+        env.close()
+    assert total_steps > 256 * 20
+
+
+@pytest.mark.parametrize('kw,what', [({'obs_channel_mode': 'original'}, "'original' channels"), ({'final_obs': True}, 'terminal observations')])
+def test_trajectory_calls_the_multi_step_kernels_do_not_cover(kw, what):
+    """Behind the same entry point: one launch per step with the slot's pointers -- every slot equals the same steps played one by one."""
+    import torch
+    from stratego_env_amd import _lib
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    a = VecStrategoEnv('short_barrage', 300, seed=77, auto_reset=True, **kw)
+    b = VecStrategoEnv('short_barrage', 300, seed=77, auto_reset=True, **kw)
+    a.reset(); b.reset(); a.sample_valid_actions(); b.sample_valid_actions()
+    T = 40
+    traj = a.alloc_trajectory(T)
+    _poison(traj)
+    a.rollout_trajectory(T, traj)
+    if 'obs_channel_mode' in kw:
+        assert a.last_launch_kind == _lib.LAUNCH_WAVE, what
+    for s in range(T):
+        b.rollout_step()
+        for k, t in (('obs', b.obs), ('mask', b.mask), ('reward', b.reward), ('done', b.done), ('player', b.player), ('invalid_action', b.invalid_action),
+                     ('ending_invalid', b.ending_invalid), ('actions', b.next_actions)):
+            assert torch.equal(traj[k][s], t), (what, k, s)
+    if a.final_obs is not None:
+        assert torch.equal(a.final_obs, b.final_obs) and bool(a.final_obs.abs().sum() > 0)
+    a.close(); b.close()
+
+
+def test_trajectory_of_compact_outputs():
+    """compact_outputs=True: the slots hold the 4-bit codes / mask bits; decoded, every slot is the contract tensor of that step."""
+    import torch
+    from stratego_env_amd import _lib
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    a = VecStrategoEnv('barrage', 500, seed=5, auto_reset=True, compact_outputs=True)
+    b = VecStrategoEnv('barrage', 500, seed=5, auto_reset=True)
+    a.reset(); b.reset(); a.sample_valid_actions(); b.sample_valid_actions()
+    T = 33
+    traj = a.alloc_trajectory(T)
+    a.rollout_trajectory(T, traj)
+    assert a.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE
+    for s in range(T):
+        b.rollout_step()
+        a.obs, a.mask = traj['obs'][s], traj['mask'][s]
+        assert torch.equal(a.decode_obs(), b.obs) and torch.equal(a.decode_mask(), b.mask), s
+        assert torch.equal(traj['reward'][s], b.reward) and torch.equal(traj['done'][s], b.done) and torch.equal(traj['actions'][s], b.next_actions)
+    a.close(); b.close()
+
+
+def test_trajectory_argument_checks():
+    import ctypes as C
+    import torch
+    from stratego_env_amd import _lib
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    env = VecStrategoEnv('barrage', 64, seed=1, auto_reset=True)
+    env.reset(); env.sample_valid_actions()
+    traj = env.alloc_trajectory(4)
+    with pytest.raises(ValueError):
+        env.rollout_trajectory(3, traj, first_slot=4)
+    before = (env.obs.data_ptr(), env.reward.data_ptr())
+    env.rollout_trajectory(0, traj)
+    assert (env.obs.data_ptr(), env.reward.data_ptr()) == before
+    t = _lib.SgxTrajIO()
+    io = env._fill_io(env.next_actions, True, True, True, 0)
+    C.memmove(C.byref(t.io), C.byref(io), C.sizeof(_lib.SgxStepIO))
+    t.n_slots, t.slot_envs = 4, 63                                   # fewer envs per slot than the handle has
+    assert env._L.sgx_step_traj(env._h, C.byref(t), 0, 2, None) == -1
+    t.slot_envs, t.n_slots = 64, 0
+    assert env._L.sgx_step_traj(env._h, C.byref(t), 0, 2, None) == -1
+    env.close()
