@@ -9,7 +9,8 @@
  *     (e.g. a torch tensor's data_ptr()); the library owns only its internal state tensor;
  *   - all device work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default stream)
  *     and is asynchronous; the entry points that wait for the device are sgx_create, sgx_destroy,
- *     sgx_set_setup_table, sgx_time_observe, sgx_alloc_outputs and sgx_free_outputs;
+ *     sgx_set_setup_table, sgx_time_observe, sgx_mem_probe, sgx_store_probe, sgx_step_sync, sgx_host_free, sgx_alloc_outputs and
+ *     sgx_free_outputs;
  *   - return 0 on success, a negative SGX_E* code on failure (sgx_last_error() has the text);
  *     nothing throws across the ABI; invalid *actions* are not API errors: they are reported per env
  *     in invalid_action[] with that env's state left unchanged (the reference raises ValueError,

@@ -22,6 +22,21 @@
 // (sgx_step.h), and sgx_set_lane_kernel(h, 0) forces that one (in-process A/B; SGX_LANE=0 sets the default of new handles).
 #pragma once
 
+// (experiment knobs, -D...: observation sub-batch of an emitter, emitter waves per workgroup, quads per lane an emitter reads ahead of its
+//  stores, occupancy promise -- the shipped values are the defaults; tools/lib_ab.py compares builds on the same buffers)
+#ifndef SGX_KSTEP_SUB
+#define SGX_KSTEP_SUB 8
+#endif
+#ifndef SGX_KSTEP_EMITTERS
+#define SGX_KSTEP_EMITTERS 3
+#endif
+#ifndef SGX_LANE_EMIT_U
+#define SGX_LANE_EMIT_U 8
+#endif
+#ifndef SGX_KSTEP_MIN_WAVES
+#define SGX_KSTEP_MIN_WAVES 4
+#endif
+
 namespace {
 
 constexpr int LANE_SUB = 16;                              // games per observation sub-batch
@@ -149,7 +164,7 @@ __device__ __forceinline__ void lane_emit_obs(const uint8_t *rec_base, const int
         // is chosen outside the loop.
         auto sweep = [&](auto nt_tag) {
             constexpr bool NT = decltype(nt_tag)::value;
-            constexpr int U = 8;
+            constexpr int U = SGX_LANE_EMIT_U;
             for (int q0 = -m0; q0 < total; q0 += 64 * U) {
                 unsigned x[U];
 #pragma unroll
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(64) void lane_kernel(const KParams P) {
 // sub-batches spread evenly over 3 waves) and runs lane_emit_obs on them.  The records travel to and from HBM once per launch
 // instead of once per step.  Same results as n_steps launches of lane_kernel / step_kernel: tests/test_gpu_lane_kernel.py.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int KSTEP_SUB = 8, KSTEP_EMITTERS = 3, KSTEP_MAX_SETS = 8;
+constexpr int KSTEP_SUB = SGX_KSTEP_SUB, KSTEP_EMITTERS = SGX_KSTEP_EMITTERS, KSTEP_MAX_SETS = 8;
 
 struct StepsParams {
     KParams k;
@@ -358,7 +373,7 @@ struct alignas(16) StepsLds {
 };
 
 template <int R_, int C_>
-__global__ __launch_bounds__(64 * (1 + KSTEP_EMITTERS), 4) void lane_steps_kernel(const StepsParams SP) {
+__global__ __launch_bounds__(64 * (1 + KSTEP_EMITTERS), SGX_KSTEP_MIN_WAVES) void lane_steps_kernel(const StepsParams SP) {
     using G = Geo<R_, C_>;
     using LG = LaneGeo<G, KSTEP_SUB>;
     static_assert(lane_geometry<G>(), "lane kernels: boards of at most 16 cells, a multiple of 4");

@@ -771,9 +771,11 @@ static int launch_wave_steps(sgx_env *h, const KParams &p_in, const OutSets &set
     const bool no_obs = !io0.obs_dev && !io0.fobs_dev && !io0.final_obs_dev && !io0.final_fobs_dev && !compact;
     if (compact && (full || io0.final_obs_dev)) return SGX_OK;             // (launch_step refuses these: let it say so)
     if (compact && ((reinterpret_cast<uintptr_t>(io0.obs_dev) | reinterpret_cast<uintptr_t>(io0.mask_dev)) & 15)) return SGX_OK;
-    // Logic-only rollouts on boards of at most 16 cells (no observation pointer): the lane-per-game kernel, one launch per step, plays these
-    // twice as fast as a wave-per-game kernel (Micro 13 against 25 us per step, DESIGN.md lane section) -- leave them to it
-    if (no_obs && lane_eligible(h, p, false, false)) return SGX_OK;
+    // Logic-only rollouts (no observation pointer) on 3x4: the lane-per-game kernel, one launch per step, stays ahead of this kernel's multi-step
+    // launch there -- 65,536 Micro games mask only 14.9 against 18.2 us per step, no outputs 13.4 against 15.7; 262,144 games 44 against 65 --
+    // while on 4x4 the multi-step launch wins (Tiny 15.0 against 17.5 us, 262,144 games 56 against 74: tools/noobs_small_ab.py,
+    // profiles/r06_noobs_small_ab.log)
+    if (no_obs && h->cfg.rows * h->cfg.cols <= 12 && lane_eligible(h, p, false, false)) return SGX_OK;
     WaveStepsParams sp;
     memset(&sp, 0, sizeof(sp));
     if (sets.strided) {

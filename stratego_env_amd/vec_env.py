@@ -490,12 +490,80 @@ class VecStrategoEnv:
                 _lib.check(self._L.sgx_step_n(self._h, C.byref(io), int(n_steps), self._stream()), self._L)
         return self.obs, self.mask, self.reward, self.done, self.player
 
+    # ---- trajectory buffers: a fresh slice per step, like the reference's fresh arrays per env.step() (impl:905, maenv:447-497) ------
+    def alloc_trajectory(self, n_slots, results=True, actions=True):
+        """Tensors with a leading slot axis for rollout_trajectory(): obs [T,N,R,C,67], mask [T,N,R,C,K] (fobs [T,N,R,C,79] with
+        full_obs=True; the compact shapes with compact_outputs=True), and -- results=True -- reward [T,N,2], done / invalid_action /
+        ending_invalid [T,N], player [T,N]; actions=True: the action every env DREW in the step, int32 [T,N] (the action the next step
+        plays: chosen from the observation and mask of the same slot).  Returns a dict of torch tensors."""
+        if not self.has_outputs:
+            raise ValueError("alloc_trajectory: this env was created with outputs=False")
+        T, N, dev = int(n_slots), self.num_envs, self.device
+        if T < 1:
+            raise ValueError("n_slots must be >= 1")
+        traj = {'obs': torch.empty((T,) + tuple(self.obs.shape), dtype=self.obs.dtype, device=dev),
+                'mask': torch.empty((T,) + tuple(self.mask.shape), dtype=self.mask.dtype, device=dev)}
+        if self.fobs is not None:
+            traj['fobs'] = torch.empty((T,) + tuple(self.fobs.shape), dtype=torch.float32, device=dev)
+        if results:
+            traj['reward'] = torch.zeros((T, N, 2), dtype=torch.float32, device=dev)
+            for k, dt in (('done', torch.uint8), ('invalid_action', torch.uint8), ('ending_invalid', torch.uint8), ('player', torch.int8)):
+                traj[k] = torch.zeros((T, N), dtype=dt, device=dev)
+        if actions:
+            traj['actions'] = torch.zeros((T, N), dtype=torch.int32, device=dev)
+        return traj
+
+    def rollout_trajectory(self, n_steps, traj, first_slot=0, emit_obs=True, emit_mask=True):
+        """`n_steps` random-valid-action rollout steps (like rollout_steps) whose step t writes slot (first_slot + t) % T of the
+        tensors of `traj` (alloc_trajectory): one library call (sgx_step_traj), and where the call is eligible ONE launch per 256 steps
+        (sgx_set_multi_step) -- for any number of slots.  Afterwards self.obs / self.mask / self.fobs (and, if `traj` holds per-slot
+        results, self.reward / done / player / invalid_action / ending_invalid) are views of the slot the LAST step wrote; next_actions
+        holds the last draw.  Returns `traj`."""
+        n_steps = int(n_steps)
+        T = int(traj['obs'].shape[0])
+        if not 0 <= first_slot < T:
+            raise ValueError("first_slot out of range")
+        for k in ('obs', 'mask'):
+            if tuple(traj[k].shape[1:]) != tuple(getattr(self, k).shape) or traj[k].dtype != getattr(self, k).dtype or not traj[k].is_contiguous():
+                raise ValueError("traj['%s'] must be a contiguous [T, %s] %s tensor" % (k, ', '.join(map(str, getattr(self, k).shape)), getattr(self, k).dtype))
+        if (self.fobs is not None) != ('fobs' in traj):
+            raise ValueError("traj['fobs'] goes with full_obs=True")
+        per_slot = 'reward' in traj
+        if not self._next_actions_fresh:
+            self.sample_valid_actions()
+        keep = (self.obs, self.mask, self.fobs, self.reward, self.done, self.player, self.invalid_action, self.ending_invalid)
+
+        def views(slot):
+            self.obs, self.mask, self.fobs = traj['obs'][slot], traj['mask'][slot], (traj['fobs'][slot] if 'fobs' in traj else None)
+            if per_slot:
+                self.reward, self.done, self.player = traj['reward'][slot], traj['done'][slot], traj['player'][slot]
+                self.invalid_action, self.ending_invalid = traj['invalid_action'][slot], traj['ending_invalid'][slot]
+        try:
+            views(0)
+            io = self._fill_io(self.next_actions, True, emit_obs, emit_mask, 0)
+            t = _lib.SgxTrajIO()
+            C.memmove(C.byref(t.io), C.byref(io), C.sizeof(_lib.SgxStepIO))
+            t.n_slots, t.results_per_slot, t.slot_envs = T, 1 if per_slot else 0, self.num_envs
+            t.actions_log_dev = traj['actions'].data_ptr() if 'actions' in traj else None
+            with torch.cuda.device(self.device):
+                _lib.check(self._L.sgx_step_traj(self._h, C.byref(t), int(first_slot), n_steps, self._stream()), self._L)
+        except BaseException:
+            (self.obs, self.mask, self.fobs, self.reward, self.done, self.player, self.invalid_action, self.ending_invalid) = keep
+            raise
+        if n_steps == 0:
+            (self.obs, self.mask, self.fobs, self.reward, self.done, self.player, self.invalid_action, self.ending_invalid) = keep
+        else:
+            views((first_slot + n_steps - 1) % T)
+        return traj
+
     def choose_actions(self, logits, temperature=1.0, mask=None, out=None):
         """The reference's chooser for a batch (examples/basic_game_loop.py:6-31): one action per game drawn from
         softmax(logits / temperature) over the VALID actions of `mask` (default: the current mask -- bytes, or the bit mask of
         compact_outputs=True), on the device (sgx_choose_actions).  logits: float32 [N, R, C, K] (or [N, R*C*K]) from the caller's
         policy.  temperature 0 = argmax.  The draw is keyed by (seed, global env id, game, turn) like the fused sampler's, and with equal
-        logits it is that sampler's action.  -> int32 [N] (`out` or next_actions: ready for step())."""
+        logits it is that sampler's action.  Weights are 2^23 fixed point: an action less than 2^-23 as likely as the most likely one is
+        never drawn; an env whose valid actions ALL have -inf / NaN logits (or whose mask is empty) gets -1, which step() would flag as
+        an invalid action.  -> int32 [N] (`out` or next_actions: ready for step())."""
         lg = logits
         if lg.dtype != torch.float32 or lg.device != self.device or not lg.is_contiguous():
             lg = lg.to(device=self.device, dtype=torch.float32).contiguous()

@@ -11,7 +11,12 @@ i=0
 for P in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
   "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
   "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT" \
-  "WRITE_SIZE" "FETCH_SIZE"; do
+  "WRITE_SIZE" "FETCH_SIZE" \
+  "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_STALL_sum" \
+  "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_WRREQ_LEVEL_sum TCC_BUSY_sum" \
+  "TCC_TAG_STALL_sum TCC_IB_STALL_sum TCC_SRC_FIFO_FULL_sum TCC_LATENCY_FIFO_FULL_sum" \
+  "TCP_PENDING_STALL_CYCLES_sum TCC_WRITE_sum TCC_WRITEBACK_sum TCC_STREAMING_REQ_sum" \
+  "TCC_CYCLE_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc$i -- python3 $R/tools/kstep_probe.py $VERSION $GAMES $STEPS > $OUT/pmc$i.log 2>&1
 done
