@@ -24,51 +24,69 @@ def _mclk_sampler(B, stop, seen, period=0.002):
         time.sleep(period)
 
 
-def store_probe_leg(B, env, achieved_gbs, passes_short=8, launches_short=6, long_bytes=320e9):
+def store_probe_leg(B, env, achieved_gbs, passes_short=8, launches_short=4, long_bytes=320e9):
     """The store-only kernel on the observation buffers of the env's ring (or its one set).  OVERWRITES them: the caller re-renders the
-    current outputs afterwards (env.observe()).  -> dict for roofline['store_probe'], plus store_peak_measured / frac_of_store_peak."""
+    current outputs afterwards (env.observe()).  Two axes: the payload (zeros / observation-like floats / incompressible bits) and how many
+    store streams the memory sees at once (resident waves per CU, sleeps between a wave's 1 KiB sweeps): the step kernel's waves do not store
+    back to back.  -> dict for roofline['store_probe'], plus store_peak_measured (the best rate of any configuration) / frac_of_store_peak."""
     import torch
     from stratego_env_amd import _lib
     L = env._L
     sets = [s[0] for s in env._ring] if env._ring else [env.obs]
     seg = int(sets[0][0].numel() * 4)                      # bytes of one game's observation: the step kernel's segment
     stream = env._stream()
-    names = {_lib_payload: n for n, _lib_payload in (("zeros", 0), ("observation_like", 1), ("random_bits", 2))}
-    per_set, best = [], 0.0
+    names = ("zeros", "observation_like", "random_bits")
     us, gbs = C.c_float(), C.c_float()
+
+    def probe(t, passes, payload, nt, waves, pace, launches):
+        _lib.check(L.sgx_store_probe(env.device.index, C.c_void_p(t.data_ptr()), int(t.numel() * 4), seg, passes, payload, nt, waves, pace, launches,
+                                     stream, C.byref(us), C.byref(gbs)), L)
+        return float(gbs.value)
+
     with torch.cuda.device(env.device):
+        # (1) how many streams at once: observation-like payload on the first set
+        sweep, best, best_cfg = [], 0.0, (24, 0)
+        for waves in (24, 16, 8):
+            for pace in (0, 1, 2, 4, 8, 16):
+                g = probe(sets[0], passes_short, 1, 1, waves, pace, launches_short)
+                sweep.append({"waves_per_cu": waves, "pace": pace, "gbps": round(g, 1)})
+                if g > best:
+                    best, best_cfg = g, (waves, pace)
+        # (2) the payload, on every set: back to back (24 waves per CU, no pacing: every resident wave stores all the time) and at the best point of (1)
+        per_set = []
         for t in sets:
             row = {"bytes": int(t.numel() * 4)}
             for payload in (0, 1, 2):
-                _lib.check(L.sgx_store_probe(env.device.index, C.c_void_p(t.data_ptr()), int(t.numel() * 4), seg, passes_short, payload, 1, launches_short,
-                                             stream, C.byref(us), C.byref(gbs)), L)
-                row[names[payload]] = round(float(gbs.value), 1)
-                best = max(best, float(gbs.value))
-            _lib.check(L.sgx_store_probe(env.device.index, C.c_void_p(t.data_ptr()), int(t.numel() * 4), seg, passes_short, 1, 0, launches_short,
-                                         stream, C.byref(us), C.byref(gbs)), L)
-            row["observation_like_plain_stores"] = round(float(gbs.value), 1)
+                row[names[payload]] = round(probe(t, passes_short, payload, 1, 24, 0, launches_short), 1)
+                g = probe(t, passes_short, payload, 1, best_cfg[0], best_cfg[1], launches_short)
+                row[names[payload] + "_at_best"] = round(g, 1)
+                best = max(best, g)
+            row["observation_like_plain_stores"] = round(probe(t, passes_short, 1, 0, 24, 0, launches_short), 1)
             per_set.append(row)
-        # ONE long launch: passes x the first set's bytes >= long_bytes, so that what L2 (32 MiB) + the Infinity Cache (256 MiB) can still hold
-        # at its end is < 0.1 % of what it wrote; the memory clock sampled while it runs
+        # (3) ONE long launch at the best point, incompressible bits: passes x the first set's bytes >= long_bytes, so that what L2 (32 MiB) + the
+        # Infinity Cache (256 MiB) can still hold at its end is < 0.1 % of what it wrote; the memory clock sampled while it runs
         t = sets[0]
         passes = max(1, int(-(-long_bytes // (t.numel() * 4))))
         stop, seen = threading.Event(), []
         th = threading.Thread(target=_mclk_sampler, args=(B, stop, seen))
         th.start()
         try:
-            _lib.check(L.sgx_store_probe(env.device.index, C.c_void_p(t.data_ptr()), int(t.numel() * 4), seg, passes, 2, 1, 2, stream, C.byref(us), C.byref(gbs)), L)
+            g_long = probe(t, passes, 2, 1, best_cfg[0], best_cfg[1], 2)
+            us_long = float(us.value)
         finally:
             stop.set()
             th.join()
-        long_launch = {"payload": "random_bits", "passes": passes, "bytes_per_launch": int(t.numel() * 4) * passes, "us_per_launch": round(float(us.value), 1),
-                       "gbps": round(float(gbs.value), 1), "cache_residue_frac_at_most": (288 << 20) / float(int(t.numel() * 4) * passes),
+        long_launch = {"payload": "random_bits", "waves_per_cu": best_cfg[0], "pace": best_cfg[1], "passes": passes,
+                       "bytes_per_launch": int(t.numel() * 4) * passes, "us_per_launch": round(us_long, 1),
+                       "gbps": round(g_long, 1), "cache_residue_frac_at_most": (288 << 20) / float(int(t.numel() * 4) * passes),
                        "mclk_mhz_seen_during": sorted(set(seen)), "mclk_samples": len(seen)}
-        best = max(best, float(gbs.value))
+        best = max(best, g_long)
     return {"store_probe": {"kernel": "store_probe_kernel: one wave per %d-byte segment, 16 B per lane, 1 KiB sweeps on 1 KiB address boundaries, whole lines "
-                                      "non-temporal, edge lines through L2, 512-thread workgroups at 6 waves per SIMD, eight XCD ranges per pass (the step "
-                                      "kernel's observation stream without the game)" % seg,
+                                      "non-temporal, edge lines through L2, 512-thread workgroups, eight XCD ranges per pass (the step kernel's observation "
+                                      "stream without the game)" % seg,
                             "buffers": "the observation tensors of the ring the headline wrote (same process, same allocations)",
-                            "passes_per_launch": passes_short, "gbps_by_set_and_payload": per_set, "long_launch": long_launch},
+                            "passes_per_launch": passes_short, "streams_at_once_sweep_set0_observation_like": sweep,
+                            "best_waves_per_cu_and_pace": list(best_cfg), "gbps_by_set_and_payload": per_set, "long_launch": long_launch},
             "store_peak_measured": best, "store_peak_unit": "GB/s",
             "frac_of_store_peak": achieved_gbs / best if best > 0 else None}
 
@@ -107,6 +125,31 @@ def trajectory_leg(B, rk, args, version='barrage', n=65536, slots=64, passes=3, 
         launch_s = e0.elapsed_time(e1) / 1e3 / steps
         assert int(traj['invalid_action'].sum()) == 0
         checked = B.verify_against_oracle(env, version, verify) if verify else 0
+        # The strided code path against the pointer-per-set path on THE SAME memory: a one-slot "trajectory" that is the env's own output set
+        # (in place) against rollout_steps into that set -- what the slot arithmetic costs, with the allocation lottery taken out
+        del traj
+        torch.cuda.empty_cache()
+        own = env.alloc_trajectory(1)
+        env.obs, env.mask = own['obs'][0], own['mask'][0]
+        env.reward, env.done, env.player = own['reward'][0], own['done'][0], own['player'][0]
+        env.invalid_action, env.ending_invalid = own['invalid_action'][0], own['ending_invalid'][0]
+        env.observe()
+
+        def timed(fn, k, reps=3):
+            best = 1e9
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                a.record(); fn(); b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b) * 1e3 / k)
+            return best
+        k = 96
+        us_ptr = timed(lambda: env.rollout_steps(k), k)
+        us_strided = timed(lambda: env.rollout_trajectory(k, own), k)
+        env.bench_steps_played += 6 * k
+        B.MULTI_STEP_TALLY["launches"] += 6
+        B.MULTI_STEP_TALLY["steps"] += 6 * k
         fused = float(slots)
         per_step = B.b_min(v, False, env.record_bytes, fused) + 4            # + the drawn action of every step (actions log)
         return {"workload": "%d concurrent %s games, rollout into a trajectory buffer of %d slots (sgx_step_traj: obs / mask / rewards / flags / drawn "
@@ -115,6 +158,7 @@ def trajectory_leg(B, rk, args, version='barrage', n=65536, slots=64, passes=3, 
                 "one_launch": kind == _lib.LAUNCH_MULTI_STEP_WAVE or kind == _lib.LAUNCH_MULTI_STEP, "launch_kind": kind,
                 "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
                 "b_min_bytes_per_step": per_step, "frac": per_step * n / launch_s / 1e9 / B.HBM_PEAK_GBS,
+                "same_memory_in_place_us_per_step": {"pointer_per_set_path (sgx_step_n)": round(us_ptr, 2), "strided_slot_path (sgx_step_traj, 1 slot)": round(us_strided, 2)},
                 "verified_envs": checked, "verified_steps": env.bench_steps_played}
     finally:
         env.close()

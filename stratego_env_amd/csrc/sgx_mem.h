@@ -28,11 +28,12 @@ __global__ __launch_bounds__(512) void mem_probe_kernel(char *__restrict__ base,
 // first and the last line of a segment, shared with the neighbouring segments, go through L2.  512-thread workgroups at the step kernel's
 // occupancy promise (6 waves per SIMD), mapped to segments like games to workgroups: eight contiguous XCD ranges PER PASS, and the passes
 // one after the other in dispatch order, so that a line is written again only after the whole range has been written in between.
+// Fewer resident waves (the host requests dynamic LDS that nothing uses) and `pace` vary how many store streams the memory sees at once.
 // PAYLOAD 0: zeros; 1: observation-like floats (0 / 1 / -1 / 0.5 decoded from a per-quad code pattern, like the kernel's own values);
 // 2: incompressible bits (a hash of the quad's address and the launch's salt).
 template <int PAYLOAD>
 __global__ __launch_bounds__(512, 6) void store_probe_kernel(char *__restrict__ base, const int64_t groups_per_pass, const int passes, const int seg_bytes,
-                                                             const int nt, const uint32_t salt) {
+                                                             const int nt, const uint32_t salt, const int pace) {
     const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
     const int64_t b = blockIdx.x, x = b & 7, i = b >> 3;               // XCD, workgroup index inside the XCD's share
     const int64_t per_xcd = groups_per_pass >> 3;                      // workgroups of one XCD in one pass
@@ -63,6 +64,9 @@ __global__ __launch_bounds__(512, 6) void store_probe_kernel(char *__restrict__ 
         const bool edge = ((q + l0) >> 3) == first_line || ((q + l0) >> 3) == last_line;
         if (in && (edge || !nt)) q4[q] = o;
         if (in && !edge && nt) __builtin_nontemporal_store(o, &q4[q]);
+        // pacing: the step kernel's waves do not store back to back -- game logic sits between a game's bursts, and at any moment only a part of
+        // the resident waves is storing; `pace` sleeps of 64 cycles after every 1 KiB sweep stand in for that
+        for (int p = 0; p < pace; ++p) __builtin_amdgcn_s_sleep(1);
     }
 }
 

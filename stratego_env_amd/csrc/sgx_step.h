@@ -757,6 +757,9 @@ __global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (steps_waves_per_simd<Geo<
         //  recomputed in every step like in a launch of its own, not hoisted out of the loop and spilled: 244 bytes of scratch otherwise)
         asm volatile("" : "+s"(sp), "+v"(lane_t), "+v"(slot_t));
         steps_outputs_of(sp, set, carry);
+#ifdef SGX_MUTANT_SKIP_STORE     // test-the-tests build only (tools/mutant_check.sh): the fourth step of every launch loses its observation store
+        if (t == 3) carry.obs = nullptr;
+#endif
         env_step<R_, C_, KIND, false, false, 0, 2>(sp->k, LW[slot_t], shared, obst_s, env, lane_t, in, nullptr, nullptr, &carry, t == n_steps - 1);
         set = set + 1 == sp->n_sets ? 0 : set + 1;
     }
