@@ -38,27 +38,28 @@ def store_probe_leg(B, env, achieved_gbs, passes_short=8, launches_short=4, long
     names = ("zeros", "observation_like", "random_bits")
     us, gbs = C.c_float(), C.c_float()
 
-    def probe(t, passes, payload, nt, waves, pace, launches):
-        _lib.check(L.sgx_store_probe(env.device.index, C.c_void_p(t.data_ptr()), int(t.numel() * 4), seg, passes, payload, nt, waves, pace, launches,
-                                     stream, C.byref(us), C.byref(gbs)), L)
+    def probe(t, passes, payload, nt, waves, pace, launches, persistent=0):
+        _lib.check(L.sgx_store_probe(env.device.index, C.c_void_p(t.data_ptr()), int(t.numel() * 4), seg, passes, payload, nt, waves, pace, persistent,
+                                     launches, stream, C.byref(us), C.byref(gbs)), L)
         return float(gbs.value)
 
     with torch.cuda.device(env.device):
         # (1) how many streams at once: observation-like payload on the first set
-        sweep, best, best_cfg = [], 0.0, (24, 0)
-        for waves in (24, 16, 8):
-            for pace in (0, 1, 2, 4, 8, 16):
-                g = probe(sets[0], passes_short, 1, 1, waves, pace, launches_short)
-                sweep.append({"waves_per_cu": waves, "pace": pace, "gbps": round(g, 1)})
-                if g > best:
-                    best, best_cfg = g, (waves, pace)
+        sweep, best, best_cfg = [], 0.0, (24, 0, 0)
+        for persistent in (0, 1):
+            for waves in (24, 16, 8):
+                for pace in (0, 1, 2, 4, 8):
+                    g = probe(sets[0], passes_short, 1, 1, waves, pace, launches_short, persistent)
+                    sweep.append({"persistent_waves": persistent, "waves_per_cu": waves, "pace": pace, "gbps": round(g, 1)})
+                    if g > best:
+                        best, best_cfg = g, (waves, pace, persistent)
         # (2) the payload, on every set: back to back (24 waves per CU, no pacing: every resident wave stores all the time) and at the best point of (1)
         per_set = []
         for t in sets:
             row = {"bytes": int(t.numel() * 4)}
             for payload in (0, 1, 2):
                 row[names[payload]] = round(probe(t, passes_short, payload, 1, 24, 0, launches_short), 1)
-                g = probe(t, passes_short, payload, 1, best_cfg[0], best_cfg[1], launches_short)
+                g = probe(t, passes_short, payload, 1, best_cfg[0], best_cfg[1], launches_short, best_cfg[2])
                 row[names[payload] + "_at_best"] = round(g, 1)
                 best = max(best, g)
             row["observation_like_plain_stores"] = round(probe(t, passes_short, 1, 0, 24, 0, launches_short), 1)
@@ -71,12 +72,12 @@ def store_probe_leg(B, env, achieved_gbs, passes_short=8, launches_short=4, long
         th = threading.Thread(target=_mclk_sampler, args=(B, stop, seen))
         th.start()
         try:
-            g_long = probe(t, passes, 2, 1, best_cfg[0], best_cfg[1], 2)
+            g_long = probe(t, passes, 2, 1, best_cfg[0], best_cfg[1], 2, best_cfg[2])
             us_long = float(us.value)
         finally:
             stop.set()
             th.join()
-        long_launch = {"payload": "random_bits", "waves_per_cu": best_cfg[0], "pace": best_cfg[1], "passes": passes,
+        long_launch = {"payload": "random_bits", "waves_per_cu": best_cfg[0], "pace": best_cfg[1], "persistent_waves": best_cfg[2], "passes": passes,
                        "bytes_per_launch": int(t.numel() * 4) * passes, "us_per_launch": round(us_long, 1),
                        "gbps": round(g_long, 1), "cache_residue_frac_at_most": (288 << 20) / float(int(t.numel() * 4) * passes),
                        "mclk_mhz_seen_during": sorted(set(seen)), "mclk_samples": len(seen)}
@@ -86,7 +87,7 @@ def store_probe_leg(B, env, achieved_gbs, passes_short=8, launches_short=4, long
                                       "stream without the game)" % seg,
                             "buffers": "the observation tensors of the ring the headline wrote (same process, same allocations)",
                             "passes_per_launch": passes_short, "streams_at_once_sweep_set0_observation_like": sweep,
-                            "best_waves_per_cu_and_pace": list(best_cfg), "gbps_by_set_and_payload": per_set, "long_launch": long_launch},
+                            "best_waves_per_cu_pace_persistent": list(best_cfg), "gbps_by_set_and_payload": per_set, "long_launch": long_launch},
             "store_peak_measured": best, "store_peak_unit": "GB/s",
             "frac_of_store_peak": achieved_gbs / best if best > 0 else None}
 

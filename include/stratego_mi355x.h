@@ -269,14 +269,17 @@ int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t launches, vo
  * payload: 0 = zeros, 1 = observation-like floats (0 / 1 / -1 / 0.5 from a per-lane code pattern), 2 = incompressible bits (a hash of
  * the address and the launch number).  How many store streams the memory sees at once is the probe's other axis -- the step kernel's waves
  * do not store back to back: waves_per_cu = resident waves per CU (0 = the kernel's own 24; 16 or 8: fewer resident workgroups), pace =
- * sleeps of 64 cycles after every 1 KiB sweep (0 .. 4096).  bench.py sweeps both and reports the best rate as roofline.store_peak_measured.
+ * sleeps of 64 cycles after every 1 KiB sweep (0 .. 4096), persistent != 0 = a grid of the RESIDENT workgroups only, every wave walking
+ * segment after segment for the whole launch (long-lived waves, like the multi-step kernel's; 0 = one short-lived workgroup per eight
+ * segments and pass, like one launch per step).  bench.py sweeps these and reports the best rate as roofline.store_peak_measured.
  * OVERWRITES the range.  Returns the average duration of `launches` timed launches (HIP events on `stream`, one untimed launch first;
  * synchronises the stream) and bytes written per launch / that time.  No reference counterpart. */
 #define SGX_PROBE_ZEROS 0
 #define SGX_PROBE_OBS_LIKE 1
 #define SGX_PROBE_RANDOM 2
 int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t seg_bytes, int32_t passes, int32_t payload, int32_t nt_stores,
-                    int32_t waves_per_cu, int32_t pace, int32_t launches, void *stream, float *microseconds_per_launch, float *gb_per_s);
+                    int32_t waves_per_cu, int32_t pace, int32_t persistent, int32_t launches, void *stream, float *microseconds_per_launch,
+                    float *gb_per_s);
 
 /* Library-owned output buffers with a bounded placement trial.  On MI355X the same launch takes
  * 313-400 us depending on which physical memory backs the big observation buffer: device memory comes in regions of two

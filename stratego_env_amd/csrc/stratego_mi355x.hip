@@ -997,7 +997,8 @@ SGX_API int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t laun
 
 // The step kernel's store stream without the game (sgx_mem.h: store_probe_kernel): what the memory takes from exactly this store shape.
 SGX_API int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t seg_bytes, int32_t passes, int32_t payload, int32_t nt_stores,
-                            int32_t waves_per_cu, int32_t pace, int32_t launches, void *stream, float *microseconds_per_launch, float *gb_per_s) {
+                            int32_t waves_per_cu, int32_t pace, int32_t persistent, int32_t launches, void *stream, float *microseconds_per_launch,
+                            float *gb_per_s) {
     if (!ptr_dev || !microseconds_per_launch || !gb_per_s || launches <= 0 || passes <= 0 || bytes <= 0) return fail(SGX_EINVAL, "sgx_store_probe: bad argument%s");
     if (seg_bytes < 16 || (seg_bytes & 15) || (reinterpret_cast<uintptr_t>(ptr_dev) & 15)) return fail(SGX_EINVAL, "sgx_store_probe: segments and the range are 16-byte aligned%s");
     if (payload < 0 || payload > 2) return fail(SGX_EINVAL, "sgx_store_probe: payload 0 (zeros), 1 (observation-like) or 2 (random bits)%s");
@@ -1005,9 +1006,16 @@ SGX_API int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t se
     if (waves_per_cu != 0 && waves_per_cu != 8 && waves_per_cu != 16 && waves_per_cu != 24) return fail(SGX_EINVAL, "sgx_store_probe: waves_per_cu 0 (= 24), 8, 16 or 24%s");
     const int64_t n_seg = (bytes / seg_bytes) & ~(int64_t)63;                 // eight waves per workgroup, eight XCD shares
     if (n_seg < 64) return fail(SGX_EINVAL, "sgx_store_probe: the range holds fewer than 64 segments%s");
-    const int64_t groups_per_pass = n_seg / 8, grid = groups_per_pass * passes;
+    const int64_t groups_per_pass = n_seg / 8;
+    int64_t grid = groups_per_pass * passes;
     if (grid > 0x7fffffff) return fail(SGX_EINVAL, "sgx_store_probe: passes x segments exceed one grid%s");
     SGX_ON_DEVICE(device);
+    if (persistent) {                                                          // the resident workgroups only: CUs x (waves per CU / 8)
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        const int64_t resident = (int64_t)prop.multiProcessorCount * ((waves_per_cu ? waves_per_cu : 24) / 8);
+        if (resident < grid) grid = resident & ~(int64_t)7;
+    }
     hipStream_t st = (hipStream_t)stream;
     // resident workgroups per CU through unused dynamic LDS: 160 KiB per CU / (what one workgroup asks for)
     const size_t dyn = waves_per_cu == 8 ? 100 * 1024 : waves_per_cu == 16 ? 60 * 1024 : 0;
@@ -1024,9 +1032,9 @@ SGX_API int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t se
     static uint32_t salt = 0x5EED5EEDu;
     auto go = [&]() {
         salt = salt * 1664525u + 1013904223u;
-        if (payload == 0) store_probe_kernel<0><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace);
-        else if (payload == 1) store_probe_kernel<1><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace);
-        else store_probe_kernel<2><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace);
+        if (payload == 0) store_probe_kernel<0><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace, persistent ? 1 : 0);
+        else if (payload == 1) store_probe_kernel<1><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace, persistent ? 1 : 0);
+        else store_probe_kernel<2><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace, persistent ? 1 : 0);
     };
     go();                                                                      // untimed first touch
     hipError_t e = hipEventRecord(e0, st);

@@ -19,7 +19,7 @@ rf = d['roofline']
 print('value %.1fM one-launch-per-step %s frac %.3f' % (d['value'] / 1e6, d.get('value_one_launch_per_step'), rf['frac']))
 print('store_peak', rf.get('store_peak_measured'), 'frac_of_store_peak', rf.get('frac_of_store_peak'))
 sp = rf.get('store_probe') or {}
-print('best', sp.get('best_waves_per_cu_and_pace'))
+print('best', sp.get('best_waves_per_cu_pace_persistent'))
 for r in sp.get('streams_at_once_sweep_set0_observation_like', []):
     print('   ', r)
 print(json.dumps(sp.get('gbps_by_set_and_payload'), indent=1))
