@@ -1404,9 +1404,11 @@ def run_rank(args):      # noqa: C901
                 rf.update(store_probe)
                 sp = store_probe["store_peak_measured"]
                 rf["frac_dram_basis"] = (
-                    "B_min bytes over the launch time of a run that writes a ring of output sets; the store-only kernel of the same shape takes %.0f GB/s on the "
-                    "same buffers (store_probe), so this launch runs at %.3f of what the memory takes from this store stream -- a memory-side rate at the "
-                    "device's boundary, not a count of DRAM pin transfers" % (sp, store_probe["frac_of_store_peak"] or 0.0))
+                    "B_min bytes over the HIP-event time of a run that writes a ring of output sets, over the spec peak: a rate at the device's memory "
+                    "boundary, not a count of DRAM pin transfers.  The store-only kernel of the same store shape (store_probe: payloads, streams at once, "
+                    "wave lifetime, rewriting, plain / non-temporal mix) takes at most %.0f GB/s from the same buffers in this process, so this launch runs "
+                    "at %.3f of it: a store-only stream is NOT an upper bound for the game kernel, and where the rate exceeds the pins' 8,192 GB/s the "
+                    "excess is unexplained (payload, cache residue and the reported clocks are excluded: DESIGN.md section 4.2)" % (sp, store_probe["frac_of_store_peak"] or 0.0))
         value = total_steps / elapsed
         out = {
             "metric": "env steps/sec", "value": None if dry else value, "unit": "env steps/s",

@@ -38,9 +38,9 @@ def store_probe_leg(B, env, achieved_gbs, passes_short=8, launches_short=4, long
     names = ("zeros", "observation_like", "random_bits")
     us, gbs = C.c_float(), C.c_float()
 
-    def probe(t, passes, payload, nt, waves, pace, launches, persistent=0):
+    def probe(t, passes, payload, nt, waves, pace, launches, persistent=0, dwell=1, ring=1):
         _lib.check(L.sgx_store_probe(env.device.index, C.c_void_p(t.data_ptr()), int(t.numel() * 4), seg, passes, payload, nt, waves, pace, persistent,
-                                     launches, stream, C.byref(us), C.byref(gbs)), L)
+                                     dwell, ring, launches, stream, C.byref(us), C.byref(gbs)), L)
         return float(gbs.value)
 
     with torch.cuda.device(env.device):
@@ -53,6 +53,21 @@ def store_probe_leg(B, env, achieved_gbs, passes_short=8, launches_short=4, long
                     sweep.append({"persistent_waves": persistent, "waves_per_cu": waves, "pace": pace, "gbps": round(g, 1)})
                     if g > best:
                         best, best_cfg = g, (waves, pace, persistent)
+        # (1b) what the multi-step kernel's waves do and a walking store stream does not: REWRITE the same segment step after step (dwell), in place
+        # or cycling through the sets of a ring -- the live window of the resident waves is 6,144 x 26.8 KB = 165 MB per set
+        rewrite = []
+        for ring in (1, 3, 8):
+            for dwell in (1, 4, 32):
+                g = probe(sets[0], 1 if dwell > 1 else 8, 1, 1, 24, 0, launches_short, 1, dwell, ring)
+                rewrite.append({"persistent_waves": 1, "ring_sub_ranges": ring, "dwell": dwell, "gbps": round(g, 1)})
+        # (1c) the MIX of the step kernel: most of its bytes are non-temporal observation stores, 12 % (mask, edge lines, results) plain stores through
+        # L2 -- every N-th sweep of the probe plain
+        mix = []
+        for every in (2, 4, 8, 16):
+            for waves, pace, persistent in ((24, 0, 0), tuple(best_cfg)):
+                g = probe(sets[0], passes_short, 1, every, waves, pace, launches_short, persistent)
+                mix.append({"plain_every_nth_sweep": every, "waves_per_cu": waves, "pace": pace, "persistent_waves": persistent, "gbps": round(g, 1)})
+                best = max(best, g)
         # (2) the payload, on every set: back to back (24 waves per CU, no pacing: every resident wave stores all the time) and at the best point of (1)
         per_set = []
         for t in sets:
@@ -87,6 +102,7 @@ def store_probe_leg(B, env, achieved_gbs, passes_short=8, launches_short=4, long
                                       "stream without the game)" % seg,
                             "buffers": "the observation tensors of the ring the headline wrote (same process, same allocations)",
                             "passes_per_launch": passes_short, "streams_at_once_sweep_set0_observation_like": sweep,
+                            "rewriting_waves_set0_observation_like": rewrite, "plain_and_non_temporal_mix_set0_observation_like": mix,
                             "best_waves_per_cu_pace_persistent": list(best_cfg), "gbps_by_set_and_payload": per_set, "long_launch": long_launch},
             "store_peak_measured": best, "store_peak_unit": "GB/s",
             "frac_of_store_peak": achieved_gbs / best if best > 0 else None}

@@ -206,6 +206,12 @@ int sgx_set_lane_kernel(sgx_env *h, int32_t mode);
  * launch per step.  SGX_MULTI_STEP=0 sets the default of handles created afterwards (SGX_MULTI_STEP_WAVE=0: the first kind only off);
  * sgx_set_lane_kernel(h, 0) switches the second kind off as well.  No reference counterpart. */
 int sgx_set_multi_step(sgx_env *h, int32_t mode);
+/* Launches that write NO observation (sgx_expand, mask-only and logic-only steps / rollouts: no obs_dev / fobs_dev / final_*_dev, no compact
+ * outputs) are bound by instruction issue, not by memory; on boards of 33 .. 128 cells they play TWO games per wave (32 lanes per game): 65,536
+ * Barrage games, logic-only rollout 60.6 -> 33.2 us per step, search expansion 0.95 -> 1.77 G states/s.  Same results
+ * (the parity suites of the no-observation kind run on it); the environment variable SGX_HALF_WAVE=0 gives handles created afterwards one
+ * game per wave again (A/B measurements: tools/half_wave_ab.py).  No reference counterpart. */
+
 /* Which kernel the handle's last sgx_step / sgx_observe / sgx_step_n / sgx_step_ring / sgx_rollout / sgx_expand launch was (diagnostics,
  * benchmarks that price a launch by its own bytes, tests that must not pass on another kernel): */
 #define SGX_LAUNCH_WAVE 0        /* one wave per game (boards of up to 32 cells: a wave's lanes shared by 2 or 4 games), one launch per step */
@@ -267,19 +273,23 @@ int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t launches, vo
  * [ptr_dev, ptr_dev + bytes) holds floor(bytes / seg_bytes) segments; ONE launch writes all of them `passes` times, pass after pass, so a
  * launch of passes x bytes >> 288 MB (L2 + Infinity Cache) leaves a negligible share of its bytes in the caches when it ends.
  * payload: 0 = zeros, 1 = observation-like floats (0 / 1 / -1 / 0.5 from a per-lane code pattern), 2 = incompressible bits (a hash of
- * the address and the launch number).  How many store streams the memory sees at once is the probe's other axis -- the step kernel's waves
+ * the address and the launch number).  nt_stores: 0 = plain stores, 1 = whole lines non-temporal, N >= 2 = every N-th 1 KiB sweep plain and the
+ * others non-temporal (the step kernel's own mix: its mask leaves as plain stores through L2).  How many store streams the memory sees at once is the probe's other axis -- the step kernel's waves
  * do not store back to back: waves_per_cu = resident waves per CU (0 = the kernel's own 24; 16 or 8: fewer resident workgroups), pace =
  * sleeps of 64 cycles after every 1 KiB sweep (0 .. 4096), persistent != 0 = a grid of the RESIDENT workgroups only, every wave walking
  * segment after segment for the whole launch (long-lived waves, like the multi-step kernel's; 0 = one short-lived workgroup per eight
- * segments and pass, like one launch per step).  bench.py sweeps these and reports the best rate as roofline.store_peak_measured.
+ * segments and pass, like one launch per step); dwell > 1 (persistent waves only) = a wave writes its segment `dwell` times before it moves
+ * on, cycling through `ring` (1 .. 8) equal sub-ranges of the buffer -- a wave of the multi-step kernel rewrites its game's observation
+ * step after step, in place or into the sets of a ring; a launch then writes passes x dwell x (one sub-range's segments).  bench.py sweeps
+ * these and reports the best rate of the non-rewriting configurations as roofline.store_peak_measured.
  * OVERWRITES the range.  Returns the average duration of `launches` timed launches (HIP events on `stream`, one untimed launch first;
  * synchronises the stream) and bytes written per launch / that time.  No reference counterpart. */
 #define SGX_PROBE_ZEROS 0
 #define SGX_PROBE_OBS_LIKE 1
 #define SGX_PROBE_RANDOM 2
 int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t seg_bytes, int32_t passes, int32_t payload, int32_t nt_stores,
-                    int32_t waves_per_cu, int32_t pace, int32_t persistent, int32_t launches, void *stream, float *microseconds_per_launch,
-                    float *gb_per_s);
+                    int32_t waves_per_cu, int32_t pace, int32_t persistent, int32_t dwell, int32_t ring, int32_t launches, void *stream,
+                    float *microseconds_per_launch, float *gb_per_s);
 
 /* Library-owned output buffers with a bounded placement trial.  On MI355X the same launch takes
  * 313-400 us depending on which physical memory backs the big observation buffer: device memory comes in regions of two

@@ -136,8 +136,7 @@ def _bind(L):
     L.sgx_step_traj.restype = C.c_int
     L.sgx_step_traj.argtypes = [vp, C.POINTER(SgxTrajIO), C.c_int32, C.c_int32, vp]
     L.sgx_store_probe.restype = C.c_int
-    L.sgx_store_probe.argtypes = [C.c_int, vp, i64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp,
-                                  C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.sgx_store_probe.argtypes = [C.c_int, vp, i64] + [C.c_int32] * 10 + [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.sgx_rollout.restype = C.c_int
     L.sgx_rollout.argtypes = [vp, C.POINTER(SgxStepIO), C.c_int32, C.c_int32, vp]
     L.sgx_compact_obs_stride.restype = i64

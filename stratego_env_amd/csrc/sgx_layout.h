@@ -82,6 +82,13 @@ struct Geo {
     static constexpr int R = R_, C = C_;
     static constexpr int RC = R * C;
     static constexpr bool BIG = VAR_ == 1;
+    // VAR_ = 2 ("HALF"): TWO games per wave on a board that is one game per wave otherwise -- the no-observation kernel kinds only (search
+    // expansion, mask-only and logic-only rollouts: sgx_step.h).  Those launches are bound by VALU issue, not by memory: 505 VALU instructions per
+    // 10x10 game-step whether 64 or 32 lanes take part, so two games share every instruction (half_wave_ok<R, C>() says where it applies).
+    // Measured, 65,536 games, us per step one / two games per wave (tools/half_wave_ab.py, profiles/r06_half_wave_ab.log): Barrage logic-only
+    // rollout 60.6 / 33.2, mask only 72.7 / 46.6, search expansion 69.2 / 37.1 (0.95 -> 1.77 G states/s); Standard 59.9 / 37.2, 75.1 / 51.4, 68.0 / 38.1.
+    // (The compact-output kind gains nothing from it -- 95 / 91 us, Standard 101 / 103: its code buffer doubles per wave -- and keeps one game per wave.)
+    static constexpr bool HALF = VAR_ == 2;
     // cell-index width of the packed record: 8 bits up to 256 cells, 10 bits beyond (up to SGX_MAX_CELLS = 1024)
     static constexpr bool WIDE = RC > 256;
     static constexpr int CELL_BITS = WIDE ? 10 : 8, CELL_MASK = (1 << CELL_BITS) - 1, CODE_BITS = 16 - CELL_BITS;
@@ -124,7 +131,7 @@ struct Geo {
     // (twice the games per wave -- 8 / 16 / 32 lanes per game, two cells per lane up to 8x8 -- is bit-exact too but 3-5 % slower on
     // every board size: the cell loops double)
     // (The general-state variant is one game per wave on every board: it only runs in the fused states_kernel, one state per block.)
-    static constexpr int LPG = (RC > 32 || BIG) ? 64 : (RC <= 16 ? 16 : 32);
+    static constexpr int LPG = BIG ? 64 : HALF ? 32 : (RC > 32 ? 64 : (RC <= 16 ? 16 : 32));
     static constexpr int GPW = 64 / LPG;              // games per wave
     // a wave may play several games in turn with the next game's reads in flight (13 more VGPRs: one-game-per-wave boards only)
     static constexpr bool PIPELINED = LPG == 64;      // observation lines written whole leave as non-temporal stores (sgx_obs.h)
@@ -135,10 +142,18 @@ struct Geo {
                                         (4 + (int)sizeof(entry_t)) * (EVL_MAX + SPECIAL_EXTRA + 8) + 64;
     // the workgroup's shared tables; WIDE boards read the default-code templates from global memory (L2) instead of an LDS copy
     static constexpr int LDS_SHARED_EST = (WIDE ? 0 : 2 * (RC * FOBS_CH / 2 + 32)) + 1024 + S;
-    static constexpr int WPB = (SGX_WPB * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? SGX_WPB
+    // (two games per wave: four waves per workgroup -- the same eight games per workgroup and the same LDS footprint as the board's ordinary kernels)
+    static constexpr int WPB = HALF ? 4 : (SGX_WPB * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? SGX_WPB
                              : (4 * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? 4
                              : (2 * GPW * LDS_GAME_EST + LDS_SHARED_EST <= 160 * 1024) ? 2 : 1;
 };
+
+// the HALF variant of a board: one-game-per-wave boards of up to 128 cells whose record image still stages as two int4 per lane
+template <int R, int C>
+constexpr bool half_wave_ok() {
+    using G0 = Geo<R, C>;
+    return G0::LPG == 64 && !G0::WIDE && G0::RC <= 128 && (G0::ST_OFF + G0::TAIL_BYTES) / 16 <= 64;
+}
 
 struct DevTables {
     // observation LUTs, rows at lut_row(ch); index = 4 * original + 2 * raw + full:

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(512) void mem_probe_kernel(char *__restrict__ base,
 // 2: incompressible bits (a hash of the quad's address and the launch's salt).
 template <int PAYLOAD>
 __global__ __launch_bounds__(512, 6) void store_probe_kernel(char *__restrict__ base, const int64_t groups_per_pass, const int passes, const int seg_bytes,
-                                                             const int nt, const uint32_t salt, const int pace, const int persistent) {
+                                                             const int nt, const uint32_t salt, const int pace, const int persistent, const int dwell,
+                                                             const int ring, const int64_t ring_bytes) {
     const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
     const int64_t b = blockIdx.x, x = b & 7;                           // XCD
     const int64_t per_xcd = groups_per_pass >> 3;                      // workgroups' worth of segments of one XCD in one pass
@@ -46,15 +47,22 @@ __global__ __launch_bounds__(512, 6) void store_probe_kernel(char *__restrict__ 
     for (int64_t i = b >> 3; i < total; i += istep) {
         const int64_t pass = i / per_xcd, j = i - pass * per_xcd;
         const int64_t seg_i = (x * per_xcd + j) * 8 + slot;
-        char *seg = base + seg_i * (int64_t)seg_bytes;
+        // dwell > 1 (persistent waves only): the wave writes its segment `dwell` times before it moves on -- what a wave of the multi-step
+        // kernel does with its game's observation, step after step -- cycling through `ring` sub-ranges of the buffer (the output sets of a ring)
+        for (int rep = 0; rep < dwell; ++rep) {
+        char *seg = base + (int64_t)(rep % ring) * ring_bytes + seg_i * (int64_t)seg_bytes;
         const int NQ = seg_bytes >> 4;
         const int m0 = (int)((reinterpret_cast<uintptr_t>(seg) >> 4) & 63), l0 = (int)((reinterpret_cast<uintptr_t>(seg) >> 4) & 7);
         const int first_line = l0 ? 0 : -1, last_line = ((l0 + NQ) & 7) ? (NQ - 1 + l0) >> 3 : -1;
         f32x4 *q4 = reinterpret_cast<f32x4 *>(seg);
+        int sweep = 0;
 #pragma unroll SGX_OBS_UNROLL
-        for (int q0 = -m0; q0 < NQ; q0 += 64) {
+        for (int q0 = -m0; q0 < NQ; q0 += 64, ++sweep) {
             const int q = q0 + lane;
             const bool in = (unsigned)q < (unsigned)NQ;
+            // nt: 0 = plain stores, 1 = non-temporal, N >= 2 = every N-th 1 KiB sweep plain and the others non-temporal -- the step kernel's mix:
+            // its mask (3,700 B per 26,800 B of observation) leaves as plain stores through L2
+            const bool nt_here = nt == 1 || (nt >= 2 && (sweep % nt) != 0);
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
             if constexpr (PAYLOAD == 1) {
                 const unsigned hq = (unsigned)q * 0x9E3779B1u;
@@ -68,11 +76,12 @@ __global__ __launch_bounds__(512, 6) void store_probe_kernel(char *__restrict__ 
                 o = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
             }
             const bool edge = ((q + l0) >> 3) == first_line || ((q + l0) >> 3) == last_line;
-            if (in && (edge || !nt)) q4[q] = o;
-            if (in && !edge && nt) __builtin_nontemporal_store(o, &q4[q]);
+            if (in && (edge || !nt_here)) q4[q] = o;
+            if (in && !edge && nt_here) __builtin_nontemporal_store(o, &q4[q]);
             // pacing: the step kernel's waves do not store back to back -- game logic sits between a game's bursts, and at any moment only a part
             // of the resident waves is storing; `pace` sleeps of 64 cycles after every 1 KiB sweep stand in for that
             for (int p = 0; p < pace; ++p) __builtin_amdgcn_s_sleep(1);
+        }
         }
     }
 }

@@ -31,7 +31,8 @@ constexpr int waves_per_simd() {
     // toy boards are latency-bound (tiny per-game work): 8 waves/SIMD measured +7 %; on 10x10 forcing 64 VGPRs spills
     // (the MAPPED instantiation's index computations take ~70 VGPRs: with the no-observation kind's small LDS footprint a promise of 8
     //  waves would cap it at 64 and spill; 6 leaves it 80)
-    constexpr int want = (MAPPED && ObsKind<KIND>::NOOBS) ? 6 : (G::RC <= 64 ? 8 : SGX_MIN_WAVES);
+    // (two games per wave: per-lane values replace wave-uniform ones -- 79 VGPRs in the 10x10 steps loop -- and 6 waves are 12 games per SIMD)
+    constexpr int want = (G::HALF || (MAPPED && ObsKind<KIND>::NOOBS)) ? 6 : (G::RC <= 64 ? 8 : SGX_MIN_WAVES);
     return w > want ? want : (w < 1 ? 1 : w);
 }
 
@@ -590,9 +591,10 @@ __device__ __forceinline__ void env_step(const KP &P, Lds<Geo<R_, C_, VAR>, ObsK
 // KIND bit 0: also renders the fully-observable observation (BOTH_OBSERVATIONS / FULLY_OBSERVABLE modes, maenv:477-492);
 // KIND bit 1: obs_channel_mode 'original' (32/33 value channels) instead of 'extended' (67/79 one-hot channels);
 // KIND bit 2 (alone: KIND 4): compact outputs -- the partial 'extended' kind whose observation / mask may leave as codes / bits
-template <int R_, int C_, int KIND, bool MAPPED>
+template <int R_, int C_, int KIND, bool MAPPED, int VAR = 0>
 __device__ __forceinline__ void game_kernel_body(const KParams &P) {
-    using G = Geo<R_, C_>;
+    using G = Geo<R_, C_, VAR>;
+    static_assert(VAR == 0 || (VAR == 2 && ObsKind<KIND>::NOOBS), "two games per wave: the no-observation kinds only");
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
     constexpr bool FULL = ObsKind<KIND>::FULL, ORIG = ObsKind<KIND>::ORIG;
@@ -633,19 +635,19 @@ __device__ __forceinline__ void game_kernel_body(const KParams &P) {
     for (int i = threadIdx.x; i < COMBAT_BYTES / 4; i += 64 * G::WPB)
         reinterpret_cast<int *>(obst_s + G::OBST_BYTES)[i] = reinterpret_cast<const int *>(P.tab->combat)[i];
     __syncthreads();   // from here on every wave works on its own game
-    if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED>(P, LW[slot], shared, obst_s, env, lane, in);
+    if (env < P.n_envs) env_step<R_, C_, KIND, MAPPED, false, VAR>(P, LW[slot], shared, obst_s, env, lane, in);
 }
 
 // sgx_step and sgx_observe run the same body (P.mode tells them apart at run time: specialising the body on the mode changed the
 // step kernel's schedule and cost 3.7 % on Barrage); two kernel symbols, so that a kernel trace keeps the env.step() launches
 // apart from the state-preserving observe launches (placement trials, reset())
-template <int R_, int C_, int KIND, bool MAPPED = false>
-__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND, MAPPED>())) void step_kernel(const KParams P) {
-    game_kernel_body<R_, C_, KIND, MAPPED>(P);
+template <int R_, int C_, int KIND, bool MAPPED = false, int VAR = 0>
+__global__ __launch_bounds__((64 * Geo<R_, C_, VAR>::WPB), (waves_per_simd<Geo<R_, C_, VAR>, KIND, MAPPED>())) void step_kernel(const KParams P) {
+    game_kernel_body<R_, C_, KIND, MAPPED, VAR>(P);
 }
-template <int R_, int C_, int KIND, bool MAPPED = false>
-__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (waves_per_simd<Geo<R_, C_>, KIND, MAPPED>())) void observe_kernel(const KParams P) {
-    game_kernel_body<R_, C_, KIND, MAPPED>(P);
+template <int R_, int C_, int KIND, bool MAPPED = false, int VAR = 0>
+__global__ __launch_bounds__((64 * Geo<R_, C_, VAR>::WPB), (waves_per_simd<Geo<R_, C_, VAR>, KIND, MAPPED>())) void observe_kernel(const KParams P) {
+    game_kernel_body<R_, C_, KIND, MAPPED, VAR>(P);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -689,9 +691,10 @@ constexpr int steps_waves_per_simd() {
     constexpr int w = waves_per_simd<G, KIND, false>();
     return (G::RC <= 64 && G::RC % 4 != 0 && !ObsKind<KIND>::NOOBS && w > 6) ? 6 : w;
 }
-template <int R_, int C_, int KIND>
-__global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (steps_waves_per_simd<Geo<R_, C_>, KIND>())) void steps_kernel(const WaveStepsParams SP) {
-    using G = Geo<R_, C_>;
+template <int R_, int C_, int KIND, int VAR = 0>
+__global__ __launch_bounds__((64 * Geo<R_, C_, VAR>::WPB), (steps_waves_per_simd<Geo<R_, C_, VAR>, KIND>())) void steps_kernel(const WaveStepsParams SP) {
+    using G = Geo<R_, C_, VAR>;
+    static_assert(VAR == 0 || (VAR == 2 && ObsKind<KIND>::NOOBS), "two games per wave: the no-observation kinds only");
     using PS = typename ObsKind<KIND>::P;
     using FS = typename ObsKind<KIND>::F;
     constexpr bool FULL = ObsKind<KIND>::FULL, ORIG = ObsKind<KIND>::ORIG;
@@ -747,7 +750,7 @@ __global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (steps_waves_per_simd<Geo<
     {   // the first step stages the record (its loads were issued before the table staging); its code is a copy of its own, so that the record's
         // registers are dead in the loop below
         steps_outputs_of(spp, set, carry);
-        env_step<R_, C_, KIND, false, false, 0, 1>(P, LW[slot], shared, obst_s, env, lane, in, nullptr, nullptr, &carry, n_steps == 1);
+        env_step<R_, C_, KIND, false, false, VAR, 1>(P, LW[slot], shared, obst_s, env, lane, in, nullptr, nullptr, &carry, n_steps == 1);
         set = set + 1 == spp->n_sets ? 0 : set + 1;
     }
     for (int t = 1; t < n_steps; ++t) {
@@ -760,7 +763,7 @@ __global__ __launch_bounds__((64 * Geo<R_, C_>::WPB), (steps_waves_per_simd<Geo<
 #ifdef SGX_MUTANT_SKIP_STORE     // test-the-tests build only (tools/mutant_check.sh): the fourth step of every launch loses its observation store
         if (t == 3) carry.obs = nullptr;
 #endif
-        env_step<R_, C_, KIND, false, false, 0, 2>(sp->k, LW[slot_t], shared, obst_s, env, lane_t, in, nullptr, nullptr, &carry, t == n_steps - 1);
+        env_step<R_, C_, KIND, false, false, VAR, 2>(sp->k, LW[slot_t], shared, obst_s, env, lane_t, in, nullptr, nullptr, &carry, t == n_steps - 1);
         set = set + 1 == sp->n_sets ? 0 : set + 1;
     }
 }

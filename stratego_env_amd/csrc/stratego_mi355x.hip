@@ -127,6 +127,7 @@ struct sgx_env {
     int multi_step_attr;         // lane_steps_kernel's dynamic-LDS attribute has been raised
     int last_kind;               // sgx_last_launch_kind: which kernel the last step / observe launch of this handle was
     int multi_step_wave;         // SGX_MULTI_STEP_WAVE: the multi-step launch of the wave-per-game kernels (steps_kernel) too
+    int half_wave;               // SGX_HALF_WAVE: launches without an observation play two games per wave where the board allows it (Geo<R, C, 2>)
 };
 
 namespace {
@@ -401,6 +402,8 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     if (const char *e = getenv("SGX_MULTI_STEP")) h->no_multi_step = !strcmp(e, "0");
     h->multi_step_wave = 1;
     if (const char *e = getenv("SGX_MULTI_STEP_WAVE")) h->multi_step_wave = strcmp(e, "0") != 0;
+    h->half_wave = 1;
+    if (const char *e = getenv("SGX_HALF_WAVE")) h->half_wave = strcmp(e, "0") != 0;
     if (const char *e = getenv("SGX_MAP")) { h->map_mode = atoi(e); if (const char *c = strchr(e, ',')) h->map_arg = atoi(c + 1); }
     const int rc_cells = cfg->rows * cfg->cols;
     {
@@ -823,8 +826,19 @@ static int launch_wave_steps(sgx_env *h, const KParams &p_in, const OutSets &set
     do {                                                                                                   \
         if (kind == 0) CALL_WSTEPS_K(R, C, 0);                                                             \
         else if (kind == 1) CALL_WSTEPS_K(R, C, 1);                                                        \
-        else if (kind == 4) CALL_WSTEPS_K(R, C, 4);                                                        \
-        else CALL_WSTEPS_K(R, C, 8);                                                                       \
+        else {                                                                                             \
+            bool half_ = false;                                                                            \
+            if constexpr (half_wave_ok<R, C>()) {                                                          \
+                if (h->half_wave && kind == 8) {             /* two games per wave (Geo<R, C, 2>) */        \
+                    using H_ = Geo<R, C, 2>;                                                               \
+                    const unsigned grid = shares_for(p, (p.n_envs - p.env_first + H_::WPB * H_::GPW - 1) / (H_::WPB * H_::GPW), skew); \
+                    sp.k = p;                                                                              \
+                    steps_kernel<R, C, 8, 2><<<grid, 64 * H_::WPB, 0, (hipStream_t)stream>>>(sp);           \
+                    half_ = true;                                                                          \
+                }                                                                                          \
+            }                                                                                              \
+            if (!half_) { if (kind == 4) CALL_WSTEPS_K(R, C, 4); else CALL_WSTEPS_K(R, C, 8); }            \
+        }                                                                                                  \
     } while (0)
         DISPATCH_GEOMETRY(h, CALL_WSTEPS);
 #undef CALL_WSTEPS
@@ -883,7 +897,20 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
 #define CALL_STEP1(R, C) CALL_STEP_KIND(R, C, 1)
 #define CALL_STEP2(R, C) CALL_STEP_KIND(R, C, 2)
 #define CALL_STEP3(R, C) CALL_STEP_KIND(R, C, 3)
-#define CALL_STEP8(R, C) CALL_STEP_KIND(R, C, 8)
+#define CALL_STEP8(R, C)                                                                           \
+    do {                                                                                           \
+        bool half_ = false;                                                                        \
+        if constexpr (half_wave_ok<R, C>()) {                                                      \
+            if (h->half_wave) {                              /* two games per wave (Geo<R, C, 2>) */ \
+                using H_ = Geo<R, C, 2>;                                                           \
+                const unsigned grid = shares_for(p, (p.n_envs - p.env_first + H_::WPB * H_::GPW - 1) / (H_::WPB * H_::GPW), skew); \
+                if (p.mode) observe_kernel<R, C, 8, false, 2><<<grid, 64 * H_::WPB, 0, (hipStream_t)stream>>>(p); \
+                else step_kernel<R, C, 8, false, 2><<<grid, 64 * H_::WPB, 0, (hipStream_t)stream>>>(p); \
+                half_ = true;                                                                      \
+            }                                                                                      \
+        }                                                                                          \
+        if (!half_) CALL_STEP_KIND(R, C, 8);                                                       \
+    } while (0)
     // no observation pointer at all (search expansions, mask-only steps, logic-only rollouts): the kind without observation tables
     const bool no_obs = !p.io.obs_dev && !p.io.fobs_dev && !p.io.final_obs_dev && !p.io.final_fobs_dev &&
                         !(p.io.flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK));
@@ -891,6 +918,17 @@ static int launch_step(sgx_env *h, const KParams &p_in, void *stream, int ring_s
         if (full || (original && !no_obs)) return fail(SGX_EINVAL, "state-coordinate masks and sgx_expand come with the 67-channel partial observation only%s");
 #define CALL_STEP_MAPPED8(R, C)                                                                    \
     do {                                                                                           \
+        bool half_ = false;                                                                        \
+        if constexpr (half_wave_ok<R, C>()) {                                                      \
+            if (h->half_wave) {                              /* two games per wave (Geo<R, C, 2>) */ \
+                using H_ = Geo<R, C, 2>;                                                           \
+                const unsigned grid = shares_for(p, (p.n_envs - p.env_first + H_::WPB * H_::GPW - 1) / (H_::WPB * H_::GPW), skew); \
+                if (p.mode) observe_kernel<R, C, 8, true, 2><<<grid, 64 * H_::WPB, 0, (hipStream_t)stream>>>(p); \
+                else step_kernel<R, C, 8, true, 2><<<grid, 64 * H_::WPB, 0, (hipStream_t)stream>>>(p); \
+                half_ = true;                                                                      \
+            }                                                                                      \
+        }                                                                                          \
+        if (half_) break;                                                                          \
         using G_ = Geo<R, C>;                                                                      \
         const unsigned grid = shares_for(p, (p.n_envs - p.env_first + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW), skew); \
         if (p.mode) observe_kernel<R, C, 8, true><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(p);  \
@@ -997,14 +1035,17 @@ SGX_API int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t laun
 
 // The step kernel's store stream without the game (sgx_mem.h: store_probe_kernel): what the memory takes from exactly this store shape.
 SGX_API int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t seg_bytes, int32_t passes, int32_t payload, int32_t nt_stores,
-                            int32_t waves_per_cu, int32_t pace, int32_t persistent, int32_t launches, void *stream, float *microseconds_per_launch,
-                            float *gb_per_s) {
+                            int32_t waves_per_cu, int32_t pace, int32_t persistent, int32_t dwell, int32_t ring, int32_t launches, void *stream,
+                            float *microseconds_per_launch, float *gb_per_s) {
     if (!ptr_dev || !microseconds_per_launch || !gb_per_s || launches <= 0 || passes <= 0 || bytes <= 0) return fail(SGX_EINVAL, "sgx_store_probe: bad argument%s");
     if (seg_bytes < 16 || (seg_bytes & 15) || (reinterpret_cast<uintptr_t>(ptr_dev) & 15)) return fail(SGX_EINVAL, "sgx_store_probe: segments and the range are 16-byte aligned%s");
     if (payload < 0 || payload > 2) return fail(SGX_EINVAL, "sgx_store_probe: payload 0 (zeros), 1 (observation-like) or 2 (random bits)%s");
     if (pace < 0 || pace > 4096) return fail(SGX_EINVAL, "sgx_store_probe: pace 0 .. 4096%s");
     if (waves_per_cu != 0 && waves_per_cu != 8 && waves_per_cu != 16 && waves_per_cu != 24) return fail(SGX_EINVAL, "sgx_store_probe: waves_per_cu 0 (= 24), 8, 16 or 24%s");
-    const int64_t n_seg = (bytes / seg_bytes) & ~(int64_t)63;                 // eight waves per workgroup, eight XCD shares
+    if (dwell < 1 || ring < 1 || ring > 8 || (dwell > 1 && !persistent)) return fail(SGX_EINVAL, "sgx_store_probe: dwell >= 1 (> 1 with persistent waves only), ring 1 .. 8%s");
+    // `ring` sub-ranges of equal size (whole segments, 1 KiB aligned starts); a pass covers ONE sub-range's segments
+    const int64_t ring_bytes = ring > 1 ? ((bytes / ring) & ~(int64_t)1023) : 0;
+    const int64_t n_seg = (((ring > 1 ? ring_bytes : bytes) / seg_bytes)) & ~(int64_t)63;   // eight waves per workgroup, eight XCD shares
     if (n_seg < 64) return fail(SGX_EINVAL, "sgx_store_probe: the range holds fewer than 64 segments%s");
     const int64_t groups_per_pass = n_seg / 8;
     int64_t grid = groups_per_pass * passes;
@@ -1032,9 +1073,9 @@ SGX_API int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t se
     static uint32_t salt = 0x5EED5EEDu;
     auto go = [&]() {
         salt = salt * 1664525u + 1013904223u;
-        if (payload == 0) store_probe_kernel<0><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace, persistent ? 1 : 0);
-        else if (payload == 1) store_probe_kernel<1><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace, persistent ? 1 : 0);
-        else store_probe_kernel<2><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace, persistent ? 1 : 0);
+        if (payload == 0) store_probe_kernel<0><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace, persistent ? 1 : 0, dwell, ring, ring_bytes);
+        else if (payload == 1) store_probe_kernel<1><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace, persistent ? 1 : 0, dwell, ring, ring_bytes);
+        else store_probe_kernel<2><<<(unsigned)grid, 512, dyn, st>>>((char *)ptr_dev, groups_per_pass, passes, seg_bytes, nt_stores, salt, pace, persistent ? 1 : 0, dwell, ring, ring_bytes);
     };
     go();                                                                      // untimed first touch
     hipError_t e = hipEventRecord(e0, st);
@@ -1048,7 +1089,7 @@ SGX_API int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t se
     (void)hipEventDestroy(e1);
     if (e != hipSuccess) return fail(SGX_EDEVICE, "sgx_store_probe: %s", hipGetErrorString(e));
     *microseconds_per_launch = ms * 1000.f / (float)launches;
-    *gb_per_s = (float)((double)n_seg * seg_bytes * passes * launches / (ms * 1e-3) / 1e9);
+    *gb_per_s = (float)((double)n_seg * seg_bytes * passes * dwell * launches / (ms * 1e-3) / 1e9);
     return SGX_OK;
 }
 

@@ -108,3 +108,51 @@ def test_steps_that_only_ask_whether_a_move_exists(name, n):
     assert torch.equal(sa, sb) and torch.equal(pa, pb)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize('name,n', [('barrage', 1003), ('standard', 517), ('octa_barrage', 1000), ('medium', 999), ('short_barrage', 2050)])
+def test_two_games_per_wave_equal_one_game_per_wave(name, n, monkeypatch):
+    """Launches without an observation play TWO games per wave on boards of 33 .. 128 cells (Geo<R, C, 2>, the default); SGX_HALF_WAVE=0 at
+    handle creation gives one game per wave.  Ragged batch sizes (partial workgroups, a wave with one game), per-step and multi-step
+    launches, mask-only and logic-only, search expansion pool to pool: identical masks, rewards, flags, draws and int64 states.  (Both are
+    compared with the oracle through the suites of the no-observation kind; this test pins the two layouts to each other on every board.)"""
+    import torch
+    from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    monkeypatch.setenv('SGX_HALF_WAVE', '0')
+    a = VecStrategoEnv(name, n, seed=21, auto_reset=True)
+    monkeypatch.setenv('SGX_HALF_WAVE', '1')
+    b = VecStrategoEnv(name, n, seed=21, auto_reset=True)
+    a.reset(); b.reset()
+    a.sample_valid_actions(); b.sample_valid_actions()
+    bad = torch.arange(n, device=a.device) % 9 == 4
+    for e in (a, b):
+        e.next_actions[bad] = -3
+        e._next_actions_fresh = True
+    for multi in (False, True):
+        a.set_multi_step(multi); b.set_multi_step(multi)
+        for kw in ({'emit_obs': False}, {'emit_obs': False, 'emit_mask': False}):
+            a.rollout_steps(37, **kw); b.rollout_steps(37, **kw)
+            for x, y, w in ((a.reward, b.reward, 'reward'), (a.done, b.done, 'done'), (a.player, b.player, 'player'), (a.next_actions, b.next_actions, 'draw'),
+                            (a.invalid_action, b.invalid_action, 'invalid'), (a.ending_invalid, b.ending_invalid, 'ending'), (a.env_info(), b.env_info(), 'info')):
+                assert torch.equal(x, y), (name, multi, kw, w)
+            if kw.get('emit_mask', True):
+                assert torch.equal(a.mask, b.mask), (name, multi)
+    sa, pa = a.export_state(); sb, pb = b.export_state()
+    assert torch.equal(sa, sb) and torch.equal(pa, pb)
+    a.observe(emit_obs=False); b.observe(emit_obs=False)
+    assert torch.equal(a.mask, b.mask)
+    # search expansion (sgx_expand: the MAPPED no-observation instantiation) from these positions, both layouts
+    kids = []
+    for mode in ('0', '1'):
+        monkeypatch.setenv('SGX_HALF_WAVE', mode)
+        pe = BatchedStrategoProceduralEnv(name, n)
+        m1 = pe.get_valid_moves_as_1d_mask(sa, pa)
+        acts = torch.argmax((m1 != 0).to(torch.int8), dim=1).to(torch.int32)
+        acts[::7] = 3                                                   # some invalid ones: the child is a copy of the parent
+        nodes, pool = pe.pack(sa, pa), pe.new_packed()
+        valid, movers = pool.expand(nodes, acts)
+        kids.append((valid.clone(), movers.clone()) + tuple(pool.unpack()) + (m1,))
+    for x, y in zip(kids[0], kids[1]):
+        assert torch.equal(x, y), name
+    a.close(); b.close()

@@ -3,4 +3,4 @@
 OUT=$1; R=$2; C=$3; shift 3
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -fvisibility=hidden -DSGX_BUILD_ID=\"variant\" -DSGX_ONLY_EXTRA -DSGX_EXTRA_R=$R -DSGX_EXTRA_C=$C "$@" \
-  -I $ROOT/include $ROOT/stratego_env_amd/csrc/stratego_mi355x.hip -o $OUT 2>&1 | grep -v "warning:" | head -5
+  -I $ROOT/include ${SGX_SRC:-$ROOT/stratego_env_amd/csrc}/stratego_mi355x.hip -o $OUT 2>&1 | grep -v "warning:" | head -5

@@ -30,7 +30,7 @@ def step_row(f, multi_steps=None):
 
 def main():
     out = 'gpurun_out/' + sys.argv[1]
-    rnd = sys.argv[2] if len(sys.argv) > 2 else 'r05'
+    rnd = sys.argv[2] if len(sys.argv) > 2 else 'r06'
     tags = tuple('%s_%s' % (rnd, t) for t in ('untuned_headline', 'inplace', 'micro', 'standard', 'both'))
     for tag in tags:
         d = 'gpurun_out/prof_%s' % tag
@@ -47,7 +47,9 @@ def main():
                      ('phase_cost.log', 'phase_cost_final.log'), ('bench_default.json', 'default_bench_line.json'),
                      ('bench_driver_style.json', 'driver_style_line.json'), ('bench_default_run2.json', 'default_bench_line_run2.json'),
                      ('bench_default_run3.json', 'default_bench_line_run3.json'),
-                     ('multi_step_ab.log', 'multi_step_ab_plain_buffers.log'), ('ring_size_probe_tuned.log', 'ring_size_probe_tuned.log')):
+                     ('multi_step_ab.log', 'multi_step_ab_plain_buffers.log'), ('ring_size_probe_tuned.log', 'ring_size_probe_tuned.log'),
+                     ('half_wave_ab.log', 'half_wave_ab.log'), ('noobs_small_ab.log', 'noobs_small_ab.log'), ('spread_probe.log', 'spread_probe_final.log'),
+                     ('facade_breakdown.log', 'facade_breakdown.log'), ('clock_probe.log', 'clock_probe.log'), ('soak_general_states.log', 'soak_general_states.log')):
         if os.path.exists(os.path.join(out, src)):
             shutil.copy(os.path.join(out, src), 'profiles/%s_%s' % (rnd, dst))
     for tag in ('procedural', 'kstep_micro'):

@@ -2,7 +2,7 @@
 # The round's measurement campaign, ONE gpurun call on the GPU box:  gpurun --timeout 4000 -- 'bash tools/final_campaign.sh <outdir name>'
 # Everything lands under gpurun_out/; tools/collect_profiles.py (in the build container, afterwards) copies what is quoted into profiles/.
 OUT=${1:-final}
-RND=${2:-r05}                                  # prefix of everything this round commits under profiles/
+RND=${2:-r06}                                  # prefix of everything this round commits under profiles/
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
@@ -17,8 +17,8 @@ bash tools/gpu_profile.sh ${RND}_micro micro 65536 --version micro --output-sets
 bash tools/gpu_profile.sh ${RND}_standard standard 262144 --version standard --envs 262144 --warmup 300 --output-sets 1 > gpurun_out/prof_${RND}_standard.log 2>&1
 bash tools/gpu_profile.sh ${RND}_both barrage+full_obs 65536 --full-obs --output-sets 1 > gpurun_out/prof_${RND}_both.log 2>&1
 cd /tmp; mkdir -p $R/gpurun_out/${RND}_tuned
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_tuned/headline -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --no-in-place-leg --no-live-traffic > $R/gpurun_out/${RND}_tuned/headline_line.json 2> $R/gpurun_out/${RND}_tuned/headline.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_tuned/inplace -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --no-live-traffic --output-sets 1 > $R/gpurun_out/${RND}_tuned/inplace_line.json 2> $R/gpurun_out/${RND}_tuned/inplace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_tuned/headline -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --no-in-place-leg --no-live-traffic --no-store-probe --no-facade-leg > $R/gpurun_out/${RND}_tuned/headline_line.json 2> $R/gpurun_out/${RND}_tuned/headline.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${RND}_tuned/inplace -- python3 $R/bench.py --no-other-workloads --no-cpu-baseline --no-two-chains --no-live-traffic --no-store-probe --no-facade-leg --output-sets 1 > $R/gpurun_out/${RND}_tuned/inplace_line.json 2> $R/gpurun_out/${RND}_tuned/inplace.err
 find $R/gpurun_out/${RND}_tuned -name "*kernel_trace.csv" -delete; find $R/gpurun_out/${RND}_tuned -name "*.db" -delete
 cd $R
 bash tools/variant_bench.sh tuned > gpurun_out/$OUT/variant_bench.log 2>&1
@@ -32,3 +32,9 @@ for v in barrage standard micro tiny fives; do python tools/phase_cost.py $v 655
 python tools/multi_step_ab.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/multi_step_ab.log
 python tools/ring_size_probe_tuned.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/ring_size_probe_tuned.log
 for i in 2 3; do python bench.py > gpurun_out/$OUT/bench_default_run$i.json 2> gpurun_out/$OUT/bench_default_run$i.err; done
+python -W ignore tools/half_wave_ab.py barrage standard octa_barrage medium 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/half_wave_ab.log
+python tools/noobs_small_ab.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/noobs_small_ab.log
+python tools/r06_spread_probe.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/spread_probe.log
+python tools/facade_breakdown.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/facade_breakdown.log
+python tools/clock_probe.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/clock_probe.log
+python tools/soak_general_states.py 40 > gpurun_out/$OUT/soak_general_states.log 2>&1; tail -1 gpurun_out/$OUT/soak_general_states.log

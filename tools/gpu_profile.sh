@@ -13,7 +13,7 @@ mkdir -p $OUT
 cd /tmp
 python3 -c "import torch,time; x=torch.empty(1<<28,device='cuda'); t=time.time()
 while time.time()-t<3: x.fill_(1.0); torch.cuda.synchronize()"
-COMMON="--no-cpu-baseline --no-other-workloads --no-two-chains --no-in-place-leg --no-settle-leg --no-live-traffic --placement plain"
+COMMON="--no-cpu-baseline --no-other-workloads --no-two-chains --no-in-place-leg --no-settle-leg --no-live-traffic --no-store-probe --no-facade-leg --placement plain"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 64 --warmup 8 $COMMON "$@" > $OUT/stats.log 2>&1
 i=0
 for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum" \
