@@ -224,7 +224,7 @@ def test_steps_kernel_reads_its_parameters_with_scalar_loads(tmp_path):
     import subprocess
     _kernel_resources(tmp_path)                      # (unbundles the gfx950 code object into tmp_path)
     co = [f for f in os.listdir(tmp_path) if 'gfx950' in f][0]
-    sym = '_ZN12_GLOBAL__N_112steps_kernelILi10ELi10ELi0EEEvNS_15WaveStepsParamsE'
+    sym = '_ZN12_GLOBAL__N_112steps_kernelILi10ELi10ELi0ELi0EEEvNS_15WaveStepsParamsE'
     asm = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '-d', '--mcpu=gfx950', '--disassemble-symbols=' + sym, str(tmp_path / co)],
                          capture_output=True, text=True, check=True).stdout
     assert asm.count('s_load_dword') > 40 and 's_endpgm' in asm
