@@ -47,8 +47,9 @@ class Follower:
     """The oracle stepped alongside a batch of GPU games: check_slot() plays ONE step of every game on the oracle and compares it with one
     slot of a trajectory buffer (already on the host)."""
 
-    def __init__(self, name, seed, g0, n, auto_reset, both=False):
+    def __init__(self, name, seed, g0, n, auto_reset, both=False, with_obs=True):
         self.name, self.seed, self.g0, self.n, self.auto_reset, self.both = name, seed, g0, n, auto_reset, both
+        self.with_obs = with_obs               # False: the rollout writes no observation (the no-observation kernel kind): masks, results and draws only
         self.cv, self.oenvs = _oracles(name, seed, g0, n, both)
         self.cur = [oe._obs(1) for oe in self.oenvs]
         self.finished = [False] * n            # (without auto-reset: a finished game only takes invalid actions from then on)
@@ -78,7 +79,8 @@ class Follower:
             except ValueError:
                 assert h['invalid_action'][s, e] == 1, tag + (e, a, 'the oracle raises, the GPU accepted')
                 assert h['done'][s, e] == (1 if self.finished[e] else 0), tag + (e,)
-                assert np.array_equal(self.cur[e][MASK], h['mask'][s, e]) and self.cur[e][POBS].tobytes() == h['obs'][s, e].tobytes(), tag + (e, 'outputs after an invalid action')
+                assert np.array_equal(self.cur[e][MASK], h['mask'][s, e]), tag + (e, 'mask after an invalid action')
+                assert not self.with_obs or self.cur[e][POBS].tobytes() == h['obs'][s, e].tobytes(), tag + (e, 'observation after an invalid action')
                 assert h['player'][s, e] == oe.player
                 assert h['actions'][s, e] == self.drawn(e), tag + (e, 'draw after an invalid action')
                 continue
@@ -99,7 +101,7 @@ class Follower:
             p = oe.player
             assert h['player'][s, e] == p, tag + (e, 'player')
             assert np.array_equal(o[p][MASK], h['mask'][s, e]), tag + (e, 'mask')
-            assert o[p][POBS].tobytes() == h['obs'][s, e].tobytes(), tag + (e, 'observation')
+            assert not self.with_obs or o[p][POBS].tobytes() == h['obs'][s, e].tobytes(), tag + (e, 'observation')
             if self.both:
                 assert o[p][FOBS].tobytes() == h['fobs'][s, e].tobytes(), tag + (e, 'full observation')
             self.cur[e] = o[p]
@@ -123,7 +125,7 @@ def _multi_kinds():
     ('barrage', 48, 64, 10, 0.2), ('standard', 16, 48, 8, 0.1), ('short_barrage', 64, 40, 8, 0.2), ('octa_barrage', 32, 64, 5, 0.2),
     ('medium', 40, 50, 6, 0.2), ('fives', 33, 30, 6, 0.2), ('standard2', 5, 24, 4, 0.1), ('tiny', 100, 64, 4, 0.2), ('micro', 130, 20, 8, 0.2),
 ])
-def test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk, n_calls, garbage, both=False, auto_reset=True, kw=None):
+def test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk, n_calls, garbage, both=False, auto_reset=True, kw=None, emit_obs=True):
     """Calls of `chunk` steps into a trajectory buffer of `chunk` slots: every slot of every call against the oracle.  Some games start
     every call from a garbage action (flagged, state unchanged, the same draw again); games end and restart inside the launches and across
     their boundaries."""
@@ -132,7 +134,7 @@ def test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk
     v = VARIANTS[name]
     seed, g0 = 0x7A3B00 + 97 * len(name) + n_envs, 7000
     env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=auto_reset, full_obs=both, **(kw or {}))
-    fo = Follower(name, seed, g0, n_envs, auto_reset, both)
+    fo = Follower(name, seed, g0, n_envs, auto_reset, both, with_obs=emit_obs)
     env.reset()
     fo.check_reset(env.obs.cpu().numpy(), env.mask.cpu().numpy(), env.fobs.cpu().numpy() if both else None)
     env.sample_valid_actions()
@@ -147,8 +149,10 @@ def test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk
                 nxt[e] = int(rs.choice([rs.randint(NA), -1, NA + 5, rs.randint(v.cells) * v.spatial_channels + v.spatial_channels - 1]))
         env.next_actions.copy_(torch.from_numpy(nxt))
         _poison(traj)
-        env.rollout_trajectory(chunk, traj)
+        env.rollout_trajectory(chunk, traj, emit_obs=emit_obs)
         assert env.last_launch_kind in _multi_kinds(), (name, 'the test must not pass on the per-step kernel')
+        if not emit_obs:
+            assert bool(torch.isnan(traj['obs']).all()), 'a rollout without an observation pointer must not touch the observation slots'
         h = _host(traj)
         acts = nxt
         for s in range(chunk):
@@ -168,6 +172,14 @@ def test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk
 def test_every_step_with_both_observations(name, n_envs, chunk, n_calls):
     """BOTH_OBSERVATIONS (the reference's default mode, maenv:53): steps_kernel<..., 1> writes the 79-channel observation as well."""
     test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk, n_calls, 0.1, both=True)
+
+
+@pytest.mark.parametrize('name,n_envs,chunk,n_calls', [('barrage', 45, 64, 8), ('standard', 19, 40, 6), ('octa_barrage', 33, 50, 4), ('medium', 47, 40, 5), ('tiny', 70, 30, 3)])
+def test_every_step_of_a_rollout_without_observation(name, n_envs, chunk, n_calls):
+    """Mask-only rollouts (no observation pointer): steps_kernel<..., 8> -- on boards of 33 .. 128 cells the TWO-games-per-wave layout
+    (Geo<R, C, 2>), ragged batches so that a wave holds one game -- every step's mask, rewards, flags, player and drawn action against the
+    oracle; the observation slots stay untouched."""
+    test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk, n_calls, 0.2, emit_obs=False)
 
 
 @pytest.mark.parametrize('name,n_envs,chunk,n_calls', [('short_barrage', 48, 64, 4), ('micro', 96, 25, 3)])
