@@ -26,7 +26,7 @@ Multi-GPU: one process per GPU.  Under a launcher (RANK / WORLD_SIZE set) this p
 initialised HIP is never re-executed; the parent does not even import torch) and relays rank 0's line.  Global env ids are sharded
 contiguously across the ranks (stratego_env_amd.sharding.shard_range), no collective on the data path: one barrier on each side
 of the timed region (host-side, gloo) and one MAX / SUM all-reduce for reporting (RCCL when EVERY rank brought it up, else gloo for all:
-class Rank).
+bench_launcher.Rank).  The legs other than the headline live in bench_legs.py.
 
 Prints ONE JSON line (rank 0) with
   `roofline`      HBM.  `achieved` = B_min x games per launch / launch time (HIP events on the launch stream over the timed region),
@@ -53,7 +53,6 @@ import argparse
 import glob
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -339,242 +338,8 @@ def parse_args(argv=None):
     return args
 
 
-# ---------------------------------------------------------------------------------------------------------------
-# Launcher: `python bench.py --gpus N` outside any launcher starts the N ranks itself
-# ---------------------------------------------------------------------------------------------------------------
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def visible_gpus():
-    """Number of AMD GPUs this process could open, WITHOUT loading torch or the HIP runtime (a launcher parent must never
-    initialise the GPU before it starts its ranks): KFD topology nodes with SIMDs, narrowed by *_VISIBLE_DEVICES."""
-    n = 0
-    for props in glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'):
-        try:
-            for line in open(props):
-                if line.startswith('simd_count') and int(line.split()[1]) > 0:
-                    n += 1
-        except Exception:
-            pass
-    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
-        v = os.environ.get(var)
-        if v is not None:
-            n = min(n, len([x for x in v.split(',') if x.strip() != '']))
-    return n
-
-
-def launch_ranks(args, argv):
-    """Start one fresh `python bench.py` process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relay rank 0's
-    stdout, return the first non-zero exit code (the other ranks are then terminated).  This process never initialises HIP
-    and never imports torch: GPUs are counted from the KFD topology in sysfs."""
-    n = args.gpus
-    if not args.dry_run:
-        have = visible_gpus()
-        need = n if not args.devices else len(set(args.devices.split(',')))
-        if have < need:
-            print("bench.py: --gpus %d but only %d GPU(s) are visible" % (n, have), file=sys.stderr)
-            return 2
-    port = _free_port()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), SGX_BENCH_LAUNCHER='bench.py')
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    pending = set(range(n))
-    while pending:
-        for r in sorted(pending):
-            code = procs[r].poll()
-            if code is None:
-                continue
-            pending.discard(r)
-            if code != 0 and rc == 0:
-                rc = code
-                print("bench.py: rank %d exited with code %d; stopping the other ranks" % (r, code), file=sys.stderr)
-                for q in pending:
-                    procs[q].terminate()
-        time.sleep(0.05)
-    return rc
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# One rank
-# ---------------------------------------------------------------------------------------------------------------
-class Rank:
-    """This process's place in the job, from the launcher's environment.  world must equal --gpus: a launcher that
-    silently started fewer ranks is an error, not a smaller run.
-
-    Process groups.  The DEFAULT group is always gloo on the host: it carries the barriers of the timed bracket (ranks parked at a
-    gloo barrier do no GPU work: the solo anchors of the scaling legs need that) and the agreement below.  The reporting reductions
-    (one MAX, one SUM) run over RCCL (backend nccl, a second group on the same store: no second port) when -- and only when -- EVERY
-    rank brought it up: (1) each rank checks what it can check alone (a GPU of its own; SGX_BENCH_FAIL_NCCL_RANKS simulates a failure)
-    and the ranks all-gather the verdicts over gloo; (2) only if all passed do they create the nccl group and probe it with one
-    all-reduce, and all-gather the outcome again.  One rank failing at either stage moves ALL ranks to gloo for the reductions, and
-    the line says which rank and why (config.reduction_backend).  Nothing on the data path depends on any of this: the games never
-    interact."""
-
-    def __init__(self, gpus, backend, use_cuda, devices=None):
-        import torch
-        self.rank = int(os.environ.get('RANK', '0'))
-        self.world = int(os.environ.get('WORLD_SIZE', '1'))
-        self.local_rank = int(os.environ.get('LOCAL_RANK', str(self.rank)))
-        if self.world != gpus:
-            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (gpus, self.world))
-        if not 0 <= self.rank < self.world:
-            raise SystemExit("bench.py: RANK=%d outside WORLD_SIZE=%d" % (self.rank, self.world))
-        self.device_index = self.local_rank
-        dmap = None
-        if devices:
-            dmap = [int(x) for x in devices.split(',')]
-            if self.local_rank >= len(dmap):
-                raise SystemExit("bench.py: --devices lists %d devices, LOCAL_RANK=%d" % (len(dmap), self.local_rank))
-            self.device_index = dmap[self.local_rank]
-        self.use_cuda = use_cuda
-        self.dist = None
-        self.red_group = None                  # None = the default (gloo) group
-        self.bringup_seconds = 0.0
-        self.backend, self.backend_note = ('gloo' if self.world > 1 else backend), None
-        self.reduce_device = 'cpu'
-        if use_cuda:
-            torch.cuda.set_device(self.device_index)
-        if self.world > 1:
-            import datetime
-            import torch.distributed as dist
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29500')
-            # (gloo announces its connections on stdout, which has to stay ONE JSON line: send that to stderr)
-            sys.stdout.flush()
-            saved = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group('gloo', rank=self.rank, world_size=self.world, timeout=datetime.timedelta(seconds=600))
-                dist.barrier()
-                if dist.get_world_size() != gpus:
-                    raise SystemExit("bench.py: process group has %d ranks, --gpus %d" % (dist.get_world_size(), gpus))
-                self.dist = dist
-                if backend == 'nccl':
-                    t_up = time.perf_counter()
-                    self._bring_up_rccl(torch, dist, dmap, datetime.timedelta(seconds=int(os.environ.get('SGX_BENCH_NCCL_TIMEOUT', '120'))))
-                    self.bringup_seconds = time.perf_counter() - t_up         # (config.reduction_bringup_s: a first-time RCCL bring-up must not stall the job)
-            finally:
-                sys.stdout.flush()
-                os.dup2(saved, 1)
-                os.close(saved)
-
-    def _agree(self, dist, ok, note):
-        """All ranks learn every rank's verdict (over gloo) -> (everybody ok, [(rank, note) of the ranks that failed])."""
-        verdicts = [None] * self.world
-        dist.all_gather_object(verdicts, (bool(ok), note))
-        failed = [(r, v[1]) for r, v in enumerate(verdicts) if not v[0]]
-        return not failed, failed
-
-    def _bring_up_rccl(self, torch, dist, dmap, timeout):
-        fake = os.environ.get('SGX_BENCH_FAKE_NCCL') == '1'      # CPU tests: a second gloo group stands in for RCCL
-        fail_ranks = [int(x) for x in os.environ.get('SGX_BENCH_FAIL_NCCL_RANKS', '').split(',') if x.strip() != '']
-        # ---- stage 1: what a rank can check on its own
-        ok, note = True, None
-        try:
-            if self.rank in fail_ranks:
-                raise RuntimeError("simulated failure (SGX_BENCH_FAIL_NCCL_RANKS)")
-            if not fake:
-                if not self.use_cuda:
-                    raise RuntimeError("nccl needs a GPU per rank (dry run)")
-                if dmap is not None and dmap.count(self.device_index) > 1 and os.environ.get('SGX_BENCH_SKIP_DEVICE_CHECK') != '1':
-                    raise RuntimeError("device %d is shared by %d ranks (RCCL refuses that: invalid usage)" % (self.device_index, dmap.count(self.device_index)))
-        except Exception as e:              # noqa: BLE001
-            ok, note = False, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else '')
-        all_ok, failed = self._agree(dist, ok, note)
-        group = None
-        if all_ok:
-            # ---- stage 2: the collective bring-up, probed with one all-reduce
-            try:
-                if self.rank in [int(x) for x in os.environ.get('SGX_BENCH_FAIL_NCCL_STAGE2_RANKS', '').split(',') if x.strip() != '']:
-                    raise RuntimeError("simulated failure inside the collective bring-up (SGX_BENCH_FAIL_NCCL_STAGE2_RANKS)")
-                if fake:
-                    group = dist.new_group(backend='gloo', timeout=timeout)
-                    probe = torch.ones(1)
-                else:
-                    # (a collective that cannot complete must RAISE after the timeout, so that this rank joins the agreement below, instead of
-                    #  having the watchdog abort the process: blocking wait; the group only ever carries two tiny reductions)
-                    os.environ.setdefault('TORCH_NCCL_BLOCKING_WAIT', '1')
-                    group = dist.new_group(backend='nccl', timeout=timeout)
-                    probe = torch.ones(1, device='cuda')
-                dist.all_reduce(probe, group=group)
-                if not fake:
-                    torch.cuda.synchronize()
-                if int(probe.item()) != self.world:
-                    raise RuntimeError("all_reduce of ones over %d ranks gave %r" % (self.world, probe.item()))
-            except Exception as e:          # noqa: BLE001 -- whatever RCCL / the rendezvous raises
-                ok, note = False, "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160] if str(e) else '')
-            all_ok, failed = self._agree(dist, ok, note)
-        if all_ok:
-            self.red_group = group
-            self.backend = 'nccl (simulated by a second gloo group)' if fake else 'nccl'
-            self.reduce_device = 'cpu' if fake else 'cuda'
-            return
-        self.backend_note = "; ".join("rank %d: %s" % (r, n) for r, n in failed[:4]) + (" (+%d more)" % (len(failed) - 4) if len(failed) > 4 else "")
-        print("bench.py rank %d: nccl (RCCL) group not usable by every rank (%s); ALL ranks use gloo for the reporting reductions"
-              % (self.rank, self.backend_note), file=sys.stderr, flush=True)
-        if group is not None:
-            try:
-                dist.destroy_process_group(group)
-            except Exception:               # noqa: BLE001
-                pass
-        self.backend, self.reduce_device, self.red_group = 'gloo', 'cpu', None
-
-    def sync(self):
-        if self.use_cuda:
-            import torch
-            torch.cuda.synchronize()
-
-    def barrier(self):
-        """barrier + device synchronize on both sides (the bench contract's bracket of the timed region).  The barrier is the host-side
-        gloo one: a rank waiting in it puts no work on its GPU."""
-        self.sync()
-        if self.dist:
-            self.dist.barrier()
-        self.sync()
-
-    def reduce(self, maxes, sums):
-        """MAX over ranks of the float list `maxes`, SUM over ranks of the int list `sums`; the only collectives of the run."""
-        if not self.dist:
-            return list(maxes), list(sums)
-        import torch
-        t = torch.tensor(list(maxes), dtype=torch.float64, device=self.reduce_device)
-        if len(maxes):
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.red_group)
-        c = torch.tensor(list(sums), dtype=torch.int64, device=self.reduce_device)
-        if len(sums):
-            self.dist.all_reduce(c, op=self.dist.ReduceOp.SUM, group=self.red_group)
-        return [float(x) for x in t], [int(x) for x in c]
-
-    def solo(self):
-        """This rank on its own: same device, no process group -- what times a leg's per-GPU workload ALONE (the other ranks parked at
-        the gloo barrier) before the ranks run it side by side."""
-        return _SoloRank(self)
-
-    def close(self):
-        if self.dist:
-            self.dist.destroy_process_group()
-
-
-class _SoloRank:
-    def __init__(self, rk):
-        self.rank, self.world, self.local_rank, self.device_index, self.use_cuda, self.dist = rk.rank, 1, rk.local_rank, rk.device_index, rk.use_cuda, None
-        self.sync = rk.sync
-
-    def barrier(self):
-        self.sync()
-
-    def reduce(self, maxes, sums):
-        return list(maxes), list(sums)
+import bench_legs  # noqa: E402  (the legs other than the headline; every function takes this module as its first argument)
+from bench_launcher import Rank, launch_ranks, visible_gpus  # noqa: E402,F401  (process plumbing: bench_launcher.py)
 
 
 def legs_for(rank, world, args, dry=False):
@@ -960,263 +725,6 @@ def fused_steps_of(env, steps):
     return steps
 
 
-def rotating_leg(rk, env, args, version, v, steps, warmup, n_sets, full_obs=False, verify=8):
-    """The rotating-outputs leg on the env object that was just timed: n_sets output sets (the env's own + n_sets - 1 more, each from
-    its own placement trial) written round-robin, sgx_step_ring.  With 3 x 2 GB of outputs nothing a launch writes can still be in
-    the 256 MiB Infinity Cache when the same addresses are written again, three launches later: this leg's launch time is DRAM's."""
-    import torch
-    budget = max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if (args.placement == 'trial' and args.placement_gb > 0) else 0
-    budget, wide = placement_budgets(args, budget)
-    tune = budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6
-    reports = env.alloc_output_ring(n_sets, tune=tune, max_extra_bytes=budget, trials=args.placement_trials, wide_extra_bytes=wide)
-    elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, warmup, ring=True)
-    assert invalid == 0
-    fused = fused_steps_of(env, steps)
-    checked = verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
-    launch_s = dev_ms / 1e3 / steps
-    per_set = [(round(r['obs'][0], 1), round(min(r['obs']), 1)) if (r and r.get('obs')) else None for r in reports]
-    set_bytes = env.obs.numel() * 4 + env.mask.numel() + (env.fobs.numel() * 4 if env.fobs is not None else 0)
-    return {"workload": "the same rollout writing %d output sets round-robin (sgx_step_ring: a trajectory buffer of the last %d steps)" % (n_sets, n_sets),
-            "output_sets": n_sets, "bytes_per_set": set_bytes, "exceeds_infinity_cache": bool((n_sets - 1) * set_bytes > (256 << 20)),
-            "value": env.num_envs * steps / elapsed, "unit": "env steps/s", "steps": steps, "warmup": warmup, "launch_us": launch_s * 1e6,
-            "frac_dram": b_min(v, full_obs, env.record_bytes, fused) * env.num_envs / launch_s / 1e9 / HBM_PEAK_GBS,
-            "steps_per_launch": fused,
-            "placement_plain_and_kept_us_per_extra_set": per_set[1:], "games_finished_in_timed_region": games,
-            "verified_envs": checked, "verified_steps": env.bench_steps_played}, launch_s
-
-
-def consumer_leg(rk, args, version='barrage', n=GAMES_1GPU, rounds=3, steps_per_round=16, n_check=8):
-    """A consumer in the loop (examples/basic_game_loop.py:6-31, 48-63 for a batch): every step is the policy of
-    stratego_env_amd/examples/batched_policy_loop.py -- logits from the observation (mean over the board, a fixed linear read-out: the
-    stand-in for a network) -- then the library's chooser sgx_choose_actions (invalid actions masked out, softmax, one sample per game
-    with the env's counter RNG: the logits and the mask the step wrote are READ on the device), then sgx_step with the chosen actions.
-    In-process A/B of the observation store policy under that reader: rounds of `steps_per_round` steps alternate between
-    sgx_set_nt_stores(1) (non-temporal interior lines: the default at this size) and (0) (plain stores) on the same env object and
-    buffers; reported per policy: whole-loop env steps/s, the step kernel's and the chooser's own time inside the loop (HIP events).
-    One more round runs the round-4 chooser composed from torch ops (masked_fill, softmax, multinomial) for comparison.  The actions of
-    `n_check` sampled envs are logged on the device and replayed on the CPU oracle afterwards (same setups by the counter RNG,
-    auto-reset included): the last step's mask / observation / rewards / flags must match bit for bit."""
-    import numpy as np
-    import torch
-    from stratego_env_amd.config import VARIANTS
-    from stratego_env_amd.examples.batched_policy_loop import choose_actions
-    v = VARIANTS[version]
-    env = make_env(version, n, 0, rk.device_index)
-    try:
-        trial = place_outputs(env, args)
-        dev = env.device
-        g = torch.Generator(device=dev)
-        g.manual_seed(1234)
-        readout = torch.randn(env.obs.shape[-1], env.mask[0].numel(), device=dev, generator=g) * 0.5
-        logits_buf = torch.empty((n, env.mask[0].numel()), dtype=torch.float32, device=dev)
-        chosen = torch.empty((n,), dtype=torch.int32, device=dev)
-        ids = np.unique(np.linspace(0, n - 1, n_check).astype(np.int64))
-        idx = torch.from_numpy(ids).to(dev)
-        total_steps = 2 * rounds * steps_per_round + steps_per_round + 8
-        act_log = torch.zeros((total_steps, len(ids)), dtype=torch.int32, device=dev)
-        done_log = torch.zeros((total_steps, len(ids)), dtype=torch.uint8, device=dev)
-        obs, mask = env.obs, env.mask
-        played = 0
-
-        def loop(k, events=None, fused=True):
-            nonlocal played, obs, mask
-            for i in range(k):
-                if fused:
-                    logits = torch.matmul(obs.mean(dim=(1, 2)), readout, out=logits_buf)
-                    if events is not None:
-                        events[i][2].record()
-                    a = env.choose_actions(logits, 1.0, out=chosen)
-                else:
-                    a = choose_actions(obs, mask, readout, g)
-                act_log[played] = a[idx]
-                if events is not None:
-                    events[i][0].record()
-                obs, mask, _, done, _ = env.step(a)
-                if events is not None:
-                    events[i][1].record()
-                done_log[played] = done[idx]
-                played += 1
-
-        loop(4)                                             # untimed: allocator warm-up of the policy's temporaries
-        loop(4, fused=False)                                # ... and of the torch-composed chooser's (its first calls load kernels and grow the cache)
-        res = {m: {"s": 0.0, "kernel_ms": 0.0, "chooser_ms": 0.0, "steps": 0} for m in (1, 0, 'torch')}
-        for rnd in range(rounds + 1):
-            for mode in ((1, 0) if rnd < rounds else ('torch',)):
-                env.set_nt_stores('auto' if mode == 'torch' else bool(mode))
-                ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(steps_per_round)]
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                loop(steps_per_round, ev, fused=mode != 'torch')
-                torch.cuda.synchronize()
-                res[mode]["s"] += time.perf_counter() - t0
-                res[mode]["kernel_ms"] += sum(e[0].elapsed_time(e[1]) for e in ev)
-                if mode != 'torch':
-                    res[mode]["chooser_ms"] += sum(e[2].elapsed_time(e[0]) for e in ev)      # (includes the copy of 8 logged actions)
-                res[mode]["steps"] += steps_per_round
-        env.set_nt_stores('auto')
-        assert int(env.invalid_action.sum()) == 0
-        # the chooser on its own: back-to-back calls on the last logits and the current mask (the in-loop figure brackets the copy of the
-        # logged actions too and starts from the caches the matmul left behind)
-        ce = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        for _ in range(3):
-            env.choose_actions(logits_buf, 1.0, out=chosen)
-        ce[0].record()
-        for _ in range(20):
-            env.choose_actions(logits_buf, 1.0, out=chosen)
-        ce[1].record()
-        torch.cuda.synchronize()
-        chooser_us = ce[0].elapsed_time(ce[1]) / 20 * 1e3
-        # ---- replay the logged actions of the sampled envs on the CPU oracle
-        orc, cv = oracle_variant(version)
-        acts, dones = act_log.cpu().numpy(), done_log.cpu().numpy()
-        mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
-        rw, dn, pl = env.reward[idx].cpu().numpy(), env.done[idx].cpu().numpy(), env.player[idx].cpu().numpy()
-        ei = env.ending_invalid[idx].cpu().numpy()
-        for c, e in enumerate(ids):
-            oe = orc.OracleEnv(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts)
-            game = 0
-            oe.reset(initial_state_override=orc.reset_state(cv, BASE_SEED, int(e), game))
-            for t in range(played):
-                o, r, d, info = oe.step({oe.player: int(acts[t, c])})
-                if bool(d["__all__"]) != bool(dones[t, c]):
-                    raise SystemExit("bench.py consumer leg: env %d done flag differs from the oracle at step %d" % (int(e), t))
-                last = (o, r, d, info)
-                if d["__all__"]:
-                    game += 1
-                    first = oe.reset(initial_state_override=orc.reset_state(cv, BASE_SEED, int(e), game))
-                    last_obs, last_player = first[1], 1
-                else:
-                    last_player = oe.player
-                    last_obs = o[last_player]
-            o, r, d, info = last
-            want_mask = last_obs[oe.MASK].astype(np.uint8)
-            want_obs = last_obs[oe.POBS]
-            want_rw = np.asarray([r.get(1, 0), r.get(-1, 0)], dtype=np.float32) if d["__all__"] else np.zeros(2, np.float32)
-            want_ei = int(bool(d["__all__"]) and info[1]['game_result_was_invalid'])
-            ok = (np.array_equal(want_mask, mk[c]) and want_obs.tobytes() == ob[c].tobytes() and np.array_equal(want_rw, rw[c])
-                  and int(dn[c]) == int(d["__all__"]) and int(pl[c]) == last_player and int(ei[c]) == want_ei)
-            if not ok:
-                raise SystemExit("bench.py consumer leg: env %d differs from the CPU oracle replaying its %d logged actions" % (int(e), played))
-
-        def rep(m):
-            r = res[m]
-            out = {"value": n * r["steps"] / r["s"], "unit": "env steps/s", "ms_per_loop_step": r["s"] / r["steps"] * 1e3,
-                   "step_kernel_us_in_loop": r["kernel_ms"] / r["steps"] * 1e3, "steps": r["steps"]}
-            if m != 'torch':
-                out["chooser_us_in_loop"] = r["chooser_ms"] / r["steps"] * 1e3
-            return out
-        nt, plain = rep(1), rep(0)
-        na = env.mask[0].numel()
-        return {"workload": "%d concurrent %s games: policy logits from the observation (mean over the board + a fixed linear read-out, torch), "
-                            "sgx_choose_actions (reads the logits + the mask: masked softmax, one sample per game with the counter RNG), then sgx_step; "
-                            "%d rounds x %d steps per store policy, interleaved" % (n, version, rounds, steps_per_round),
-                "nt_stores": nt, "plain_stores": plain,
-                "chooser": {"kernel": "choose_kernel<%d,%d,4,false>" % (v.rows, v.columns), "bytes_per_game": 4 * na + na + 4 + 32,
-                            "us_per_call_back_to_back": chooser_us, "bound": "hbm (reads)",
-                            "frac": (4 * na + na + 36) * n / (chooser_us * 1e-6) / 1e9 / HBM_PEAK_GBS},
-                "torch_composed_chooser": dict(rep('torch'), note="the round-4 consumer: masked_fill + softmax + multinomial as torch ops"),
-                "default_policy_at_this_size": "nt_stores (observation bytes per launch > 300 MB)",
-                "nt_over_plain_step_kernel": nt["step_kernel_us_in_loop"] / plain["step_kernel_us_in_loop"],
-                "verified_envs": int(len(ids)), "verified_steps": played, "placement": trial}
-    finally:
-        env.close()
-        del env
-        torch.cuda.empty_cache()
-
-
-def compact_leg(rk, args, version='barrage', n=GAMES_1GPU, seconds=0.5, verify=8):
-    """Opt-in compact outputs (SGX_STEP_COMPACT_OBS / _MASK; never the headline): the same rollout writing 4-bit codes + mask bits -- 1/8 of
-    the bytes per step -- and, separately, the decode ops that expand a batch to the contract's float32 observation / uint8 mask.
-    Verified like every leg (the DECODED last step against the oracle)."""
-    import torch
-    from stratego_env_amd.config import VARIANTS
-    v = VARIANTS[version]
-    env = make_env(version, n, 0, rk.device_index, compact=True)
-    try:
-        _, probe_ms, _, _, _ = time_workload(rk, env, 8, 8)
-        steps = int(max(16, min(4096, seconds * 1e3 / max(probe_ms / 8, 1e-3))))
-        elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, 4)
-        assert invalid == 0
-        checked = verify_against_oracle(env, version, verify) if verify else 0
-        launch_s = dev_ms / 1e3 / steps
-        per_step = 2 * env.record_bytes + 8 + env.compact_obs_stride + 4 * env.compact_mask_words + 12
-        obs_out, mask_out = env.decode_obs(), env.decode_mask()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        torch.cuda.synchronize()
-        ev[0].record()
-        for _ in range(20):
-            env.decode_obs(obs_out)
-        ev[1].record()
-        for _ in range(20):
-            env.decode_mask(mask_out)
-        ev[2].record()
-        torch.cuda.synchronize()
-        dec_obs_us, dec_mask_us = ev[0].elapsed_time(ev[1]) / 20 * 1e3, ev[1].elapsed_time(ev[2]) / 20 * 1e3
-        return {"workload": "%d concurrent %s games, same rollout with COMPACT outputs (opt-in: uint8 codes [N,%d] + int32 mask bits [N,%d])"
-                            % (n, version, env.compact_obs_stride, env.compact_mask_words),
-                "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
-                "bytes_per_step": per_step, "frac": per_step * n / launch_s / 1e9 / HBM_PEAK_GBS,
-                "decode_obs_us_per_batch": dec_obs_us, "decode_mask_us_per_batch": dec_mask_us,
-                "decode_obs_frac": (env.compact_obs_stride + 4 * 67 * v.rows * v.columns) * n / (dec_obs_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "games_finished_in_timed_region": games, "verified_envs": checked}
-    finally:
-        env.close()
-        del env
-        torch.cuda.empty_cache()
-
-
-def other_workload(rk, args, version, n, seconds=1.0, chains=1, full_obs=False, verify=8, rotate_sets=0):
-    """One of the other BASELINE configs on this GPU, about `seconds` of timed steps; output buffers built like the headline's."""
-    import torch
-    from stratego_env_amd.config import VARIANTS
-    v = VARIANTS[version]
-    env = make_env(version, n, 0, rk.device_index, full_obs=full_obs)
-    try:
-        trial = place_outputs(env, args)
-        _, probe_ms, _, _, _ = time_workload(rk, env, 8, 8)
-        steps = int(max(16, min(4096, seconds * 1e3 / max(probe_ms / 8, 1e-3))))
-        elapsed, dev_ms, _, games, invalid = time_workload(rk, env, steps, 4)
-        fused = fused_steps_of(env, steps)                 # multi-step launches: the games stay on the chip between the steps, the record travels once per launch
-        two, per_step_launches = None, None
-        if chains > 1:                     # the same steps with the batch split over concurrent chains of launches (sgx_rollout)
-            e2, d2, _, _, inv2 = time_workload(rk, env, steps, 4, chains=chains)
-            assert inv2 == 0
-            two = {"chains": chains, "value": n * steps / e2, "us_per_step": d2 / steps * 1e3,
-                   "frac": b_min(v, full_obs, env.record_bytes) * n / (d2 / 1e3 / steps) / 1e9 / HBM_PEAK_GBS}
-        if fused > 1 and chains > 1:       # ... and one launch per step (what every round before this one measured), same env object
-            env.set_multi_step(False)
-            e3, d3, _, _, inv3 = time_workload(rk, env, steps, 4)
-            env.set_multi_step(True)
-            assert inv3 == 0
-            per_step_launches = {"value": n * steps / e3, "us_per_step": d3 / steps * 1e3,
-                                 "frac": b_min(v, full_obs, env.record_bytes) * n / (d3 / 1e3 / steps) / 1e9 / HBM_PEAK_GBS}
-        assert invalid == 0
-        checked = verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
-        launch_s = dev_ms / 1e3 / steps
-        rot, rot_s = None, None
-        if rotate_sets >= 2:               # (toy boards: 3 x 248 MB of outputs rotate past the Infinity Cache too)
-            rot, rot_s = rotating_leg(rk, env, args, version, v, steps, 4, rotate_sets, full_obs=full_obs, verify=verify)
-        rf = roofline(version, v, n, launch_s, full_obs=full_obs, rec_bytes=env.record_bytes, build_id=env.build_id, rotating=rot_s, fused_steps=fused)
-        # on the plain first allocation: this leg's step time scaled by the trial's observe launches, first candidate / kept one (the
-        # observe launch itself is not this leg's step: cheaper on the toy boards, and in BOTH mode the candidates were timed per buffer)
-        tr = trial or {}
-        first, kept = tr.get('fobs_plain_us' if full_obs else 'plain_us'), tr.get('fobs_kept_us' if full_obs else 'kept_us')
-        rf["frac_untuned"] = rf["frac"] * kept / first if (first and kept) else None
-        return {"workload": "%d concurrent %s games (%dx%d)%s, same rollout" % (n, version, v.rows, v.columns,
-                                                                                 ", BOTH_OBSERVATIONS (67 + 79 channels)" if full_obs else ""),
-                "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
-                "frac": rf["frac"], "frac_dram": rf["frac_dram"], "frac_untuned": rf["frac_untuned"],
-                "b_min_bytes_per_step": rf["b_min_bytes_per_step"], "traffic": rf["traffic"], "traffic_source": rf["traffic_source"],
-                "survey_8d": rf["survey_8d"], "kernel": rf["kernel"],
-                "games_finished_in_timed_region": games, "concurrent_chains": two, "rotating_outputs": rot, "verified_envs": checked,
-                "steps_per_launch": fused, "one_launch_per_step": per_step_launches,
-                "placement": trial}
-    finally:
-        env.close()
-        del env
-        torch.cuda.empty_cache()
-
-
 def solo_anchor(rk, env, steps, warmup, **kw):
     """The per-GPU workload of a multi-GPU leg timed on rank 0 ALONE -- same process, same env object, same output buffers, same K / W,
     the other ranks parked at the host-side gloo barrier with no GPU work -- directly before the ranks run it side by side.  The games
@@ -1384,7 +892,6 @@ def run_rank(args):      # noqa: C901
     store_probe = None
     if 'store_probe' in legs_on:
         # the step kernel's store stream without the game, on the very buffers the headline wrote (they are re-rendered afterwards)
-        import bench_legs
         store_probe = bench_legs.store_probe_leg(sys.modules[__name__], env, per_step * n / ((dev_ms or 0.0) / 1e3 / args.steps) / 1e9)
         env.observe()
 
@@ -1475,17 +982,15 @@ def run_rank(args):      # noqa: C901
         out["config"]["consumer_in_loop"] = None
         if 'other_workloads' in legs_on:
             if 'consumer_in_loop' in legs_on:
-                out["config"]["consumer_in_loop"] = consumer_leg(rk, args)
-            out["config"]["other_workloads"] = [other_workload(rk, args, 'standard', 262144, chains=2),
-                                                other_workload(rk, args, 'micro', 65536, chains=2, rotate_sets=args.rotate_sets),
-                                                other_workload(rk, args, 'barrage', 65536, full_obs=True),
+                out["config"]["consumer_in_loop"] = bench_legs.consumer_leg(sys.modules[__name__], rk, args)
+            out["config"]["other_workloads"] = [bench_legs.other_workload(sys.modules[__name__], rk, args, 'standard', 262144, chains=2),
+                                                bench_legs.other_workload(sys.modules[__name__], rk, args, 'micro', 65536, chains=2, rotate_sets=args.rotate_sets),
+                                                bench_legs.other_workload(sys.modules[__name__], rk, args, 'barrage', 65536, full_obs=True),
                                                 # BASELINE config 5's per-GPU size on ONE GPU: the G = 1 anchor of the 1 / 2 / 4 / 8 curve
-                                                other_workload(rk, args, 'barrage', GAMES_PER_GPU_MULTI)]
-            out["config"]["compact_outputs"] = compact_leg(rk, args)
-            import bench_legs
+                                                bench_legs.other_workload(sys.modules[__name__], rk, args, 'barrage', GAMES_PER_GPU_MULTI)]
+            out["config"]["compact_outputs"] = bench_legs.compact_leg(sys.modules[__name__], rk, args)
             out["config"]["trajectory"] = bench_legs.trajectory_leg(sys.modules[__name__], rk, args, slots=args.trajectory_slots) if 'trajectory' in legs_on else None
         if 'facade_n1' in legs_on:
-            import bench_legs
             out["config"]["facade_n1"] = bench_legs.facade_leg(sys.modules[__name__])
         if 'live_traffic' in legs_on:
             # the counter bytes of the headline's kernel, measured now (after every timed region): two children under rocprofv3 --pmc

@@ -1,4 +1,9 @@
-"""Legs of bench.py's 1-GPU line that were added in round 6 (kept out of bench.py, which holds the contract and the headline):
+"""The legs of bench.py's 1-GPU line other than the headline (kept out of bench.py, which holds the contract, the headline and the roofline):
+
+  rotating_leg       a workload's steps into a ring of output sets (the DRAM-side figure of the legs)
+  consumer_leg       config.consumer_in_loop: sgx_step alternating with a device policy that READS the observation and the mask
+  compact_leg        config.compact_outputs: the opt-in 4-bit-code / mask-bit outputs
+  other_workload     config.other_workloads: BASELINE configs 3 and 4, BOTH_OBSERVATIONS, config 5's per-GPU size
 
   store_probe_leg    roofline.store_peak_measured: the step kernel's store stream WITHOUT the game (sgx_store_probe) on the very ring buffers
                      the headline wrote, in the same process -- zeros, observation-like floats and incompressible bits as payload; one launch
@@ -224,3 +229,260 @@ def facade_leg(B, n_steps=3000, version='barrage', runs=3, good_enough=None):
     best["workload"] = ("ONE %s game behind StrategoMultiAgentEnv.step (dict in, dict out; outputs in host memory the kernel writes directly), "
                         "a random valid action per step chosen on the host, reset() between games; best of %d runs" % (version, best["runs"]))
     return best
+
+
+def rotating_leg(B, rk, env, args, version, v, steps, warmup, n_sets, full_obs=False, verify=8):
+    """The rotating-outputs leg on the env object that was just timed: n_sets output sets (the env's own + n_sets - 1 more, each from
+    its own placement trial) written round-robin, sgx_step_ring.  With 3 x 2 GB of outputs nothing a launch writes can still be in
+    the 256 MiB Infinity Cache when the same addresses are written again, three launches later: this leg's launch time is DRAM's."""
+    import torch
+    budget = max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4) if (args.placement == 'trial' and args.placement_gb > 0) else 0
+    budget, wide = B.placement_budgets(args, budget)
+    tune = budget >= env.obs.numel() * 4 and env.obs.numel() * 4 > 300e6
+    reports = env.alloc_output_ring(n_sets, tune=tune, max_extra_bytes=budget, trials=args.placement_trials, wide_extra_bytes=wide)
+    elapsed, dev_ms, _, games, invalid = B.time_workload(rk, env, steps, warmup, ring=True)
+    assert invalid == 0
+    fused = B.fused_steps_of(env, steps)
+    checked = B.verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
+    launch_s = dev_ms / 1e3 / steps
+    per_set = [(round(r['obs'][0], 1), round(min(r['obs']), 1)) if (r and r.get('obs')) else None for r in reports]
+    set_bytes = env.obs.numel() * 4 + env.mask.numel() + (env.fobs.numel() * 4 if env.fobs is not None else 0)
+    return {"workload": "the same rollout writing %d output sets round-robin (sgx_step_ring: a trajectory buffer of the last %d steps)" % (n_sets, n_sets),
+            "output_sets": n_sets, "bytes_per_set": set_bytes, "exceeds_infinity_cache": bool((n_sets - 1) * set_bytes > (256 << 20)),
+            "value": env.num_envs * steps / elapsed, "unit": "env steps/s", "steps": steps, "warmup": warmup, "launch_us": launch_s * 1e6,
+            "frac_dram": B.b_min(v, full_obs, env.record_bytes, fused) * env.num_envs / launch_s / 1e9 / B.HBM_PEAK_GBS,
+            "steps_per_launch": fused,
+            "placement_plain_and_kept_us_per_extra_set": per_set[1:], "games_finished_in_timed_region": games,
+            "verified_envs": checked, "verified_steps": env.bench_steps_played}, launch_s
+
+
+def consumer_leg(B, rk, args, version='barrage', n=65536, rounds=3, steps_per_round=16, n_check=8):
+    """A consumer in the loop (examples/basic_game_loop.py:6-31, 48-63 for a batch): every step is the policy of
+    stratego_env_amd/examples/batched_policy_loop.py -- logits from the observation (mean over the board, a fixed linear read-out: the
+    stand-in for a network) -- then the library's chooser sgx_choose_actions (invalid actions masked out, softmax, one sample per game
+    with the env's counter RNG: the logits and the mask the step wrote are READ on the device), then sgx_step with the chosen actions.
+    In-process A/B of the observation store policy under that reader: rounds of `steps_per_round` steps alternate between
+    sgx_set_nt_stores(1) (non-temporal interior lines: the default at this size) and (0) (plain stores) on the same env object and
+    buffers; reported per policy: whole-loop env steps/s, the step kernel's and the chooser's own time inside the loop (HIP events).
+    One more round runs the round-4 chooser composed from torch ops (masked_fill, softmax, multinomial) for comparison.  The actions of
+    `n_check` sampled envs are logged on the device and replayed on the CPU oracle afterwards (same setups by the counter RNG,
+    auto-reset included): the last step's mask / observation / rewards / flags must match bit for bit."""
+    import numpy as np
+    import torch
+    from stratego_env_amd.config import VARIANTS
+    from stratego_env_amd.examples.batched_policy_loop import choose_actions
+    v = VARIANTS[version]
+    env = B.make_env(version, n, 0, rk.device_index)
+    try:
+        trial = B.place_outputs(env, args)
+        dev = env.device
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234)
+        readout = torch.randn(env.obs.shape[-1], env.mask[0].numel(), device=dev, generator=g) * 0.5
+        logits_buf = torch.empty((n, env.mask[0].numel()), dtype=torch.float32, device=dev)
+        chosen = torch.empty((n,), dtype=torch.int32, device=dev)
+        ids = np.unique(np.linspace(0, n - 1, n_check).astype(np.int64))
+        idx = torch.from_numpy(ids).to(dev)
+        total_steps = 2 * rounds * steps_per_round + steps_per_round + 8
+        act_log = torch.zeros((total_steps, len(ids)), dtype=torch.int32, device=dev)
+        done_log = torch.zeros((total_steps, len(ids)), dtype=torch.uint8, device=dev)
+        obs, mask = env.obs, env.mask
+        played = 0
+
+        def loop(k, events=None, fused=True):
+            nonlocal played, obs, mask
+            for i in range(k):
+                if fused:
+                    logits = torch.matmul(obs.mean(dim=(1, 2)), readout, out=logits_buf)
+                    if events is not None:
+                        events[i][2].record()
+                    a = env.choose_actions(logits, 1.0, out=chosen)
+                else:
+                    a = choose_actions(obs, mask, readout, g)
+                act_log[played] = a[idx]
+                if events is not None:
+                    events[i][0].record()
+                obs, mask, _, done, _ = env.step(a)
+                if events is not None:
+                    events[i][1].record()
+                done_log[played] = done[idx]
+                played += 1
+
+        loop(4)                                             # untimed: allocator warm-up of the policy's temporaries
+        loop(4, fused=False)                                # ... and of the torch-composed chooser's (its first calls load kernels and grow the cache)
+        res = {m: {"s": 0.0, "kernel_ms": 0.0, "chooser_ms": 0.0, "steps": 0} for m in (1, 0, 'torch')}
+        for rnd in range(rounds + 1):
+            for mode in ((1, 0) if rnd < rounds else ('torch',)):
+                env.set_nt_stores('auto' if mode == 'torch' else bool(mode))
+                ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(steps_per_round)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loop(steps_per_round, ev, fused=mode != 'torch')
+                torch.cuda.synchronize()
+                res[mode]["s"] += time.perf_counter() - t0
+                res[mode]["kernel_ms"] += sum(e[0].elapsed_time(e[1]) for e in ev)
+                if mode != 'torch':
+                    res[mode]["chooser_ms"] += sum(e[2].elapsed_time(e[0]) for e in ev)      # (includes the copy of 8 logged actions)
+                res[mode]["steps"] += steps_per_round
+        env.set_nt_stores('auto')
+        assert int(env.invalid_action.sum()) == 0
+        # the chooser on its own: back-to-back calls on the last logits and the current mask (the in-loop figure brackets the copy of the
+        # logged actions too and starts from the caches the matmul left behind)
+        ce = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for _ in range(3):
+            env.choose_actions(logits_buf, 1.0, out=chosen)
+        ce[0].record()
+        for _ in range(20):
+            env.choose_actions(logits_buf, 1.0, out=chosen)
+        ce[1].record()
+        torch.cuda.synchronize()
+        chooser_us = ce[0].elapsed_time(ce[1]) / 20 * 1e3
+        # ---- replay the logged actions of the sampled envs on the CPU oracle
+        orc, cv = B.oracle_variant(version)
+        acts, dones = act_log.cpu().numpy(), done_log.cpu().numpy()
+        mk, ob = env.mask[idx].cpu().numpy(), env.obs[idx].cpu().numpy()
+        rw, dn, pl = env.reward[idx].cpu().numpy(), env.done[idx].cpu().numpy(), env.player[idx].cpu().numpy()
+        ei = env.ending_invalid[idx].cpu().numpy()
+        for c, e in enumerate(ids):
+            oe = orc.OracleEnv(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts)
+            game = 0
+            oe.reset(initial_state_override=orc.reset_state(cv, B.BASE_SEED, int(e), game))
+            for t in range(played):
+                o, r, d, info = oe.step({oe.player: int(acts[t, c])})
+                if bool(d["__all__"]) != bool(dones[t, c]):
+                    raise SystemExit("bench.py consumer leg: env %d done flag differs from the oracle at step %d" % (int(e), t))
+                last = (o, r, d, info)
+                if d["__all__"]:
+                    game += 1
+                    first = oe.reset(initial_state_override=orc.reset_state(cv, B.BASE_SEED, int(e), game))
+                    last_obs, last_player = first[1], 1
+                else:
+                    last_player = oe.player
+                    last_obs = o[last_player]
+            o, r, d, info = last
+            want_mask = last_obs[oe.MASK].astype(np.uint8)
+            want_obs = last_obs[oe.POBS]
+            want_rw = np.asarray([r.get(1, 0), r.get(-1, 0)], dtype=np.float32) if d["__all__"] else np.zeros(2, np.float32)
+            want_ei = int(bool(d["__all__"]) and info[1]['game_result_was_invalid'])
+            ok = (np.array_equal(want_mask, mk[c]) and want_obs.tobytes() == ob[c].tobytes() and np.array_equal(want_rw, rw[c])
+                  and int(dn[c]) == int(d["__all__"]) and int(pl[c]) == last_player and int(ei[c]) == want_ei)
+            if not ok:
+                raise SystemExit("bench.py consumer leg: env %d differs from the CPU oracle replaying its %d logged actions" % (int(e), played))
+
+        def rep(m):
+            r = res[m]
+            out = {"value": n * r["steps"] / r["s"], "unit": "env steps/s", "ms_per_loop_step": r["s"] / r["steps"] * 1e3,
+                   "step_kernel_us_in_loop": r["kernel_ms"] / r["steps"] * 1e3, "steps": r["steps"]}
+            if m != 'torch':
+                out["chooser_us_in_loop"] = r["chooser_ms"] / r["steps"] * 1e3
+            return out
+        nt, plain = rep(1), rep(0)
+        na = env.mask[0].numel()
+        return {"workload": "%d concurrent %s games: policy logits from the observation (mean over the board + a fixed linear read-out, torch), "
+                            "sgx_choose_actions (reads the logits + the mask: masked softmax, one sample per game with the counter RNG), then sgx_step; "
+                            "%d rounds x %d steps per store policy, interleaved" % (n, version, rounds, steps_per_round),
+                "nt_stores": nt, "plain_stores": plain,
+                "chooser": {"kernel": "choose_kernel<%d,%d,4,false>" % (v.rows, v.columns), "bytes_per_game": 4 * na + na + 4 + 32,
+                            "us_per_call_back_to_back": chooser_us, "bound": "hbm (reads)",
+                            "frac": (4 * na + na + 36) * n / (chooser_us * 1e-6) / 1e9 / B.HBM_PEAK_GBS},
+                "torch_composed_chooser": dict(rep('torch'), note="the round-4 consumer: masked_fill + softmax + multinomial as torch ops"),
+                "default_policy_at_this_size": "nt_stores (observation bytes per launch > 300 MB)",
+                "nt_over_plain_step_kernel": nt["step_kernel_us_in_loop"] / plain["step_kernel_us_in_loop"],
+                "verified_envs": int(len(ids)), "verified_steps": played, "placement": trial}
+    finally:
+        env.close()
+        del env
+        torch.cuda.empty_cache()
+
+
+def compact_leg(B, rk, args, version='barrage', n=65536, seconds=0.5, verify=8):
+    """Opt-in compact outputs (SGX_STEP_COMPACT_OBS / _MASK; never the headline): the same rollout writing 4-bit codes + mask bits -- 1/8 of
+    the bytes per step -- and, separately, the decode ops that expand a batch to the contract's float32 observation / uint8 mask.
+    Verified like every leg (the DECODED last step against the oracle)."""
+    import torch
+    from stratego_env_amd.config import VARIANTS
+    v = VARIANTS[version]
+    env = B.make_env(version, n, 0, rk.device_index, compact=True)
+    try:
+        _, probe_ms, _, _, _ = B.time_workload(rk, env, 8, 8)
+        steps = int(max(16, min(4096, seconds * 1e3 / max(probe_ms / 8, 1e-3))))
+        elapsed, dev_ms, _, games, invalid = B.time_workload(rk, env, steps, 4)
+        assert invalid == 0
+        checked = B.verify_against_oracle(env, version, verify) if verify else 0
+        launch_s = dev_ms / 1e3 / steps
+        per_step = 2 * env.record_bytes + 8 + env.compact_obs_stride + 4 * env.compact_mask_words + 12
+        obs_out, mask_out = env.decode_obs(), env.decode_mask()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(20):
+            env.decode_obs(obs_out)
+        ev[1].record()
+        for _ in range(20):
+            env.decode_mask(mask_out)
+        ev[2].record()
+        torch.cuda.synchronize()
+        dec_obs_us, dec_mask_us = ev[0].elapsed_time(ev[1]) / 20 * 1e3, ev[1].elapsed_time(ev[2]) / 20 * 1e3
+        return {"workload": "%d concurrent %s games, same rollout with COMPACT outputs (opt-in: uint8 codes [N,%d] + int32 mask bits [N,%d])"
+                            % (n, version, env.compact_obs_stride, env.compact_mask_words),
+                "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
+                "bytes_per_step": per_step, "frac": per_step * n / launch_s / 1e9 / B.HBM_PEAK_GBS,
+                "decode_obs_us_per_batch": dec_obs_us, "decode_mask_us_per_batch": dec_mask_us,
+                "decode_obs_frac": (env.compact_obs_stride + 4 * 67 * v.rows * v.columns) * n / (dec_obs_us * 1e-6) / 1e9 / B.HBM_PEAK_GBS,
+                "games_finished_in_timed_region": games, "verified_envs": checked}
+    finally:
+        env.close()
+        del env
+        torch.cuda.empty_cache()
+
+
+def other_workload(B, rk, args, version, n, seconds=1.0, chains=1, full_obs=False, verify=8, rotate_sets=0):
+    """One of the other BASELINE configs on this GPU, about `seconds` of timed steps; output buffers built like the headline's."""
+    import torch
+    from stratego_env_amd.config import VARIANTS
+    v = VARIANTS[version]
+    env = B.make_env(version, n, 0, rk.device_index, full_obs=full_obs)
+    try:
+        trial = B.place_outputs(env, args)
+        _, probe_ms, _, _, _ = B.time_workload(rk, env, 8, 8)
+        steps = int(max(16, min(4096, seconds * 1e3 / max(probe_ms / 8, 1e-3))))
+        elapsed, dev_ms, _, games, invalid = B.time_workload(rk, env, steps, 4)
+        fused = B.fused_steps_of(env, steps)                 # multi-step launches: the games stay on the chip between the steps, the record travels once per launch
+        two, per_step_launches = None, None
+        if chains > 1:                     # the same steps with the batch split over concurrent chains of launches (sgx_rollout)
+            e2, d2, _, _, inv2 = B.time_workload(rk, env, steps, 4, chains=chains)
+            assert inv2 == 0
+            two = {"chains": chains, "value": n * steps / e2, "us_per_step": d2 / steps * 1e3,
+                   "frac": B.b_min(v, full_obs, env.record_bytes) * n / (d2 / 1e3 / steps) / 1e9 / B.HBM_PEAK_GBS}
+        if fused > 1 and chains > 1:       # ... and one launch per step (what every round before this one measured), same env object
+            env.set_multi_step(False)
+            e3, d3, _, _, inv3 = B.time_workload(rk, env, steps, 4)
+            env.set_multi_step(True)
+            assert inv3 == 0
+            per_step_launches = {"value": n * steps / e3, "us_per_step": d3 / steps * 1e3,
+                                 "frac": B.b_min(v, full_obs, env.record_bytes) * n / (d3 / 1e3 / steps) / 1e9 / B.HBM_PEAK_GBS}
+        assert invalid == 0
+        checked = B.verify_against_oracle(env, version, verify, both=full_obs) if verify else 0
+        launch_s = dev_ms / 1e3 / steps
+        rot, rot_s = None, None
+        if rotate_sets >= 2:               # (toy boards: 3 x 248 MB of outputs rotate past the Infinity Cache too)
+            rot, rot_s = rotating_leg(B, rk, env, args, version, v, steps, 4, rotate_sets, full_obs=full_obs, verify=verify)
+        rf = B.roofline(version, v, n, launch_s, full_obs=full_obs, rec_bytes=env.record_bytes, build_id=env.build_id, rotating=rot_s, fused_steps=fused)
+        # on the plain first allocation: this leg's step time scaled by the trial's observe launches, first candidate / kept one (the
+        # observe launch itself is not this leg's step: cheaper on the toy boards, and in BOTH mode the candidates were timed per buffer)
+        tr = trial or {}
+        first, kept = tr.get('fobs_plain_us' if full_obs else 'plain_us'), tr.get('fobs_kept_us' if full_obs else 'kept_us')
+        rf["frac_untuned"] = rf["frac"] * kept / first if (first and kept) else None
+        return {"workload": "%d concurrent %s games (%dx%d)%s, same rollout" % (n, version, v.rows, v.columns,
+                                                                                 ", BOTH_OBSERVATIONS (67 + 79 channels)" if full_obs else ""),
+                "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
+                "frac": rf["frac"], "frac_dram": rf["frac_dram"], "frac_untuned": rf["frac_untuned"],
+                "b_min_bytes_per_step": rf["b_min_bytes_per_step"], "traffic": rf["traffic"], "traffic_source": rf["traffic_source"],
+                "survey_8d": rf["survey_8d"], "kernel": rf["kernel"],
+                "games_finished_in_timed_region": games, "concurrent_chains": two, "rotating_outputs": rot, "verified_envs": checked,
+                "steps_per_launch": fused, "one_launch_per_step": per_step_launches,
+                "placement": trial}
+    finally:
+        env.close()
+        del env
+        torch.cuda.empty_cache()
