@@ -6,10 +6,12 @@
  *   gcc -std=c11 -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_rollout.c \
  *       -Lstratego_env_amd/_build -lstratego_mi355x -L/opt/rocm/lib -lamdhip64 \
  *       -Wl,-rpath,$PWD/stratego_env_amd/_build -Wl,-rpath,/opt/rocm/lib -o examples/c_rollout
- *   examples/c_rollout stratego_env_amd/inits/barrage_setups.npy [n_envs] [steps] [seed] [bench]
+ *   examples/c_rollout stratego_env_amd/inits/barrage_setups.npy [n_envs] [steps] [seed] [bench | traj]
  *
- * With a fifth argument the steps are enqueued by one sgx_step_n call, nothing is copied to the host, and the program
- * prints env steps per second measured with HIP events (the bench.py figure, from C).
+ * With `bench` as the fifth argument the steps are enqueued by one sgx_step_n call, nothing is copied to the host, and the program
+ * prints env steps per second measured with HIP events (the bench.py figure, from C).  With `traj` the steps are ONE sgx_step_traj call
+ * into a trajectory buffer [steps][n_envs]... (every step's outputs kept: the reference returns a fresh observation array per step,
+ * impl:905) and the digest is computed from env 0's slots afterwards -- the same digest as the step-by-step mode.
  *
  * Prints games finished, invalid actions (must be 0) and the rolling FNV-1a digest of env 0's outputs
  * (mask, observation, rewards, done/player/ending_invalid), which tests/test_gpu_c_example.py compares with the oracle.
@@ -105,6 +107,56 @@ int main(int argc, char **argv) {
     io.next_actions_dev = actions;      /* the step draws each env's next action itself */
     io.auto_reset = 1;
 
+    if (argc > 5 && strcmp(argv[5], "traj") == 0) {
+        /* the same rollout as ONE call: slot t of the trajectory tensors receives step t (sgx_step_traj: all steps in one launch per 256) */
+        const int T = steps;
+        float *tobs, *trew;
+        uint8_t *tmask, *tdone, *tinv, *tend;
+        int8_t *tpl;
+        int32_t *tact;
+        HIP_OK(hipMalloc((void **)&tobs, (size_t)T * N * obs_n * sizeof(float)));
+        HIP_OK(hipMalloc((void **)&tmask, (size_t)T * N * mask_n));
+        HIP_OK(hipMalloc((void **)&trew, (size_t)T * N * 2 * sizeof(float)));
+        HIP_OK(hipMalloc((void **)&tdone, (size_t)T * N));
+        HIP_OK(hipMalloc((void **)&tinv, (size_t)T * N));
+        HIP_OK(hipMalloc((void **)&tend, (size_t)T * N));
+        HIP_OK(hipMalloc((void **)&tpl, (size_t)T * N));
+        HIP_OK(hipMalloc((void **)&tact, (size_t)T * N * sizeof(int32_t)));
+        sgx_traj_io tr;
+        memset(&tr, 0, sizeof(tr));
+        tr.io = io;
+        tr.io.obs_dev = tobs; tr.io.mask_dev = tmask; tr.io.reward_dev = trew; tr.io.done_dev = tdone; tr.io.invalid_action_dev = tinv;
+        tr.io.ending_invalid_dev = tend; tr.io.player_dev = tpl;
+        tr.n_slots = T; tr.results_per_slot = 1; tr.slot_envs = N; tr.actions_log_dev = tact;
+        SGX_TRY(sgx_step_traj(h, &tr, 0, T, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        float *obs_h = (float *)malloc(obs_n * sizeof(float));
+        uint8_t *mask_h = (uint8_t *)malloc(mask_n), *flag_h = (uint8_t *)malloc((size_t)N);
+        uint64_t digest = 0xCBF29CE484222325ull;
+        long long finished = 0, invalid_total = 0;
+        for (int t = 0; t < T; t++) {
+            float rw[2]; uint8_t ei; int8_t pl; uint8_t d0;
+            HIP_OK(hipMemcpy(obs_h, tobs + (size_t)t * N * obs_n, obs_n * sizeof(float), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(mask_h, tmask + (size_t)t * N * mask_n, mask_n, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(rw, trew + (size_t)t * N * 2, sizeof(rw), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(&ei, tend + (size_t)t * N, 1, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(&pl, tpl + (size_t)t * N, 1, hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(flag_h, tdone + (size_t)t * N, (size_t)N, hipMemcpyDeviceToHost));
+            d0 = flag_h[0];
+            for (int64_t i = 0; i < N; i++) finished += flag_h[i];
+            HIP_OK(hipMemcpy(flag_h, tinv + (size_t)t * N, (size_t)N, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < N; i++) invalid_total += flag_h[i];
+            const int32_t tail[4] = {d0, pl, ei, 0};
+            digest = fnv1a(digest, mask_h, mask_n);
+            digest = fnv1a(digest, obs_h, obs_n * sizeof(float));
+            digest = fnv1a(digest, rw, sizeof(rw));
+            digest = fnv1a(digest, tail, sizeof(tail));
+        }
+        printf("trajectory of %d slots: envs %lld steps %d seed 0x%llx games_finished %lld invalid_actions %lld env0_digest 0x%016llx launch_kind %d\n", T,
+               (long long)N, steps, (unsigned long long)seed, finished, invalid_total, (unsigned long long)digest, sgx_last_launch_kind(h));
+        SGX_TRY(sgx_destroy(h));
+        return invalid_total == 0 ? 0 : 4;
+    }
     if (argc > 5) {
         /* which physical memory backs the observation buffer decides up to 20 % of a step's time: let the
          * library pick its output buffers with its bounded placement trial (never more than 8 GiB held beyond what it returns) */

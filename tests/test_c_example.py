@@ -49,6 +49,28 @@ def test_c_rollout_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_c_rollout_trajectory_mode_matches_oracle_and_the_step_by_step_mode():
+    """`c_rollout <table> <envs> <steps> <seed> traj`: the same rollout as ONE sgx_step_traj call from plain C into [steps][envs]... tensors
+    (per-slot results, drawn actions); the digest over env 0's slots equals the oracle's rolling digest, i.e. the step-by-step mode's, and
+    the steps ran as a multi-step launch (SGX_LAUNCH_MULTI_STEP_WAVE = 3)."""
+    from oracle import oracle as orc
+    from stratego_env_amd import setups as S
+    from stratego_env_amd.config import VARIANTS
+    exe = compile_example()
+    n_envs, steps, seed = 777, 120, 0xBADC0DE
+    out = subprocess.check_output([exe, TABLE, str(n_envs), str(steps), hex(seed), 'traj'], text=True)
+    m = re.search(r'trajectory of 120 slots: .* games_finished (\d+) invalid_actions (\d+) env0_digest 0x([0-9a-f]+) launch_kind (\d+)', out)
+    assert m and int(m.group(2)) == 0 and int(m.group(4)) == 3, out
+    v = VARIANTS['barrage']
+    cv = orc.make_cvariant(v.rows, v.columns, v.max_turns, v.obstacle_locations, v.piece_counts, v.initial_state_usable_rows,
+                           setups=S.load_setup_table('barrage'))
+    _, d, _ = orc.rollout(cv, seed, 0, 1, steps, threads=1)
+    assert int(d[0]) == int(m.group(3), 16)
+    step_by_step = subprocess.check_output([exe, TABLE, str(n_envs), str(steps), hex(seed)], text=True)
+    assert re.search(r'env0_digest 0x([0-9a-f]+)', step_by_step).group(1) == m.group(3)
+
+
+@pytest.mark.gpu
 def test_c_rollout_bench_mode_uses_library_owned_outputs():
     """`c_rollout <table> <envs> <steps> <seed> bench`: output buffers from sgx_alloc_outputs (bounded placement trial), K steps
     through sgx_step_n -- plain C, no torch in the process."""
