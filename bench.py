@@ -797,6 +797,33 @@ def scaling_leg(rk, args, per_gpu, total_envs, label, output_sets=1):
             torch.cuda.empty_cache()
 
 
+def line_summary(out):
+    """The figures of the legs once more, as the LAST key of the line: whoever keeps only the tail of this (long) line still sees BASELINE
+    configs 3 and 4, config 5's per-GPU size, the trajectory and facade legs and the store-only probe next to the headline."""
+    def pick(d, *keys):
+        return {k: (round(d[k], 4) if isinstance(d.get(k), float) else d.get(k)) for k in keys if d and k in d} if d else None
+    c, rf = out.get("config") or {}, out.get("roofline") or {}
+    ow = c.get("other_workloads") or []
+    names = ("config3_standard_262144", "config4_micro_65536", "both_observations_65536", "config5_per_gpu_size_barrage_262144")
+    s = {"value": out.get("value"), "value_one_launch_per_step": out.get("value_one_launch_per_step"), "n_gpus": out.get("n_gpus"),
+         "frac": rf.get("frac"), "frac_untuned": rf.get("frac_untuned"), "traffic_over_b_min": rf.get("traffic_over_b_min"),
+         "store_peak_measured_gbps": rf.get("store_peak_measured"), "frac_of_store_peak": rf.get("frac_of_store_peak"),
+         "verified_envs": out.get("verified_envs"), "scaling_x": c.get("scaling_x")}
+    for name, w in zip(names, ow):
+        s[name] = pick(w, "value", "launch_us", "frac", "verified_envs")
+        if w and w.get("rotating_outputs"):
+            s[name]["ring_of_3"] = pick(w["rotating_outputs"], "value", "launch_us", "frac_dram")
+    s["in_place"] = pick(c.get("in_place"), "value", "launch_us", "rate_over_spec_peak")
+    s["trajectory"] = pick(c.get("trajectory"), "slots", "value", "launch_us", "frac", "one_launch", "verified_envs")
+    s["compact_outputs"] = pick(c.get("compact_outputs"), "value", "launch_us", "frac")
+    s["consumer_in_loop"] = pick((c.get("consumer_in_loop") or {}).get("nt_stores"), "value", "step_kernel_us_in_loop")
+    s["facade_n1"] = pick(c.get("facade_n1"), "steps_per_s", "env_step_calls_per_s")
+    s["scaling_legs"] = [pick(l, "games_per_gpu", "value", "scaling_x", "per_gpu_value_min_over_solo") for l in (c.get("scaling_legs") or [])] or None
+    cb = out.get("cpu_baseline") or {}
+    s["cpu_baseline"] = pick(cb, "value", "cores", "kind")
+    return s
+
+
 def run_rank(args):      # noqa: C901
     global DRY_RUN, SETTLE_SECONDS
     dry = DRY_RUN = args.dry_run
@@ -1006,6 +1033,7 @@ def run_rank(args):      # noqa: C901
             out["cpu_baseline"] = cpu_baseline(args.version, BASE_SEED, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
+        out["summary_at_the_end_of_the_line"] = line_summary(out)
         print(json.dumps(out), flush=True)
     rk.close()
 

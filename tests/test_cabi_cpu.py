@@ -34,6 +34,8 @@ def test_struct_sizes_match_header():
     # sgx_config: 4 + 12 + 1 int32 + SGX_MAX_CELLS bytes; sgx_step_io: 12 pointers + 2 int32
     assert C.sizeof(_lib.SgxConfig) == 17 * 4 + 1024
     assert C.sizeof(_lib.SgxStepIO) == 12 * 8 + 8
+    assert C.sizeof(_lib.SgxTrajIO) == (12 * 8 + 8) + 2 * 4 + 8 + 8          # sgx_traj_io: the step io, n_slots, results_per_slot, slot_envs, actions_log_dev
+    assert _lib.SgxTrajIO.slot_envs.offset == 112 and _lib.SgxTrajIO.actions_log_dev.offset == 120
     assert C.sizeof(_lib.SgxOutputs) == 3 * 8 + 4 * 8 + 2 * 4 + 2 * 64 * 4 + 2 * 4  # sgx_outputs of the header, field by field
 
 
