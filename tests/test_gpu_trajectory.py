@@ -125,21 +125,22 @@ def _multi_kinds():
     ('barrage', 48, 64, 10, 0.2), ('standard', 16, 48, 8, 0.1), ('short_barrage', 64, 40, 8, 0.2), ('octa_barrage', 32, 64, 5, 0.2),
     ('medium', 40, 50, 6, 0.2), ('fives', 33, 30, 6, 0.2), ('standard2', 5, 24, 4, 0.1), ('tiny', 100, 64, 4, 0.2), ('micro', 130, 20, 8, 0.2),
 ])
-def test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk, n_calls, garbage, both=False, auto_reset=True, kw=None, emit_obs=True):
+def test_every_step_of_a_multi_step_launch_equals_the_oracle(name, n_envs, chunk, n_calls, garbage, both=False, auto_reset=True, kw=None, emit_obs=True,
+                                                             seed_salt=0):
     """Calls of `chunk` steps into a trajectory buffer of `chunk` slots: every slot of every call against the oracle.  Some games start
     every call from a garbage action (flagged, state unchanged, the same draw again); games end and restart inside the launches and across
     their boundaries."""
     import torch
     from stratego_env_amd.vec_env import VecStrategoEnv
     v = VARIANTS[name]
-    seed, g0 = 0x7A3B00 + 97 * len(name) + n_envs, 7000
+    seed, g0 = 0x7A3B00 + 97 * len(name) + n_envs + 104729 * seed_salt, 7000 + 13 * seed_salt       # (tools/soak_trajectory.py varies the salt)
     env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=auto_reset, full_obs=both, **(kw or {}))
     fo = Follower(name, seed, g0, n_envs, auto_reset, both, with_obs=emit_obs)
     env.reset()
     fo.check_reset(env.obs.cpu().numpy(), env.mask.cpu().numpy(), env.fobs.cpu().numpy() if both else None)
     env.sample_valid_actions()
     traj = env.alloc_trajectory(chunk)
-    rs = np.random.RandomState(11)
+    rs = np.random.RandomState(11 + seed_salt)
     NA = v.num_spatial_actions
     for call in range(n_calls):
         nxt = env.next_actions.cpu().numpy().copy()
