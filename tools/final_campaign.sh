@@ -23,6 +23,7 @@ find $R/gpurun_out/${RND}_tuned -name "*kernel_trace.csv" -delete; find $R/gpuru
 cd $R
 bash tools/variant_bench.sh tuned > gpurun_out/$OUT/variant_bench.log 2>&1
 python tools/soak_parity.py ${SOAK_SECONDS:-150} > gpurun_out/$OUT/soak_parity.log 2>&1; tail -1 gpurun_out/$OUT/soak_parity.log
+python tools/soak_trajectory.py 120 > gpurun_out/$OUT/soak_trajectory.log 2>&1; tail -1 gpurun_out/$OUT/soak_trajectory.log
 python tools/soak_procedural.py 60 > gpurun_out/$OUT/soak_procedural.log 2>&1; tail -1 gpurun_out/$OUT/soak_procedural.log
 python tools/lane_ab.py --specs micro:65536,tiny:65536,micro:262144 --rounds 2 > gpurun_out/$OUT/lane_ab.log 2>&1
 bash tools/procedural_profile.sh ${RND}_procedural barrage 65536 > gpurun_out/$OUT/procedural_profile.log 2>&1
