@@ -31,7 +31,7 @@ bench_launcher.Rank).  The legs other than the headline live in bench_legs.py.
 Prints ONE JSON line (rank 0) with
   `roofline`      HBM.  `achieved` = B_min x games per launch / launch time (HIP events on the launch stream over the timed region),
                   B_min = the packed layout's own byte minimum per env step (record in + record out + action in + next action out +
-                  float32 observation + uint8 mask + results: 31,544 B for Barrage; DESIGN.md section 3.2) -- what the kernel cannot avoid
+                  float32 observation + uint8 mask + results: 31,544 B for Barrage; DESIGN.md section 4) -- what the kernel cannot avoid
                   moving; `frac` = achieved / 8 TB/s, and with the ring headline that is a DRAM fraction (`frac_dram` repeats it).
                   `in_place_rate_over_spec_peak` = the same bytes over the in-place leg's launch time: a memory-side rate that can touch
                   the spec peak, deliberately not called a fraction.  `traffic` = counter bytes per launch from the committed rocprofv3
@@ -106,11 +106,11 @@ def record_bytes(v):
 
 
 def b_min(v, full_obs=False, rec_bytes=None, fused_steps=1):
-    """The packed layout's own byte minimum of one env step (DESIGN.md section 3.1) -- what `roofline` is priced on: the record read
+    """The packed layout's own byte minimum of one env step (DESIGN.md section 4) -- what `roofline` is priced on: the record read
     once and written once, the action read (4) and the next action written (4), the float32 observation(s), the uint8 mask and
     12 B of results (two float32 rewards, done, invalid_action, ending_invalid, player).  Barrage 31,544 B, Standard 31,800 B,
     Micro 3,624 B.  fused_steps = K > 1: the K steps of one multi-step launch (boards of at most 16 cells: the games stay in registers,
-    DESIGN.md section 3.3) move the record and the action once per LAUNCH: per step (2 x record + 8) / K + outputs -- Micro 3,368 B + 264 / K."""
+    DESIGN.md section 3) move the record and the action once per LAUNCH: per step (2 x record + 8) / K + outputs -- Micro 3,368 B + 264 / K."""
     rc = v.rows * v.columns
     k = 2 * (v.rows - 1) + 2 * (v.columns - 1) + 1
     rb = rec_bytes if rec_bytes else record_bytes(v)
@@ -629,11 +629,11 @@ def placement_budgets(args, budget):
 
 
 def place_outputs(env, args):
-    """Library-owned output buffers from sgx_alloc_outputs' bounded placement trial (DESIGN.md section 4), unless --placement plain.
+    """Library-owned output buffers from sgx_alloc_outputs' bounded placement trial (DESIGN.md section 4.3), unless --placement plain.
     -> {'candidates', 'plain_us' (the allocation a caller would have got first), 'kept_us', 'median_us', 'max_us', 'peak_extra_gb'}."""
     if args.placement != 'trial' or getattr(env, 'compact', False):
         return None
-    # No candidate of the fast class (>= 14 % below the slowest, DESIGN.md section 4) in the first budget: tune_placement's second pass
+    # No candidate of the fast class (>= 14 % below the slowest, DESIGN.md section 4.3) in the first budget: tune_placement's second pass
     # samples a much wider range with the same number of candidates and is kept only if it found something faster.  (One box: 32
     # candidates at 338-340 us within 8 GiB, 275.9 us in the 64 GB pass.)
     # (a 7 GB observation buffer -- 262,144 games -- would have 1 GB of the default budget left for its candidates: four buffer sizes then)
@@ -898,7 +898,7 @@ def run_rank(args):      # noqa: C901
     if 'in_place' in legs_on:
         # The same K / W on the same env object into ONE set of tensors (the set the ring wrote last), step after step: what rounds 1-3
         # reported as the headline.  Rewriting the same 1-2 GB back to back is 8-10 % faster than anything that cannot reuse its lines
-        # (DESIGN.md section 3.2), so its rate is a memory-side figure that can touch the 8 TB/s spec peak: a ratio, not a DRAM fraction.
+        # (DESIGN.md section 4.1), so its rate is a memory-side figure that can touch the 8 TB/s spec peak: a ratio, not a DRAM fraction.
         e1, d1, _, g1, inv1 = time_workload(rk, env, args.steps, args.warmup)
         assert inv1 == 0
         in_place = {"workload": "the same rollout writing one set of output tensors in place", "value": total * args.steps / e1,
@@ -977,7 +977,7 @@ def run_rank(args):      # noqa: C901
                        # collective loses nothing as long as these stay at the 1-GPU rate of the same games-per-GPU size
                        "per_gpu_value_min": n * args.steps / own[1], "per_gpu_value_max": n * args.steps / own[0],
                        "outputs_checksum": checksum,
-                       # sgx_alloc_outputs' report: observe-launch time on the plain first allocation and on the candidate it kept (DESIGN.md section 4)
+                       # sgx_alloc_outputs' report: observe-launch time on the plain first allocation and on the candidate it kept (DESIGN.md section 4.3)
                        "placement": placement},
             "roofline": rf,
         }

@@ -191,7 +191,7 @@ class VecStrategoEnv:
 
     def set_nt_stores(self, mode='auto'):
         """Store policy of the observation writes (sgx_set_nt_stores): 'auto' (by the launch's output size), False or True.
-        Results are identical in every mode; it only moves the launch time (DESIGN.md section 3.1)."""
+        Results are identical in every mode; it only moves the launch time (DESIGN.md section 3)."""
         if mode is None or mode == 'auto' or (mode == -1 and mode is not True):
             m = -1
         elif mode is True or mode is False or mode in (0, 1):
@@ -278,7 +278,7 @@ class VecStrategoEnv:
 
     def tune_placement_once(self, trials=None, max_extra_bytes=8 << 30):
         """Move the big output tensors (obs, fobs, mask) into library-owned buffers picked by a bounded placement trial
-        (sgx_alloc_outputs, DESIGN.md section 4).
+        (sgx_alloc_outputs, DESIGN.md section 4.3).
 
         Measured on MI355X: device memory comes in regions of two kinds; an observation buffer lying inside one region runs at
         that region's rate (about 350 or 380-395 us per launch of 65,536 Barrage games), one whose pages mix both kinds at
