@@ -173,14 +173,14 @@ int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64_t seed,
 int sgx_destroy(sgx_env *h);
 
 /* Store policy of the observation writes of sgx_step / sgx_observe.  Lines a wave writes whole can leave as non-temporal stores:
- * faster when a launch's observations do not fit the 256 MiB Infinity Cache, slower when they do (DESIGN.md section 3.1).
+ * faster when a launch's observations do not fit the 256 MiB Infinity Cache, slower when they do (DESIGN.md section 3).
  * mode -1 (default): decided per launch from the observation bytes it writes (> 300 MB: non-temporal); 0: never; 1: always.
  * The environment variable SGX_NT=0|1|auto sets the default of handles created afterwards.  Results are identical in every
  * mode (tests/test_gpu_nt_stores.py runs the parity suites with the mode forced).  No reference counterpart. */
 int sgx_set_nt_stores(sgx_env *h, int32_t mode);
 
 /* Kernel choice on boards of at most 16 cells with a multiple of 4 cells (Micro 3x4, Tiny 4x4).  A second kernel plays ONE GAME PER LANE
- * there (64 games per wave, boards as nibbles in registers).  It is eligible for sgx_step / sgx_observe / sgx_step_n /
+ * there (64 games per wave, boards as nibbles in registers; docs/DESIGN_rounds_4-5.md section 3.3).  It is eligible for sgx_step / sgx_observe / sgx_step_n /
  * sgx_rollout / sgx_step_ring calls that ask for the 67-channel partial observation of an 'extended' channel mode (or none), masks in the
  * mover's perspective, no terminal-observation buffers and 16-byte aligned output tensors.  Measured: its game logic is twice as fast
  * (65,536 Micro games without outputs 13 against 26 us, mask only 15 against 30 us), but with the observation emitted one launch is slower
@@ -198,19 +198,21 @@ int sgx_set_lane_kernel(sgx_env *h, int32_t mode);
  *    registers; every step's outputs are written like those of a launch of its own; the record is read once and written once per LAUNCH.
  *    No barrier after the prologue: the waves drift out of phase, one wave's stores run under another's game logic.  The 67-channel kind,
  *    BOTH observations, compact outputs and calls without an observation.  65,536 Barrage games into a ring of three output sets:
- *    284-287 -> 246-249 us per step; 262,144 Standard games 1,210-1,233 -> 977-991 us.
+ *    284-287 -> 246-249 us per step; 262,144 Standard games 1,210-1,233 -> 977-991 us (DESIGN.md sections 3 and 4).
  *  - Boards of at most 16 cells with a multiple of 4 cells, the 67-channel kind with an observation tensor (lane_steps_kernel): a 256-thread
  *    workgroup keeps 64 games in the registers of one wave, which plays step t + 1 while the other three waves store the observations of
- *    step t.  65,536 Micro games 42.1 -> 29.2 us per step (DESIGN.md section 3.3).
+ *    step t.  65,536 Micro games 42.1 -> 29.2 us per step (DESIGN.md section 4.4).
  * Same results as n_steps launches of sgx_step (tests/test_gpu_multi_step.py, tests/test_gpu_lane_kernel.py).  mode 1 (default): on; 0: one
  * launch per step.  SGX_MULTI_STEP=0 sets the default of handles created afterwards (SGX_MULTI_STEP_WAVE=0: the first kind only off);
  * sgx_set_lane_kernel(h, 0) switches the second kind off as well.  No reference counterpart. */
 int sgx_set_multi_step(sgx_env *h, int32_t mode);
 /* Launches that write NO observation (sgx_expand, mask-only and logic-only steps / rollouts: no obs_dev / fobs_dev / final_*_dev, no compact
  * outputs) are bound by instruction issue, not by memory; on boards of 33 .. 128 cells they play TWO games per wave (32 lanes per game): 65,536
- * Barrage games, logic-only rollout 60.6 -> 33.2 us per step, search expansion 0.95 -> 1.77 G states/s.  Same results
- * (the parity suites of the no-observation kind run on it); the environment variable SGX_HALF_WAVE=0 gives handles created afterwards one
- * game per wave again (A/B measurements: tools/half_wave_ab.py).  No reference counterpart. */
+ * Barrage games, logic-only rollout 60.6 -> 33.7 us per step, search expansion 0.96 -> 1.75 G states/s.  Same results
+ * (the parity suites of the no-observation kind run on it).  mode 1 (default): two games per wave where the board allows it; 0: one game
+ * per wave everywhere (A/B measurements: tools/half_wave_ab.py).  The environment variable SGX_HALF_WAVE=0|1 sets the default of handles
+ * created afterwards.  No reference counterpart. */
+int sgx_set_half_wave(sgx_env *h, int32_t mode);
 
 /* Which kernel the handle's last sgx_step / sgx_observe / sgx_step_n / sgx_step_ring / sgx_rollout / sgx_expand launch was (diagnostics,
  * benchmarks that price a launch by its own bytes, tests that must not pass on another kernel): */
@@ -222,7 +224,7 @@ int sgx_last_launch_kind(const sgx_env *h);
 
 /* Shares of the eight XCDs in a launch of sgx_step / sgx_observe.  Under a saturating write stream the odd XCDs of MI355X drain their
  * eighth of the games ~20 % slower than the even ones, so with equal eighths the even XCDs idle at the end of every launch; the
- * library gives the even XCD of each pair `per_mille` more than the mean share and the odd one as much less (DESIGN.md section 3.1:
+ * library gives the even XCD of each pair `per_mille` more than the mean share and the odd one as much less (DESIGN.md section 3:
  * -3 ... -5 % launch time where the write stream bounds the kernel: 8x8 and 10x10 boards; +3 ... +7 % where the game logic shares the
  * critical path: 6x6, 15x15, Micro).  -1 (default): 100 per mille on boards of 64 .. 100 cells when a launch's observations do not fit
  * the Infinity Cache, equal shares otherwise; 0: always equal; 1 .. 900: always that.  SGX_XCD_SKEW=<per mille>|auto sets the default of
@@ -252,7 +254,7 @@ int sgx_observe(sgx_env *h, float *obs_dev, float *fobs_dev, uint8_t *mask_dev, 
 
 /* Average duration in microseconds of `launches` sgx_observe calls writing obs_dev / mask_dev (either may be NULL), measured
  * with HIP events on `stream`; synchronises that stream.  The caller owns the output buffers, and on MI355X the same kernel
- * runs 312-400 us depending on WHICH allocation the observation buffer is (DESIGN.md section 4): a host allocates a few
+ * runs 312-400 us depending on WHICH allocation the observation buffer is (DESIGN.md section 4.3): a host allocates a few
  * candidates, times each with this call and keeps the fastest (what VecStrategoEnv.tune_placement does from Python).
  * No reference counterpart. */
 int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int32_t launches, void *stream, float *microseconds);
@@ -260,7 +262,7 @@ int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int32_t laun
 /* Write-stream rate (GB/s) of the device memory range [ptr_dev, ptr_dev + bytes) under the step kernel's store pattern: one wave
  * per 26 KiB segment, 1 KiB non-temporal store instructions, eight concurrent fronts -- the observation stream without the game.
  * OVERWRITES the range.  On MI355X device memory comes in large regions of two kinds that differ by ~25 % under this pattern (and
- * not under a sequential fill), DESIGN.md section 4; a host that allocates its own output tensors can tell with this call which kind
+ * not under a sequential fill), DESIGN.md section 4.3; a host that allocates its own output tensors can tell with this call which kind
  * an allocation is.  ptr_dev 1 KiB aligned; `launches` timed launches after one untimed; synchronises `stream`.  No reference
  * counterpart. */
 int sgx_mem_probe(int device, void *ptr_dev, int64_t bytes, int32_t launches, void *stream, float *gb_per_s);
@@ -291,7 +293,7 @@ int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t seg_bytes,
                     int32_t waves_per_cu, int32_t pace, int32_t persistent, int32_t dwell, int32_t ring, int32_t launches, void *stream,
                     float *microseconds_per_launch, float *gb_per_s);
 
-/* Library-owned output buffers with a bounded placement trial (DESIGN.md section 4).  On MI355X the same launch takes
+/* Library-owned output buffers with a bounded placement trial (DESIGN.md section 4.3).  On MI355X the same launch takes
  * 313-400 us depending on which physical memory backs the big observation buffer: device memory comes in regions of two
  * kinds, a buffer lying inside one region runs at that region's rate (~350 or ~380-395 us for 65,536 Barrage games), and
  * only a buffer whose pages MIX both kinds reaches the fast class (313-325 us).  Which one a plain allocation gets depends
@@ -390,7 +392,7 @@ int sgx_step_traj(sgx_env *h, const sgx_traj_io *t, int32_t first_slot, int32_t 
  * stream of its own: games never interact, so the ranges' launches may overlap, and the ramp-up / drain of one range's step is filled
  * by the other's (a launch that lasts tens of microseconds spends a third of its time with the chip half empty).  The caller's
  * stream waits for all chains; results are identical to sgx_step_n.  Measured with chains = 2 on 65,536 games: Micro 41.3 -> 37.2 us per
- * step of all games, 5x5 107.6 -> 96.0 us, 8x8 198 -> 183 us, Barrage 322 -> 304 us.  chains = 0 lets the
+ * step of all games, 5x5 107.6 -> 96.0 us, 8x8 198 -> 183 us, Barrage 322 -> 304 us (docs/DESIGN_rounds_1-3.md).  chains = 0 lets the
  * library choose by the rule measured on the current kernels (2 for boards of up to 36 cells and for boards whose cell count is no
  * multiple of 4, else 1: 8x8 and 10x10 launches already stream at the memory rate and lose 2-5 % to a second chain) -- after trying
  * the multi-step launch of sgx_set_multi_step, which is faster than any number of chains wherever the call is eligible.  No reference

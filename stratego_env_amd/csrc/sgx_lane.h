@@ -15,7 +15,7 @@
 //   move application  impl:894-1028                                        lane_apply
 //   valid moves       impl:399-517                                         lane_gen_moves (bitboards, mover's perspective)
 //   endings           impl:1031-1043                                       lane_finish
-//   random setups     util.py:13-53 (counter RNG)     lane_sample_boards
+//   random setups     util.py:13-53 (counter RNG, sgx_layout.h)               lane_sample_boards
 #pragma once
 
 #ifndef SGX_HD

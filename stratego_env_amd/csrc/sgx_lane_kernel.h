@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64) void lane_kernel(const KParams P) {
 // lane_steps_kernel: K fused rollout steps of 64 games in ONE launch (sgx_step_n / sgx_step_ring on boards of at most 16 cells).
 //
 // Why.  One launch per step puts the game logic and the stores of 237 MB in series: every wave plays, then every wave stores (65,536
-// Micro games: 13 us of logic + 31 us of stores).  Here a 256-thread workgroup keeps its 64 games in the
+// Micro games: 13 us of logic + 31 us of stores; docs/DESIGN_rounds_4-5.md section 3.3).  Here a 256-thread workgroup keeps its 64 games in the
 // REGISTERS of wave 0 for all K steps -- the lane-per-game rules of sgx_lane.h, the next action drawn in place -- and waves 1 .. 3 do
 // nothing but emit observations: wave 0 plays step t + 1 while they sweep out step t.  Per step wave 0 writes what the emitters need --
 // the 64 record images -- into one of TWO LDS buffers, the results and the mask rows (coalesced, by itself), and meets the emitters at

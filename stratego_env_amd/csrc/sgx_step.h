@@ -655,7 +655,7 @@ __global__ __launch_bounds__((64 * Geo<R_, C_, VAR>::WPB), (waves_per_simd<Geo<R
 // every wave then plays its game step after step (env_step<PERSIST>): the boards stay in LDS, the scalars and the drawn action in
 // registers; the record is read once and written once per launch.  No barrier after the table staging: the waves of a workgroup -- and
 // of the chip -- drift out of phase within a few steps, so one wave's stores run under another's game logic (with one launch per step
-// every residency round starts, plays and stores together: DESIGN.md section 7).  Same results as n_steps launches of step_kernel.
+// every residency round starts, plays and stores together: docs/DESIGN_rounds_4-5.md section 7).  Same results as n_steps launches of step_kernel.
 // ---------------------------------------------------------------------------------------------
 constexpr int WSTEPS_MAX_SETS = 8;
 struct WaveStepsParams {

@@ -508,6 +508,12 @@ SGX_API int sgx_set_multi_step(sgx_env *h, int32_t mode) {
     return SGX_OK;
 }
 
+SGX_API int sgx_set_half_wave(sgx_env *h, int32_t mode) {
+    if (!h || mode < 0 || mode > 1) return fail(SGX_EINVAL, "sgx_set_half_wave: mode must be 0 or 1%s");
+    h->half_wave = mode;
+    return SGX_OK;
+}
+
 SGX_API int sgx_set_lane_kernel(sgx_env *h, int32_t mode) {
     if (!h || mode < -1 || mode > 1) return fail(SGX_EINVAL, "sgx_set_lane_kernel: mode must be -1 (auto), 0 or 1%s");
     h->lane_mode = mode;
@@ -615,7 +621,7 @@ static void launch_shares(const sgx_env *h, bool streaming, int32_t *w) {
 static bool lane_eligible(const sgx_env *h, const KParams &p, bool full, bool original, bool multi_step = false) {
     const int cells = h->cfg.rows * h->cfg.cols;
     auto aligned = [](const void *ptr, uintptr_t a) { return (reinterpret_cast<uintptr_t>(ptr) & (a - 1)) == 0; };
-    // -1 (auto): only where it is the faster kernel -- launches that emit no observation (2 x on Micro / Tiny) and
+    // -1 (auto): only where it is the faster kernel -- launches that emit no observation (2 x on Micro / Tiny, docs/DESIGN_rounds_4-5.md section 3.3) and
     // the fused multi-step launches of sgx_step_n / sgx_step_ring (lane_steps_kernel: the logic of step t + 1 under the stores of step t)
     if (h->lane_mode < 0 && p.io.obs_dev && !multi_step) return false;
     return h->lane_mode != 0 && !p.multi_ev && !(p.io.flags & (SGX_STEP_COMPACT_OBS | SGX_STEP_COMPACT_MASK)) && cells <= 16 && cells % 4 == 0 && !full && !original && h->map_mode == 0 &&
@@ -998,7 +1004,7 @@ SGX_API int sgx_time_observe(sgx_env *h, float *obs_dev, uint8_t *mask_dev, int3
     return rc;
 }
 
-// ---- device-memory probe (DESIGN.md section 4)
+// ---- device-memory probe (DESIGN.md section 4.3)
 namespace {
 // GB/s of `launches` probe launches over [ptr, ptr + bytes) (one untimed first touch); e0 / e1: scratch events
 int probe_range(void *ptr, int64_t bytes, int32_t launches, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, float *gbps) {
@@ -1093,7 +1099,7 @@ SGX_API int sgx_store_probe(int device, void *ptr_dev, int64_t bytes, int32_t se
     return SGX_OK;
 }
 
-// ---- library-owned output buffers with a bounded placement trial (DESIGN.md section 4)
+// ---- library-owned output buffers with a bounded placement trial (DESIGN.md section 4.3)
 namespace {
 
 struct TrialCtx {
@@ -1163,7 +1169,7 @@ int pick_buffer(TrialCtx &c, int which, size_t bytes, float *obs_fixed, uint8_t 
         *n_trials = k + 1;
         if (us < best_us) { (void)hipFree(best); best = cand; best_us = us; *best_out = best; }
         else (void)hipFree(cand);
-        // Early stop: the classes lie >= 10 % apart (DESIGN.md section 4); once the kept candidate beats the slowest one seen by
+        // Early stop: the classes lie >= 10 % apart (DESIGN.md section 4.3); once the kept candidate beats the slowest one seen by
         // that much the fast class has been found and more candidates would only cost start-up time.  (A run of equally slow
         // candidates is no reason to stop: fast memory was found behind six and more slow candidates on several boxes.)
         // Two steps: the classes are ~255-265 / 300-310 / 320-330 / ~345 us (65,536 Barrage games): a candidate 9 % below the slowest may

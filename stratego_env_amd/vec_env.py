@@ -206,6 +206,11 @@ class VecStrategoEnv:
         m = -1 if mode in ('auto', None) else int(bool(mode))
         _lib.check(self._L.sgx_set_lane_kernel(self._h, m), self._L)
 
+    def set_half_wave(self, on=True):
+        """Launches without an observation (mask-only / logic-only steps and rollouts, search expansion) on boards of 33 .. 128 cells: True
+        (default) = two games per wave, False = one (sgx_set_half_wave).  Results are identical either way."""
+        _lib.check(self._L.sgx_set_half_wave(self._h, 1 if on else 0), self._L)
+
     def set_multi_step(self, on=True):
         """rollout_steps() on boards of at most 16 cells: True (default) = all steps of a call in one launch where eligible
         (sgx_set_multi_step: the games stay in registers, the logic of step t + 1 runs under the stores of step t); False = one launch

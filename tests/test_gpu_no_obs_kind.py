@@ -112,17 +112,16 @@ def test_steps_that_only_ask_whether_a_move_exists(name, n):
 
 @pytest.mark.parametrize('name,n', [('barrage', 1003), ('standard', 517), ('octa_barrage', 1000), ('medium', 999), ('short_barrage', 2050)])
 def test_two_games_per_wave_equal_one_game_per_wave(name, n, monkeypatch):
-    """Launches without an observation play TWO games per wave on boards of 33 .. 128 cells (Geo<R, C, 2>, the default); SGX_HALF_WAVE=0 at
-    handle creation gives one game per wave.  Ragged batch sizes (partial workgroups, a wave with one game), per-step and multi-step
+    """Launches without an observation play TWO games per wave on boards of 33 .. 128 cells (Geo<R, C, 2>, the default); sgx_set_half_wave(h, 0)
+    (or SGX_HALF_WAVE=0 at handle creation: the pools of the functional API below) gives one game per wave.  Ragged batch sizes (partial workgroups, a wave with one game), per-step and multi-step
     launches, mask-only and logic-only, search expansion pool to pool: identical masks, rewards, flags, draws and int64 states.  (Both are
     compared with the oracle through the suites of the no-observation kind; this test pins the two layouts to each other on every board.)"""
     import torch
     from stratego_env_amd.procedural_env import BatchedStrategoProceduralEnv
     from stratego_env_amd.vec_env import VecStrategoEnv
-    monkeypatch.setenv('SGX_HALF_WAVE', '0')
     a = VecStrategoEnv(name, n, seed=21, auto_reset=True)
-    monkeypatch.setenv('SGX_HALF_WAVE', '1')
-    b = VecStrategoEnv(name, n, seed=21, auto_reset=True)
+    a.set_half_wave(False)                                              # one game per wave (sgx_set_half_wave)
+    b = VecStrategoEnv(name, n, seed=21, auto_reset=True)               # the default: two
     a.reset(); b.reset()
     a.sample_valid_actions(); b.sample_valid_actions()
     bad = torch.arange(n, device=a.device) % 9 == 4

@@ -23,8 +23,10 @@ def timed(fn, k):
 
 
 def make(name, n, mode, **kw):
-    os.environ['SGX_HALF_WAVE'] = str(mode)
+    os.environ['SGX_HALF_WAVE'] = str(mode)               # (development builds take 2 = four games per wave through the variable only)
     e = VecStrategoEnv(name, n, seed=9, auto_reset=True, **kw)
+    if mode in (0, 1):
+        e.set_half_wave(bool(mode))
     e.reset()
     e.rollout_steps(30)
     return e
