@@ -501,11 +501,9 @@ MULTI_STEP_TALLY = {"launches": 0, "steps": 0}      # multi-step launches of thi
 def _tally(env, k):
     """After a rollout call of k steps: count it if it went out as multi-step launches (a kernel trace's total duration of steps_kernel /
     lane_steps_kernel divided by the tally's steps is the per-step time the line reports)."""
-    from stratego_env_amd import _lib
     if DRY_RUN or k <= 0 or not fused_launch(env):
         return
-    per = WSTEPS_MAX_PER_LAUNCH if env.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE else k
-    MULTI_STEP_TALLY["launches"] += -(-k // per)
+    MULTI_STEP_TALLY["launches"] += -(-k // WSTEPS_MAX_PER_LAUNCH)         # (both multi-step kernels go out in launches of at most 256 steps)
     MULTI_STEP_TALLY["steps"] += k
 
 
@@ -702,7 +700,7 @@ def roofline(version, v, n, launch_s, traffic_override=None, full_obs=False, fir
     return out
 
 
-WSTEPS_MAX_PER_LAUNCH = 256       # SGX_WSTEPS_MAX_PER_LAUNCH: a rollout call of the wave-per-game kernels goes out in launches of at most this many steps
+WSTEPS_MAX_PER_LAUNCH = 256       # SGX_STEPS_MAX_PER_LAUNCH: a rollout call of the multi-step kernels goes out in launches of at most this many steps
 
 
 def fused_launch(env):
@@ -715,14 +713,11 @@ def fused_launch(env):
 
 def fused_steps_of(env, steps):
     """Steps per launch of the env's last rollout of `steps` steps (1 = one launch per step): what the per-step byte minimum divides the
-    record traffic by.  The wave-per-game multi-step kernel chunks a call into launches of at most WSTEPS_MAX_PER_LAUNCH steps."""
-    from stratego_env_amd import _lib
+    record traffic by.  Both multi-step kernels chunk a call into launches of at most WSTEPS_MAX_PER_LAUNCH steps."""
     if DRY_RUN or not fused_launch(env):
         return 1
-    if env.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE:
-        n_launches = -(-steps // WSTEPS_MAX_PER_LAUNCH)
-        return steps / float(n_launches)
-    return steps
+    n_launches = -(-steps // WSTEPS_MAX_PER_LAUNCH)
+    return steps / float(n_launches)
 
 
 def solo_anchor(rk, env, steps, warmup, **kw):
