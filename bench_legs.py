@@ -173,6 +173,28 @@ def trajectory_leg(B, rk, args, version='barrage', n=65536, slots=64, passes=3, 
         env.bench_steps_played += 6 * k
         B.MULTI_STEP_TALLY["launches"] += 6
         B.MULTI_STEP_TALLY["steps"] += 6 * k
+        # The same T steps into a RING of T SEPARATE sets, each from its own placement search (sgx_step_ring: beyond 8 sets the pointers travel in a
+        # device table; still one launch per call): what a trajectory buffer costs when every slot's memory is of the fast class
+        ring = None
+        free, _ = torch.cuda.mem_get_info()
+        if args.placement == 'trial' and slots * per_slot < 0.6 * free:
+            del own
+            B.place_outputs(env, args)
+            t_search = time.perf_counter()
+            budget, _wide = B.placement_budgets(args, max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4))
+            reps = env.alloc_output_ring(slots, tune=True, max_extra_bytes=budget, trials=16)      # (bounded: 16 candidates per set, no wide pass)
+            t_search = time.perf_counter() - t_search
+            env.rollout_steps(slots, ring=True)                       # first touch, untimed
+            ring_kind = env.last_launch_kind
+            us_ring = timed(lambda: env.rollout_steps(slots, ring=True), slots)
+            env.bench_steps_played += 4 * slots
+            B.MULTI_STEP_TALLY["launches"] += 4
+            B.MULTI_STEP_TALLY["steps"] += 4 * slots
+            kept = [min(r['obs']) for r in reps[1:] if r and r.get('obs')]
+            ring = {"sets": slots, "one_launch": ring_kind in (_lib.LAUNCH_MULTI_STEP_WAVE, _lib.LAUNCH_MULTI_STEP), "launch_us": round(us_ring, 2),
+                    "value": n / (us_ring * 1e-6), "frac": B.b_min(v, False, env.record_bytes, float(slots)) * n / (us_ring * 1e-6) / 1e9 / B.HBM_PEAK_GBS,
+                    "placement_search_seconds": round(t_search, 1), "kept_us_min_max": [round(min(kept), 1), round(max(kept), 1)] if kept else None,
+                    "verified_envs": B.verify_against_oracle(env, version, verify) if verify else 0}
         fused = float(slots)
         per_step = B.b_min(v, False, env.record_bytes, fused) + 4            # + the drawn action of every step (actions log)
         return {"workload": "%d concurrent %s games, rollout into a trajectory buffer of %d slots (sgx_step_traj: obs / mask / rewards / flags / drawn "
@@ -182,6 +204,7 @@ def trajectory_leg(B, rk, args, version='barrage', n=65536, slots=64, passes=3, 
                 "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
                 "b_min_bytes_per_step": per_step, "frac": per_step * n / launch_s / 1e9 / B.HBM_PEAK_GBS,
                 "same_memory_in_place_us_per_step": {"pointer_per_set_path (sgx_step_n)": round(us_ptr, 2), "strided_slot_path (sgx_step_traj, 1 slot)": round(us_strided, 2)},
+                "ring_of_separately_placed_sets": ring,
                 "verified_envs": checked, "verified_steps": env.bench_steps_played}
     finally:
         env.close()

@@ -191,8 +191,9 @@ int sgx_set_lane_kernel(sgx_env *h, int32_t mode);
 
 /* Multi-step launches.  A rollout call -- sgx_step_n / sgx_step_ring: n_steps >= 2 consecutive steps, each playing the action the one
  * before drew -- runs its steps in ONE launch (launches of at most 256 steps, on every board) where it is eligible: flat perspective actions,
- * masks in the mover's perspective, an 'extended' channel mode, at most 8 output sets that differ in their observation / mask tensors only
- * (sgx_step_ring; a trajectory buffer of ANY number of slots goes through sgx_step_traj, which names its slots by a stride).
+ * masks in the mover's perspective, an 'extended' channel mode, output sets that differ in their observation / mask tensors only (any number
+ * of them: beyond 8 sets sgx_step_ring passes their pointers through a small device table; a trajectory buffer in ONE allocation goes through
+ * sgx_step_traj, which names its slots by a stride).
  *  - Boards of more than 16 cells (steps_kernel): a workgroup stages its games once and every wave plays its game step after step -- the
  *    dense boards, never-moved flags, recent-move codes and capture events stay in LDS, the record's scalars and the drawn action in
  *    registers; every step's outputs are written like those of a launch of its own; the record is read once and written once per LAUNCH.

@@ -347,14 +347,18 @@ constexpr int KSTEP_SUB = SGX_KSTEP_SUB, KSTEP_EMITTERS = SGX_KSTEP_EMITTERS, KS
 struct StepsParams {
     KParams k;
     int32_t n_steps, n_sets, first_set;
-    int32_t strided;                      // sgx_step_traj: set s = the tensors of set 0 + s x the byte strides below (any number of slots)
-    int64_t obs_slot_bytes, mask_slot_bytes;
+    int32_t strided;                      // 1 (sgx_step_traj): set s = the tensors of set 0 + s x the byte strides below (any number of slots);
+    int64_t obs_slot_bytes, mask_slot_bytes;       // 2: more separate sets than fit the kernel arguments -- pointer tables in device memory
+    float *const *obs_tab;
+    uint8_t *const *mask_tab;
     float *obs[KSTEP_MAX_SETS];           // the observation / mask tensor of output set s (sgx_step_ring); one set: sgx_step_n, in place
     uint8_t *mask[KSTEP_MAX_SETS];
     __device__ __forceinline__ float *obs_of(int set) const {
-        return strided ? reinterpret_cast<float *>(reinterpret_cast<char *>(obs[0]) + (int64_t)set * obs_slot_bytes) : obs[set];
+        return strided == 2 ? table_entry(obs_tab, set) : strided ? reinterpret_cast<float *>(reinterpret_cast<char *>(obs[0]) + (int64_t)set * obs_slot_bytes) : obs[set];
     }
-    __device__ __forceinline__ uint8_t *mask_of(int set) const { return strided ? (mask[0] ? mask[0] + (int64_t)set * mask_slot_bytes : nullptr) : mask[set]; }
+    __device__ __forceinline__ uint8_t *mask_of(int set) const {
+        return strided == 2 ? table_entry(mask_tab, set) : strided ? (mask[0] ? mask[0] + (int64_t)set * mask_slot_bytes : nullptr) : mask[set];
+    }
 };
 
 template <class G>

@@ -182,6 +182,17 @@ struct DevTables {
 #else
 #define SGX_KERNARG
 #endif
+// An entry of a small read-only pointer table in global memory (the output sets of a ring with more sets than fit the kernel arguments), read
+// through the constant address space: with a uniform index that is a scalar load, which does not queue behind the wave's own stores.
+template <class T>
+__device__ __forceinline__ T table_entry(T const *tab, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return ((const SGX_KERNARG T *)tab)[i];
+#else
+    return tab[i];
+#endif
+}
+
 struct KParams {
     int8_t *boards;
     const DevTables *tab;

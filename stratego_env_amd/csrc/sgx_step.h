@@ -661,17 +661,25 @@ constexpr int WSTEPS_MAX_SETS = 8;
 struct WaveStepsParams {
     KParams k;
     int32_t n_steps, n_sets, first_set;
-    // sgx_step_traj: the n_sets "sets" are the slots of a trajectory buffer -- slot s = the tensors of slot 0 (obs[0] / fobs[0] / mask[0]) + s x
-    // these byte strides (0 for a tensor that is NULL); any number of slots.  0: the tensors of set s are obs[s] / fobs[s] / mask[s].
+    // strided 1 (sgx_step_traj): the n_sets "sets" are the slots of a trajectory buffer -- slot s = the tensors of slot 0 (obs[0] / fobs[0] /
+    // mask[0]) + s x these byte strides (0 for a tensor that is NULL); any number of slots.  0: the tensors of set s are obs[s] / fobs[s] /
+    // mask[s] (at most WSTEPS_MAX_SETS).  2 (sgx_step_ring with MORE separate sets than fit the kernel arguments): the pointers of set s are
+    // obs_tab[s] / fobs_tab[s] / mask_tab[s], tables in device memory the host filled before the launch (read with scalar loads).
     int32_t strided;
     int64_t obs_slot_bytes, fobs_slot_bytes, mask_slot_bytes;
+    float *const *obs_tab, *const *fobs_tab;
+    uint8_t *const *mask_tab;
     float *obs[WSTEPS_MAX_SETS], *fobs[WSTEPS_MAX_SETS];      // the output tensors of set s (sgx_step_ring); one set: in place
     uint8_t *mask[WSTEPS_MAX_SETS];
 };
 // the output tensors of set / slot `set` (scalar arithmetic on kernel arguments)
 template <class SPP>
 __device__ __forceinline__ void steps_outputs_of(const SPP sp, const int set, StepCarry &carry) {
-    if (sp->strided) {
+    if (sp->strided == 2) {
+        carry.obs = table_entry(sp->obs_tab, set);
+        carry.fobs = table_entry(sp->fobs_tab, set);
+        carry.mask = table_entry(sp->mask_tab, set);
+    } else if (sp->strided) {
         carry.obs = reinterpret_cast<float *>(reinterpret_cast<char *>(sp->obs[0]) + (int64_t)set * sp->obs_slot_bytes);
         carry.fobs = reinterpret_cast<float *>(reinterpret_cast<char *>(sp->fobs[0]) + (int64_t)set * sp->fobs_slot_bytes);
         carry.mask = sp->mask[0] + (int64_t)set * sp->mask_slot_bytes;

@@ -128,6 +128,12 @@ struct sgx_env {
     int last_kind;               // sgx_last_launch_kind: which kernel the last step / observe launch of this handle was
     int multi_step_wave;         // SGX_MULTI_STEP_WAVE: the multi-step launch of the wave-per-game kernels (steps_kernel) too
     int half_wave;               // SGX_HALF_WAVE: launches without an observation play two games per wave where the board allows it (Geo<R, C, 2>)
+    // sgx_step_ring with more output sets than fit the kernel arguments: the sets' pointers in a device table (filled through a pinned host
+    // copy; the event guards the staging buffer against being rewritten before the previous upload has run)
+    void **ring_tab_dev, **ring_tab_host;
+    int ring_tab_cap, ring_tab_n;
+    hipEvent_t ring_tab_ev;
+    hipStream_t ring_tab_stream;
 };
 
 namespace {
@@ -478,6 +484,9 @@ SGX_API int sgx_destroy(sgx_env *h) {
     if (h->sync_count) (void)hipFree(h->sync_count);
     if (h->san_flags) (void)hipFree(h->san_flags);
     if (h->redo_list) (void)hipFree(h->redo_list);
+    if (h->ring_tab_dev) (void)hipFree(h->ring_tab_dev);
+    if (h->ring_tab_host) (void)hipHostFree(h->ring_tab_host);
+    if (h->ring_tab_ev) (void)hipEventDestroy(h->ring_tab_ev);
     delete h;
     return SGX_OK;
 }
@@ -675,6 +684,44 @@ static int launch_set_step(sgx_env *h, const KParams &p_in, const OutSets &sets,
     return SGX_OK;
 }
 
+// More separate output sets than the kernel arguments hold (sgx_step_ring with n_sets > 8, e.g. a ring of 64 sets that each came from its own
+// placement search): the pointers of the sets go into a device table -- [obs x n][fobs x n][mask x n] -- that the multi-step kernels read with
+// scalar loads.  Uploaded only when the ring changed; ordered on `stream` before the launch that reads it.
+static int upload_ring_table(sgx_env *h, const OutSets &sets, hipStream_t stream, void ***tab_out) {
+    const int n = sets.n_sets;
+    if (n > h->ring_tab_cap) {
+        if (h->ring_tab_ev) HIP_TRY(hipEventSynchronize(h->ring_tab_ev));
+        if (h->ring_tab_dev) HIP_TRY(hipFree(h->ring_tab_dev));
+        if (h->ring_tab_host) HIP_TRY(hipHostFree(h->ring_tab_host));
+        h->ring_tab_dev = h->ring_tab_host = nullptr;
+        h->ring_tab_cap = h->ring_tab_n = 0;
+        HIP_TRY(hipMalloc((void **)&h->ring_tab_dev, (size_t)3 * n * sizeof(void *)));
+        HIP_TRY(hipHostMalloc((void **)&h->ring_tab_host, (size_t)3 * n * sizeof(void *), hipHostMallocDefault));
+        h->ring_tab_cap = n;
+    }
+    if (!h->ring_tab_ev) HIP_TRY(hipEventCreateWithFlags(&h->ring_tab_ev, hipEventDisableTiming));
+    std::vector<void *> want((size_t)3 * n);
+    for (int k = 0; k < n; ++k) {
+        want[k] = sets.ios[k].obs_dev;
+        want[n + k] = sets.ios[k].fobs_dev;
+        want[2 * n + k] = sets.ios[k].mask_dev;
+    }
+    const bool same = h->ring_tab_n == n && memcmp(h->ring_tab_host, want.data(), want.size() * sizeof(void *)) == 0;
+    if (!same) {
+        if (h->ring_tab_n) HIP_TRY(hipEventSynchronize(h->ring_tab_ev));          // (the staging buffer's previous upload has run)
+        memcpy(h->ring_tab_host, want.data(), want.size() * sizeof(void *));
+        // (laid out for capacity n: a smaller ring after a larger one re-packs the three sections)
+        HIP_TRY(hipMemcpyAsync(h->ring_tab_dev, h->ring_tab_host, want.size() * sizeof(void *), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(h->ring_tab_ev, stream));
+        h->ring_tab_n = n;
+        h->ring_tab_stream = stream;
+    } else if (h->ring_tab_stream != stream) {
+        HIP_TRY(hipStreamWaitEvent(stream, h->ring_tab_ev, 0));                     // (uploaded on another stream: order this launch behind it)
+    }
+    *tab_out = h->ring_tab_dev;
+    return SGX_OK;
+}
+
 // A rollout call goes out in launches of at most SGX_STEPS_MAX_PER_LAUNCH steps (a workgroup should not own the chip for seconds: work on
 // other streams, or a second rank sharing the GPU, gets in between the launches).
 #define SGX_STEPS_MAX_PER_LAUNCH 256
@@ -685,7 +732,8 @@ static int launch_set_step(sgx_env *h, const KParams &p_in, const OutSets &sets,
 static int launch_lane_steps(sgx_env *h, const KParams &p_in, const OutSets &sets, int32_t first_set, int32_t n_steps, void *stream, bool *launched) {
     *launched = false;
     const int32_t n_sets = sets.n_sets;
-    if (n_steps < 2 || (!sets.strided && n_sets > KSTEP_MAX_SETS) || h->lane_mode == 0 || h->no_multi_step) return SGX_OK;
+    if (n_steps < 2 || h->lane_mode == 0 || h->no_multi_step) return SGX_OK;
+    const bool table = !sets.strided && n_sets > KSTEP_MAX_SETS;        // more separate sets than the kernel arguments hold: a device table
     KParams p = p_in;
     p.mode = 0;
     p.io = sets.ios[sets.strided ? 0 : first_set];
@@ -710,10 +758,19 @@ static int launch_lane_steps(sgx_env *h, const KParams &p_in, const OutSets &set
             // everything but the observation / mask tensors is shared by the sets (the kernel writes the results through set first_set's pointers)
             if (pk.io.reward_dev != p.io.reward_dev || pk.io.done_dev != p.io.done_dev || pk.io.player_dev != p.io.player_dev ||
                 pk.io.invalid_action_dev != p.io.invalid_action_dev || pk.io.ending_invalid_dev != p.io.ending_invalid_dev) return SGX_OK;
-            sp.obs[k] = pk.io.obs_dev;
-            sp.mask[k] = pk.io.mask_dev;
+            if (!table) {
+                sp.obs[k] = pk.io.obs_dev;
+                sp.mask[k] = pk.io.mask_dev;
+            }
         }
     if (int rc = check_step_io(h, p)) return rc;
+    if (table) {
+        void **tab = nullptr;
+        if (int rc = upload_ring_table(h, sets, (hipStream_t)stream, &tab)) return rc;
+        sp.strided = 2;
+        sp.obs_tab = reinterpret_cast<float *const *>(tab);
+        sp.mask_tab = reinterpret_cast<uint8_t *const *>(tab + 2 * n_sets);
+    }
     p.map_mode = h->map_mode; p.map_arg = h->map_arg;
     const bool streaming = launch_streams_past_cache(h, p, n_sets);
     p.nt_stores = h->nt_mode < 0 ? (streaming ? 1 : 0) : h->nt_mode;
@@ -769,7 +826,8 @@ static int launch_lane_steps(sgx_env *h, const KParams &p_in, const OutSets &set
 static int launch_wave_steps(sgx_env *h, const KParams &p_in, const OutSets &sets, int32_t first_set, int32_t n_steps, void *stream, bool *launched) {
     *launched = false;
     const int32_t n_sets = sets.n_sets;
-    if (n_steps < 2 || (!sets.strided && n_sets > WSTEPS_MAX_SETS) || h->no_multi_step || !h->multi_step_wave || h->map_mode != 0) return SGX_OK;
+    if (n_steps < 2 || h->no_multi_step || !h->multi_step_wave || h->map_mode != 0) return SGX_OK;
+    const bool table = !sets.strided && n_sets > WSTEPS_MAX_SETS;       // more separate sets than the kernel arguments hold: a device table
     KParams p = p_in;
     p.mode = 0;
     p.io = sets.ios[sets.strided ? 0 : first_set];
@@ -801,9 +859,17 @@ static int launch_wave_steps(sgx_env *h, const KParams &p_in, const OutSets &set
                 (io.obs_dev == nullptr) != (io0.obs_dev == nullptr) || (io.fobs_dev == nullptr) != (io0.fobs_dev == nullptr) ||
                 (io.mask_dev == nullptr) != (io0.mask_dev == nullptr)) return SGX_OK;
             if (compact && ((reinterpret_cast<uintptr_t>(io.obs_dev) | reinterpret_cast<uintptr_t>(io.mask_dev)) & 15)) return SGX_OK;
-            sp.obs[k] = io.obs_dev; sp.fobs[k] = io.fobs_dev; sp.mask[k] = io.mask_dev;
+            if (!table) { sp.obs[k] = io.obs_dev; sp.fobs[k] = io.fobs_dev; sp.mask[k] = io.mask_dev; }
         }
     if (int rc = check_step_io(h, p)) return rc;
+    if (table) {
+        void **tab = nullptr;
+        if (int rc = upload_ring_table(h, sets, (hipStream_t)stream, &tab)) return rc;
+        sp.strided = 2;
+        sp.obs_tab = reinterpret_cast<float *const *>(tab);
+        sp.fobs_tab = reinterpret_cast<float *const *>(tab + n_sets);
+        sp.mask_tab = reinterpret_cast<uint8_t *const *>(tab + 2 * n_sets);
+    }
     p.map_mode = 0; p.map_arg = h->map_arg;
     const bool streaming = launch_streams_past_cache(h, p, n_sets);
     p.nt_stores = h->nt_mode < 0 ? (streaming ? 1 : 0) : h->nt_mode;

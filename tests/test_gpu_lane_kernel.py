@@ -176,8 +176,8 @@ def test_multi_step_launch_with_forced_non_temporal_stores_and_raw_players():
 
 
 def test_multi_step_launch_falls_back_where_it_does_not_apply():
-    """More output sets than the multi-step kernel takes (8), a call of ONE step, a call without an observation: one launch per step, same
-    results as ever; `chains='auto'` prefers the multi-step launch to two chains where it applies."""
+    """A call of ONE step: one launch; rings of nine (pointers in a device table) and of eight sets (pointers in the kernel arguments): multi-step
+    launches with the results of one launch per step; `chains='auto'` prefers the multi-step launch to two chains where it applies."""
     import torch
     from stratego_env_amd import _lib
     from stratego_env_amd.vec_env import VecStrategoEnv
@@ -192,7 +192,7 @@ def test_multi_step_launch_falls_back_where_it_does_not_apply():
     assert torch.equal(a.obs, b.obs) and torch.equal(a.mask, b.mask) and torch.equal(a.env_info(), b.env_info())
     a.alloc_output_ring(9); b.alloc_output_ring(9)
     a.rollout_steps(20, ring=True); b.rollout_steps(20, ring=True)
-    assert a.last_launch_kind == _lib.LAUNCH_WAVE                     # nine sets: one launch per step
+    assert a.last_launch_kind == _lib.LAUNCH_MULTI_STEP               # nine sets: their pointers travel in a device table
     for (oa, ma, _), (ob, mb, _) in zip(a._ring, b._ring):
         assert torch.equal(oa, ob) and torch.equal(ma, mb)
     a.alloc_output_ring(8); b.alloc_output_ring(8)

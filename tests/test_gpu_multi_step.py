@@ -121,7 +121,9 @@ def test_multi_step_launch_is_not_taken_where_it_does_not_apply():
     a, b = _pair('barrage', 256)
     a.alloc_output_ring(9); b.alloc_output_ring(9)
     a.rollout_steps(20, ring=True); b.rollout_steps(20, ring=True)
-    assert a.last_launch_kind == _lib.LAUNCH_WAVE                     # nine output sets
+    assert a.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE          # nine output sets: more than the kernel arguments hold -- a device table of pointers
+    for (oa, ma, _), (ob, mb, _) in zip(a._ring, b._ring):
+        assert torch.equal(oa, ob) and torch.equal(ma, mb)
     a.rollout_steps(1)
     assert a.last_launch_kind == _lib.LAUNCH_WAVE                     # a single step
     a.rollout_steps(6, chains=2)

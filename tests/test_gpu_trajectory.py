@@ -247,9 +247,10 @@ def test_slots_wrap_around_from_a_first_slot(name, n_envs):
     env.close(); twin.close()
 
 
-def test_ring_of_separate_sets_every_set_equals_the_oracle():
-    """sgx_step_ring with one separately allocated output set per step (n_sets = n_steps = 8, the most a ring may have): every SET's mask and
-    observation against the oracle; the shared results are the last step's."""
+@pytest.mark.parametrize('S', [8, 21])
+def test_ring_of_separate_sets_every_set_equals_the_oracle(S):
+    """sgx_step_ring with one separately allocated output set per step (n_sets = n_steps = S: 8 = the most whose pointers fit the kernel
+    arguments, 21 = pointers in a device table): every SET's mask and observation against the oracle; the shared results are the last step's."""
     import torch
     from stratego_env_amd import _lib
     from stratego_env_amd.vec_env import VecStrategoEnv
@@ -259,29 +260,29 @@ def test_ring_of_separate_sets_every_set_equals_the_oracle():
         fo = Follower(name, seed, g0, n_envs, True)
         env.reset()
         env.sample_valid_actions()
-        env.alloc_output_ring(8)
+        env.alloc_output_ring(S)
         log = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True)    # per-step results / draws of the same games
         log.reset(); log.sample_valid_actions()
-        for call in range(6):
+        for call in range(6 if S == 8 else 3):
             acts = env.next_actions.cpu().numpy().copy()
             first = env._ring_pos
             for o, m, _ in env._ring:
                 o.fill_(float('nan')); m.fill_(0x5A)
-            env.rollout_steps(8, ring=True)
+            env.rollout_steps(S, ring=True)
             assert env.last_launch_kind in _multi_kinds()
-            res = log.alloc_trajectory(8)
-            log.rollout_trajectory(8, res)
+            res = log.alloc_trajectory(S)
+            log.rollout_trajectory(S, res)
             hr = _host(res)
             h = dict(hr)
-            order = [(first + t) % 8 for t in range(8)]
+            order = [(first + t) % S for t in range(S)]
             h['obs'] = np.stack([env._ring[s][0].cpu().numpy() for s in order])
             h['mask'] = np.stack([env._ring[s][1].cpu().numpy() for s in order])
-            for t in range(8):
+            for t in range(S):
                 fo.check_slot(acts, h, t, 'ring call %d' % call)
                 acts = h['actions'][t]
             for k, t in (('reward', env.reward), ('done', env.done), ('player', env.player), ('ending_invalid', env.ending_invalid)):
-                assert np.array_equal(t.cpu().numpy(), hr[k][7]), (name, k)
-            assert torch.equal(env.next_actions, res['actions'][7])
+                assert np.array_equal(t.cpu().numpy(), hr[k][S - 1]), (name, k)
+            assert torch.equal(env.next_actions, res['actions'][S - 1])
         env.close(); log.close()
 
 
