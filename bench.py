@@ -810,9 +810,9 @@ def line_summary(out):
             s[name]["ring_of_3"] = pick(w["rotating_outputs"], "value", "launch_us", "frac_dram")
     s["in_place"] = pick(c.get("in_place"), "value", "launch_us", "rate_over_spec_peak")
     s["trajectory"] = pick(c.get("trajectory"), "slots", "value", "launch_us", "frac", "one_launch", "verified_envs")
-    if s["trajectory"] and (c.get("trajectory") or {}).get("ring_of_separately_placed_sets"):
-        s["trajectory"]["ring_of_separately_placed_sets"] = pick(c["trajectory"]["ring_of_separately_placed_sets"], "sets", "value", "launch_us", "frac", "one_launch")
-    s["compact_outputs"] = pick(c.get("compact_outputs"), "value", "launch_us", "frac")
+    if s["trajectory"] and ((c.get("trajectory") or {}).get("ring_of_separately_placed_sets") or {}).get("value"):
+        s["trajectory"]["ring_of_separately_placed_sets"] = pick(c["trajectory"]["ring_of_separately_placed_sets"], "sets", "value", "launch_us", "frac", "one_launch", "same_memory")
+    s["compact_outputs"] = pick(c.get("compact_outputs"), "value", "launch_us", "frac", "trajectory_64_slots")
     s["consumer_in_loop"] = pick((c.get("consumer_in_loop") or {}).get("nt_stores"), "value", "step_kernel_us_in_loop")
     s["facade_n1"] = pick(c.get("facade_n1"), "steps_per_s", "env_step_calls_per_s")
     s["scaling_legs"] = [pick(l, "games_per_gpu", "value", "scaling_x", "per_gpu_value_min_over_solo") for l in (c.get("scaling_legs") or [])] or None

@@ -176,13 +176,30 @@ def trajectory_leg(B, rk, args, version='barrage', n=65536, slots=64, passes=3, 
         # The same T steps into a RING of T SEPARATE sets, each from its own placement search (sgx_step_ring: beyond 8 sets the pointers travel in a
         # device table; still one launch per call): what a trajectory buffer costs when every slot's memory is of the fast class
         ring = None
+        torch.cuda.empty_cache()                  # (the 64-slot buffer was still referenced by the env's views when the cache was emptied above)
         free, _ = torch.cuda.mem_get_info()
-        if args.placement == 'trial' and slots * per_slot < 0.6 * free:
+        if args.placement != 'trial' or slots * per_slot >= 0.6 * free:
+            ring = {"skipped": "--placement plain" if args.placement != 'trial' else "%.0f GB free, %.0f GB needed" % (free / 1e9, slots * per_slot / 0.6 / 1e9)}
+        else:
             del own
             B.place_outputs(env, args)
+            budget, wide = B.placement_budgets(args, max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4))
+            # (1) the table path against the kernel-argument path on THE SAME memory: a ring of three placed sets, then `slots` ring entries
+            # over those three buffers (entry i = set i mod 3)
+            env.alloc_output_ring(3, tune=True, max_extra_bytes=budget, wide_extra_bytes=wide)
+            env.rollout_steps(slots, ring=True)
+            us_ring3 = timed(lambda: env.rollout_steps(slots, ring=True), slots, reps=5)
+            env.repeat_output_ring(slots)
+            env.rollout_steps(slots, ring=True)
+            tab_kind = env.last_launch_kind
+            us_tab = timed(lambda: env.rollout_steps(slots, ring=True), slots, reps=5)
+            env.bench_steps_played += 12 * slots
+            B.MULTI_STEP_TALLY["launches"] += 12
+            B.MULTI_STEP_TALLY["steps"] += 12 * slots
+            checked_tab = B.verify_against_oracle(env, version, verify) if verify else 0
+            # (2) `slots` SEPARATE sets, each from a search of its own
             t_search = time.perf_counter()
-            budget, _wide = B.placement_budgets(args, max(int(args.placement_gb * (1 << 30)), 4 * env.obs.numel() * 4))
-            reps = env.alloc_output_ring(slots, tune=True, max_extra_bytes=budget, trials=16)      # (bounded: 16 candidates per set, no wide pass)
+            reps = env.alloc_output_ring(slots, tune=True, max_extra_bytes=budget, trials=24, wide_extra_bytes=wide)
             t_search = time.perf_counter() - t_search
             env.rollout_steps(slots, ring=True)                       # first touch, untimed
             ring_kind = env.last_launch_kind
@@ -190,11 +207,18 @@ def trajectory_leg(B, rk, args, version='barrage', n=65536, slots=64, passes=3, 
             env.bench_steps_played += 4 * slots
             B.MULTI_STEP_TALLY["launches"] += 4
             B.MULTI_STEP_TALLY["steps"] += 4 * slots
-            kept = [min(r['obs']) for r in reps[1:] if r and r.get('obs')]
-            ring = {"sets": slots, "one_launch": ring_kind in (_lib.LAUNCH_MULTI_STEP_WAVE, _lib.LAUNCH_MULTI_STEP), "launch_us": round(us_ring, 2),
-                    "value": n / (us_ring * 1e-6), "frac": B.b_min(v, False, env.record_bytes, float(slots)) * n / (us_ring * 1e-6) / 1e9 / B.HBM_PEAK_GBS,
-                    "placement_search_seconds": round(t_search, 1), "kept_us_min_max": [round(min(kept), 1), round(max(kept), 1)] if kept else None,
-                    "verified_envs": B.verify_against_oracle(env, version, verify) if verify else 0}
+            kept = sorted(min(r['obs']) for r in reps[1:] if r and r.get('obs'))
+            multi = (_lib.LAUNCH_MULTI_STEP_WAVE, _lib.LAUNCH_MULTI_STEP)
+            frac_of = lambda us: B.b_min(v, False, env.record_bytes, float(slots)) * n / (us * 1e-6) / 1e9 / B.HBM_PEAK_GBS
+            ring = {"sets": slots, "one_launch": ring_kind in multi, "launch_us": round(us_ring, 2), "value": n / (us_ring * 1e-6), "frac": frac_of(us_ring),
+                    "placement_search_seconds": round(t_search, 1),
+                    "kept_in_place_us_min_median_max": [round(kept[0], 1), round(kept[len(kept) // 2], 1), round(kept[-1], 1)] if kept else None,
+                    "sets_of_the_slow_class (in place > 1.1 x the fastest)": sum(1 for k in kept if k > 1.1 * kept[0]) if kept else None,
+                    "verified_envs": B.verify_against_oracle(env, version, verify) if verify else 0,
+                    "same_memory": {"what": "a ring of 3 placed sets (pointers in the kernel arguments) against %d ring entries over the same three buffers "
+                                            "(pointers in the device table), %d steps per launch" % (slots, slots),
+                                    "ring_of_3_us": round(us_ring3, 2), "table_of_%d_us" % slots: round(us_tab, 2), "table_over_ring_of_3": round(us_tab / us_ring3, 4),
+                                    "one_launch": tab_kind in multi, "frac_table": frac_of(us_tab), "verified_envs": checked_tab}}
         fused = float(slots)
         per_step = B.b_min(v, False, env.record_bytes, fused) + 4            # + the drawn action of every step (actions log)
         return {"workload": "%d concurrent %s games, rollout into a trajectory buffer of %d slots (sgx_step_traj: obs / mask / rewards / flags / drawn "
@@ -205,6 +229,9 @@ def trajectory_leg(B, rk, args, version='barrage', n=65536, slots=64, passes=3, 
                 "b_min_bytes_per_step": per_step, "frac": per_step * n / launch_s / 1e9 / B.HBM_PEAK_GBS,
                 "same_memory_in_place_us_per_step": {"pointer_per_set_path (sgx_step_n)": round(us_ptr, 2), "strided_slot_path (sgx_step_traj, 1 slot)": round(us_strided, 2)},
                 "ring_of_separately_placed_sets": ring,
+                "bound": "address translation, not DRAM: the same launch runs at 8.2 TB/s while the sets it writes cover <= 16 GB and falls to 6.9 TB/s "
+                         "from 64 GB on, whatever the placement class of each set (tools/ring_footprint_probe.py); under it GRBM_UTCL2_BUSY is 41 % of the "
+                         "cycles against 0.3 %, TCP_UTCL1_TRANSLATION_MISS 196 x (profiles/r06_ring_footprint_counters.txt); DRAM-side counters equal",
                 "verified_envs": checked, "verified_steps": env.bench_steps_played}
     finally:
         env.close()
@@ -447,12 +474,30 @@ def compact_leg(B, rk, args, version='barrage', n=65536, seconds=0.5, verify=8):
         ev[2].record()
         torch.cuda.synchronize()
         dec_obs_us, dec_mask_us = ev[0].elapsed_time(ev[1]) / 20 * 1e3, ev[1].elapsed_time(ev[2]) / 20 * 1e3
+        # a 64-slot trajectory buffer of compact outputs: 1/8 of the float32 buffer's bytes -- inside the reach of the address translation caches,
+        # which a 128 GB float32 buffer is not (trajectory leg)
+        slots = 64
+        traj = env.alloc_trajectory(slots)
+        env.rollout_trajectory(slots, traj)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            env.rollout_trajectory(slots, traj)
+        e1.record()
+        torch.cuda.synchronize()
+        env.bench_steps_played += 4 * slots
+        traj_us = e0.elapsed_time(e1) * 1e3 / (3 * slots)
+        traj_gb = sum(t.numel() * t.element_size() for t in traj.values()) / 1e9
+        traj_checked = B.verify_against_oracle(env, version, verify) if verify else 0
+        del traj
         return {"workload": "%d concurrent %s games, same rollout with COMPACT outputs (opt-in: uint8 codes [N,%d] + int32 mask bits [N,%d])"
                             % (n, version, env.compact_obs_stride, env.compact_mask_words),
                 "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
                 "bytes_per_step": per_step, "frac": per_step * n / launch_s / 1e9 / B.HBM_PEAK_GBS,
                 "decode_obs_us_per_batch": dec_obs_us, "decode_mask_us_per_batch": dec_mask_us,
                 "decode_obs_frac": (env.compact_obs_stride + 4 * 67 * v.rows * v.columns) * n / (dec_obs_us * 1e-6) / 1e9 / B.HBM_PEAK_GBS,
+                "trajectory_64_slots": {"buffer_gb": round(traj_gb, 1), "launch_us": round(traj_us, 2), "value": n / (traj_us * 1e-6),
+                                        "frac": (per_step + 4) * n / (traj_us * 1e-6) / 1e9 / B.HBM_PEAK_GBS, "verified_envs": traj_checked},
                 "games_finished_in_timed_region": games, "verified_envs": checked}
     finally:
         env.close()

@@ -404,6 +404,21 @@ class VecStrategoEnv:
         self._ring_ios = (_lib.SgxStepIO * n_sets)()
         return reports
 
+    def repeat_output_ring(self, n_entries):
+        """The ring of alloc_output_ring() as a ring of `n_entries` entries over the SAME buffers (entry i = set i mod n_sets): what a long
+        ring costs on the memory of a short one -- beyond 8 entries sgx_step_ring reads the pointers from a device table (bench.py's trajectory leg
+        times exactly this).  The buffers are rewritten every n_sets steps as before."""
+        if not self._ring:
+            raise ValueError("repeat_output_ring() needs alloc_output_ring() first")
+        n_entries, base = int(n_entries), len(self._ring)
+        if n_entries < base:
+            raise ValueError("repeat_output_ring: fewer entries than the ring has sets")
+        pos = (self._ring_pos - 1) % base              # the set holding the current position's outputs keeps that role
+        self._ring = [self._ring[i % base] for i in range(n_entries)]
+        self._ring_owners = [self._ring_owners[i % base] for i in range(n_entries)]
+        self._ring_pos = (pos + 1) % n_entries
+        self._ring_ios = (_lib.SgxStepIO * n_entries)()
+
     def _release_outputs(self):
         """Drops the env's own reference to library-owned output buffers; they are freed when the last tensor viewing them goes."""
         self._outputs_owner = None

@@ -286,6 +286,39 @@ def test_ring_of_separate_sets_every_set_equals_the_oracle(S):
         env.close(); log.close()
 
 
+def test_repeated_ring_entries_over_three_buffers_keep_the_last_three_steps():
+    """repeat_output_ring(): 21 ring entries over the three buffers of a ring of 3 (pointers in the device table) -- after a call of n steps the
+    three buffers hold the last three steps' outputs, bit for bit what a trajectory of the same games holds in those slots."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    for name, n_envs in (('barrage', 48), ('tiny', 128)):
+        seed, g0, E = 0x7AB1E, 16, 21        # (a multiple of 3: consecutive steps never share a buffer across the wrap)
+        env = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True)
+        log = VecStrategoEnv(name, n_envs, seed=seed, env_id_offset=g0, auto_reset=True)
+        for e in (env, log):
+            e.reset(); e.sample_valid_actions()
+        env.alloc_output_ring(3)
+        bufs = [o.data_ptr() for o, _, _ in env._ring]
+        env.repeat_output_ring(E)
+        assert [o.data_ptr() for o, _, _ in env._ring] == [bufs[i % 3] for i in range(E)]
+        with pytest.raises(ValueError):
+            env.repeat_output_ring(2)
+        for n_steps in (E, 7, 33):
+            first = env._ring_pos
+            env.rollout_steps(n_steps, ring=True)
+            assert env.last_launch_kind in _multi_kinds()
+            res = log.alloc_trajectory(n_steps)
+            log.rollout_trajectory(n_steps, res)
+            for back in range(3):
+                t = n_steps - 1 - back
+                o, m, _ = env._ring[(first + t) % E]
+                assert torch.equal(m, res['mask'][t]), (name, n_steps, back)
+                assert torch.equal(o.view(torch.int32), res['obs'][t].view(torch.int32)), (name, n_steps, back)
+            assert torch.equal(env.next_actions, res['actions'][n_steps - 1])
+            assert torch.equal(env.reward, res['reward'][n_steps - 1]) and torch.equal(env.done, res['done'][n_steps - 1])
+        env.close(); log.close()
+
+
 def test_config2_256_heldout_seeds_to_termination_through_the_multi_step_kernel():
     """BASELINE config 2's bit-exact check on the kernel bench.py times: 256 held-out seeds BASE_SEED + 1 .. + 256, env id 0,
     each played by multi-step launches of 64 steps into a 64-slot trajectory buffer until its first game ends -- every step's drawn action,
