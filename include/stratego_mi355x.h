@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SGX_ABI_VERSION 14
+#define SGX_ABI_VERSION 15
 #define SGX_MAX_CELLS 1024       /* rows*cols <= 1024 (largest reference variant: 15x15 = 225; the reference's StrategoProceduralEnv
                                     takes any size, penv:27-36: boards of more than 256 cells use 10-bit cell indices in the record) */
 #define SGX_PO_OBS_CHANNELS 67   /* impl:1332 */
@@ -214,6 +214,15 @@ int sgx_set_multi_step(sgx_env *h, int32_t mode);
  * per wave everywhere (A/B measurements: tools/half_wave_ab.py).  The environment variable SGX_HALF_WAVE=0|1 sets the default of handles
  * created afterwards.  No reference counterpart. */
 int sgx_set_half_wave(sgx_env *h, int32_t mode);
+/* Multi-step launches of the wave-per-game kernel (sgx_step_n / sgx_step_ring / sgx_step_traj on boards of more than 16 cells): should the waves of a
+ * workgroup -- 8 adjacent games -- meet at a barrier before every step?  Without it they drift apart within a few steps, which lets one wave's
+ * stores run under another's game logic; with MORE THAN 8 output sets / trajectory slots that drift spreads a workgroup's writes over up to 8 sets
+ * at a time, and a launch whose writes cover more memory than the address translation caches reach (from ~16 GB) runs 3-9 %
+ * faster with the waves in step (64-slot trajectory buffer of 65,536 Barrage games: 295 -> 282 us per step).  mode -1 (default): the barrier where
+ * it was measured to pay -- more than 8 sets / slots and float32 observations; 0: never; 1: in every multi-step launch (A/B runs and the parity
+ * tests).  Same results in every mode (tests/test_gpu_multi_step.py).  SGX_STEPS_BARRIER=-1|0|1 sets the default of handles created afterwards.
+ * No reference counterpart. */
+int sgx_set_steps_barrier(sgx_env *h, int32_t mode);
 
 /* Which kernel the handle's last sgx_step / sgx_observe / sgx_step_n / sgx_step_ring / sgx_rollout / sgx_expand launch was (diagnostics,
  * benchmarks that price a launch by its own bytes, tests that must not pass on another kernel): */

@@ -14,7 +14,7 @@ PO_OBS_CHANNELS = 67
 FO_OBS_CHANNELS = 79
 PO_OBS_CHANNELS_ORIGINAL = 32
 FO_OBS_CHANNELS_ORIGINAL = 33
-ABI_VERSION = 14
+ABI_VERSION = 15
 STEP_ACTIONS_1D, STEP_ALLOW_OSCILLATION, STEP_RAW_OBS, STEP_ACTIONS_POSITIONS, STEP_ORIGINAL_CHANNELS = 1, 2, 4, 8, 16
 STEP_MASK_1D, STEP_MASK_STATE_COORDS = 32, 64
 STEP_COMPACT_OBS, STEP_COMPACT_MASK = 128, 256
@@ -24,7 +24,7 @@ LAUNCH_WAVE, LAUNCH_LANE, LAUNCH_MULTI_STEP, LAUNCH_MULTI_STEP_WAVE = 0, 1, 2, 3
 # every symbol include/stratego_mi355x.h declares
 EXPORTED_SYMBOLS = (
     'sgx_abi_version', 'sgx_build_id', 'sgx_supports_geometry', 'sgx_last_error', 'sgx_num_envs', 'sgx_record_bytes', 'sgx_spatial_channels', 'sgx_num_spatial_actions',
-    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_nt_stores', 'sgx_set_lane_kernel', 'sgx_set_half_wave', 'sgx_set_multi_step', 'sgx_last_launch_kind', 'sgx_set_xcd_skew', 'sgx_set_xcd_shares', 'sgx_get_xcd_shares', 'sgx_set_setup_table', 'sgx_reset',
+    'sgx_action_size_1d', 'sgx_build_obs_lut', 'sgx_build_full_obs_lut', 'sgx_build_original_obs_lut', 'sgx_create', 'sgx_destroy', 'sgx_set_nt_stores', 'sgx_set_lane_kernel', 'sgx_set_half_wave', 'sgx_set_steps_barrier', 'sgx_set_multi_step', 'sgx_last_launch_kind', 'sgx_set_xcd_skew', 'sgx_set_xcd_shares', 'sgx_get_xcd_shares', 'sgx_set_setup_table', 'sgx_reset',
     'sgx_observe', 'sgx_time_observe', 'sgx_mem_probe', 'sgx_store_probe', 'sgx_alloc_outputs', 'sgx_set_placement_target', 'sgx_free_outputs', 'sgx_step', 'sgx_host_alloc', 'sgx_host_free', 'sgx_step_sync', 'sgx_step_n', 'sgx_step_ring', 'sgx_step_traj', 'sgx_rollout', 'sgx_compact_obs_stride', 'sgx_compact_mask_words', 'sgx_decode_obs', 'sgx_decode_mask', 'sgx_sample_valid', 'sgx_choose_actions', 'sgx_export_state', 'sgx_import_state', 'sgx_import_state_checked', 'sgx_step_states', 'sgx_set_general_states', 'sgx_copy_envs', 'sgx_expand', 'sgx_get_env_info',
 )
 
@@ -97,6 +97,8 @@ def _bind(L):
     L.sgx_set_lane_kernel.argtypes = [vp, C.c_int32]
     L.sgx_set_half_wave.restype = C.c_int
     L.sgx_set_half_wave.argtypes = [vp, C.c_int32]
+    L.sgx_set_steps_barrier.restype = C.c_int
+    L.sgx_set_steps_barrier.argtypes = [vp, C.c_int32]
     L.sgx_set_multi_step.restype = C.c_int
     L.sgx_set_multi_step.argtypes = [vp, C.c_int32]
     L.sgx_last_launch_kind.restype = C.c_int

@@ -666,6 +666,10 @@ struct WaveStepsParams {
     // mask[s] (at most WSTEPS_MAX_SETS).  2 (sgx_step_ring with MORE separate sets than fit the kernel arguments): the pointers of set s are
     // obs_tab[s] / fobs_tab[s] / mask_tab[s], tables in device memory the host filled before the launch (read with scalar loads).
     int32_t strided;
+    // != 0: the waves of a workgroup meet at a barrier before every step (sgx_set_steps_barrier: rings of more than 8 sets -- the workgroup's
+    // games then write ONE set at a time, 8 adjacent regions of it, instead of up to 8 sets; the host never sets it on a launch whose last
+    // workgroup is partly empty)
+    int32_t barrier;
     int64_t obs_slot_bytes, fobs_slot_bytes, mask_slot_bytes;
     float *const *obs_tab, *const *fobs_tab;
     uint8_t *const *mask_tab;
@@ -767,6 +771,7 @@ __global__ __launch_bounds__((64 * Geo<R_, C_, VAR>::WPB), (steps_waves_per_simd
         // (the step's reads of the parameters start here; and what a step derives from the lane -- dozens of cell / entry offsets -- is
         //  recomputed in every step like in a launch of its own, not hoisted out of the loop and spilled: 244 bytes of scratch otherwise)
         asm volatile("" : "+s"(sp), "+v"(lane_t), "+v"(slot_t));
+        if (sp->barrier) __builtin_amdgcn_s_barrier();
         steps_outputs_of(sp, set, carry);
 #ifdef SGX_MUTANT_SKIP_STORE     // test-the-tests build only (tools/mutant_check.sh): the fourth step of every launch loses its observation store
         if (t == 3) carry.obs = nullptr;

@@ -127,6 +127,7 @@ struct sgx_env {
     int multi_step_attr;         // lane_steps_kernel's dynamic-LDS attribute has been raised
     int last_kind;               // sgx_last_launch_kind: which kernel the last step / observe launch of this handle was
     int multi_step_wave;         // SGX_MULTI_STEP_WAVE: the multi-step launch of the wave-per-game kernels (steps_kernel) too
+    int steps_barrier;           // sgx_set_steps_barrier / SGX_STEPS_BARRIER: -1 auto (rings of more than 8 sets that render float32 observations), 0 never, 1 always
     int half_wave;               // SGX_HALF_WAVE: launches without an observation play two games per wave where the board allows it (Geo<R, C, 2>)
     // sgx_step_ring with more output sets than fit the kernel arguments: the sets' pointers in a device table (filled through a pinned host
     // copy; the event guards the staging buffer against being rewritten before the previous upload has run)
@@ -410,6 +411,8 @@ SGX_API int sgx_create(const sgx_config *cfg, int64_t n_envs, int device, uint64
     if (const char *e = getenv("SGX_MULTI_STEP_WAVE")) h->multi_step_wave = strcmp(e, "0") != 0;
     h->half_wave = 1;
     if (const char *e = getenv("SGX_HALF_WAVE")) h->half_wave = strcmp(e, "0") != 0;
+    h->steps_barrier = -1;
+    if (const char *e = getenv("SGX_STEPS_BARRIER")) h->steps_barrier = !strcmp(e, "0") ? 0 : !strcmp(e, "1") ? 1 : -1;
     if (const char *e = getenv("SGX_MAP")) { h->map_mode = atoi(e); if (const char *c = strchr(e, ',')) h->map_arg = atoi(c + 1); }
     const int rc_cells = cfg->rows * cfg->cols;
     {
@@ -520,6 +523,12 @@ SGX_API int sgx_set_multi_step(sgx_env *h, int32_t mode) {
 SGX_API int sgx_set_half_wave(sgx_env *h, int32_t mode) {
     if (!h || mode < 0 || mode > 1) return fail(SGX_EINVAL, "sgx_set_half_wave: mode must be 0 or 1%s");
     h->half_wave = mode;
+    return SGX_OK;
+}
+
+SGX_API int sgx_set_steps_barrier(sgx_env *h, int32_t mode) {
+    if (!h || mode < -1 || mode > 1) return fail(SGX_EINVAL, "sgx_set_steps_barrier: mode must be -1 (auto), 0 or 1%s");
+    h->steps_barrier = mode;
     return SGX_OK;
 }
 
@@ -877,6 +886,12 @@ static int launch_wave_steps(sgx_env *h, const KParams &p_in, const OutSets &set
     launch_shares(h, streaming, skew);
     const int kind = compact ? 4 : no_obs ? 8 : full ? 1 : 0;
     sp.n_sets = n_sets;
+    // A barrier per step between the waves of a workgroup: with more than 8 sets / slots (the launch's writes cover more memory than the address
+    // translation caches reach: DESIGN.md section 4.4) the workgroup's games then write one set at a time -- 64-slot trajectory buffer: 10x10
+    // 295.0 -> 282.1 us per step, 8x8 202.5 -> 197.1, 6x6 229.2 -> 208.0, 15x15 205.4 -> 193.7 (in-process A/B, tools/traj_lib_ab.py) -- while short
+    // rings gain nothing (10x10 ring of 3: 243.6 -> 242.1) and launches that render no float32 observation lose 3-8 % (compact, mask-only,
+    // logic-only; 5x5 and 15x15 in place).  Never on a launch with a partly empty last workgroup (its missing waves have left the kernel).
+    const bool want_barrier = h->steps_barrier > 0 || (h->steps_barrier < 0 && n_sets > WSTEPS_MAX_SETS && (kind == 0 || kind == 1));
     for (int32_t done = 0; done < n_steps; ) {
         const int32_t now = n_steps - done > SGX_STEPS_MAX_PER_LAUNCH ? SGX_STEPS_MAX_PER_LAUNCH : n_steps - done;
         const int32_t set = (int32_t)(((int64_t)first_set + done) % n_sets);
@@ -892,6 +907,7 @@ static int launch_wave_steps(sgx_env *h, const KParams &p_in, const OutSets &set
         using G_ = Geo<R, C>;                                                                              \
         const unsigned grid = shares_for(p, (p.n_envs - p.env_first + G_::WPB * G_::GPW - 1) / (G_::WPB * G_::GPW), skew); \
         sp.k = p;                                                                                          \
+        sp.barrier = want_barrier && (p.n_envs - p.env_first) % (G_::WPB * G_::GPW) == 0;                  \
         steps_kernel<R, C, KIND><<<grid, 64 * G_::WPB, 0, (hipStream_t)stream>>>(sp);                      \
     } while (0)
 #define CALL_WSTEPS(R, C)                                                                                  \
@@ -905,6 +921,7 @@ static int launch_wave_steps(sgx_env *h, const KParams &p_in, const OutSets &set
                     using H_ = Geo<R, C, 2>;                                                               \
                     const unsigned grid = shares_for(p, (p.n_envs - p.env_first + H_::WPB * H_::GPW - 1) / (H_::WPB * H_::GPW), skew); \
                     sp.k = p;                                                                              \
+                    sp.barrier = want_barrier && (p.n_envs - p.env_first) % (H_::WPB * H_::GPW) == 0;      \
                     steps_kernel<R, C, 8, 2><<<grid, 64 * H_::WPB, 0, (hipStream_t)stream>>>(sp);           \
                     half_ = true;                                                                          \
                 }                                                                                          \

@@ -206,6 +206,12 @@ class VecStrategoEnv:
         m = -1 if mode in ('auto', None) else int(bool(mode))
         _lib.check(self._L.sgx_set_lane_kernel(self._h, m), self._L)
 
+    def set_steps_barrier(self, mode=-1):
+        """Multi-step launches of the wave-per-game kernel: a barrier between the 8 waves of a workgroup before every step?  -1 (default) = where
+        it pays (more than 8 output sets / trajectory slots, float32 observations), 0 = never, 1 = always (sgx_set_steps_barrier).  Results
+        are identical in every mode."""
+        _lib.check(self._L.sgx_set_steps_barrier(self._h, int(mode)), self._L)
+
     def set_half_wave(self, on=True):
         """Launches without an observation (mask-only / logic-only steps and rollouts, search expansion) on boards of 33 .. 128 cells: True
         (default) = two games per wave, False = one (sgx_set_half_wave).  Results are identical either way."""

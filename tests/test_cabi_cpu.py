@@ -27,7 +27,7 @@ def test_header_symbols_all_exported(lib):
     assert declared == sorted(_lib.EXPORTED_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.sgx_abi_version() == _lib.ABI_VERSION == 14
+    assert lib.sgx_abi_version() == _lib.ABI_VERSION == 15
 
 
 def test_struct_sizes_match_header():

@@ -65,6 +65,61 @@ def test_multi_step_launch_equals_one_launch_per_step(name, n, T):
     a.close(); b.close()
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('name,n', [('barrage', 1024), ('standard', 512), ('octa_barrage', 768), ('medium', 1024), ('fives', 1024), ('standard2', 64),
+                                    ('barrage', 1021)])
+def test_barrier_per_step_leaves_the_same_results(name, n):
+    """sgx_set_steps_barrier: the waves of a workgroup in step (1 = in every multi-step launch; -1 = the default: with more than 8 output sets and
+    float32 observations) against waves that drift (0) -- in place, into a ring of 12 sets, into a 20-slot trajectory buffer, with both
+    observations, with compact outputs and without any output: the same bytes.  (n = 1021: the last workgroup is partly empty -- the library
+    leaves the barrier out of that launch, whatever the mode.)"""
+    import torch
+    from stratego_env_amd import _lib
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    for kw in ({}, {'full_obs': True}, {'compact_outputs': True}):
+        envs = []
+        for mode in (0, 1, -1):
+            e = VecStrategoEnv(name, n, seed=99, env_id_offset=7, auto_reset=True, **kw)
+            e.set_steps_barrier(mode)
+            e.reset(); e.sample_valid_actions()
+            envs.append(e)
+        base = envs[0]
+        for e in envs:
+            e.rollout_steps(33)
+            assert e.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE
+        for e in envs[1:]:
+            _same(base, e, (name, kw, 'in place'))
+        for e in envs:
+            e.alloc_output_ring(12)
+            e.rollout_steps(29, ring=True)
+            assert e.last_launch_kind == _lib.LAUNCH_MULTI_STEP_WAVE
+        for e in envs[1:]:
+            for (oa, ma, fa), (ob, mb, fb) in zip(base._ring, e._ring):
+                assert torch.equal(oa, ob) and torch.equal(ma, mb) and (fa is None or torch.equal(fa, fb)), (name, kw, 'ring of 12')
+            _same(base, e, (name, kw, 'ring of 12'))
+        trajs = []
+        for e in envs:
+            t = e.alloc_trajectory(20)
+            e.rollout_trajectory(27, t)
+            trajs.append(t)
+        for t in trajs[1:]:
+            for k in trajs[0]:
+                assert torch.equal(trajs[0][k].view(torch.uint8), t[k].view(torch.uint8)), (name, kw, 'trajectory', k)
+        for e in envs:
+            e.rollout_steps(13, emit_obs=False, emit_mask=False)
+            e.rollout_steps(3)
+        for e in envs[1:]:
+            _same(base, e, (name, kw, 'after a logic-only rollout'))
+        for e in envs:
+            e.close()
+    with pytest.raises(Exception):
+        bad = VecStrategoEnv(name, 8, seed=1)
+        try:
+            bad.set_steps_barrier(2)
+        finally:
+            bad.close()
+
+
 def test_multi_step_launch_in_chunks_and_against_the_oracle():
     """600 steps = three launches (256 + 256 + 88); sampled games against the oracle's digests of the last step and its counters."""
     import torch

@@ -49,7 +49,8 @@ def main():
                      ('bench_default_run3.json', 'default_bench_line_run3.json'),
                      ('multi_step_ab.log', 'multi_step_ab_plain_buffers.log'), ('ring_size_probe_tuned.log', 'ring_size_probe_tuned.log'),
                      ('half_wave_ab.log', 'half_wave_ab.log'), ('noobs_small_ab.log', 'noobs_small_ab.log'), ('spread_probe.log', 'spread_probe_final.log'),
-                     ('facade_breakdown.log', 'facade_breakdown.log'), ('clock_probe.log', 'clock_probe.log'), ('soak_general_states.log', 'soak_general_states.log'), ('soak_trajectory.log', 'soak_trajectory.log')):
+                     ('facade_breakdown.log', 'facade_breakdown.log'), ('clock_probe.log', 'clock_probe.log'), ('soak_general_states.log', 'soak_general_states.log'), ('soak_trajectory.log', 'soak_trajectory.log'),
+                     ('ring_footprint_probe.log', 'ring_footprint_probe.log'), ('ring_chunk_probe.log', 'ring_chunk_probe.log')):
         if os.path.exists(os.path.join(out, src)):
             shutil.copy(os.path.join(out, src), 'profiles/%s_%s' % (rnd, dst))
     for tag in ('procedural', 'kstep_micro'):

@@ -38,4 +38,6 @@ python tools/noobs_small_ab.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/noobs_sm
 python tools/r06_spread_probe.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/spread_probe.log
 python tools/facade_breakdown.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/facade_breakdown.log
 python tools/clock_probe.py 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/clock_probe.log
+python -W ignore tools/ring_footprint_probe.py 64 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/ring_footprint_probe.log
+python -W ignore tools/ring_chunk_probe.py 64 2>&1 | grep -v "^/opt" > gpurun_out/$OUT/ring_chunk_probe.log
 python tools/soak_general_states.py 40 > gpurun_out/$OUT/soak_general_states.log 2>&1; tail -1 gpurun_out/$OUT/soak_general_states.log
