@@ -148,6 +148,20 @@ def trajectory_leg(B, rk, args, version='barrage', n=65536, slots=64, passes=3, 
         launch_s = e0.elapsed_time(e1) / 1e3 / steps
         assert int(traj['invalid_action'].sum()) == 0
         checked = B.verify_against_oracle(env, version, verify) if verify else 0
+        # the same launch with the workgroups' waves left to drift (sgx_set_steps_barrier 0; the default keeps them in step beyond 8 slots)
+        env.set_steps_barrier(0)
+        env.rollout_trajectory(slots, traj)
+        d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        d0.record()
+        for _ in range(passes):
+            env.rollout_trajectory(slots, traj)
+        d1.record()
+        torch.cuda.synchronize()
+        env.set_steps_barrier(-1)
+        env.bench_steps_played += (passes + 1) * slots
+        B.MULTI_STEP_TALLY["launches"] += passes + 1
+        B.MULTI_STEP_TALLY["steps"] += (passes + 1) * slots
+        drift_us = d0.elapsed_time(d1) * 1e3 / steps
         # The strided code path against the pointer-per-set path on THE SAME memory: a one-slot "trajectory" that is the env's own output set
         # (in place) against rollout_steps into that set -- what the slot arithmetic costs, with the allocation lottery taken out
         del traj
@@ -227,11 +241,13 @@ def trajectory_leg(B, rk, args, version='barrage', n=65536, slots=64, passes=3, 
                 "one_launch": kind == _lib.LAUNCH_MULTI_STEP_WAVE or kind == _lib.LAUNCH_MULTI_STEP, "launch_kind": kind,
                 "value": n * steps / elapsed, "unit": "env steps/s", "steps": steps, "launch_us": launch_s * 1e6,
                 "b_min_bytes_per_step": per_step, "frac": per_step * n / launch_s / 1e9 / B.HBM_PEAK_GBS,
+                "launch_us_with_drifting_waves (sgx_set_steps_barrier 0)": round(drift_us, 2),
                 "same_memory_in_place_us_per_step": {"pointer_per_set_path (sgx_step_n)": round(us_ptr, 2), "strided_slot_path (sgx_step_traj, 1 slot)": round(us_strided, 2)},
                 "ring_of_separately_placed_sets": ring,
                 "bound": "address translation, not DRAM: the same launch runs at 8.2 TB/s while the sets it writes cover <= 16 GB and falls to 6.9 TB/s "
                          "from 64 GB on, whatever the placement class of each set (tools/ring_footprint_probe.py); under it GRBM_UTCL2_BUSY is 41 % of the "
-                         "cycles against 0.3 %, TCP_UTCL1_TRANSLATION_MISS 196 x (profiles/r06_ring_footprint_counters.txt); DRAM-side counters equal",
+                         "cycles against 0.3 %, TCP_UTCL1_TRANSLATION_MISS 196 x (profiles/r06_ring_footprint_counters.txt); DRAM-side counters equal.  Beyond 8 sets "
+                         "the waves of a workgroup are kept in step (sgx_set_steps_barrier), which recovers 3-5 % of it",
                 "verified_envs": checked, "verified_steps": env.bench_steps_played}
     finally:
         env.close()
