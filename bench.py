@@ -808,7 +808,7 @@ def line_summary(out):
         s[name] = pick(w, "value", "launch_us", "frac", "verified_envs")
         if w and w.get("rotating_outputs"):
             s[name]["ring_of_3"] = pick(w["rotating_outputs"], "value", "launch_us", "frac_dram")
-    s["in_place"] = pick(c.get("in_place"), "value", "launch_us", "rate_over_spec_peak")
+    s["in_place"] = pick(c.get("in_place"), "value", "launch_us", "rate_over_spec_peak", "one_launch_per_step")
     s["trajectory"] = pick(c.get("trajectory"), "slots", "value", "launch_us", "frac", "one_launch", "verified_envs")
     if s["trajectory"] and ((c.get("trajectory") or {}).get("ring_of_separately_placed_sets") or {}).get("value"):
         s["trajectory"]["ring_of_separately_placed_sets"] = pick(c["trajectory"]["ring_of_separately_placed_sets"], "sets", "value", "launch_us", "frac", "one_launch", "same_memory")
@@ -904,6 +904,14 @@ def run_rank(args):      # noqa: C901
                     "rate_is": "memory side including the 256 MiB Infinity Cache and whatever else favours rewriting the same lines; not a DRAM fraction",
                     "verified_envs": verify_against_oracle(env, args.version, min(args.verify_envs, 8), both=args.full_obs) if args.verify_envs else 0,
                     "verified_steps": env.bench_steps_played}
+        if fused > 1:
+            # ... and as K launches of the per-step kernel into the same tensors: what env.step() with a policy between the steps does by default
+            env.set_multi_step(False)
+            e5, d5, _, _, inv5 = time_workload(rk, env, args.steps, args.warmup)
+            env.set_multi_step(True)
+            assert inv5 == 0
+            in_place["one_launch_per_step"] = {"value": total * args.steps / e5, "launch_us": d5 / args.steps * 1e3,
+                                               "rate_over_spec_peak": b_min(v, args.full_obs, rec_bytes) * n / (d5 / 1e3 / args.steps) / 1e9 / HBM_PEAK_GBS}
     if 'two_chains' in legs_on:
         # The same K steps (in place) with the batch split into two ranges of games whose launches overlap (sgx_rollout, chains = 2)
         e2, d2, _, _, inv2 = time_workload(rk, env, args.steps, args.warmup, False, 2)
