@@ -792,11 +792,23 @@ def scaling_leg(rk, args, per_gpu, total_envs, label, output_sets=1):
             torch.cuda.empty_cache()
 
 
+def optional_leg(fn, *a, **kw):
+    """One of the line's EXTRA legs (other workloads, compact outputs, trajectory buffer, facade).  A leg that cannot run on this box -- out of
+    device memory next to another tenant, say -- reports {"failed": ...} and leaves the headline its line; a leg whose outputs differ from the
+    oracle still ends the run (verify_against_oracle raises SystemExit, which is not caught here)."""
+    try:
+        return fn(*a, **kw)
+    except Exception as e:      # noqa: BLE001
+        import torch
+        torch.cuda.empty_cache()
+        return {"failed": "%s: %s" % (type(e).__name__, str(e)[:300]), "workload": "%s%r" % (fn.__name__, tuple(x for x in a[3:]))}
+
+
 def line_summary(out):
     """The figures of the legs once more, as the LAST key of the line: whoever keeps only the tail of this (long) line still sees BASELINE
     configs 3 and 4, config 5's per-GPU size, the trajectory and facade legs and the store-only probe next to the headline."""
     def pick(d, *keys):
-        return {k: (round(d[k], 4) if isinstance(d.get(k), float) else d.get(k)) for k in keys if d and k in d} if d else None
+        return {k: (round(d[k], 4) if isinstance(d.get(k), float) else d.get(k)) for k in keys + ("failed",) if d and k in d} if d else None
     c, rf = out.get("config") or {}, out.get("roofline") or {}
     ow = c.get("other_workloads") or []
     names = ("config3_standard_262144", "config4_micro_65536", "both_observations_65536", "config5_per_gpu_size_barrage_262144")
@@ -1015,15 +1027,16 @@ def run_rank(args):      # noqa: C901
         if 'other_workloads' in legs_on:
             if 'consumer_in_loop' in legs_on:
                 out["config"]["consumer_in_loop"] = bench_legs.consumer_leg(sys.modules[__name__], rk, args)
-            out["config"]["other_workloads"] = [bench_legs.other_workload(sys.modules[__name__], rk, args, 'standard', 262144, chains=2),
-                                                bench_legs.other_workload(sys.modules[__name__], rk, args, 'micro', 65536, chains=2, rotate_sets=args.rotate_sets),
-                                                bench_legs.other_workload(sys.modules[__name__], rk, args, 'barrage', 65536, full_obs=True),
+            B = sys.modules[__name__]
+            out["config"]["other_workloads"] = [optional_leg(bench_legs.other_workload, B, rk, args, 'standard', 262144, chains=2),
+                                                optional_leg(bench_legs.other_workload, B, rk, args, 'micro', 65536, chains=2, rotate_sets=args.rotate_sets),
+                                                optional_leg(bench_legs.other_workload, B, rk, args, 'barrage', 65536, full_obs=True),
                                                 # BASELINE config 5's per-GPU size on ONE GPU: the G = 1 anchor of the 1 / 2 / 4 / 8 curve
-                                                bench_legs.other_workload(sys.modules[__name__], rk, args, 'barrage', GAMES_PER_GPU_MULTI)]
-            out["config"]["compact_outputs"] = bench_legs.compact_leg(sys.modules[__name__], rk, args)
-            out["config"]["trajectory"] = bench_legs.trajectory_leg(sys.modules[__name__], rk, args, slots=args.trajectory_slots) if 'trajectory' in legs_on else None
+                                                optional_leg(bench_legs.other_workload, B, rk, args, 'barrage', GAMES_PER_GPU_MULTI)]
+            out["config"]["compact_outputs"] = optional_leg(bench_legs.compact_leg, B, rk, args)
+            out["config"]["trajectory"] = optional_leg(bench_legs.trajectory_leg, B, rk, args, slots=args.trajectory_slots) if 'trajectory' in legs_on else None
         if 'facade_n1' in legs_on:
-            out["config"]["facade_n1"] = bench_legs.facade_leg(sys.modules[__name__])
+            out["config"]["facade_n1"] = optional_leg(bench_legs.facade_leg, sys.modules[__name__])
         if 'live_traffic' in legs_on:
             # the counter bytes of the headline's kernel, measured now (after every timed region): two children under rocprofv3 --pmc
             rf = out["roofline"]

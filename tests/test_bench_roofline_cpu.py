@@ -1,5 +1,6 @@
 """bench.py's roofline object: every fraction is priced on B_min, the packed layout's own byte minimum per env step -- never on a
 count that overstates what the kernel moves -- and the SURVEY 8d formula only appears as a labelled comparison."""
+import pytest
 import types
 
 import bench
@@ -75,3 +76,22 @@ def test_placement_budgets_are_capped_by_free_memory(monkeypatch):
     assert bench.placement_budgets(args, 8 << 30) == (5 << 30, 5 << 30)           # 40 GiB / 8 ranks
     args.devices = '0,1,2,3,4,5,6,7'
     assert bench.ranks_sharing_device(args) == 1
+
+
+def test_an_extra_leg_that_cannot_run_leaves_the_line_but_a_parity_failure_does_not():
+    """bench.optional_leg: resource failures of the extra legs become {"failed": ...} (and show in the summary at the end of the line); the
+    SystemExit verify_against_oracle raises on a mismatch passes through."""
+    import bench
+
+    def no_memory(*a, **k):
+        raise RuntimeError("HIP out of memory")
+
+    def mismatch(*a, **k):
+        raise SystemExit("bench.py: env 3 differs from the CPU oracle")
+    leg = bench.optional_leg(no_memory, None, None, None, 'standard', 262144)
+    assert leg["failed"].startswith("RuntimeError: HIP out of memory") and "262144" in leg["workload"]
+    with pytest.raises(SystemExit):
+        bench.optional_leg(mismatch, None, None, None)
+    out = {"value": 1.0, "roofline": {}, "config": {"other_workloads": [leg] * 4, "trajectory": leg, "compact_outputs": None, "facade_n1": None}}
+    s = bench.line_summary(out)
+    assert s["config3_standard_262144"] == {"failed": leg["failed"]} and s["trajectory"] == {"failed": leg["failed"]}
