@@ -216,12 +216,12 @@ int sgx_set_multi_step(sgx_env *h, int32_t mode);
 int sgx_set_half_wave(sgx_env *h, int32_t mode);
 /* Multi-step launches of the wave-per-game kernel (sgx_step_n / sgx_step_ring / sgx_step_traj on boards of more than 16 cells): should the waves of a
  * workgroup -- 8 adjacent games -- meet at a barrier before every step?  Without it they drift apart within a few steps, which lets one wave's
- * stores run under another's game logic; with MORE THAN 8 output sets / trajectory slots that drift spreads a workgroup's writes over up to 8 sets
- * at a time, and a launch whose writes cover more memory than the address translation caches reach (from ~16 GB) runs 3-9 %
+ * stores run under another's game logic; on a LONG ring or trajectory buffer that drift spreads a workgroup's writes over up to 8 sets at a time,
+ * and a launch whose resident waves cycle through more sets than the address translation caches hold pages for runs 1-7 %
  * faster with the waves in step (64-slot trajectory buffer of 65,536 Barrage games: 295 -> 282 us per step).  mode -1 (default): the barrier where
- * it was measured to pay -- more than 8 sets / slots and float32 observations; 0: never; 1: in every multi-step launch (A/B runs and the parity
- * tests).  Same results in every mode (tests/test_gpu_multi_step.py).  SGX_STEPS_BARRIER=-1|0|1 sets the default of handles created afterwards.
- * No reference counterpart. */
+ * it was measured to pay -- float32 observations, one game per wave (36 .. 225 cells), from 9 sets / slots on 10x10 and from 16 elsewhere; 0: never;
+ * 1: in every multi-step launch (A/B runs and the parity tests).  Same results in every mode (tests/test_gpu_multi_step.py).
+ * SGX_STEPS_BARRIER=-1|0|1 sets the default of handles created afterwards.  No reference counterpart. */
 int sgx_set_steps_barrier(sgx_env *h, int32_t mode);
 
 /* Which kernel the handle's last sgx_step / sgx_observe / sgx_step_n / sgx_step_ring / sgx_rollout / sgx_expand launch was (diagnostics,

@@ -127,7 +127,7 @@ struct sgx_env {
     int multi_step_attr;         // lane_steps_kernel's dynamic-LDS attribute has been raised
     int last_kind;               // sgx_last_launch_kind: which kernel the last step / observe launch of this handle was
     int multi_step_wave;         // SGX_MULTI_STEP_WAVE: the multi-step launch of the wave-per-game kernels (steps_kernel) too
-    int steps_barrier;           // sgx_set_steps_barrier / SGX_STEPS_BARRIER: -1 auto (rings of more than 8 sets that render float32 observations), 0 never, 1 always
+    int steps_barrier;           // sgx_set_steps_barrier / SGX_STEPS_BARRIER: -1 auto (long rings that render float32 observations: launch_wave_steps), 0 never, 1 always
     int half_wave;               // SGX_HALF_WAVE: launches without an observation play two games per wave where the board allows it (Geo<R, C, 2>)
     // sgx_step_ring with more output sets than fit the kernel arguments: the sets' pointers in a device table (filled through a pinned host
     // copy; the event guards the staging buffer against being rewritten before the previous upload has run)
@@ -886,12 +886,21 @@ static int launch_wave_steps(sgx_env *h, const KParams &p_in, const OutSets &set
     launch_shares(h, streaming, skew);
     const int kind = compact ? 4 : no_obs ? 8 : full ? 1 : 0;
     sp.n_sets = n_sets;
-    // A barrier per step between the waves of a workgroup: with more than 8 sets / slots (the launch's writes cover more memory than the address
-    // translation caches reach: DESIGN.md section 4.4) the workgroup's games then write one set at a time -- 64-slot trajectory buffer: 10x10
-    // 295.0 -> 282.1 us per step, 8x8 202.5 -> 197.1, 6x6 229.2 -> 208.0, 15x15 205.4 -> 193.7 (in-process A/B, tools/traj_lib_ab.py) -- while short
-    // rings gain nothing (10x10 ring of 3: 243.6 -> 242.1) and launches that render no float32 observation lose 3-8 % (compact, mask-only,
-    // logic-only; 5x5 and 15x15 in place).  Never on a launch with a partly empty last workgroup (its missing waves have left the kernel).
-    const bool want_barrier = h->steps_barrier > 0 || (h->steps_barrier < 0 && n_sets > WSTEPS_MAX_SETS && (kind == 0 || kind == 1));
+    // A barrier per step between the waves of a workgroup: on a long ring or trajectory buffer (the resident waves cycle through more sets than
+    // the address translation caches hold pages for: DESIGN.md section 4.4) the workgroup's games then write one set at a time.  In-process A/B
+    // of the two modes, drifting -> in step (tools/barrier_footprint_ab.py; profiles/r06_barrier_boards_ab.log, r06_barrier_footprint_ab.log):
+    //   10x10  trajectory buffer of 12 / 16 / 64 slots -1.1 / -1.7 / -4.1 %, rings of 12 / 16 / 24 / 32 / 64 separate sets -1.1 / -1.9 / -2.9 / -3.3 /
+    //          -4.2 %, ring of 3 (tuned buffers) 243.6 -> 242.1 us
+    //   6x6    16 / 32 / 64 slots -4.2 / -6.3 / -9.3 %, rings of 12 / 24 / 32 / 64 sets +1.7 / +0.1 / -7.2 / -7.3 %
+    //   8x8    16 / 32 / 64 slots -2.2 / -2.4 / -2.8 %, rings of 12 ... 64 sets 0.0 ... -0.9 %
+    //   15x15  16 / 32 / 64 slots -2.0 / -2.3 / -2.4 %, rings of 24 ... 64 sets +1.0 ... -0.2 %, of 8 / 12 sets +2 ... +3 %
+    //   5x5 (two games per wave) +3 ... +9 % on rings, -4 / +6 % on 64 slots by batch size;  launches that render no float32 observation
+    //   (compact, mask-only, logic-only) +3 ... +8 %
+    // so: float32 observations, one game per wave (36 .. 225 cells), from 9 sets / slots on 10x10 and from 16 elsewhere.  Never on a launch with a
+    // partly empty last workgroup (its missing waves have left the kernel).
+    const int cells = h->cfg.rows * h->cfg.cols;
+    const bool pays = (kind == 0 || kind == 1) && cells >= 36 && cells <= 225 && n_sets >= (cells == 100 ? WSTEPS_MAX_SETS + 1 : 16);
+    const bool want_barrier = h->steps_barrier > 0 || (h->steps_barrier < 0 && pays);
     for (int32_t done = 0; done < n_steps; ) {
         const int32_t now = n_steps - done > SGX_STEPS_MAX_PER_LAUNCH ? SGX_STEPS_MAX_PER_LAUNCH : n_steps - done;
         const int32_t set = (int32_t)(((int64_t)first_set + done) % n_sets);

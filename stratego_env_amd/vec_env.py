@@ -208,7 +208,7 @@ class VecStrategoEnv:
 
     def set_steps_barrier(self, mode=-1):
         """Multi-step launches of the wave-per-game kernel: a barrier between the 8 waves of a workgroup before every step?  -1 (default) = where
-        it pays (more than 8 output sets / trajectory slots, float32 observations), 0 = never, 1 = always (sgx_set_steps_barrier).  Results
+        it pays (long rings / trajectory buffers of float32 observations: include/stratego_mi355x.h), 0 = never, 1 = always (sgx_set_steps_barrier).  Results
         are identical in every mode."""
         _lib.check(self._L.sgx_set_steps_barrier(self._h, int(mode)), self._L)
 
