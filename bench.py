@@ -467,8 +467,9 @@ def make_env(version, n, first, device_index, full_obs=False, compact=False):
     if DRY_RUN:
         return _StubEnv(first, n)
     from stratego_env_amd.vec_env import VecStrategoEnv
+    # (placement='plain': the line reports the plain first allocation as frac_untuned and runs its own, larger search -- place_outputs)
     env = VecStrategoEnv(version, n, device=device_index, seed=BASE_SEED, env_id_offset=first, auto_reset=True, full_obs=full_obs,
-                         compact_outputs=compact)
+                         compact_outputs=compact, placement='plain')
     env.reset()
     env.bench_steps_played = 0               # rollout steps since reset(): what the oracle replays in verify_against_oracle
     return env

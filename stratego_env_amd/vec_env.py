@@ -17,6 +17,7 @@ buffers and the stream.  Outputs are written in place into preallocated tensors:
 There is no CPU fallback: construction fails if the HIP library is missing or no GPU is visible.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -72,15 +73,25 @@ def _wrap_device(ptr, shape, dtype, device, owner):
 class VecStrategoEnv:
     def __init__(self, version='barrage', num_envs=1, device=0, seed=0, env_id_offset=0, human_inits=None,
                  auto_reset=False, final_obs=False, full_obs=False, lib_path=None, obs_channel_mode='extended', compact_outputs=False,
-                 outputs=True):
+                 outputs=True, placement=None):
         """human_inits: None = use the Gravon table when the variant has one (util.py:301-319), False = uniformly
         random back-row placement (util.py:33-53), True = require the table.
         obs_channel_mode: 'extended' (67 / 79 one-hot channels) or 'original' (the deprecated 32 / 33 value channels,
         maenv:67, 368-375).
         outputs=False: a pool of game records without observation / mask tensors (`obs`, `mask`, `fobs` are None): what
-        snapshot() and the packed search pools of procedural_env hold -- 0.5 KB per Barrage game instead of 31 KB."""
+        snapshot() and the packed search pools of procedural_env hold -- 0.5 KB per Barrage game instead of 31 KB.
+        placement: 'search' (default) = the first reset() of all envs moves obs / mask / fobs into library-owned buffers picked by the bounded
+        placement search (tune_placement(): ~10 ms, at most min(8 GiB, a quarter of the free device memory) held beyond the buffers for a
+        moment; which physical memory an allocation gets decides 0.76-0.93 against 0.95-1.04 of the roofline) -- only
+        where there are placement classes (observations of more than 300 MB, not compact); 'plain' = torch.empty tensors, always.  None =
+        the environment variable SGX_PLACEMENT, else 'search'."""
         if obs_channel_mode not in ('extended', 'original'):
             raise ValueError("obs_channel_mode must be 'extended' or 'original'")
+        placement = placement if placement is not None else (os.environ.get('SGX_PLACEMENT') or 'search')
+        if placement not in ('plain', 'search'):
+            raise ValueError("placement must be 'plain' or 'search' (SGX_PLACEMENT=%r)" % placement)
+        self._placement_pending = placement == 'search'
+        self.placement_report = None         # what the search of placement='search' saw (tune_placement's report)
         # compact_outputs=True (opt-in): `obs` is uint8 [N, compact_obs_stride] -- the 4-bit codes the float32 observation decodes from --
         # and `mask` int32 [N, compact_mask_words] -- one bit per action: 1/8 of the bytes per step.  decode_obs() / decode_mask() give the
         # contract tensors, byte-identical to a non-compact step (include/stratego_mi355x.h: SGX_STEP_COMPACT_OBS).
@@ -258,6 +269,15 @@ class VecStrategoEnv:
         with torch.cuda.device(self.device):
             _lib.check(self._L.sgx_reset(self._h, _ptr(sel), _ptr(m1), _ptr(m2), self._stream()), self._L)
         self._next_actions_fresh = False
+        if self._placement_pending and sel is None:
+            # placement='search': once, now that every record holds a game the trial launches can render
+            self._placement_pending = False
+            if self.has_outputs and not self.compact and self.obs.numel() * 4 > 300e6:
+                free, _ = torch.cuda.mem_get_info(self.device)
+                try:
+                    self.placement_report = self.tune_placement(max_extra_bytes=min(8 << 30, free // 4))
+                except RuntimeError as e:          # (no memory for candidates next to another tenant: the plain tensors stay)
+                    self.placement_report = {'failed': str(e)}
         return self.observe()
 
     def observe(self, raw=False, emit_obs=True, emit_mask=True):

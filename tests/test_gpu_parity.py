@@ -417,6 +417,53 @@ def test_placement_target_for_ring_sets():
     twin.close()
 
 
+def test_placement_search_as_a_constructor_argument(monkeypatch):
+    """VecStrategoEnv(placement='search'), the default (SGX_PLACEMENT=plain switches it off): the first full reset() moves the outputs into
+    buffers from the bounded search -- where there are placement classes (more than 300 MB of observations) -- and nothing else changes;
+    small batches, compact outputs and record pools stay as they are; unknown values are refused."""
+    import torch
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    n = 12288                                                     # 329 MB of observations
+    plain = VecStrategoEnv('barrage', n, seed=21, auto_reset=True, placement='plain')
+    env = VecStrategoEnv('barrage', n, seed=21, auto_reset=True)                    # 'search' is the default
+    assert env.placement_report is None and env._outputs is None
+    plain.reset(); env.reset()
+    assert env.placement_report and len(env.placement_report['obs']) >= 1 and env.obs.data_ptr() == env._outputs.obs_dev
+    assert env.placement_peak_extra_bytes <= 8 << 30
+    first = env.obs.data_ptr()
+    for e in (plain, env):
+        e.rollout_steps(40)
+        e.reset(env_select=(torch.arange(n, device=e.device) % 3 == 0))      # (a partial reset never searches)
+        e.rollout_steps(9)
+        e.reset()
+        e.rollout_steps(5)
+    assert env.obs.data_ptr() == first and plain._outputs is None and plain.placement_report is None      # searched once; 'plain' never
+    assert torch.equal(env.obs, plain.obs) and torch.equal(env.mask, plain.mask) and torch.equal(env.env_info(), plain.env_info())
+    env.close(); plain.close()
+    monkeypatch.setenv('SGX_PLACEMENT', 'plain')
+    off = VecStrategoEnv('barrage', n, seed=1)
+    off.reset()
+    assert off.placement_report is None and off._outputs is None               # the environment variable switches the default off
+    off.close()
+    monkeypatch.setenv('SGX_PLACEMENT', 'search')
+    small = VecStrategoEnv('barrage', 512, seed=1)
+    small.reset()
+    assert small.placement_report is None and small._outputs is None           # nothing to search for below 300 MB
+    small.close()
+    compact = VecStrategoEnv('barrage', n, seed=1, compact_outputs=True)
+    compact.reset()
+    assert compact.placement_report is None
+    compact.close()
+    pool = VecStrategoEnv('barrage', 4096, seed=1, outputs=False)
+    pool.close()
+    monkeypatch.setenv('SGX_PLACEMENT', 'fastest')
+    with pytest.raises(ValueError):
+        VecStrategoEnv('barrage', 8, seed=1)
+    monkeypatch.delenv('SGX_PLACEMENT')
+    with pytest.raises(ValueError):
+        VecStrategoEnv('barrage', 8, seed=1, placement='auto')
+
+
 def test_tune_placement_keeps_outputs():
     """Placement trials only swap which allocation the outputs live in."""
     from stratego_env_amd.vec_env import VecStrategoEnv
