@@ -349,10 +349,11 @@ class VecStrategoEnv:
         """Hash of the sources the loaded library was compiled from (sgx_build_id)."""
         return self._L.sgx_build_id().decode('ascii', 'replace')
 
-    def alloc_output_ring(self, n_sets, tune=False, max_extra_bytes=8 << 30, trials=None, wide_extra_bytes=0):
+    def alloc_output_ring(self, n_sets, tune=None, max_extra_bytes=8 << 30, trials=None, wide_extra_bytes=0):
         """A ring of `n_sets` output sets (obs, mask[, fobs]) for rollout_steps(..., ring=True): step i writes set i mod n_sets -- a
         rollout into a trajectory buffer that keeps the last n_sets steps (sgx_step_ring).  Set 0 is the env's current set; the others
-        are torch.empty tensors or, with tune=True, library-owned buffers from the placement trial (one sgx_alloc_outputs each; a set
+        are torch.empty tensors or, with tune=True (the default, tune=None, where the env's own set came from the placement search --
+        placement='search' or tune_placement()), library-owned buffers from the placement trial (one sgx_alloc_outputs each; a set
         whose search ends more than 3 % above the env's own set is searched once more over `wide_extra_bytes`, like tune_placement's
         wide pass, and the faster of the two is kept; if the extra sets turn out more than 3 % faster than the env's own set, that one
         is searched once more against them).  Returns the per-set trial reports (None for untuned sets and for set 0 unless it was
@@ -360,6 +361,8 @@ class VecStrategoEnv:
         n_sets = int(n_sets)
         if n_sets < 1:
             raise ValueError("n_sets must be >= 1")
+        if tune is None:
+            tune = getattr(self, '_outputs', None) is not None and not self.compact
         # every extra set should be as fast as the env's own: the searches go on until a candidate is within 3 % of what the first
         # search kept (sgx_set_placement_target), inside the same budget
         target = 0.0

@@ -438,6 +438,11 @@ def test_placement_search_as_a_constructor_argument(monkeypatch):
         e.reset()
         e.rollout_steps(5)
     assert env.obs.data_ptr() == first and plain._outputs is None and plain.placement_report is None      # searched once; 'plain' never
+    # the extra sets of a ring follow the env's own set: searched where that one was, plain tensors otherwise
+    reps, plain_reps = env.alloc_output_ring(3), plain.alloc_output_ring(3)
+    assert all(r and len(r['obs']) >= 1 for r in reps[1:]) and plain_reps == [None, None, None]
+    for e in (plain, env):
+        e.rollout_steps(11, ring=True)
     assert torch.equal(env.obs, plain.obs) and torch.equal(env.mask, plain.mask) and torch.equal(env.env_info(), plain.env_info())
     env.close(); plain.close()
     monkeypatch.setenv('SGX_PLACEMENT', 'plain')
