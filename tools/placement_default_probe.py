@@ -31,9 +31,13 @@ for placement in ('plain', 'search'):
     multi = timed(lambda: env.rollout_steps(128), 128)
     env.set_multi_step(False)
     per = timed(lambda: env.rollout_steps(64), 64)
+    env.set_multi_step(True)
+    ring_reps = env.alloc_output_ring(3)
+    env.rollout_steps(64, ring=True)
+    ring = timed(lambda: env.rollout_steps(128, ring=True), 128)
     rep = env.placement_report or {}
-    print("placement=%-6s first reset() %.2f s; rollout call %6.1f us per step = %5.1f M steps/s; one launch per step %6.1f us = %5.1f M; candidates %s; held for a moment %.1f GB"
-          % (placement, t_reset, multi, 65536 / multi, per, 65536 / per, ' '.join('%.0f' % x for x in rep.get('obs', [])) or '-', env.placement_peak_extra_bytes / 1e9), flush=True)
+    print("placement=%-6s first reset() %.2f s; rollout call %6.1f us per step = %5.1f M steps/s; one launch per step %6.1f us = %5.1f M; ring of 3 (alloc_output_ring(3)) %6.1f us = %5.1f M; candidates %s; held for a moment %.1f GB"
+          % (placement, t_reset, multi, 65536 / multi, per, 65536 / per, ring, 65536 / ring, ' '.join('%.0f' % x for x in rep.get('obs', [])) or '-', env.placement_peak_extra_bytes / 1e9), flush=True)
     env.close()
     del env
     torch.cuda.empty_cache()
