@@ -826,6 +826,7 @@ def line_summary(out):
     if s["trajectory"] and ((c.get("trajectory") or {}).get("ring_of_separately_placed_sets") or {}).get("value"):
         s["trajectory"]["ring_of_separately_placed_sets"] = pick(c["trajectory"]["ring_of_separately_placed_sets"], "sets", "value", "launch_us", "frac", "one_launch", "same_memory")
     s["compact_outputs"] = pick(c.get("compact_outputs"), "value", "launch_us", "frac", "trajectory_64_slots")
+    s["as_it_comes"] = pick(c.get("as_it_comes"), "value", "launch_us", "frac", "in_place_one_launch_per_step", "verified_envs")
     s["consumer_in_loop"] = pick((c.get("consumer_in_loop") or {}).get("nt_stores"), "value", "step_kernel_us_in_loop")
     s["facade_n1"] = pick(c.get("facade_n1"), "steps_per_s", "env_step_calls_per_s")
     s["scaling_legs"] = [pick(l, "games_per_gpu", "value", "scaling_x", "per_gpu_value_min_over_solo") for l in (c.get("scaling_legs") or [])] or None
@@ -1036,6 +1037,7 @@ def run_rank(args):      # noqa: C901
                                                 optional_leg(bench_legs.other_workload, B, rk, args, 'barrage', GAMES_PER_GPU_MULTI)]
             out["config"]["compact_outputs"] = optional_leg(bench_legs.compact_leg, B, rk, args)
             out["config"]["trajectory"] = optional_leg(bench_legs.trajectory_leg, B, rk, args, slots=args.trajectory_slots) if 'trajectory' in legs_on else None
+            out["config"]["as_it_comes"] = optional_leg(bench_legs.as_it_comes_leg, B, rk, args)
         if 'facade_n1' in legs_on:
             out["config"]["facade_n1"] = optional_leg(bench_legs.facade_leg, sys.modules[__name__])
         if 'live_traffic' in legs_on:

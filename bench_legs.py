@@ -4,6 +4,7 @@
   consumer_leg       config.consumer_in_loop: sgx_step alternating with a device policy that READS the observation and the mask
   compact_leg        config.compact_outputs: the opt-in 4-bit-code / mask-bit outputs
   other_workload     config.other_workloads: BASELINE configs 3 and 4, BOTH_OBSERVATIONS, config 5's per-GPU size
+  as_it_comes_leg    config.as_it_comes: VecStrategoEnv with every default on the headline's workload
 
   store_probe_leg    roofline.store_peak_measured: the step kernel's store stream WITHOUT the game (sgx_store_probe) on the very ring buffers
                      the headline wrote, in the same process -- zeros, observation-like floats and incompressible bits as payload; one launch
@@ -250,6 +251,60 @@ def trajectory_leg(B, rk, args, version='barrage', n=65536, slots=64, passes=3, 
                          "the waves of a workgroup are kept in step (sgx_set_steps_barrier), which recovers 3-5 % of it",
                 "verified_envs": checked, "verified_steps": env.bench_steps_played}
     finally:
+        env.close()
+        del env
+        torch.cuda.empty_cache()
+
+
+def as_it_comes_leg(B, rk, args, version='barrage', n=65536, steps=128, verify=8):
+    """What a caller who changes nothing gets: VecStrategoEnv(...) with its default placement (the bounded search of its first reset()),
+    alloc_output_ring(3) with its defaults, rollout_steps(..., ring=True) -- the headline's workload without bench.py's own, larger search --
+    and the same env stepping in place with one launch per step (env.step()'s shape)."""
+    import torch
+    from stratego_env_amd.config import VARIANTS
+    from stratego_env_amd.vec_env import VecStrategoEnv
+    v = VARIANTS[version]
+    env = VecStrategoEnv(version, n, device=rk.device_index, seed=B.BASE_SEED, env_id_offset=0, auto_reset=True)
+    try:
+        t0 = time.perf_counter()
+        env.reset()
+        torch.cuda.synchronize()
+        t_reset = time.perf_counter() - t0
+        env.bench_steps_played = 0
+        env.sample_valid_actions()
+        ring_reps = env.alloc_output_ring(3)
+
+        def timed(fn, k, reps=3):
+            best = 1e9
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                a.record(); fn(); b.record()
+                torch.cuda.synchronize()
+                best = min(best, a.elapsed_time(b) * 1e3 / k)
+            return best
+        env.rollout_steps(steps, ring=True)
+        us_ring = timed(lambda: env.rollout_steps(steps, ring=True), steps)
+        env.set_multi_step(False)
+        env.rollout_steps(16)
+        us_step = timed(lambda: env.rollout_steps(steps // 2), steps // 2)
+        env.set_multi_step(True)
+        env.bench_steps_played += 4 * steps + 16 + 3 * (steps // 2)
+        B.MULTI_STEP_TALLY["launches"] += 4
+        B.MULTI_STEP_TALLY["steps"] += 4 * steps
+        rep = env.placement_report or {}
+        return {"workload": "%d concurrent %s games, VecStrategoEnv with every default (placement='search' at the first reset()), alloc_output_ring(3), "
+                            "rollout_steps(%d, ring=True)" % (n, version, steps),
+                "value": n / (us_ring * 1e-6), "unit": "env steps/s", "launch_us": us_ring,
+                "frac": B.b_min(v, False, env.record_bytes, float(steps)) * n / (us_ring * 1e-6) / 1e9 / B.HBM_PEAK_GBS,
+                "in_place_one_launch_per_step": {"value": n / (us_step * 1e-6), "launch_us": us_step,
+                                                 "rate_over_spec_peak": B.b_min(v, False, env.record_bytes) * n / (us_step * 1e-6) / 1e9 / B.HBM_PEAK_GBS},
+                "first_reset_seconds": round(t_reset, 3), "search_candidates_us": [round(x, 1) for x in rep.get('obs', [])],
+                "ring_sets_candidates_us": [[round(x, 1) for x in (r or {}).get('obs', [])] for r in ring_reps[1:]],
+                "held_for_a_moment_gb": round(env.placement_peak_extra_bytes / 1e9, 2),
+                "verified_envs": B.verify_against_oracle(env, version, verify) if verify else 0, "verified_steps": env.bench_steps_played}
+    finally:
+        env._ring = None
         env.close()
         del env
         torch.cuda.empty_cache()
