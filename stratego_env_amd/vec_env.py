@@ -84,7 +84,8 @@ class VecStrategoEnv:
         placement search (tune_placement(): ~10 ms, at most min(8 GiB, a quarter of the free device memory) held beyond the buffers for a
         moment; which physical memory an allocation gets decides 0.76-0.93 against 0.95-1.04 of the roofline) -- only
         where there are placement classes (observations of more than 300 MB, not compact); 'plain' = torch.empty tensors, always.  None =
-        the environment variable SGX_PLACEMENT, else 'search'."""
+        the environment variable SGX_PLACEMENT, else 'search'.  (Use the tensors reset() / step() RETURN, or env.obs / env.mask read
+        after the first reset(): that reset may replace the ones allocated here.)"""
         if obs_channel_mode not in ('extended', 'original'):
             raise ValueError("obs_channel_mode must be 'extended' or 'original'")
         placement = placement if placement is not None else (os.environ.get('SGX_PLACEMENT') or 'search')
