@@ -18,6 +18,7 @@ There is no CPU fallback: construction fails if the HIP library is missing or no
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import torch
@@ -45,10 +46,10 @@ class _OutputsOwner:
         # Runs wherever the garbage collector drops the last tensor.  sgx_free_outputs selects the buffers' device for the free and
         # puts the calling thread's device back (DeviceGuard); at interpreter shutdown the HIP runtime may already be gone and the
         # process's memory is released anyway: nothing to do then.
-        import sys
-        if sys is None or sys.is_finalizing():
-            return
+        # (module globals may already be None at shutdown, and an import here would raise: everything inside the try)
         try:
+            if sys is None or sys.is_finalizing():
+                return
             self._L.sgx_free_outputs(None, C.byref(self.out))      # (works without the handle: the record names its device)
         except Exception:
             pass
