@@ -1030,13 +1030,16 @@ def run_rank(args):      # noqa: C901
             if 'consumer_in_loop' in legs_on:
                 out["config"]["consumer_in_loop"] = bench_legs.consumer_leg(sys.modules[__name__], rk, args)
             B = sys.modules[__name__]
+            # (first, while this process's device memory has seen only the headline's buffers: a learner allocates its 128 GB buffer early too;
+            #  after the other legs' allocations the same buffer ran 10 % slower in one line -- profiles/r06_default_bench_line_run4.json)
+            traj_leg = optional_leg(bench_legs.trajectory_leg, B, rk, args, slots=args.trajectory_slots) if 'trajectory' in legs_on else None
             out["config"]["other_workloads"] = [optional_leg(bench_legs.other_workload, B, rk, args, 'standard', 262144, chains=2),
                                                 optional_leg(bench_legs.other_workload, B, rk, args, 'micro', 65536, chains=2, rotate_sets=args.rotate_sets),
                                                 optional_leg(bench_legs.other_workload, B, rk, args, 'barrage', 65536, full_obs=True),
                                                 # BASELINE config 5's per-GPU size on ONE GPU: the G = 1 anchor of the 1 / 2 / 4 / 8 curve
                                                 optional_leg(bench_legs.other_workload, B, rk, args, 'barrage', GAMES_PER_GPU_MULTI)]
             out["config"]["compact_outputs"] = optional_leg(bench_legs.compact_leg, B, rk, args)
-            out["config"]["trajectory"] = optional_leg(bench_legs.trajectory_leg, B, rk, args, slots=args.trajectory_slots) if 'trajectory' in legs_on else None
+            out["config"]["trajectory"] = traj_leg
             out["config"]["as_it_comes"] = optional_leg(bench_legs.as_it_comes_leg, B, rk, args)
         if 'facade_n1' in legs_on:
             out["config"]["facade_n1"] = optional_leg(bench_legs.facade_leg, sys.modules[__name__])
